@@ -1,0 +1,319 @@
+// Host factor + permuted solve of (A A^T + eps I): the engine's replacement for the reference's
+// CholeskySolverCPU (include/cuadmm/cholesky_cpu.h:62-155), which wraps CHOLMOD's simplicial
+// LDL^T with `cholmod_analyze` ordering and `cholmod_solve2(CHOLMOD_LDLt)`.
+//
+// SuiteSparse is not available to this build, so the three pieces are implemented here:
+//   1. B = A A^T + eps I by row-wise sparse accumulation,
+//   2. a fill-reducing ordering: quotient-graph approximate minimum degree with element
+//      absorption and aggressive absorption,
+//   3. an up-looking sparse LDL^T (elimination tree + row-pattern reach) and the two
+//      triangular solves.
+// Contract kept from the reference: the solve works on the PERMUTED system and applies no
+// permutation itself (cholesky_cpu.h:146-155; solver.cu:487,500 permute around it).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "common.h"
+
+struct cuadmm_aat {
+  int m = 0;
+  std::vector<int> perm, iperm;
+  std::vector<int64_t> Lp;  // column pointers of unit-lower L (strict part), m+1
+  std::vector<int> Li;
+  std::vector<double> Lx;
+  std::vector<double> D;
+  double analyze_s = 0, factor_s = 0;
+};
+
+namespace {
+
+using cuadmm::set_error;
+
+// ---------------------------------------------------------------------------------------
+// Approximate minimum degree on the pattern of a symmetric matrix (diagonal ignored).
+// Quotient graph: variables keep a list of adjacent variables (edges not yet covered by an
+// element) and a list of adjacent elements; an element keeps its variable list.
+// ---------------------------------------------------------------------------------------
+void min_degree_order(int n, const std::vector<int64_t>& Bp, const std::vector<int>& Bi, std::vector<int>& perm) {
+  perm.resize(n);
+  std::vector<std::vector<int>> adj(n), elems(n), evars(n);
+  for (int i = 0; i < n; ++i) {
+    adj[i].reserve((size_t)(Bp[i + 1] - Bp[i]));
+    for (int64_t p = Bp[i]; p < Bp[i + 1]; ++p)
+      if (Bi[p] != i) adj[i].push_back(Bi[p]);
+  }
+  // state: 0 live variable, 1 live element, 2 dead (absorbed element)
+  std::vector<char> state(n, 0);
+  std::vector<int> deg(n), head(n + 1, -1), nxt(n, -1), prv(n, -1);
+  auto bucket_insert = [&](int v, int d) {
+    deg[v] = d; prv[v] = -1; nxt[v] = head[d];
+    if (head[d] >= 0) prv[head[d]] = v;
+    head[d] = v;
+  };
+  auto bucket_remove = [&](int v) {
+    int d = deg[v];
+    if (prv[v] >= 0) nxt[prv[v]] = nxt[v]; else head[d] = nxt[v];
+    if (nxt[v] >= 0) prv[nxt[v]] = prv[v];
+  };
+  for (int i = 0; i < n; ++i) bucket_insert(i, (int)adj[i].size());
+  std::vector<int> mark(n, -1), wstamp(n, -1), wcnt(n, 0), Lp;
+  int mindeg = 0;
+  for (int k = 0; k < n; ++k) {
+    while (head[mindeg] < 0) ++mindeg;
+    int p = head[mindeg];
+    bucket_remove(p);
+    perm[k] = p;
+    // variables of the new element p
+    Lp.clear();
+    mark[p] = k;
+    for (int v : adj[p])
+      if (state[v] == 0 && mark[v] != k) { mark[v] = k; Lp.push_back(v); }
+    for (int e : elems[p]) {
+      if (state[e] != 1) continue;
+      for (int v : evars[e])
+        if (mark[v] != k) { mark[v] = k; Lp.push_back(v); }
+      state[e] = 2;
+      std::vector<int>().swap(evars[e]);
+    }
+    state[p] = 1;
+    std::vector<int>().swap(adj[p]);
+    std::vector<int>().swap(elems[p]);
+    // |L_e ∩ L_p| for every live element touching L_p
+    for (int i : Lp)
+      for (int e : elems[i]) {
+        if (state[e] != 1) continue;
+        if (wstamp[e] != k) { wstamp[e] = k; wcnt[e] = 0; }
+        wcnt[e]++;
+      }
+    const int lp_size = (int)Lp.size();
+    for (int i : Lp) {
+      bucket_remove(i);
+      // edges to members of L_p are now represented by element p
+      auto& a = adj[i];
+      size_t w = 0;
+      for (size_t t = 0; t < a.size(); ++t) {
+        int v = a[t];
+        if (state[v] == 0 && mark[v] != k) a[w++] = v;
+      }
+      a.resize(w);
+      long long d = (long long)w + (lp_size - 1);
+      auto& el = elems[i];
+      w = 0;
+      for (size_t t = 0; t < el.size(); ++t) {
+        int e = el[t];
+        if (state[e] != 1) continue;
+        int ext = (int)evars[e].size() - wcnt[e];
+        if (ext <= 0) {  // e is a subset of L_p: aggressive absorption
+          state[e] = 2;
+          std::vector<int>().swap(evars[e]);
+          continue;
+        }
+        d += ext;
+        el[w++] = e;
+      }
+      el.resize(w);
+      el.push_back(p);
+      long long bound = (long long)deg[i] + (lp_size - 1);
+      if (d > bound) d = bound;
+      if (d > n - k - 1) d = n - k - 1;
+      if (d < 0) d = 0;
+      bucket_insert(i, (int)d);
+      if ((int)d < mindeg) mindeg = (int)d;
+    }
+    evars[p] = Lp;
+  }
+}
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double* Ax, double eps, cuadmm_aat** out) {
+  if (!out || m < 0 || L < 0 || !Acp) { set_error("aat_create: bad arguments"); return CUADMM_ERR_INVALID; }
+  *out = nullptr;
+  double t0 = now_s();
+  const int64_t nnz = Acp[L];
+  // rows of A (CSR) from its columns (CSC)
+  std::vector<int64_t> Rp((size_t)m + 1, 0);
+  for (int64_t p = 0; p < nnz; ++p) {
+    if (Ari[p] < 0 || Ari[p] >= m) { set_error("aat_create: row index %d out of range", Ari[p]); return CUADMM_ERR_INVALID; }
+    Rp[(size_t)Ari[p] + 1]++;
+  }
+  for (int i = 0; i < m; ++i) Rp[i + 1] += Rp[i];
+  std::vector<int> Rc((size_t)nnz);
+  std::vector<double> Rx((size_t)nnz);
+  {
+    std::vector<int64_t> pos(Rp.begin(), Rp.end() - 1);
+    for (int k = 0; k < L; ++k)
+      for (int64_t p = Acp[k]; p < Acp[k + 1]; ++p) {
+        int64_t q = pos[Ari[p]]++;
+        Rc[q] = k; Rx[q] = Ax[p];
+      }
+  }
+  // B = A A^T + eps I, full symmetric pattern, one row at a time
+  std::vector<int64_t> Bp((size_t)m + 1, 0);
+  std::vector<int> Bi;
+  std::vector<double> Bx;
+  {
+    std::vector<int> where(m, -1);
+    std::vector<double> acc(m, 0.0);
+    std::vector<int> touched;
+    for (int i = 0; i < m; ++i) {
+      touched.clear();
+      for (int64_t p = Rp[i]; p < Rp[i + 1]; ++p) {
+        int k = Rc[p];
+        double a = Rx[p];
+        for (int64_t q = Acp[k]; q < Acp[k + 1]; ++q) {
+          int j = Ari[q];
+          if (where[j] != i) { where[j] = i; acc[j] = 0.0; touched.push_back(j); }
+          acc[j] += a * Ax[q];
+        }
+      }
+      if (where[i] != i) { where[i] = i; acc[i] = 0.0; touched.push_back(i); }
+      acc[i] += eps;
+      std::sort(touched.begin(), touched.end());
+      for (int j : touched) { Bi.push_back(j); Bx.push_back(acc[j]); }
+      Bp[i + 1] = (int64_t)Bi.size();
+    }
+  }
+  cuadmm_aat* f = new cuadmm_aat();
+  f->m = m;
+  double t_b = now_s();
+  min_degree_order(m, Bp, Bi, f->perm);
+  if (getenv("CUADMM_AAT_TIMING")) fprintf(stderr, "[aat] build B %.3fs (nnz %lld), ordering %.3fs\n", t_b - t0, (long long)Bi.size(), now_s() - t_b);
+  f->iperm.resize(m);
+  for (int i = 0; i < m; ++i) f->iperm[f->perm[i]] = i;
+
+  // C = P B P^T, upper triangle by columns (column k holds rows i <= k)
+  std::vector<int64_t> Cp((size_t)m + 1, 0);
+  for (int i = 0; i < m; ++i) {
+    int pi = f->iperm[i];
+    for (int64_t p = Bp[i]; p < Bp[i + 1]; ++p) {
+      int pj = f->iperm[Bi[p]];
+      if (pi <= pj) Cp[(size_t)pj + 1]++;
+    }
+  }
+  for (int i = 0; i < m; ++i) Cp[i + 1] += Cp[i];
+  std::vector<int> Ci((size_t)Cp[m]);
+  std::vector<double> Cx((size_t)Cp[m]);
+  {
+    std::vector<int64_t> pos(Cp.begin(), Cp.end() - 1);
+    for (int i = 0; i < m; ++i) {
+      int pi = f->iperm[i];
+      for (int64_t p = Bp[i]; p < Bp[i + 1]; ++p) {
+        int pj = f->iperm[Bi[p]];
+        if (pi <= pj) { int64_t q = pos[pj]++; Ci[q] = pi; Cx[q] = Bx[p]; }
+      }
+    }
+  }
+  std::vector<int64_t>().swap(Bp); std::vector<int>().swap(Bi); std::vector<double>().swap(Bx);
+
+  // symbolic: elimination tree and column counts of L
+  std::vector<int> parent(m, -1), flag(m, -1);
+  std::vector<int64_t> Lnz(m, 0);
+  for (int k = 0; k < m; ++k) {
+    flag[k] = k;
+    for (int64_t p = Cp[k]; p < Cp[k + 1]; ++p) {
+      int i = Ci[p];
+      while (i < k && flag[i] != k) {
+        if (parent[i] < 0) parent[i] = k;
+        Lnz[i]++;
+        flag[i] = k;
+        i = parent[i];
+      }
+    }
+  }
+  f->Lp.assign((size_t)m + 1, 0);
+  for (int k = 0; k < m; ++k) f->Lp[k + 1] = f->Lp[k] + Lnz[k];
+  f->analyze_s = now_s() - t0;
+  t0 = now_s();
+  try {
+    f->Li.resize((size_t)f->Lp[m]);
+    f->Lx.resize((size_t)f->Lp[m]);
+  } catch (const std::bad_alloc&) {
+    set_error("aat_create: factor with %lld nonzeros does not fit in host memory", (long long)f->Lp[m]);
+    delete f;
+    return CUADMM_ERR_FACTOR;
+  }
+  f->D.assign(m, 0.0);
+
+  // numeric: up-looking LDL^T, row k of L from the reach of column k of C in the etree
+  std::vector<double> Y(m, 0.0);
+  std::vector<int> pattern(m);
+  std::fill(flag.begin(), flag.end(), -1);
+  std::fill(Lnz.begin(), Lnz.end(), 0);
+  for (int k = 0; k < m; ++k) {
+    int top = m;
+    flag[k] = k;
+    for (int64_t p = Cp[k]; p < Cp[k + 1]; ++p) {
+      int i = Ci[p];
+      Y[i] += Cx[p];
+      int len = 0;
+      while (i < k && flag[i] != k) { pattern[len++] = i; flag[i] = k; i = parent[i]; }
+      while (len > 0) pattern[--top] = pattern[--len];
+    }
+    double dk = Y[k];
+    Y[k] = 0.0;
+    for (; top < m; ++top) {
+      int i = pattern[top];
+      double yi = Y[i];
+      Y[i] = 0.0;
+      int64_t p2 = f->Lp[i] + Lnz[i];
+      const int* li = f->Li.data();
+      const double* lx = f->Lx.data();
+      for (int64_t p = f->Lp[i]; p < p2; ++p) Y[li[p]] -= lx[p] * yi;
+      double lki = yi / f->D[i];
+      dk -= lki * yi;
+      f->Li[p2] = k;
+      f->Lx[p2] = lki;
+      Lnz[i]++;
+    }
+    if (dk == 0.0 || !std::isfinite(dk)) {
+      set_error("Factorization fails! (zero or non-finite pivot at permuted row %d)", k);
+      delete f;
+      return CUADMM_ERR_FACTOR;
+    }
+    f->D[k] = dk;
+  }
+  f->factor_s = now_s() - t0;
+  if (getenv("CUADMM_AAT_TIMING")) fprintf(stderr, "[aat] analyze %.3fs numeric %.3fs nnz(L) %lld\n", f->analyze_s, f->factor_s, (long long)f->Lp[m]);
+  *out = f;
+  return CUADMM_OK;
+}
+
+const int* cuadmm_aat_perm(const cuadmm_aat* f) { return f ? f->perm.data() : nullptr; }
+int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f) { return f ? f->Lp[f->m] : 0; }
+
+int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x) {
+  if (!f || !rhs || !x) { set_error("aat_solve: null argument"); return CUADMM_ERR_INVALID; }
+  const int m = f->m;
+  if (x != rhs) std::memcpy(x, rhs, sizeof(double) * (size_t)m);
+  const int64_t* Lp = f->Lp.data();
+  const int* Li = f->Li.data();
+  const double* Lx = f->Lx.data();
+  const double* D = f->D.data();
+  for (int j = 0; j < m; ++j) {  // L z = b
+    double xj = x[j];
+    if (xj != 0.0)
+      for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
+  }
+  for (int j = 0; j < m; ++j) x[j] /= D[j];
+  for (int j = m - 1; j >= 0; --j) {  // L^T x = z
+    double s = x[j];
+    for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
+    x[j] = s;
+  }
+  return CUADMM_OK;
+}
+
+void cuadmm_aat_free(cuadmm_aat* f) { delete f; }
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// Shared host-side declarations of the engine (error plumbing, small helpers).
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "cuadmm_amd.h"
+
+namespace cuadmm {
+
+// thread-local message returned by cuadmm_last_error()
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+struct ProblemData {
+  int vec_len = 0, con_num = 0, mat_num = 0;
+  std::vector<int> At_col_ptrs, At_row_ids, At_coo_col_ids;
+  std::vector<double> At_vals;
+  std::vector<int> b_idx, C_idx;
+  std::vector<double> b_vals, C_vals;
+  std::vector<int> blk;
+  std::vector<char> blk_types;
+};
+
+// io.cpp
+int read_blk_file(const std::string& fn, std::vector<char>& types, std::vector<int>& sizes);
+int read_triplets(const std::string& fn, std::vector<int>& r, std::vector<int>& c, std::vector<double>& v, bool allow_missing);
+int read_numbers(const std::string& fn, std::vector<double>& vals);
+void coo_to_csc(std::vector<int>& col_ptrs, std::vector<int>& col_ids, std::vector<int>& row_ids,
+                std::vector<double>& vals, int nnz, int col_num);
+int load_problem_txt(const std::string& prefix, ProblemData& p, bool verbose);
+
+// blocks.cpp
+bool is_large_mat(int mat_size, int mat_num);
+void analyze_blk(const int* blk, int mat_num, std::vector<int>& sizes, std::vector<int>& nums);
+struct MatrixSizes {
+  std::vector<int> large_sizes, large_nums, small_sizes, small_nums;
+  std::vector<long long> large_start, large_W_start, small_start, small_W_start;
+  long long total_large = 0, total_small = 0, sum_large = 0, sum_small = 0;
+  int large_num = 0, small_num = 0;
+  void init(const std::vector<int>& sizes, const std::vector<int>& nums);
+  bool is_large(int s) const;
+  void print() const;
+  std::vector<std::pair<int, bool>> cls;  // (size, is_large)
+};
+void print_blk_census(const std::vector<int>& sizes, const std::vector<int>& nums);
+void partition_blocks(const int* blk, int mat_num, int world, std::vector<int>& first);
+
+}  // namespace cuadmm

@@ -1,0 +1,20 @@
+// HIP error plumbing shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+#define CUADMM_HIP_TRY(expr)                                                                      \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      ::cuadmm::set_error("HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e),       \
+                          __FILE__, __LINE__, #expr);                                             \
+      return CUADMM_ERR_NO_DEVICE;                                                                \
+    }                                                                                             \
+  } while (0)
+
+namespace cuadmm {
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB LDS per CU / per workgroup
+constexpr int kMaxBlockSize = 4000;           // single-workgroup HBM-resident path limit (5n doubles of LDS)
+}  // namespace cuadmm

@@ -1,0 +1,869 @@
+// The SDP-ADMM iteration engine: MI355X-native replacement of SDPSolver::init / ::solve
+// (reference src/solver.cu:27-342 and :355-823).
+//
+// Data layout (all fp64, resident in HBM for the whole solve):
+//   X, S, C, Rd1, Xb, Xproj : svec vectors of this rank's contiguous block range
+//   At_csr  : rows = local svec slots, columns = constraints in the factor's PERMUTED order
+//   A_csr   : rows = constraints in permuted order, columns = local svec slots
+//   out     : [A*X (m) | sum Rd^2 | sum C.X | A*(S-C) (m)]  -> one D2H per (half-)iteration
+// The constraint-space vectors (y, b, Rp, rhs; length m) live on the host in permuted order, next
+// to the host LDL^T factor of P(AA^T + eps I)P^T, so the reference's two scatter kernels per solve
+// (perform_permutation, solver.cu:487,500) disappear: permutation is folded into the matrices.
+// Host<->device traffic per iteration: m doubles up (y), 2m+2 doubles down (ADMM phase).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <dlfcn.h>
+#include <iostream>
+#include <numeric>
+
+#include "device_util.h"
+#include "psd_plan.h"
+#include "vec_kernels.h"
+
+using namespace cuadmm;
+
+namespace {
+
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return CUADMM_OK;
+    CUADMM_HIP_TRY(hipMalloc(&p, sizeof(T) * count));
+    return CUADMM_OK;
+  }
+  int upload(const T* h, size_t count) {
+    if (count == 0) return CUADMM_OK;
+    CUADMM_HIP_TRY(hipMemcpy(p, h, sizeof(T) * count, hipMemcpyHostToDevice));
+    return CUADMM_OK;
+  }
+  int from(const std::vector<T>& h) {
+    int rc = alloc(h.size());
+    if (rc) return rc;
+    return upload(h.data(), h.size());
+  }
+  void release() {
+    if (p) { hipError_t e = hipFree(p); (void)e; }
+    p = nullptr; n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+template <class T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return CUADMM_OK;
+    CUADMM_HIP_TRY(hipHostMalloc(&p, sizeof(T) * count, hipHostMallocDefault));
+    return CUADMM_OK;
+  }
+  void release() {
+    if (p) { hipError_t e = hipHostFree(p); (void)e; }
+    p = nullptr; n = 0;
+  }
+  ~PinnedBuf() { release(); }
+};
+
+enum KClass { K_ATY = 0, K_PSD = 1, K_POST = 2, K_SPMV = 3, K_COPY = 4, K_HOST = 5, K_COMM = 6, K_NUM = CUADMM_NUM_KCLASS };
+
+// direct RCCL binding (symbols resolved at run time so that a process that already loaded an RCCL,
+// e.g. through torch, shares it)
+struct NcclUid { char internal[128]; };
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclUid*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  bool load() {
+    if (AllReduce) return true;
+    void* h = dlopen(nullptr, RTLD_NOW);
+    if (!h || !dlsym(h, "ncclAllReduce")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    lib = h;
+    GetUniqueId = (int (*)(NcclUid*))dlsym(h, "ncclGetUniqueId");
+    CommInitRank = (int (*)(void**, int, NcclUid, int))dlsym(h, "ncclCommInitRank");
+    AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    return GetUniqueId && CommInitRank && AllReduce;
+  }
+};
+RcclApi g_rccl;
+
+}  // namespace
+
+struct cuadmm_solver {
+  // options
+  int device = 0, verbose = 1, rank = 0, world = 1, profile = 0;
+  cuadmm_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  void* rccl_comm = nullptr;
+
+  bool initialised = false;
+  hipStream_t st = nullptr;
+  double t_init0 = 0, total_time = 0;
+
+  // global dims
+  int L_full = 0, m = 0, nblk_full = 0;
+  // shard
+  int blk_begin = 0, blk_end = 0;
+  long long sv_begin = 0, sv_end = 0;
+  long long L = 0;
+  std::vector<int> blk_local;
+
+  // host state (constraint space, permuted order unless noted)
+  cuadmm_aat* fac = nullptr;
+  std::vector<int> perm, perm_inv;
+  std::vector<double> normA;      // original order
+  std::vector<double> normA_p, b_p, y_p, Rp_p, ASmC_p, rhs_p, y_best_p;
+  double norm_borg = 1, norm_Corg = 1, bscale = 1, Cscale = 1, objscale = 1;
+  double sig = 1, errRp = 0, errRd = 0, maxfeas = 0, pobj = 0, dobj = 0, relgap = 0, feasratio = 0;
+  int prim_win = 0, dual_win = 0;
+  double ratioconst = 1, sigmax = 1e3, sigmin = 1e-3;
+  double best_KKT = 0, sgs_KKT = 0;
+  bool have_best = false;
+  int eig_fail_total = 0;
+
+  // info
+  int info_iter_num = 0;
+  std::vector<double> info[8];
+
+  // device
+  DevBuf<int> At_rp, At_ci, A_rp, A_ci;
+  DevBuf<double> At_v, A_v;
+  DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
+  PinnedBuf<double> h_out, h_y;
+  double A_avg_nnz = 1;
+  PsdPlan plan;
+
+  // profiling
+  hipEvent_t ev0[K_NUM][2] = {}, ev1[K_NUM][2] = {};
+  int ev_used[K_NUM] = {0};
+  double prof_count[K_NUM] = {0}, prof_ms[K_NUM] = {0}, prof_bytes[K_NUM] = {0};
+
+  ~cuadmm_solver() {
+    if (fac) cuadmm_aat_free(fac);
+    for (int k = 0; k < K_NUM; ++k)
+      for (int j = 0; j < 2; ++j) {
+        if (ev0[k][j]) { hipError_t e = hipEventDestroy(ev0[k][j]); (void)e; }
+        if (ev1[k][j]) { hipError_t e = hipEventDestroy(ev1[k][j]); (void)e; }
+      }
+    if (st) { hipError_t e = hipStreamDestroy(st); (void)e; }
+  }
+
+  void prof_begin(int k) {
+    if (!profile || ev_used[k] >= 2) return;
+    hipError_t e = hipEventRecord(ev0[k][ev_used[k]], st); (void)e;
+  }
+  void prof_end(int k, double bytes) {
+    if (!profile || ev_used[k] >= 2) return;
+    hipError_t e = hipEventRecord(ev1[k][ev_used[k]], st); (void)e;
+    ev_used[k]++;
+    prof_bytes[k] = bytes;
+  }
+  void prof_collect() {  // call after a stream synchronize
+    if (!profile) return;
+    for (int k = 0; k < K_NUM; ++k) {
+      for (int j = 0; j < ev_used[k]; ++j) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0[k][j], ev1[k][j]) == hipSuccess) { prof_ms[k] += ms; prof_count[k] += 1; }
+      }
+      ev_used[k] = 0;
+    }
+  }
+  void prof_host(int k, double seconds) {
+    if (!profile) return;
+    prof_ms[k] += seconds * 1e3; prof_count[k] += 1;
+  }
+
+  int do_allreduce(double* buf, size_t count) {
+    if (world <= 1) return CUADMM_OK;
+    prof_begin(K_COMM);
+    int rc = 0;
+    if (allreduce) {
+      rc = allreduce(allreduce_user, buf, count, (void*)st);
+    } else if (rccl_comm) {
+      rc = g_rccl.AllReduce(buf, buf, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, rccl_comm, st);
+    } else {
+      set_error("world=%d but no all-reduce hook installed (cuadmm_set_allreduce / cuadmm_use_rccl)", world);
+      return CUADMM_ERR_COMM;
+    }
+    prof_end(K_COMM, (double)count * 8);
+    if (rc) { set_error("all-reduce hook failed with code %d", rc); return CUADMM_ERR_COMM; }
+    return CUADMM_OK;
+  }
+
+  int host_solve() {  // y_p = (P(AA^T+eps I)P^T)^-1 rhs_p
+    double t0 = wall_s();
+    const double isig = 1 / sig;
+    for (int i = 0; i < m; ++i) rhs_p[i] = -ASmC_p[i] + isig * Rp_p[i];   // solver.cu:478-482
+    int rc = cuadmm_aat_solve_permuted(fac, rhs_p.data(), y_p.data());     // solver.cu:494
+    prof_host(K_HOST, wall_s() - t0);
+    return rc;
+  }
+
+  int upload_y() {
+    prof_begin(K_COPY);
+    std::memcpy(h_y.p, y_p.data(), sizeof(double) * (size_t)m);
+    CUADMM_HIP_TRY(hipMemcpyAsync(y_d.p, h_y.p, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, st));
+    prof_end(K_COPY, (double)m * 8);
+    return CUADMM_OK;
+  }
+
+  // D2H of out_d[first, first+count) after the optional all-reduce; blocks until it has landed
+  int fetch_out(size_t first, size_t count) {
+    int rc = do_allreduce(out_d.p + first, count);
+    if (rc) return rc;
+    CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    prof_collect();
+    return CUADMM_OK;
+  }
+
+  int launch_aty(bool write_xb) {
+    prof_begin(K_ATY);
+    int rc = launch_aty_xb(write_xb, L, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st);
+    prof_end(K_ATY, (write_xb ? 32.0 : 16.0) * (double)L + 4.0 * (double)L);
+    return rc;
+  }
+  int launch_spmv(bool doX, bool doS) {
+    prof_begin(K_SPMV);
+    int rc = launch_spmv_rows(m, A_avg_nnz, A_rp.p, A_ci.p, A_v.p, X.p, S.p, C.p, doX ? out_d.p : nullptr,
+                              doS ? out_d.p + m + 2 : nullptr, st);
+    prof_end(K_SPMV, 12.0 * (double)A_v.n + 8.0 * m * ((doX ? 1 : 0) + (doS ? 1 : 0)));
+    return rc;
+  }
+  int launch_project() {
+    prof_begin(K_PSD);
+    int rc = plan.project(Xb.p, Xproj.p, st);
+    prof_end(K_PSD, 16.0 * (double)L);
+    return rc;
+  }
+  int launch_post_mode(int mode, double tau) {
+    prof_begin(K_POST);
+    int rc = launch_post(mode, L, Xproj.p, Rd1.p, C.p, X.p, S.p, 1 / sig, tau * sig, partials.p, out_d.p + (size_t)m, st);
+    prof_end(K_POST, (mode == 0 ? 48.0 : (mode == 1 ? 32.0 : 40.0)) * (double)L);
+    return rc;
+  }
+};
+
+using Solver = cuadmm_solver;
+
+static int check_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device available (hipGetDeviceCount: %s); this engine has no CPU fallback", hipGetErrorString(e));
+    return CUADMM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return CUADMM_ERR_NO_DEVICE; }
+  CUADMM_HIP_TRY(hipSetDevice(device));
+  return CUADMM_OK;
+}
+
+extern "C" {
+
+const char* cuadmm_last_error(void) { return get_error(); }
+const char* cuadmm_version(void) { return "cuadmm_amd 0.1 (gfx950)"; }
+int cuadmm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int cuadmm_create(cuadmm_solver** out) {
+  if (!out) { set_error("create: null"); return CUADMM_ERR_INVALID; }
+  *out = new cuadmm_solver();
+  return CUADMM_OK;
+}
+void cuadmm_destroy(cuadmm_solver* s) { delete s; }
+
+int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
+  if (!s || !key) { set_error("set_option: null"); return CUADMM_ERR_INVALID; }
+  std::string k(key);
+  if (k == "device") s->device = (int)value;
+  else if (k == "verbose") s->verbose = (int)value;
+  else if (k == "rank") s->rank = (int)value;
+  else if (k == "world") s->world = (int)value;
+  else if (k == "profile") s->profile = (int)value;
+  else if (k == "graph") {}
+  else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
+  return CUADMM_OK;
+}
+
+int cuadmm_set_allreduce(cuadmm_solver* s, cuadmm_allreduce_fn fn, void* user) {
+  if (!s) { set_error("set_allreduce: null"); return CUADMM_ERR_INVALID; }
+  s->allreduce = fn; s->allreduce_user = user;
+  return CUADMM_OK;
+}
+
+int cuadmm_rccl_unique_id(char out128[128]) {
+  if (!g_rccl.load()) { set_error("RCCL not loadable"); return CUADMM_ERR_COMM; }
+  NcclUid id;
+  if (g_rccl.GetUniqueId(&id)) { set_error("ncclGetUniqueId failed"); return CUADMM_ERR_COMM; }
+  std::memcpy(out128, id.internal, 128);
+  return CUADMM_OK;
+}
+
+int cuadmm_use_rccl(cuadmm_solver* s, const char unique_id128[128], int rank, int world) {
+  if (!s || !unique_id128) { set_error("use_rccl: null"); return CUADMM_ERR_INVALID; }
+  if (!g_rccl.load()) { set_error("RCCL not loadable"); return CUADMM_ERR_COMM; }
+  int rc = check_device(s->device);
+  if (rc) return rc;
+  NcclUid id;
+  std::memcpy(id.internal, unique_id128, 128);
+  if (g_rccl.CommInitRank(&s->rccl_comm, world, id, rank)) { set_error("ncclCommInitRank failed"); return CUADMM_ERR_COMM; }
+  s->rank = rank; s->world = world;
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SDPSolver::init
+// ------------------------------------------------------------------------------------------
+int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread_num, int vec_len, int con_num,
+                const int* At_cp, const int* At_ri, const double* At_vx, int At_nnz, const int* b_idx,
+                const double* b_vals, int b_nnz, const int* C_idx, const double* C_vals, int C_nnz,
+                const int* blk, int mat_num, const double* X0, const double* y0, const double* S0, double sig) {
+  (void)eig_stream_num_per_gpu; (void)cpu_eig_thread_num;
+  if (!s) { set_error("init: null solver"); return CUADMM_ERR_INVALID; }
+  if (s->initialised) { set_error("init: solver already initialised (one init per object, as in the reference)"); return CUADMM_ERR_INVALID; }
+  if (vec_len < 0 || con_num < 0 || At_nnz < 0 || b_nnz < 0 || C_nnz < 0 || mat_num < 0 || !At_cp || !blk ||
+      (At_nnz > 0 && (!At_ri || !At_vx)) || (b_nnz > 0 && (!b_idx || !b_vals)) || (C_nnz > 0 && (!C_idx || !C_vals))) {
+    set_error("init: invalid argument");
+    return CUADMM_ERR_INVALID;
+  }
+  if (s->world < 1 || s->rank < 0 || s->rank >= s->world) { set_error("init: bad rank/world %d/%d", s->rank, s->world); return CUADMM_ERR_INVALID; }
+  long long Lchk = 0;
+  for (int k = 0; k < mat_num; ++k) {
+    if (blk[k] < 1) { set_error("init: block %d has size %d", k, blk[k]); return CUADMM_ERR_INVALID; }
+    Lchk += (long long)blk[k] * (blk[k] + 1) / 2;
+  }
+  if (Lchk != vec_len) { set_error("init: vec_len %d does not match blk (sum n(n+1)/2 = %lld)", vec_len, Lchk); return CUADMM_ERR_INVALID; }
+  if (At_cp[0] != 0 || At_cp[con_num] != At_nnz) { set_error("init: At column pointers inconsistent with At_nnz"); return CUADMM_ERR_INVALID; }
+  for (int p = 0; p < At_nnz; ++p)
+    if (At_ri[p] < 0 || At_ri[p] >= vec_len) { set_error("init: At row index %d out of range at %d", At_ri[p], p); return CUADMM_ERR_INVALID; }
+
+  int rc = check_device(s->device);
+  if (rc) return rc;
+  s->t_init0 = wall_s();                                  // the reference's timer starts in init (solver.cu:41-44)
+  CUADMM_HIP_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+  if (s->profile)
+    for (int k = 0; k < K_NUM; ++k)
+      for (int j = 0; j < 2; ++j) { CUADMM_HIP_TRY(hipEventCreate(&s->ev0[k][j])); CUADMM_HIP_TRY(hipEventCreate(&s->ev1[k][j])); }
+
+  const int m = con_num;
+  const long long Lf = vec_len;
+  s->m = m; s->L_full = vec_len; s->nblk_full = mat_num; s->sig = sig;
+
+  // --- get_normA (sparse_matrix_norm.cu:11-31): norm_j = max(1,||col j||), column scaled in place
+  std::vector<double> vals(At_vx, At_vx + At_nnz);
+  s->normA.assign(m, 1.0);
+  for (int j = 0; j < m; ++j) {
+    double nrm = 0.0;
+    for (int p = At_cp[j]; p < At_cp[j + 1]; ++p) nrm += vals[p] * vals[p];
+    nrm = std::max(1.0, std::sqrt(nrm));
+    s->normA[j] = nrm;
+    for (int p = At_cp[j]; p < At_cp[j + 1]; ++p) vals[p] /= nrm;
+  }
+
+  // --- At in CSR over the svec rows (== CSC of A), solver.cu:83-88
+  std::vector<int> rp((size_t)Lf + 1, 0), rci((size_t)At_nnz);
+  std::vector<double> rv((size_t)At_nnz);
+  for (int p = 0; p < At_nnz; ++p) rp[(size_t)At_ri[p] + 1]++;
+  for (long long i = 0; i < Lf; ++i) rp[i + 1] += rp[i];
+  {
+    std::vector<int> pos(rp.begin(), rp.end() - 1);
+    for (int j = 0; j < m; ++j)
+      for (int p = At_cp[j]; p < At_cp[j + 1]; ++p) {
+        int q = pos[At_ri[p]]++;
+        rci[q] = j; rv[q] = vals[p];
+      }
+  }
+
+  // --- host factor of A A^T + 1e-15 I (solver.cu:91-96, cholesky_cpu.h:62-141)
+  rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
+  if (rc) return rc;
+  s->perm.assign(cuadmm_aat_perm(s->fac), cuadmm_aat_perm(s->fac) + m);
+  s->perm_inv.assign(m, 0);
+  for (int i = 0; i < m; ++i) s->perm_inv[s->perm[i]] = i;
+
+  // --- census (analyze_blk.cu:63-99, matrix_sizes.cu:75-113)
+  if (s->verbose) {
+    std::vector<int> sizes, nums;
+    analyze_blk(blk, mat_num, sizes, nums);
+    print_blk_census(sizes, nums);
+    MatrixSizes ms;
+    ms.init(sizes, nums);
+    ms.print();
+  }
+
+  // --- shard: contiguous block range of this rank
+  std::vector<int> first;
+  partition_blocks(blk, mat_num, s->world, first);
+  s->blk_begin = first[s->rank]; s->blk_end = first[s->rank + 1];
+  long long off = 0;
+  s->sv_begin = 0;
+  for (int k = 0; k < mat_num; ++k) {
+    if (k == s->blk_begin) s->sv_begin = off;
+    off += (long long)blk[k] * (blk[k] + 1) / 2;
+    if (k + 1 == s->blk_end) s->sv_end = off;
+  }
+  if (s->blk_begin == s->blk_end) { s->sv_begin = s->sv_end = (s->blk_begin == mat_num ? off : s->sv_begin); }
+  const long long L = s->sv_end - s->sv_begin;
+  s->L = L;
+  s->blk_local.assign(blk + s->blk_begin, blk + s->blk_end);
+  rc = s->plan.build(s->blk_local.data(), (int)s->blk_local.size());
+  if (rc) return rc;
+
+  // --- device matrices with the permutation folded in
+  {
+    std::vector<int> lrp((size_t)L + 1, 0), lci;
+    std::vector<double> lv;
+    const int base = rp[s->sv_begin];
+    const int cnt = rp[s->sv_end] - base;
+    lci.resize(cnt); lv.resize(cnt);
+    for (long long i = 0; i <= L; ++i) lrp[i] = rp[s->sv_begin + i] - base;
+    for (int q = 0; q < cnt; ++q) { lci[q] = s->perm_inv[rci[base + q]]; lv[q] = rv[base + q]; }
+    if ((rc = s->At_rp.from(lrp)) || (rc = s->At_ci.from(lci)) || (rc = s->At_v.from(lv))) return rc;
+    // A rows in permuted order, local columns
+    std::vector<int> arp((size_t)m + 1, 0), aci;
+    std::vector<double> av;
+    aci.reserve(cnt); av.reserve(cnt);
+    for (int pidx = 0; pidx < m; ++pidx) {
+      const int j = s->perm[pidx];
+      for (int p = At_cp[j]; p < At_cp[j + 1]; ++p) {
+        const long long r = At_ri[p];
+        if (r >= s->sv_begin && r < s->sv_end) { aci.push_back((int)(r - s->sv_begin)); av.push_back(vals[p]); }
+      }
+      arp[pidx + 1] = (int)aci.size();
+    }
+    s->A_avg_nnz = m > 0 ? (double)aci.size() / m : 1.0;
+    if ((rc = s->A_rp.from(arp)) || (rc = s->A_ci.alloc(std::max<size_t>(aci.size(), 1))) || (rc = s->A_v.alloc(std::max<size_t>(av.size(), 1)))) return rc;
+    if ((rc = s->A_ci.upload(aci.data(), aci.size())) || (rc = s->A_v.upload(av.data(), av.size()))) return rc;
+    s->A_v.n = av.size();
+  }
+
+  // --- scaling (solver.cu:169-191)
+  double nb = 0, nc = 0;
+  for (int i = 0; i < b_nnz; ++i) nb += b_vals[i] * b_vals[i];
+  for (int i = 0; i < C_nnz; ++i) nc += C_vals[i] * C_vals[i];
+  s->norm_borg = 1 + std::sqrt(nb);
+  s->norm_Corg = 1 + std::sqrt(nc);
+  std::vector<double> bfull(m, 0.0);
+  double nb2 = 0;
+  for (int i = 0; i < b_nnz; ++i) {
+    if (b_idx[i] < 0 || b_idx[i] >= m) { set_error("init: b index %d out of range", b_idx[i]); return CUADMM_ERR_INVALID; }
+    double v = b_vals[i] / s->normA[b_idx[i]];             // sparse_dense.cu:11-20
+    bfull[b_idx[i]] = v;
+    nb2 += v * v;
+  }
+  s->bscale = 1 + std::sqrt(nb2);
+  s->Cscale = 1 + std::sqrt(nc);
+  s->objscale = s->bscale * s->Cscale;
+  const double ibs = 1 / s->bscale, ics = 1 / s->Cscale;   // *_div_scalar multiply by 1/s (dense_scalar.cu:77-81)
+  s->normA_p.resize(m); s->b_p.resize(m); s->y_p.assign(m, 0.0); s->Rp_p.assign(m, 0.0);
+  s->ASmC_p.assign(m, 0.0); s->rhs_p.assign(m, 0.0); s->y_best_p.assign(m, 0.0);
+  for (int pidx = 0; pidx < m; ++pidx) {
+    const int j = s->perm[pidx];
+    s->normA_p[pidx] = s->normA[j];
+    s->b_p[pidx] = bfull[j] * ibs;
+    if (y0) s->y_p[pidx] = (y0[j] * s->normA[j]) * ics;     // solver.cu:182,191
+  }
+  {
+    std::vector<double> Cl((size_t)L, 0.0);
+    for (int i = 0; i < C_nnz; ++i) {
+      if (C_idx[i] < 0 || C_idx[i] >= vec_len) { set_error("init: C index %d out of range", C_idx[i]); return CUADMM_ERR_INVALID; }
+      if (C_idx[i] >= s->sv_begin && C_idx[i] < s->sv_end) Cl[C_idx[i] - s->sv_begin] = C_vals[i] * ics;
+    }
+    if ((rc = s->C.from(Cl))) return rc;
+    std::vector<double> tmp((size_t)L, 0.0);
+    if (X0) for (long long i = 0; i < L; ++i) tmp[i] = X0[s->sv_begin + i] * ibs;
+    if ((rc = s->X.from(tmp))) return rc;
+    if (S0) for (long long i = 0; i < L; ++i) tmp[i] = S0[s->sv_begin + i] * ics;
+    else std::fill(tmp.begin(), tmp.end(), 0.0);
+    if ((rc = s->S.from(tmp))) return rc;
+  }
+  if ((rc = s->Rd1.alloc(L)) || (rc = s->Xb.alloc(L)) || (rc = s->Xproj.alloc(L)) || (rc = s->y_d.alloc(std::max(m, 1))) ||
+      (rc = s->out_d.alloc(2 * (size_t)m + 2)) || (rc = s->partials.alloc(2 * (size_t)post_grid(L) + 2)) ||
+      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))))
+    return rc;
+  CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
+
+  // --- initial residuals (solver.cu:195-228)
+  if ((rc = s->upload_y())) return rc;
+  if ((rc = s->launch_aty(false))) return rc;                               // Rd1 = At*y - C
+  if ((rc = launch_post(2, L, s->Xproj.p, s->Rd1.p, s->C.p, s->X.p, s->S.p, 1.0, 0.0, s->partials.p,
+                        s->out_d.p + (size_t)m, s->st)))                    // Rd = Rd1 + S, sums (X untouched)
+    return rc;
+  if ((rc = s->launch_spmv(true, true))) return rc;
+  if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
+  {
+    double nr = 0, bty = 0;
+    for (int i = 0; i < m; ++i) {
+      s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i];
+      s->ASmC_p[i] = s->h_out.p[m + 2 + i];
+      double ro = s->normA_p[i] * s->Rp_p[i] * s->bscale;
+      nr += ro * ro;
+      bty += s->b_p[i] * s->y_p[i];
+    }
+    s->errRp = std::sqrt(nr) / s->norm_borg;
+    s->errRd = std::sqrt(s->h_out.p[(size_t)m]) * s->Cscale / s->norm_Corg;
+    s->maxfeas = std::max(s->errRp, s->errRd);
+    s->pobj = s->h_out.p[(size_t)m + 1] * s->objscale;
+    s->dobj = bty * s->objscale;
+    s->relgap = std::fabs(s->pobj - s->dobj) / (1 + std::fabs(s->pobj) + std::fabs(s->dobj));
+  }
+  s->prim_win = 0; s->dual_win = 0; s->ratioconst = 1e0; s->sigmax = 1e3; s->sigmin = 1e-3;
+  s->initialised = true;
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SDPSolver::solve
+// ------------------------------------------------------------------------------------------
+int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update_threshold, int sig_update_stage_1,
+                 int sig_update_stage_2, int switch_admm, double sigscale, int if_first) {
+  if (!s || !s->initialised) { set_error("solve: solver not initialised"); return CUADMM_ERR_INVALID; }
+  if (sig_update_stage_1 <= 0 || sig_update_stage_2 <= 0) { set_error("solve: sig_update stages must be positive"); return CUADMM_ERR_INVALID; }
+  int rc = check_device(s->device);
+  if (rc) return rc;
+  const int m = s->m;
+  const long long L = s->L;
+  const bool verbose = s->verbose && s->rank == 0;
+  bool breakyes = false;
+  std::string final_msg;
+  s->info_iter_num = 0;
+
+  if (verbose) {
+    printf("\n -------------------------------------------------------------------------------");
+    printf("\n                                    cuADMM");
+    printf("\n -------------------------------------------------------------------------------");
+    printf("\n norm of C = %2.1e, norm of b = %2.1e\n", s->norm_Corg, s->norm_borg);
+  }
+
+  if (!if_first) {   // solver.cu:385-409: X,y,S currently hold UNSCALED values
+    for (int i = 0; i < m; ++i) s->y_p[i] = (s->y_p[i] * s->normA_p[i]) * (1 / s->Cscale);
+    if ((rc = launch_scale(s->X.p, L, 1 / s->bscale, s->st))) return rc;
+    if ((rc = launch_scale(s->S.p, L, 1 / s->Cscale, s->st))) return rc;
+    if ((rc = s->launch_spmv(true, true))) return rc;
+    if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
+    for (int i = 0; i < m; ++i) { s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i]; s->ASmC_p[i] = s->h_out.p[m + 2 + i]; }
+  }
+
+  if (verbose) {
+    std::cout << std::endl << "  it. | p infeas d infeas | primal obj.   dual obj. rel. gap |  time |   sigma | " << std::endl;
+    std::cout << " -------------------------------------------------------------------------------" << std::endl;
+  }
+
+  for (int iter = 1; iter <= max_iter + 1; ++iter) {
+    // ---- Step 0 (solver.cu:419-467)
+    if (std::max(s->maxfeas, s->relgap) < stop_tol) { breakyes = true; final_msg = "Solver ended: converged."; }
+    if (iter > max_iter) { breakyes = true; final_msg = "Solver ended: maximum iteration reached"; }
+    const double seconds = wall_s() - s->t_init0;
+    if (verbose && (breakyes || (iter <= 200 && iter % 50 == 1) || (iter > 200 && iter % 100 == 1))) {
+      printf(" %4d | %3.2e %3.2e | %- 5.4e %- 5.4e %3.2e | %5.1f | %2.1e |", iter - 1, s->errRp, s->errRd, s->pobj,
+             s->dobj, s->relgap, seconds, s->sig);
+      std::cout << std::endl;
+    }
+    if (breakyes) {
+      if (verbose) {
+        printf("\n -------------------------------------------------------------------------------\n\n");
+        std::cout << final_msg << std::endl;
+        printf("\n primal infeasibility = %2.1e \n dual   infeasibility = %2.1e \n relative gap         = %2.1e", s->errRp,
+               s->errRd, s->relgap);
+        printf("\n primal objective = %- 9.8e \n dual   objective = %- 9.8e", s->pobj, s->dobj);
+        printf("\n\n time per iteration = %2.4fs \n total time         = %2.1fs", seconds / iter, seconds);
+        printf("\n -------------------------------------------------------------------------------\n\n");
+      }
+      s->total_time = wall_s() - s->t_init0;
+    }
+
+    // ---- Step 1 (solver.cu:478-500): y = (AA^T)^-1 (Rp/sig - A(S-C))
+    if ((rc = s->host_solve())) return rc;
+
+    if (breakyes) {   // solver.cu:567-576
+      if (iter > switch_admm && s->have_best) {
+        CUADMM_HIP_TRY(hipMemcpyAsync(s->X.p, s->X_best.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
+        CUADMM_HIP_TRY(hipMemcpyAsync(s->S.p, s->S_best.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
+        CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+        s->y_p = s->y_best_p;
+        if (verbose) printf("best max KKT residual after switch  = %2.1e \n", s->best_KKT);
+      }
+      break;
+    }
+
+    // ---- Step 2 (solver.cu:514-656)
+    if ((rc = s->upload_y())) return rc;
+    if ((rc = s->launch_aty(true))) return rc;
+    if ((rc = s->launch_project())) return rc;
+
+    double tau = (iter < switch_admm) ? 1.95 : 1.618;                    // solver.cu:747-754
+    if (s->errRd < stop_tol) tau = std::max(1.618, tau / 1.1);
+
+    // does this iteration snapshot the iterate between the S update and the X update?
+    bool snapshot = false;
+    if (iter == switch_admm) {                                           // solver.cu:681-690
+      if (verbose) std::cout << " switching to normal ADMM!" << std::endl;
+      sig_update_stage_2 = sig_update_stage_2 / 2;
+      if (sig_update_stage_2 < 1) sig_update_stage_2 = 1;
+      sigscale = sigscale * 1.23;
+      s->sgs_KKT = std::max(s->maxfeas, s->relgap);
+      s->best_KKT = s->sgs_KKT;
+      snapshot = true;
+    } else if (iter > switch_admm && s->have_best && s->best_KKT > std::max(s->maxfeas, s->relgap)) {
+      s->best_KKT = std::max(s->maxfeas, s->relgap);                     // solver.cu:732-741
+      snapshot = true;
+    }
+
+    if (iter < switch_admm) {
+      // sGS half step: S^{k+1}, second solve with it, Rd1 from the new y (solver.cu:693-729)
+      if ((rc = s->launch_post_mode(1, tau))) return rc;
+      if ((rc = s->launch_spmv(false, true))) return rc;
+      if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
+      for (int i = 0; i < m; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i];
+      if ((rc = s->host_solve())) return rc;
+      if ((rc = s->upload_y())) return rc;
+      if ((rc = s->launch_aty(false))) return rc;
+      if ((rc = s->launch_post_mode(2, tau))) return rc;
+      if ((rc = s->launch_spmv(true, false))) return rc;
+      if ((rc = s->fetch_out(0, (size_t)m + 2))) return rc;            // [A*X | sums]; A*(S-C) unchanged since the half step
+    } else {
+      if (snapshot) {
+        if (!s->X_best.p && L > 0) { if ((rc = s->X_best.alloc(L)) || (rc = s->S_best.alloc(L))) return rc; }
+        if ((rc = s->launch_post_mode(1, tau))) return rc;
+        s->prof_begin(K_COPY);
+        CUADMM_HIP_TRY(hipMemcpyAsync(s->X_best.p, s->X.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
+        CUADMM_HIP_TRY(hipMemcpyAsync(s->S_best.p, s->S.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
+        s->prof_end(K_COPY, 32.0 * (double)L);
+        s->y_best_p = s->y_p;
+        s->have_best = true;
+        if ((rc = s->launch_post_mode(2, tau))) return rc;
+      } else {
+        if ((rc = s->launch_post_mode(0, tau))) return rc;
+      }
+      if ((rc = s->launch_spmv(true, true))) return rc;
+      if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
+      for (int i = 0; i < m; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i];
+    }
+
+    // ---- Step 5 (solver.cu:764-799)
+    {
+      double t0 = wall_s();
+      double nr = 0, bty = 0;
+      const double* ax = s->h_out.p;
+      for (int i = 0; i < m; ++i) {
+        const double rp = -ax[i] + s->b_p[i];
+        s->Rp_p[i] = rp;
+        const double ro = s->normA_p[i] * rp * s->bscale;
+        nr += ro * ro;
+        bty += s->b_p[i] * s->y_p[i];
+      }
+      s->errRp = std::sqrt(nr) / s->norm_borg;
+      s->pobj = s->h_out.p[(size_t)m + 1] * s->objscale;
+      s->errRd = std::sqrt(s->h_out.p[(size_t)m]) * s->Cscale / s->norm_Corg;
+      s->dobj = bty * s->objscale;
+      s->maxfeas = std::max(s->errRp, s->errRd);
+      s->relgap = std::fabs(s->pobj - s->dobj) / (1 + std::fabs(s->pobj) + std::fabs(s->dobj));
+      s->feasratio = s->ratioconst * s->errRp / s->errRd;
+      if (s->feasratio < 1) s->prim_win += 1; else s->dual_win += 1;
+      if ((iter <= sig_update_threshold && iter % sig_update_stage_1 == 1) ||
+          (iter > sig_update_threshold && iter % sig_update_stage_2 == 1)) {
+        if (s->prim_win > 1.2 * s->dual_win) { s->prim_win = 0; s->sig = std::min(s->sigmax, s->sig * sigscale); }
+        else if (s->dual_win > 1.2 * s->prim_win) { s->dual_win = 0; s->sig = std::max(s->sigmin, s->sig / sigscale); }
+      }
+      s->prof_host(K_HOST, wall_s() - t0);
+    }
+    s->info[CUADMM_INFO_POBJ].push_back(s->pobj); s->info[CUADMM_INFO_DOBJ].push_back(s->dobj);
+    s->info[CUADMM_INFO_ERRRP].push_back(s->errRp); s->info[CUADMM_INFO_ERRRD].push_back(s->errRd);
+    s->info[CUADMM_INFO_RELGAP].push_back(s->relgap); s->info[CUADMM_INFO_SIG].push_back(s->sig);
+    s->info[CUADMM_INFO_BSCALE].push_back(s->bscale); s->info[CUADMM_INFO_CSCALE].push_back(s->Cscale);
+    s->info_iter_num++;
+  }
+
+  // unscale (solver.cu:814-816)
+  if ((rc = launch_scale(s->X.p, L, s->bscale, s->st))) return rc;
+  if ((rc = launch_scale(s->S.p, L, s->Cscale, s->st))) return rc;
+  CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+  for (int i = 0; i < m; ++i) s->y_p[i] = s->y_p[i] / s->normA_p[i] * s->Cscale;
+  s->eig_fail_total = s->plan.fail_count(s->st);
+  if (s->eig_fail_total > 0) {
+    set_error("solve: %d block projections hit the QL sweep cap", s->eig_fail_total);
+    return CUADMM_ERR_EIG;
+  }
+  return CUADMM_OK;
+}
+
+int cuadmm_get_dims(const cuadmm_solver* s, int* vec_len, int* con_num, int* mat_num) {
+  if (!s) { set_error("get_dims: null"); return CUADMM_ERR_INVALID; }
+  if (vec_len) *vec_len = s->L_full;
+  if (con_num) *con_num = s->m;
+  if (mat_num) *mat_num = s->nblk_full;
+  return CUADMM_OK;
+}
+
+static int get_vec(cuadmm_solver* s, const DevBuf<double>& v, double* out) {
+  if (!s || !s->initialised || !out) { set_error("get: bad arguments"); return CUADMM_ERR_INVALID; }
+  int rc = check_device(s->device);
+  if (rc) return rc;
+  CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+  if (s->L > 0) CUADMM_HIP_TRY(hipMemcpy(out, v.p, sizeof(double) * (size_t)s->L, hipMemcpyDeviceToHost));
+  return CUADMM_OK;
+}
+// world>1: writes this rank's shard (length svec_end - svec_begin) at out[0..)
+int cuadmm_get_X(cuadmm_solver* s, double* out) { return get_vec(s, s->X, out); }
+int cuadmm_get_S(cuadmm_solver* s, double* out) { return get_vec(s, s->S, out); }
+int cuadmm_get_y(cuadmm_solver* s, double* out) {
+  if (!s || !s->initialised || !out) { set_error("get_y: bad arguments"); return CUADMM_ERR_INVALID; }
+  for (int i = 0; i < s->m; ++i) out[s->perm[i]] = s->y_p[i];          // y[perm[i]] = y_perm[i], solver.cu:500
+  return CUADMM_OK;
+}
+
+int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const double* S, double sig) {
+  if (!s || !s->initialised) { set_error("set_XyS: not initialised"); return CUADMM_ERR_INVALID; }
+  int rc = check_device(s->device);
+  if (rc) return rc;
+  if (X && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->X.p, X + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
+  if (S && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->S.p, S + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
+  if (y) for (int i = 0; i < s->m; ++i) s->y_p[i] = y[s->perm[i]];
+  if (sig > 0) s->sig = sig;
+  return CUADMM_OK;
+}
+
+int cuadmm_get_device_ptrs(cuadmm_solver* s, double** X, double** y, double** S) {
+  if (!s || !s->initialised) { set_error("get_device_ptrs: not initialised"); return CUADMM_ERR_INVALID; }
+  if (X) *X = s->X.p;
+  if (y) *y = s->y_d.p;
+  if (S) *S = s->S.p;
+  return CUADMM_OK;
+}
+
+int cuadmm_get_shard(const cuadmm_solver* s, int64_t* b, int64_t* e, int* kb, int* ke) {
+  if (!s || !s->initialised) { set_error("get_shard: not initialised"); return CUADMM_ERR_INVALID; }
+  if (b) *b = s->sv_begin;
+  if (e) *e = s->sv_end;
+  if (kb) *kb = s->blk_begin;
+  if (ke) *ke = s->blk_end;
+  return CUADMM_OK;
+}
+
+int cuadmm_get_info_iter_num(const cuadmm_solver* s) { return s ? s->info_iter_num : 0; }
+int cuadmm_get_info_array(const cuadmm_solver* s, int which, double* out, int cap) {
+  if (!s || which < 0 || which >= 8 || !out) { set_error("get_info_array: bad arguments"); return CUADMM_ERR_INVALID; }
+  // the reference appends across solve() calls (vectors are never cleared, solver.cu:802-809)
+  int n = std::min<int>(cap, (int)s->info[which].size());
+  std::copy(s->info[which].begin(), s->info[which].begin() + n, out);
+  return n;
+}
+double cuadmm_get_total_time(const cuadmm_solver* s) { return s ? s->total_time : 0.0; }
+int cuadmm_get_state(const cuadmm_solver* s, double o[12]) {
+  if (!s || !o) { set_error("get_state: null"); return CUADMM_ERR_INVALID; }
+  o[0] = s->errRp; o[1] = s->errRd; o[2] = s->pobj; o[3] = s->dobj; o[4] = s->relgap; o[5] = s->sig;
+  o[6] = s->bscale; o[7] = s->Cscale; o[8] = s->norm_borg; o[9] = s->norm_Corg; o[10] = s->best_KKT;
+  o[11] = (double)s->eig_fail_total;
+  return CUADMM_OK;
+}
+
+int cuadmm_get_profile(const cuadmm_solver* s, double out[3 * CUADMM_NUM_KCLASS]) {
+  if (!s || !out) { set_error("get_profile: null"); return CUADMM_ERR_INVALID; }
+  for (int k = 0; k < K_NUM; ++k) { out[3 * k] = s->prof_count[k]; out[3 * k + 1] = s->prof_ms[k]; out[3 * k + 2] = s->prof_bytes[k]; }
+  return CUADMM_OK;
+}
+int cuadmm_reset_profile(cuadmm_solver* s) {
+  if (!s) { set_error("reset_profile: null"); return CUADMM_ERR_INVALID; }
+  for (int k = 0; k < K_NUM; ++k) { s->prof_count[k] = 0; s->prof_ms[k] = 0; }
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// op-level entry points that need the planner
+// ------------------------------------------------------------------------------------------
+int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, void* stream) {
+  return psd_batch_eig(mat, W, info, n, count, (hipStream_t)stream);
+}
+
+int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream) {
+  if (!blk_host || mat_num < 0) { set_error("psd_project: bad arguments"); return CUADMM_ERR_INVALID; }
+  PsdPlan plan;
+  int rc = plan.build(blk_host, mat_num);
+  if (rc) return rc;
+  rc = plan.project(Xb, Xproj, (hipStream_t)stream);
+  if (rc) return rc;
+  int fails = plan.fail_count((hipStream_t)stream);   // synchronises the stream
+  if (fails != 0) { set_error("psd_project: %d blocks hit the QL sweep cap", fails); return CUADMM_ERR_EIG; }
+  return CUADMM_OK;
+}
+
+int cuadmm_dev_malloc(void** ptr, size_t bytes) { CUADMM_HIP_TRY(hipMalloc(ptr, bytes ? bytes : 8)); return CUADMM_OK; }
+int cuadmm_dev_free(void* ptr) { if (ptr) CUADMM_HIP_TRY(hipFree(ptr)); return CUADMM_OK; }
+int cuadmm_memcpy_h2d(void* dst, const void* src, size_t bytes) { if (bytes) CUADMM_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return CUADMM_OK; }
+int cuadmm_memcpy_d2h(void* dst, const void* src, size_t bytes) { if (bytes) CUADMM_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return CUADMM_OK; }
+int cuadmm_dev_sync(void) { CUADMM_HIP_TRY(hipDeviceSynchronize()); return CUADMM_OK; }
+
+// ------------------------------------------------------------------------------------------
+// TXT problem objects
+// ------------------------------------------------------------------------------------------
+struct cuadmm_problem { ProblemData d; };
+
+int cuadmm_problem_from_txt(const char* prefix, cuadmm_problem** out) {
+  if (!prefix || !out) { set_error("problem_from_txt: null"); return CUADMM_ERR_INVALID; }
+  cuadmm_problem* p = new cuadmm_problem();
+  int rc = load_problem_txt(prefix, p->d, true);
+  if (rc) { delete p; return rc; }
+  *out = p;
+  return CUADMM_OK;
+}
+int cuadmm_problem_view_get(const cuadmm_problem* p, cuadmm_problem_view* v) {
+  if (!p || !v) { set_error("problem_view: null"); return CUADMM_ERR_INVALID; }
+  const ProblemData& d = p->d;
+  v->vec_len = d.vec_len; v->con_num = d.con_num; v->mat_num = d.mat_num;
+  v->At_nnz = (int)d.At_vals.size(); v->b_nnz = (int)d.b_vals.size(); v->C_nnz = (int)d.C_vals.size();
+  v->At_csc_col_ptrs = d.At_col_ptrs.data(); v->At_csc_row_ids = d.At_row_ids.data(); v->At_csc_vals = d.At_vals.data();
+  v->b_indices = d.b_idx.data(); v->b_vals = d.b_vals.data(); v->C_indices = d.C_idx.data(); v->C_vals = d.C_vals.data();
+  v->blk_vals = d.blk.data();
+  return CUADMM_OK;
+}
+void cuadmm_problem_free(cuadmm_problem* p) { delete p; }
+
+int cuadmm_coo_to_csc(int* col_ptrs, int* col_ids, int* row_ids, double* vals, int nnz, int col_num) {
+  if (nnz < 0 || col_num < 0 || !col_ptrs) { set_error("coo_to_csc: bad arguments"); return CUADMM_ERR_INVALID; }
+  std::vector<int> cp, c(col_ids, col_ids + nnz), r(row_ids, row_ids + nnz);
+  std::vector<double> v(vals, vals + nnz);
+  coo_to_csc(cp, c, r, v, nnz, col_num);
+  std::copy(cp.begin(), cp.end(), col_ptrs);
+  std::copy(c.begin(), c.end(), col_ids);
+  std::copy(r.begin(), r.end(), row_ids);
+  std::copy(v.begin(), v.end(), vals);
+  return CUADMM_OK;
+}
+
+int cuadmm_read_blk(const char* filename, char* types, int* sizes, int cap) {
+  std::vector<char> t;
+  std::vector<int> sz;
+  int rc = read_blk_file(filename, t, sz);
+  if (rc) return rc;
+  for (size_t i = 0; i < sz.size() && (int)i < cap; ++i) { if (types) types[i] = t[i]; if (sizes) sizes[i] = sz[i]; }
+  return (int)sz.size();
+}
+
+int cuadmm_write_dense_txt(const char* filename, const double* vals, int64_t n) {
+  FILE* f = fopen(filename, "w");
+  if (!f) { set_error("Failed to open file: %s", filename); return CUADMM_ERR_IO; }
+  for (int64_t i = 0; i < n; ++i) fprintf(f, "%.32f\n", vals[i]);     // memory.h:278-294
+  fclose(f);
+  return CUADMM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+// PSD-cone projection kernels (gfx950) and their host-side planner/launcher.
+//
+// One launch per size class:
+//   n <= 4 / 8 / 16 / 32 : psd_small_kernel<LPB>: a block per LPB-lane group, 64/LPB blocks per
+//                          wavefront, everything in LDS (one wavefront per workgroup)
+//   33 <= n <= ~136      : psd_wg_kernel<NT,false>: one workgroup per block, matrix in LDS
+//   larger               : psd_wg_kernel<NT,true>: one workgroup per block, matrix in an HBM workspace
+// MODE 0: svec in -> projected svec out (the fused replacement of solver.cu:534-647)
+// MODE 1: dense column-major symmetric in -> eigenvectors (column-major) + ascending eigenvalues
+//         (the contract of the reference's cuSOLVER wrappers, cusolver.h:76-95,154-171)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "device_util.h"
+#include "psd_device.h"
+#include "psd_plan.h"
+
+namespace cuadmm {
+
+struct PsdArgs {
+  const double* in;
+  double* out;
+  double* Wout;            // MODE 1
+  int* info;               // MODE 1: per matrix flag; MODE 0: single counter (may be null)
+  const int* ids;          // class member -> block id (null: identity)
+  const long long* boff;   // svec offset per block (MODE 0)
+  const int* bn;           // size per block (MODE 0)
+  int count;               // members in this launch
+  int n_uniform;           // MODE 1
+  double* workspace;       // GLOBAL variant
+  const long long* ws_off; // GLOBAL variant: workspace offset per member
+};
+
+template <int LPB, int MODE>
+__global__ __launch_bounds__(64) void psd_small_kernel(PsdArgs a) {
+  constexpr int BPW = 64 / LPB;
+  constexpr int LD = LPB + 1;
+  constexpr int PER = LPB * LD + 5 * LPB;
+  __shared__ double smem[BPW * PER];
+  using Gp = SubGroup<LPB>;
+  const int lane = lane_id();
+  const int slot0 = (int)blockIdx.x * BPW;
+
+  // cooperative, coalesced load of the wavefront's blocks into LDS
+  for (int gg = 0; gg < BPW; ++gg) {
+    const int slot = slot0 + gg;
+    if (slot >= a.count) break;
+    const int bi = a.ids ? a.ids[slot] : slot;
+    double* Mg = smem + gg * PER;
+    if (MODE == 0) {
+      const int n = a.bn[bi];
+      const double* src = a.in + a.boff[bi];
+      const int len = n * (n + 1) / 2;
+      for (int e = lane; e < len; e += 64) {
+        int i, j;
+        tri_decode(e, i, j);
+        double v = src[e];
+        if (i != j) v *= kSqrt2Inv;
+        Mg[j * LD + i] = v;
+        Mg[i * LD + j] = v;
+      }
+    } else {
+      const int n = a.n_uniform;
+      const double* src = a.in + (long long)bi * n * n;
+      for (int idx = lane; idx < n * n; idx += 64) {
+        const int c = idx / n, r = idx - c * n;
+        if (r >= c) {  // lower triangle is the input (uplo = LOWER, cusolver.h:36,117)
+          const double v = src[idx];
+          Mg[r * LD + c] = v;
+          Mg[c * LD + r] = v;
+        }
+      }
+    }
+  }
+  wave_fence();
+
+  const int g = lane / LPB;
+  const int slot = slot0 + g;
+  if (slot >= a.count) return;
+  const int bi = a.ids ? a.ids[slot] : slot;
+  const int n = (MODE == 0) ? a.bn[bi] : a.n_uniform;
+  double* M = smem + g * PER;
+  double* d = M + LPB * LD;
+  double* e = d + LPB;
+  double* tau = e + LPB;
+  double* vv = tau + LPB;
+  double* ww = vv + LPB;
+  const int fail = sym_eig_inplace<Gp>(M, LD, n, d, e, tau, vv, ww, d, e, nullptr);
+  if (MODE == 0) {
+    reconstruct_to_svec<Gp>(M, LD, n, d, vv, a.out + a.boff[bi]);
+    if (fail && Gp::rank() == 0 && a.info) atomicAdd(a.info, 1);
+  } else {
+    write_sorted_eig<Gp>(M, LD, n, d, a.out + (long long)bi * n * n, a.Wout + (long long)bi * n);
+    if (Gp::rank() == 0 && a.info) a.info[bi] = fail;
+  }
+}
+
+template <int NT, int MODE, bool GLOBAL_M>
+__global__ __launch_bounds__(NT) void psd_wg_kernel(PsdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  using Gp = WgGroup<NT>;
+  constexpr int NW = NT / 64;
+  const int slot = (int)blockIdx.x;
+  const int bi = a.ids ? a.ids[slot] : slot;
+  const int n = (MODE == 0) ? a.bn[bi] : a.n_uniform;
+  const int ld = n | 1;
+  double* M;
+  double* vecs;
+  if (GLOBAL_M) {
+    M = a.workspace + a.ws_off[slot];
+    vecs = dsm;
+  } else {
+    M = dsm;
+    vecs = dsm + (size_t)n * ld;
+  }
+  double* dsh = vecs;
+  double* esh = dsh + n;
+  double* tau = esh + n;
+  double* vv = tau + n;
+  double* ww = vv + n;
+  double* scratch = ww + n;                 // NW doubles (padded to 8)
+  double* dq = (NW > 1) ? scratch + 8 + (size_t)(threadIdx.x >> 6) * 2 * n : dsh;
+  double* eq = (NW > 1) ? dq + n : esh;
+
+  const int tid = (int)threadIdx.x;
+  if (MODE == 0) {
+    const double* src = a.in + a.boff[bi];
+    const int len = n * (n + 1) / 2;
+    for (int e = tid; e < len; e += NT) {
+      int i, j;
+      tri_decode(e, i, j);
+      double v = src[e];
+      if (i != j) v *= kSqrt2Inv;
+      M[(size_t)j * ld + i] = v;
+      M[(size_t)i * ld + j] = v;
+    }
+  } else {
+    const double* src = a.in + (long long)bi * n * n;
+    for (int idx = tid; idx < n * n; idx += NT) {
+      const int c = idx / n, r = idx - c * n;
+      if (r >= c) {
+        const double v = src[idx];
+        M[(size_t)r * ld + c] = v;
+        M[(size_t)c * ld + r] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int fail = sym_eig_inplace<Gp>(M, ld, n, dsh, esh, tau, vv, ww, dq, eq, scratch);
+  if (MODE == 0) {
+    reconstruct_to_svec<Gp>(M, ld, n, dq, vv, a.out + a.boff[bi]);
+    if (fail && tid == 0 && a.info) atomicAdd(a.info, 1);
+  } else {
+    write_sorted_eig<Gp>(M, ld, n, dq, a.out + (long long)bi * n * n, a.Wout + (long long)bi * n);
+    if (tid == 0 && a.info) a.info[bi] = fail;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------------------
+static size_t wg_lds_bytes(int n, int nt, bool global_m) {
+  const int ld = n | 1;
+  const int nw = nt / 64;   // a single wavefront runs QL directly on the shared d/e
+  size_t doubles = (global_m ? 0 : (size_t)n * ld) + 5 * (size_t)n + 8 + (nw > 1 ? 2 * (size_t)n * nw : 0);
+  return doubles * sizeof(double);
+}
+
+static int wg_threads_lds(int n) { return n <= 64 ? 64 : (n <= 128 ? 128 : 256); }
+
+int psd_class_of(int n) {
+  if (n <= 4) return 0;
+  if (n <= 8) return 1;
+  if (n <= 16) return 2;
+  if (n <= 32) return 3;
+  if (wg_lds_bytes(n, wg_threads_lds(n), false) <= kMaxLdsBytes) return 4;
+  return 5;
+}
+
+int PsdPlan::build(const int* blk, int mat_num) {
+  release();
+  nblk = mat_num;
+  std::vector<long long> off((size_t)mat_num + 1, 0);
+  for (int k = 0; k < mat_num; ++k) {
+    if (blk[k] < 1) { set_error("block %d has size %d", k, blk[k]); return CUADMM_ERR_INVALID; }
+    if (blk[k] > kMaxBlockSize) { set_error("block %d has size %d > %d (largest supported this build)", k, blk[k], kMaxBlockSize); return CUADMM_ERR_INVALID; }
+    off[k + 1] = off[k] + (long long)blk[k] * (blk[k] + 1) / 2;
+  }
+  vec_len = off[mat_num];
+  std::vector<int> ids;
+  std::vector<long long> wsoff;
+  long long ws_total = 0;
+  for (int c = 0; c < kNumPsdClasses; ++c) {
+    cls_begin[c] = (int)ids.size();
+    std::vector<int> members;
+    for (int k = 0; k < mat_num; ++k)
+      if (psd_class_of(blk[k]) == c) members.push_back(k);
+    std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return blk[x] > blk[y]; });
+    for (int k : members) {
+      ids.push_back(k);
+      if (c == 5) { wsoff.push_back(ws_total); ws_total += (long long)blk[k] * (blk[k] | 1); }
+      if (c >= 4) cls_maxn[c] = std::max(cls_maxn[c], blk[k]);
+    }
+    cls_count[c] = (int)ids.size() - cls_begin[c];
+  }
+  CUADMM_HIP_TRY(hipMalloc(&d_off, sizeof(long long) * ((size_t)mat_num + 1)));
+  CUADMM_HIP_TRY(hipMalloc(&d_n, sizeof(int) * (size_t)std::max(mat_num, 1)));
+  CUADMM_HIP_TRY(hipMalloc(&d_ids, sizeof(int) * (size_t)std::max(mat_num, 1)));
+  CUADMM_HIP_TRY(hipMalloc(&d_fail, sizeof(int)));
+  CUADMM_HIP_TRY(hipMemcpy(d_off, off.data(), sizeof(long long) * ((size_t)mat_num + 1), hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMemcpy(d_n, blk, sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
+  if (ws_total > 0) {
+    CUADMM_HIP_TRY(hipMalloc(&d_ws, sizeof(double) * (size_t)ws_total));
+    CUADMM_HIP_TRY(hipMalloc(&d_wsoff, sizeof(long long) * wsoff.size()));
+    CUADMM_HIP_TRY(hipMemcpy(d_wsoff, wsoff.data(), sizeof(long long) * wsoff.size(), hipMemcpyHostToDevice));
+  }
+  // nominal flops 10.67 n^3 per block, GEMM-shaped part 2 n^3
+  sum_n3 = 0;
+  for (int k = 0; k < mat_num; ++k) sum_n3 += (double)blk[k] * blk[k] * blk[k];
+  return CUADMM_OK;
+}
+
+void PsdPlan::release() {
+  if (d_off) hipFree(d_off);
+  if (d_n) hipFree(d_n);
+  if (d_ids) hipFree(d_ids);
+  if (d_fail) hipFree(d_fail);
+  if (d_ws) hipFree(d_ws);
+  if (d_wsoff) hipFree(d_wsoff);
+  d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
+  for (int c = 0; c < kNumPsdClasses; ++c) { cls_begin[c] = cls_count[c] = 0; cls_maxn[c] = 0; }
+}
+
+template <int NT, int MODE, bool GLOBAL_M>
+static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
+  const size_t lds = wg_lds_bytes(maxn, NT, GLOBAL_M);
+  if (lds > kMaxLdsBytes) { set_error("psd: block of size %d needs %zu bytes of LDS", maxn, lds); return CUADMM_ERR_INVALID; }
+  auto kern = psd_wg_kernel<NT, MODE, GLOBAL_M>;
+  if (lds > 48 * 1024)
+    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(a.count), dim3(NT), lds, st, a);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+template <int MODE>
+static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
+  if (a.count <= 0) return CUADMM_OK;
+  switch (c) {
+    case 0: hipLaunchKernelGGL((psd_small_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((psd_small_kernel<8, MODE>), dim3((a.count + 7) / 8), dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((psd_small_kernel<16, MODE>), dim3((a.count + 3) / 4), dim3(64), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((psd_small_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
+    case 4:
+      if (maxn <= 64) return launch_wg<64, MODE, false>(a, maxn, st);
+      if (maxn <= 128) return launch_wg<128, MODE, false>(a, maxn, st);
+      return launch_wg<256, MODE, false>(a, maxn, st);
+    case 5:
+      if (wg_lds_bytes(maxn, 256, true) <= kMaxLdsBytes) return launch_wg<256, MODE, true>(a, maxn, st);
+      return launch_wg<64, MODE, true>(a, maxn, st);
+    default: break;
+  }
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// Xproj = Pi_+(Xb) over all blocks of the plan (device pointers, svec layout)
+int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
+  for (int c = 0; c < kNumPsdClasses; ++c) {
+    if (cls_count[c] == 0) continue;
+    PsdArgs a{};
+    a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
+    a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
+    a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff;
+    int rc = launch_class<0>(c, a, cls_maxn[c], st);
+    if (rc) return rc;
+  }
+  return CUADMM_OK;
+}
+
+int PsdPlan::fail_count(hipStream_t st) const {
+  int h = 0;
+  if (!d_fail) return 0;
+  if (hipMemcpyAsync(&h, d_fail, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+  hipStreamSynchronize(st);
+  return h;
+}
+
+// `count` dense n x n matrices: eigenvectors in place + ascending eigenvalues
+int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream_t st) {
+  if (n < 1 || count < 0) { set_error("batch_eig: bad n/count"); return CUADMM_ERR_INVALID; }
+  if (n > kMaxBlockSize) { set_error("batch_eig: n=%d > %d", n, kMaxBlockSize); return CUADMM_ERR_INVALID; }
+  if (count == 0) return CUADMM_OK;
+  const int c = psd_class_of(n);
+  PsdArgs a{};
+  a.in = mat; a.out = mat; a.Wout = W; a.info = info; a.ids = nullptr; a.boff = nullptr; a.bn = nullptr;
+  a.count = count; a.n_uniform = n;
+  double* ws = nullptr;
+  long long* wsoff = nullptr;
+  if (c == 5) {
+    std::vector<long long> off((size_t)count);
+    for (int i = 0; i < count; ++i) off[i] = (long long)i * n * (n | 1);
+    CUADMM_HIP_TRY(hipMalloc(&ws, sizeof(double) * (size_t)count * n * (n | 1)));
+    CUADMM_HIP_TRY(hipMalloc(&wsoff, sizeof(long long) * (size_t)count));
+    CUADMM_HIP_TRY(hipMemcpy(wsoff, off.data(), sizeof(long long) * (size_t)count, hipMemcpyHostToDevice));
+    a.workspace = ws; a.ws_off = wsoff;
+  }
+  int rc = launch_class<1>(c, a, n, st);
+  if (c == 5) {
+    hipStreamSynchronize(st);
+    hipFree(ws);
+    hipFree(wsoff);
+  }
+  return rc;
+}
+
+}  // namespace cuadmm

@@ -1,0 +1,33 @@
+// Planner for the PSD projection: block descriptors on the device, size classes, launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_util.h"
+
+namespace cuadmm {
+
+constexpr int kNumPsdClasses = 6;
+int psd_class_of(int n);
+
+struct PsdPlan {
+  int nblk = 0;
+  long long vec_len = 0;
+  double sum_n3 = 0;
+  long long* d_off = nullptr;  // nblk+1 svec offsets
+  int* d_n = nullptr;          // block sizes
+  int* d_ids = nullptr;        // block ids grouped by class
+  int* d_fail = nullptr;       // number of blocks whose QL iteration hit its cap (cumulative)
+  double* d_ws = nullptr;      // HBM workspace of the large-block path
+  long long* d_wsoff = nullptr;
+  int cls_begin[kNumPsdClasses] = {0}, cls_count[kNumPsdClasses] = {0}, cls_maxn[kNumPsdClasses] = {0};
+
+  int build(const int* blk, int mat_num);
+  void release();
+  int project(const double* Xb, double* Xproj, hipStream_t st) const;
+  int fail_count(hipStream_t st) const;
+  ~PsdPlan() { release(); }
+};
+
+int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream_t st);
+
+}  // namespace cuadmm

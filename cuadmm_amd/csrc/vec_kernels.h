@@ -1,0 +1,23 @@
+// Launchers of the HBM-bound iteration kernels (definitions in vec_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cuadmm {
+
+// Rd1 = At*y - C ; optionally Xb = X + sig*Rd1.   At in CSR over the L svec rows.
+int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, const double* av, const double* y,
+                  const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st);
+
+// mode 0: S, Rd, X update, sums | mode 1: S only | mode 2: Rd, X update, sums.
+// sums_out[0] = sum Rd^2, sums_out[1] = sum C.*X (device pointer); partials: 2*post_grid(L) doubles.
+int post_grid(long long L);
+int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, const double* C, double* X, double* S,
+                double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st);
+
+// outX = A*X, outS = A*(S-C) over the rows of A (either output may be null)
+int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, const double* av, const double* X,
+                     const double* S, const double* C, double* outX, double* outS, hipStream_t st);
+
+int launch_scale(double* v, long long n, double s, hipStream_t st);
+
+}  // namespace cuadmm

@@ -1,0 +1,424 @@
+// HBM-bound kernels of the ADMM iteration (gfx950): fused vector updates, the two SpMVs,
+// deterministic reductions, plus the op-level kernels that mirror the reference's own
+// element-wise CUDA kernels one to one (used by the parity tests through the C ABI).
+//
+// Fusion map (reference call sites in src/solver.cu):
+//   aty_xb     : SpMV At*y (:514) + D2D copy (:518) + Rd1 -= C (:520) + Xb = X + sig*Rd1 (:527)
+//   post_admm  : Xdiff (:652) + S (:656) + Rd (:746) + X update (:758) + ||Rd||^2 (:775-776)
+//                + <C,X> (:774), one pass
+//   post_S / post_X : the same split around the second sGS solve (:693-729)
+//   spmv_rows  : -A*SmC (:478,:695) and -A*X (:764) in one pass over A (SmC = S - C formed on the fly,
+//                :672-674 removed)
+// All reductions are two-stage (per-workgroup partials, then one workgroup) => run-to-run
+// deterministic, unlike atomics.
+#include <hip/hip_runtime.h>
+
+#include "device_util.h"
+#include "vec_kernels.h"
+
+namespace cuadmm {
+
+constexpr int kVecThreads = 256;
+
+static inline int grid_for(long long n, int per_block, int cap = 256 * 8) {
+  long long g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// block-wide sums of up to 2 values; result valid in thread 0
+template <int NT>
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double sa[NT / 64], sb[NT / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0, tb = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { ta += sa[i]; tb += sb[i]; }
+    a = ta; b = tb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rd1 = At*y - C ; Xb = X + sig*Rd1          (one thread per svec row; rows are mostly 0..few nnz)
+// ------------------------------------------------------------------------------------------
+template <bool WRITE_XB>
+__global__ __launch_bounds__(kVecThreads) void aty_xb_kernel(long long L, const int* __restrict__ rp,
+                                                             const int* __restrict__ ci, const double* __restrict__ av,
+                                                             const double* __restrict__ y, const double* __restrict__ C,
+                                                             const double* __restrict__ X, double sig,
+                                                             double* __restrict__ Rd1, double* __restrict__ Xb) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
+    const int p0 = rp[i], p1 = rp[i + 1];
+    double t = 0.0;
+    for (int p = p0; p < p1; ++p) t += av[p] * y[ci[p]];
+    const double r = t - C[i];
+    Rd1[i] = r;
+    if (WRITE_XB) Xb[i] = X[i] + r * sig;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// after the projection
+// ------------------------------------------------------------------------------------------
+// mode 0 (ADMM): S = (Xproj - X)/sig - Rd1 ; Rd = Rd1 + S ; X += tau*sig*Rd ; sums
+// mode 1 (sGS first half): S only
+// mode 2 (sGS second half): Rd = Rd1 + S ; X += tau*sig*Rd ; sums        (S read, not written)
+template <int MODE>
+__global__ __launch_bounds__(kVecThreads) void post_kernel(long long L, const double* __restrict__ Xproj,
+                                                           const double* __restrict__ Rd1, const double* __restrict__ C,
+                                                           double* __restrict__ X, double* __restrict__ S,
+                                                           double inv_sig, double tau_sig, double* __restrict__ partials) {
+  double s_rd = 0.0, s_cx = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
+    const double x = X[i];
+    const double r1 = Rd1[i];
+    double s;
+    if (MODE == 2) {
+      s = S[i];
+    } else {
+      const double xdiff = Xproj[i] - x;
+      s = inv_sig * xdiff - r1;
+      S[i] = s;
+    }
+    if (MODE != 1) {
+      const double rd = r1 + s;
+      const double xn = x + tau_sig * rd;
+      X[i] = xn;
+      s_rd += rd * rd;
+      s_cx += C[i] * xn;
+    }
+  }
+  if (MODE != 1) {
+    block_sum2<kVecThreads>(s_rd, s_cx);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_rd; partials[2 * blockIdx.x + 1] = s_cx; }
+  }
+}
+
+// sums `nparts` (a,b) pairs into out[0], out[1]
+__global__ __launch_bounds__(kVecThreads) void reduce_pairs_kernel(const double* __restrict__ partials, int nparts,
+                                                                   double* __restrict__ out) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  block_sum2<kVecThreads>(a, b);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
+// ------------------------------------------------------------------------------------------
+// rows of A (constraints, already in the solver's permuted order): T lanes per row.
+//   outX[row]  = sum a * X[col]            (if outX)
+//   outS[row]  = sum a * (S[col] - C[col]) (if outS)
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kVecThreads) void spmv_rows_kernel(int rows, const int* __restrict__ rp,
+                                                                const int* __restrict__ ci, const double* __restrict__ av,
+                                                                const double* __restrict__ X, const double* __restrict__ S,
+                                                                const double* __restrict__ C, double* __restrict__ outX,
+                                                                double* __restrict__ outS) {
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub = (int)(threadIdx.x & (T - 1));
+  const long long nsub = (long long)gridDim.x * blockDim.x / T;
+  const bool doX = outX != nullptr, doS = outS != nullptr;
+  for (long long row = gtid / T; row < rows; row += nsub) {
+    const int p0 = rp[row], p1 = rp[row + 1];
+    double ax = 0.0, as = 0.0;
+    for (int p = p0 + sub; p < p1; p += T) {
+      const int c = ci[p];
+      const double a = av[p];
+      if (doX) ax += a * X[c];
+      if (doS) as += a * (S[c] - C[c]);
+    }
+#pragma unroll
+    for (int o = T >> 1; o > 0; o >>= 1) {
+      ax += __shfl_xor(ax, o, 64);
+      as += __shfl_xor(as, o, 64);
+    }
+    if (sub == 0) {
+      if (doX) outX[row] = ax;
+      if (doS) outS[row] = as;
+    }
+  }
+}
+
+int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, const double* av, const double* y,
+                  const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st) {
+  const int grid = grid_for(L, kVecThreads, 256 * 16);
+  if (write_xb)
+    hipLaunchKernelGGL(aty_xb_kernel<true>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb);
+  else
+    hipLaunchKernelGGL(aty_xb_kernel<false>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+int post_grid(long long L) { return grid_for(L, kVecThreads * 4, 256 * 8); }
+
+int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, const double* C, double* X, double* S,
+                double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st) {
+  const int grid = post_grid(L);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(post_kernel<0>, dim3(grid), dim3(kVecThreads), 0, st, L, Xproj, Rd1, C, X, S, inv_sig, tau_sig, partials); break;
+    case 1: hipLaunchKernelGGL(post_kernel<1>, dim3(grid), dim3(kVecThreads), 0, st, L, Xproj, Rd1, C, X, S, inv_sig, tau_sig, partials); break;
+    default: hipLaunchKernelGGL(post_kernel<2>, dim3(grid), dim3(kVecThreads), 0, st, L, Xproj, Rd1, C, X, S, inv_sig, tau_sig, partials); break;
+  }
+  CUADMM_HIP_TRY(hipGetLastError());
+  if (mode != 1) {
+    hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(kVecThreads), 0, st, partials, grid, sums_out);
+    CUADMM_HIP_TRY(hipGetLastError());
+  }
+  return CUADMM_OK;
+}
+
+int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, const double* av, const double* X,
+                     const double* S, const double* C, double* outX, double* outS, hipStream_t st) {
+  if (rows <= 0) return CUADMM_OK;
+  int T = 1;
+  while (T < 64 && T < avg_nnz) T <<= 1;
+  const int grid = grid_for((long long)rows * T, kVecThreads, 256 * 16);
+#define CUADMM_SPMV_CASE(TT) \
+  case TT: hipLaunchKernelGGL(spmv_rows_kernel<TT>, dim3(grid), dim3(kVecThreads), 0, st, rows, rp, ci, av, X, S, C, outX, outS); break;
+  switch (T) {
+    CUADMM_SPMV_CASE(1) CUADMM_SPMV_CASE(2) CUADMM_SPMV_CASE(4) CUADMM_SPMV_CASE(8)
+    CUADMM_SPMV_CASE(16) CUADMM_SPMV_CASE(32) CUADMM_SPMV_CASE(64)
+  }
+#undef CUADMM_SPMV_CASE
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers used by the engine
+// ------------------------------------------------------------------------------------------
+__global__ void scale_kernel(double* v, long long n, double s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) v[i] *= s;
+}
+int launch_scale(double* v, long long n, double s, hipStream_t st) {
+  if (n <= 0) return CUADMM_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, kVecThreads)), dim3(kVecThreads), 0, st, v, n, s);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// op-level kernels: one per reference kernel (same element-wise semantics)
+// ------------------------------------------------------------------------------------------
+// src/kernels/vec_mat_conversion.cu:11-34
+__global__ void v2m_kernel(const double* Xb, double* large_mat, double* small_mat, const int* mB, const int* m1,
+                           const int* m2, int vec_len) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < vec_len) {
+    const int a = m1[idx], b = m2[idx];
+    const double v = (a == b) ? Xb[idx] : Xb[idx] * 0x1.6a09e667f3bcdp-1;
+    double* dst = (mB[idx] == 0) ? large_mat : small_mat;
+    dst[a] = v;
+    dst[b] = v;
+  }
+}
+// src/kernels/vec_mat_conversion.cu:36-57
+__global__ void m2v_kernel(double* Xb, const double* large_mat, const double* small_mat, const int* mB, const int* m1,
+                           const int* m2, int vec_len) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < vec_len) {
+    const int a = m1[idx], b = m2[idx];
+    const double* src = (mB[idx] == 0) ? large_mat : small_mat;
+    const double v = src[a];
+    Xb[idx] = (a == b) ? v : v * 0x1.6a09e667f3bccp+0;
+  }
+}
+// src/kernels/dense_scalar.cu:41-47
+__global__ void max_zero_kernel(double* w, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = fmax(w[i], 0.0);
+}
+// src/kernels/diagonal_batch.cu:11-23 (column-major: scales column j of matrix k by w[k*n+j])
+__global__ void mul_diag_kernel(double* out, const double* in, const double* w, int n, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) {
+    const long long n2 = (long long)n * n;
+    const long long k = idx / n2;
+    const int col = (int)((idx - k * n2) / n);
+    out[idx] = in[idx] * w[k * n + col];
+  }
+}
+// src/kernels/permutation.cu:12-18 (scatter)
+__global__ void permute_kernel(double* v1, const double* v2, const int* perm, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v1[perm[i]] = v2[i];
+}
+// src/kernels/sparse_matrix_norm.cu:11-31
+__global__ void normA_kernel(const int* cp, double* vals, double* normA, int con_num) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < con_num) {
+    double nrm = 0.0;
+    for (int p = cp[j]; p < cp[j + 1]; ++p) nrm += vals[p] * vals[p];
+    nrm = fmax(1.0, sqrt(nrm));
+    normA[j] = nrm;
+    for (int p = cp[j]; p < cp[j + 1]; ++p) vals[p] /= nrm;
+  }
+}
+// src/kernels/dense_dense.cu:15-24 / :28-37
+__global__ void axpby2_kernel(double* v1, const double* v2, double a, double b, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v1[i] = a * v1[i] + b * v2[i];
+}
+__global__ void axpby3_kernel(double* v1, const double* v2, const double* v3, double a, double b, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v1[i] = a * v2[i] + b * v3[i];
+}
+// general CSR SpMV y = alpha*A*x + beta*y (include/cuadmm/cusparse.h:70-83), one wavefront-quarter per row
+__global__ void spmv_csr_kernel(int rows, const int* rp, const int* ci, const double* av, const double* x, double* y,
+                                double alpha, double beta) {
+  constexpr int T = 16;
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub = (int)(threadIdx.x & (T - 1));
+  const long long nsub = (long long)gridDim.x * blockDim.x / T;
+  for (long long row = gtid / T; row < rows; row += nsub) {
+    double acc = 0.0;
+    for (int p = rp[row] + sub; p < rp[row + 1]; p += T) acc += av[p] * x[ci[p]];
+#pragma unroll
+    for (int o = T >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0) y[row] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * y[row];
+  }
+}
+__global__ __launch_bounds__(kVecThreads) void sumsq_partial_kernel(const double* v, long long n, double* partials) {
+  double a = 0.0, b = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a += v[i] * v[i];
+  block_sum2<kVecThreads>(a, b);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = 0.0; }
+}
+
+// P = T * V^T per n x n column-major matrix on the FP64 matrix cores
+// (the reference's cublasDgemmStridedBatched(N,T), include/cuadmm/cublas.h:18-35).
+// One wavefront per 16x16 tile of P; v_mfma_f64_16x16x4_f64: lane l feeds A[i=l&15][k=l>>4],
+// B[k=l>>4][j=l&15]; D[row=(l>>4)+4*reg][col=l&15].
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mul_trans_mfma_kernel(double* __restrict__ P, const double* __restrict__ T,
+                                                             const double* __restrict__ V, int n, int count,
+                                                             int tiles_per_dim) {
+  const int wave = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  const int tiles = tiles_per_dim * tiles_per_dim;
+  const int mat = wave / tiles;
+  if (mat >= count) return;
+  const int tile = wave - mat * tiles;
+  const int ti = tile % tiles_per_dim, tj = tile / tiles_per_dim;
+  const double* Tm = T + (long long)mat * n * n;
+  const double* Vm = V + (long long)mat * n * n;
+  double* Pm = P + (long long)mat * n * n;
+  const int i = ti * 16 + (lane & 15);   // row of T feeding A
+  const int j = tj * 16 + (lane & 15);   // row of V feeding B (B[k][j] = V[j][k])
+  const int kk = lane >> 4;
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    const int k = k0 + kk;
+    const double a = (i < n && k < n) ? Tm[(long long)k * n + i] : 0.0;
+    const double b = (j < n && k < n) ? Vm[(long long)k * n + j] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  const int col = tj * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ti * 16 + (lane >> 4) + 4 * r;
+    if (row < n && col < n) Pm[(long long)col * n + row] = acc[r];
+  }
+}
+
+}  // namespace cuadmm
+
+using namespace cuadmm;
+
+#define ST(s) ((hipStream_t)(s))
+#define LAUNCH1D(kern, n, st, ...)                                                          \
+  do {                                                                                      \
+    long long _n = (n);                                                                     \
+    if (_n > 0) {                                                                           \
+      hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, ST(st), __VA_ARGS__); \
+      CUADMM_HIP_TRY(hipGetLastError());                                                    \
+    }                                                                                       \
+  } while (0)
+
+extern "C" {
+
+int cuadmm_op_vector_to_matrices(const double* Xb, double* large_mat, double* small_mat, const int* map_B,
+                                 const int* map_M1, const int* map_M2, int vec_len, void* stream) {
+  LAUNCH1D(v2m_kernel, vec_len, stream, Xb, large_mat, small_mat, map_B, map_M1, map_M2, vec_len);
+  return CUADMM_OK;
+}
+int cuadmm_op_matrices_to_vector(double* Xb, const double* large_mat, const double* small_mat, const int* map_B,
+                                 const int* map_M1, const int* map_M2, int vec_len, void* stream) {
+  LAUNCH1D(m2v_kernel, vec_len, stream, Xb, large_mat, small_mat, map_B, map_M1, map_M2, vec_len);
+  return CUADMM_OK;
+}
+int cuadmm_op_max_zero(double* w, int64_t n, void* stream) {
+  LAUNCH1D(max_zero_kernel, n, stream, w, (long long)n);
+  return CUADMM_OK;
+}
+int cuadmm_op_mul_diag_batch(double* out, const double* in, const double* w, int n, int count, void* stream) {
+  const long long total = (long long)n * n * count;
+  LAUNCH1D(mul_diag_kernel, total, stream, out, in, w, n, total);
+  return CUADMM_OK;
+}
+int cuadmm_op_mul_trans_batch(double* P, const double* T, const double* V, int n, int count, void* stream) {
+  if (n <= 0 || count <= 0) return CUADMM_OK;
+  const int tpd = (n + 15) / 16;
+  const long long waves = (long long)tpd * tpd * count;
+  const long long blocks = (waves + 3) / 4;
+  hipLaunchKernelGGL(mul_trans_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), P, T, V, n, count, tpd);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+int cuadmm_op_permute(double* v1, const double* v2, const int* perm, int n, void* stream) {
+  LAUNCH1D(permute_kernel, n, stream, v1, v2, perm, n);
+  return CUADMM_OK;
+}
+int cuadmm_op_get_normA(const int* col_ptrs, double* vals, double* normA, int con_num, void* stream) {
+  LAUNCH1D(normA_kernel, con_num, stream, col_ptrs, vals, normA, con_num);
+  return CUADMM_OK;
+}
+int cuadmm_op_spmv_csr(int rows, const int* row_ptrs, const int* col_ids, const double* vals, const double* x, double* y,
+                       double alpha, double beta, void* stream) {
+  if (rows <= 0) return CUADMM_OK;
+  const int grid = grid_for((long long)rows * 16, 256, 256 * 16);
+  hipLaunchKernelGGL(spmv_csr_kernel, dim3(grid), dim3(256), 0, ST(stream), rows, row_ptrs, col_ids, vals, x, y, alpha, beta);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+int cuadmm_op_axpby2(double* v1, const double* v2, double alpha, double beta, int64_t n, void* stream) {
+  LAUNCH1D(axpby2_kernel, n, stream, v1, v2, alpha, beta, (long long)n);
+  return CUADMM_OK;
+}
+int cuadmm_op_axpby3(double* v1, const double* v2, const double* v3, double alpha, double beta, int64_t n, void* stream) {
+  LAUNCH1D(axpby3_kernel, n, stream, v1, v2, v3, alpha, beta, (long long)n);
+  return CUADMM_OK;
+}
+int cuadmm_op_norm2(const double* v, int64_t n, double* host_out, void* stream) {
+  if (!host_out) { set_error("norm2: null output"); return CUADMM_ERR_INVALID; }
+  *host_out = 0.0;
+  if (n <= 0) return CUADMM_OK;
+  const int grid = grid_for(n, kVecThreads * 4, 1024);
+  double* buf = nullptr;
+  CUADMM_HIP_TRY(hipMalloc(&buf, sizeof(double) * (2 * (size_t)grid + 2)));
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(kVecThreads), 0, ST(stream), v, (long long)n, buf);
+  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(kVecThreads), 0, ST(stream), buf, grid, buf + 2 * grid);
+  double h[2] = {0, 0};
+  hipError_t e = hipMemcpyAsync(h, buf + 2 * grid, sizeof(h), hipMemcpyDeviceToHost, ST(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(ST(stream));
+  hipError_t e2 = hipFree(buf);
+  (void)e2;
+  CUADMM_HIP_TRY(e);
+  *host_out = sqrt(h[0]);
+  return CUADMM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+/*
+ * cuadmm_amd.h -- C ABI of the MI355X-native SDP-ADMM iteration engine.
+ *
+ * Drop-in boundary for the hot path of ComputationalRobotics/cuADMM: the class
+ * SDPSolver (reference include/cuadmm/solver.h:30-248, src/solver.cu) as driven by its two
+ * front ends (src/main.cu:22-41, MATLAB/cuadmm_MATLAB.cu:342-424).  The reference has no
+ * FFI layer; a maintainer binds these entry points where the reference constructs and
+ * calls SDPSolver.  Plain pointers and sizes only; all indices are
+ * 0-based int32 as in the reference; all vectors fp64.
+ *
+ * Every function returns CUADMM_OK (0) or a negative error code; cuadmm_last_error()
+ * returns a human readable message for the calling thread.  Nothing here falls back to a
+ * CPU implementation of the device path: without a usable gfx950 device the compute entry
+ * points fail with CUADMM_ERR_NO_DEVICE.
+ */
+#ifndef CUADMM_AMD_H
+#define CUADMM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUADMM_OK 0
+#define CUADMM_ERR_INVALID (-1)    /* bad argument / bad state                          */
+#define CUADMM_ERR_NO_DEVICE (-2)  /* no HIP device, or a HIP call failed               */
+#define CUADMM_ERR_IO (-3)         /* unreadable / malformed input file                 */
+#define CUADMM_ERR_FACTOR (-4)     /* A A^T factorisation failed                        */
+#define CUADMM_ERR_EIG (-5)        /* an eigen-iteration hit its iteration cap          */
+#define CUADMM_ERR_COMM (-6)       /* collective hook failed                            */
+
+const char* cuadmm_last_error(void);
+const char* cuadmm_version(void);
+/* number of visible HIP devices (0 if none); never initialises a device context */
+int cuadmm_device_count(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Solver object: replaces `SDPSolver solver;` (reference src/main.cu:21).               */
+/* ------------------------------------------------------------------------------------ */
+typedef struct cuadmm_solver cuadmm_solver;
+
+int cuadmm_create(cuadmm_solver** out);
+void cuadmm_destroy(cuadmm_solver* s);
+
+/* Engine options; call before cuadmm_init.  Unknown keys -> CUADMM_ERR_INVALID.
+ *   "device"        HIP device ordinal (default 0; the reference hard-wires GPU0, utils.h:4)
+ *   "verbose"       1 = print the reference's census + iteration table to stdout (default 1)
+ *   "rank","world"  shard blocks by index over `world` engines (default 0,1); see
+ *                   cuadmm_set_allreduce
+ *   "profile"       1 = time every kernel class with HIP events on the engine stream
+ *   "graph"         reserved
+ */
+int cuadmm_set_option(cuadmm_solver* s, const char* key, double value);
+
+/* Collective hook for block-sharded multi-GPU runs.  `fn` must sum
+ * `count` doubles at device pointer `buf` over all ranks, in place, ordered on `hip_stream`
+ * (a hipStream_t).  bench.py installs torch.distributed (RCCL) here; cuadmm_use_rccl
+ * installs a direct RCCL communicator instead. */
+typedef int (*cuadmm_allreduce_fn)(void* user, double* buf, size_t count, void* hip_stream);
+int cuadmm_set_allreduce(cuadmm_solver* s, cuadmm_allreduce_fn fn, void* user);
+/* Direct RCCL: `unique_id` is the 128-byte ncclUniqueId shared by all ranks
+ * (cuadmm_rccl_unique_id fills one on rank 0). */
+int cuadmm_rccl_unique_id(char out128[128]);
+int cuadmm_use_rccl(cuadmm_solver* s, const char unique_id128[128], int rank, int world);
+
+/* SDPSolver::init  (reference include/cuadmm/solver.h:208-223, src/solver.cu:27-342).
+ * Same argument list and meaning.  At is the CSC of A^T (vec_len x con_num): column j =
+ * constraint j, row ids = svec indices.  X/y/S may be NULL (cold start, zeros).  Caller keeps
+ * ownership of every array; they are copied.  `eig_stream_num_per_gpu` and
+ * `cpu_eig_thread_num` are accepted for signature compatibility (the reference ignores the
+ * latter too, solver.cu:29). */
+int cuadmm_init(cuadmm_solver* s,
+                int eig_stream_num_per_gpu, int cpu_eig_thread_num,
+                int vec_len, int con_num,
+                const int* At_csc_col_ptrs, const int* At_csc_row_ids, const double* At_csc_vals, int At_nnz,
+                const int* b_indices, const double* b_vals, int b_nnz,
+                const int* C_indices, const double* C_vals, int C_nnz,
+                const int* blk_vals, int mat_num,
+                const double* X, const double* y, const double* S,
+                double sig);
+
+/* SDPSolver::solve  (reference solver.h:236-244, src/solver.cu:355-823).  Reference
+ * defaults: sig_update_threshold=500, stage_1=50, stage_2=100, switch_admm=11000,
+ * sigscale=1.05, if_first=1. */
+int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol,
+                 int sig_update_threshold, int sig_update_stage_1, int sig_update_stage_2,
+                 int switch_admm, double sigscale, int if_first);
+
+/* Results: the reference exposes public members X.vals / y.vals / S.vals (device pointers,
+ * unscaled after solve, solver.cu:814-816) and info_* vectors (solver.h:149-161). */
+int cuadmm_get_dims(const cuadmm_solver* s, int* vec_len, int* con_num, int* mat_num);
+int cuadmm_get_X(cuadmm_solver* s, double* host_out /* vec_len */);
+int cuadmm_get_y(cuadmm_solver* s, double* host_out /* con_num */);
+int cuadmm_get_S(cuadmm_solver* s, double* host_out /* vec_len */);
+/* replace the (unscaled) iterate between two solve() calls, as the reference allows by
+ * writing through X.vals/y.vals/S.vals before solve(..., if_first=false) (solver.cu:385-409);
+ * NULL leaves that vector untouched */
+int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const double* S, double sig);
+/* device pointers of this rank's shard (scaled inside solve, unscaled after) */
+int cuadmm_get_device_ptrs(cuadmm_solver* s, double** X, double** y, double** S);
+/* svec range [begin,end) owned by this rank (whole vector when world==1) */
+int cuadmm_get_shard(const cuadmm_solver* s, int64_t* svec_begin, int64_t* svec_end, int* blk_begin, int* blk_end);
+
+#define CUADMM_INFO_POBJ 0
+#define CUADMM_INFO_DOBJ 1
+#define CUADMM_INFO_ERRRP 2
+#define CUADMM_INFO_ERRRD 3
+#define CUADMM_INFO_RELGAP 4
+#define CUADMM_INFO_SIG 5
+#define CUADMM_INFO_BSCALE 6
+#define CUADMM_INFO_CSCALE 7
+int cuadmm_get_info_iter_num(const cuadmm_solver* s);
+/* copies min(cap, iter_num) entries of info_<which>_arr; returns the number copied */
+int cuadmm_get_info_array(const cuadmm_solver* s, int which, double* out, int cap);
+double cuadmm_get_total_time(const cuadmm_solver* s);
+/* scalars of the current state: errRp, errRd, pobj, dobj, relgap, sig, bscale, Cscale,
+ * norm_borg, norm_Corg, best_KKT, eig_not_converged (12 doubles) */
+int cuadmm_get_state(const cuadmm_solver* s, double out12[12]);
+
+/* Per-kernel-class timing collected when option "profile"=1 (HIP events on the engine
+ * stream).  Classes: 0 aty_xb, 1 psd_project, 2 post_proj, 3 spmv_A, 4 copies/h2d/d2h,
+ * 5 host_solve (wall), 6 allreduce.  out[3*k+0]=launches, [3*k+1]=total ms, [3*k+2]=bytes
+ * (algorithmic HBM bytes per launch).  */
+#define CUADMM_NUM_KCLASS 8
+int cuadmm_get_profile(const cuadmm_solver* s, double out[3 * CUADMM_NUM_KCLASS]);
+int cuadmm_reset_profile(cuadmm_solver* s);
+
+/* ------------------------------------------------------------------------------------ */
+/* TXT problem loader: Problem::from_txt (reference src/problem.cu:11-83, src/utils/io.cu). */
+/* ------------------------------------------------------------------------------------ */
+typedef struct cuadmm_problem cuadmm_problem;
+typedef struct {
+  int vec_len, con_num, mat_num;
+  int At_nnz, b_nnz, C_nnz;
+  const int* At_csc_col_ptrs;
+  const int* At_csc_row_ids;
+  const double* At_csc_vals;
+  const int* b_indices;
+  const double* b_vals;
+  const int* C_indices;
+  const double* C_vals;
+  const int* blk_vals;
+} cuadmm_problem_view;
+
+/* prefix must end in '/' exactly like the reference CLI (problem.cu:12 concatenates) */
+int cuadmm_problem_from_txt(const char* prefix, cuadmm_problem** out);
+int cuadmm_problem_view_get(const cuadmm_problem* p, cuadmm_problem_view* view);
+void cuadmm_problem_free(cuadmm_problem* p);
+/* COO_to_CSC (io.cu:187-243): sorts triplets by (col,row) in place and fills col_ptrs[col_num+1] */
+int cuadmm_coo_to_csc(int* col_ptrs, int* col_ids, int* row_ids, double* vals, int nnz, int col_num);
+/* read_blk (io.cu:296-329): returns number of entries; types[i] in 'a'..'z','A'..'Z' */
+int cuadmm_read_blk(const char* filename, char* types, int* sizes, int cap);
+/* DeviceDenseVector::to_txt format (memory.h:278-294): one "%.32f\n" per entry */
+int cuadmm_write_dense_txt(const char* filename, const double* vals, int64_t n);
+
+/* ------------------------------------------------------------------------------------ */
+/* Block bookkeeping (host): analyze_blk / is_large_mat / MatrixSizes / get_maps.          */
+/* ------------------------------------------------------------------------------------ */
+/* is_large_mat (src/matrix_sizes.cu:14-19) */
+int cuadmm_is_large_mat(int mat_size, int mat_num);
+/* analyze_blk (src/utils/analyze_blk.cu:63-99): ascending unique sizes + counts; returns #sizes */
+int cuadmm_analyze_blk(const int* blk, int mat_num, int* sizes_out, int* nums_out, int cap);
+/* get_maps (src/utils/get_maps.cu:80-135): the reference's int32 svec->dense maps.  The
+ * engine itself computes indices from (offset,n) per block; these are exported so that the
+ * svec index contract can be checked bit-for-bit against the reference's test vectors. */
+int cuadmm_get_maps(const int* blk, int mat_num, int vec_len, int* map_B, int* map_M1, int* map_M2);
+/* get_maps_duo (get_maps.cu:21-68) */
+int cuadmm_get_maps_duo(const int* blk, int mat_num, int LARGE, int SMALL, int vec_len,
+                        int* map_B, int* map_M1, int* map_M2);
+/* get_inverse_permutation (src/utils/inverse_permutation.cu:17-30) */
+int cuadmm_inverse_permutation(const int* perm, int n, int* perm_inv);
+/* contiguous block ranges per rank balanced by sum n^3; out has world+1 entries */
+int cuadmm_partition_blocks(const int* blk, int mat_num, int world, int* first_block_out);
+
+/* ------------------------------------------------------------------------------------ */
+/* Host (A A^T + eps I) factor + permuted solve: CholeskySolverCPU                        */
+/* (reference include/cuadmm/cholesky_cpu.h:62-155; CHOLMOD simplicial LDL^T there).      */
+/* ------------------------------------------------------------------------------------ */
+typedef struct cuadmm_aat cuadmm_aat;
+/* A is given in CSC (col_ptrs over the vec_len columns = the reference's At_csr arrays,
+ * solver.cu:91-95).  Factors P (A A^T + eps I) P^T = L D L^T with a fill-reducing P. */
+int cuadmm_aat_create(int con_num, int vec_len, const int* A_col_ptrs, const int* A_row_ids,
+                      const double* A_vals, double eps, cuadmm_aat** out);
+/* CHOLMOD L->Perm semantics: row i of the permuted system is original row perm[i] */
+const int* cuadmm_aat_perm(const cuadmm_aat* f);
+int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f);
+/* cholmod_solve2(CHOLMOD_LDLt): NO permutation applied inside (cholesky_cpu.h:146-155);
+ * caller does rhs_perm[perm_inv[i]] = rhs[i] and y[perm[i]] = sol_perm[i] (solver.cu:487,500) */
+int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs_perm, double* sol_perm);
+void cuadmm_aat_free(cuadmm_aat* f);
+
+/* ------------------------------------------------------------------------------------ */
+/* Op-level device entry points (pointers are DEVICE pointers; `stream` is a hipStream_t   */
+/* or NULL).  Each mirrors one reference kernel/wrapper so parity can be tested per op.    */
+/* ------------------------------------------------------------------------------------ */
+/* vector_to_matrices / matrices_to_vector (src/kernels/vec_mat_conversion.cu:11-98) */
+int cuadmm_op_vector_to_matrices(const double* Xb, double* large_mat, double* small_mat,
+                                 const int* map_B, const int* map_M1, const int* map_M2,
+                                 int vec_len, void* stream);
+int cuadmm_op_matrices_to_vector(double* Xb, const double* large_mat, const double* small_mat,
+                                 const int* map_B, const int* map_M1, const int* map_M2,
+                                 int vec_len, void* stream);
+/* batch_eig_cusolver / single_eig_cusolver (include/cuadmm/cusolver.h:76-95,154-171):
+ * `count` contiguous n x n column-major symmetric matrices, overwritten by eigenvectors
+ * (column-major, column k <-> W[k]); W ascending; info[i] = 0 or 1 (iteration cap hit). */
+int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, void* stream);
+/* max_dense_vector_zero (src/kernels/dense_scalar.cu:41-47,93-97) */
+int cuadmm_op_max_zero(double* w, int64_t n, void* stream);
+/* dense_matrix_mul_diag_batch (src/kernels/diagonal_batch.cu:11-62): out = in * diag(w) per matrix */
+int cuadmm_op_mul_diag_batch(double* out, const double* in, const double* w, int n, int count, void* stream);
+/* dense_matrix_mul_trans_batch (include/cuadmm/cublas.h:18-35): P = T * V^T per matrix (MFMA f64) */
+int cuadmm_op_mul_trans_batch(double* P, const double* T, const double* V, int n, int count, void* stream);
+/* fused PSD-cone projection over blocks laid out in svec form (solver.cu:534-647):
+ * blk[mat_num] sizes in blk.txt order; Xproj may alias Xb.  eig_fail (device int, may be
+ * NULL) is incremented per block whose QL iteration hit its cap. */
+int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream);
+/* perform_permutation (src/kernels/permutation.cu:12-33): v1[perm[i]] = v2[i] */
+int cuadmm_op_permute(double* v1, const double* v2, const int* perm, int n, void* stream);
+/* get_normA (src/kernels/sparse_matrix_norm.cu:11-44): per CSC column norm=max(1,||col||), col/=norm */
+int cuadmm_op_get_normA(const int* col_ptrs, double* vals, double* normA, int con_num, void* stream);
+/* SpMV_cusparse (include/cuadmm/cusparse.h:70-83): y = alpha*A*x + beta*y, CSR int32 */
+int cuadmm_op_spmv_csr(int rows, const int* row_ptrs, const int* col_ids, const double* vals,
+                       const double* x, double* y, double alpha, double beta, void* stream);
+/* dense_dense.cu wrappers */
+int cuadmm_op_axpby2(double* v1, const double* v2, double alpha, double beta, int64_t n, void* stream);           /* v1=a*v1+b*v2 (:92-100)  */
+int cuadmm_op_axpby3(double* v1, const double* v2, const double* v3, double alpha, double beta, int64_t n, void* stream); /* v1=a*v2+b*v3 (:103-111) */
+/* get_norm (include/cuadmm/memory.h:238-247): 2-norm, deterministic two-stage reduction */
+int cuadmm_op_norm2(const double* v, int64_t n, double* host_out, void* stream);
+
+/* device memory helpers for bindings that do not own a device allocator */
+int cuadmm_dev_malloc(void** ptr, size_t bytes);
+int cuadmm_dev_free(void* ptr);
+int cuadmm_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int cuadmm_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int cuadmm_dev_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUADMM_AMD_H */

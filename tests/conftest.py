@@ -1,0 +1,81 @@
+import gzip
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: longer CPU test")
+
+
+def _have_gpu():
+    try:
+        import cuadmm_amd
+        return cuadmm_amd.load().cuadmm_device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def problem_dirs(tmp_path_factory):
+    """Unpacks tests/golden/problems/<name>/*.txt.gz into a temp dir; returns name -> 'dir/'."""
+    base = tmp_path_factory.mktemp("problems")
+    out = {}
+    src = os.path.join(GOLDEN, "problems")
+    for name in sorted(os.listdir(src)):
+        d = os.path.join(src, name)
+        if not os.path.isdir(d):
+            continue
+        dst = os.path.join(str(base), name)
+        os.makedirs(dst, exist_ok=True)
+        for fn in os.listdir(d):
+            with gzip.open(os.path.join(d, fn), "rb") as f, open(os.path.join(dst, fn[:-3]), "wb") as g:
+                shutil.copyfileobj(f, g)
+        out[name] = dst + "/"
+    return out
+
+
+@pytest.fixture(scope="session")
+def ref_logs():
+    with open(os.path.join(GOLDEN, "ref_logs.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle_traj():
+    with open(os.path.join(GOLDEN, "oracle_traj.json")) as f:
+        return json.load(f)
+
+
+def load_npz_problem(name):
+    """PlanarHand / pendulum inputs rebuilt from the reference's .mat files (make_golden.py)."""
+    from oracle import cuadmm_oracle as orc
+    d = np.load(os.path.join(GOLDEN, "problems", name + ".npz"))
+    cp, ri, v = orc.coo_to_csc(d["At_col"], d["At_row"], d["At_val"], int(d["con_num"]))
+    blk = d["blk"]
+    L = int(orc.svec_block_offsets(blk)[-1])
+    return orc.Problem(L, int(d["con_num"]), blk.astype(np.int32), cp, ri, v, d["b_idx"], d["b_val"], d["C_idx"], d["C_val"])

@@ -1,0 +1,67 @@
+"""Small helpers for the GPU parity tests: device buffers through the C ABI (no torch needed)."""
+import ctypes as C
+
+import numpy as np
+
+import cuadmm_amd
+from cuadmm_amd._lib import check
+
+
+class Dev:
+    """numpy array mirrored in device memory via cuadmm_dev_malloc / memcpy."""
+
+    def __init__(self, arr=None, shape=None, dtype=np.float64):
+        self.lib = cuadmm_amd.load()
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            shape, dtype = arr.shape, arr.dtype
+        self.shape, self.dtype = tuple(np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape, np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(self.lib.cuadmm_dev_malloc(C.byref(p), max(self.nbytes, 8)))
+        self.ptr = p
+        if arr is not None and self.nbytes:
+            check(self.lib.cuadmm_memcpy_h2d(self.ptr, arr.ctypes.data_as(C.c_void_p), self.nbytes))
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        check(self.lib.cuadmm_dev_sync())
+        if self.nbytes:
+            check(self.lib.cuadmm_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.cuadmm_dev_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def psd_project_gpu(x, blk):
+    lib = cuadmm_amd.load()
+    blk = np.ascontiguousarray(blk, dtype=np.int32)
+    din = Dev(np.ascontiguousarray(x, dtype=np.float64))
+    dout = Dev(shape=(x.size,), dtype=np.float64)
+    check(lib.cuadmm_op_psd_project(din.ptr, dout.ptr, blk.ctypes.data_as(C.c_void_p), int(blk.size), None))
+    return dout.get()
+
+
+def batch_eig_gpu(mats):
+    """mats: (count, n, n) symmetric -> (W (count,n) ascending, V (count,n,n) with V[i][:,k] eigenvector k, info)."""
+    lib = cuadmm_amd.load()
+    count, n, _ = mats.shape
+    colmajor = np.ascontiguousarray(np.swapaxes(mats, 1, 2))      # element (r,c) at c*n+r
+    dm = Dev(colmajor)
+    dw = Dev(shape=(count, n), dtype=np.float64)
+    di = Dev(np.zeros(count, np.int32))
+    check(lib.cuadmm_op_batch_eig(dm.ptr, dw.ptr, di.ptr, n, count, None))
+    V = np.swapaxes(dm.get(), 1, 2)
+    return dw.get(), V, di.get()
+
+
+def problem_to_amd(p):
+    """oracle Problem -> cuadmm_amd.Problem"""
+    return cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals,
+                              p.b_idx, p.b_vals, p.C_idx, p.C_vals)

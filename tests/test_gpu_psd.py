@@ -1,0 +1,137 @@
+"""GPU parity: fused PSD projection and the eigensolver vs the oracle (LAPACK dsyevd path).
+
+Tolerances: projection <= 1e-12 * max(1,||X_blk||_F) per entry; eigenvalues
+<= 1e-12 * ||A||_2; svec index layout bit-exact (checked through the round-trip of PSD inputs).
+"""
+import numpy as np
+import pytest
+
+from oracle import cuadmm_oracle as orc
+from tests.helpers import batch_eig_gpu, psd_project_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_svec(blk, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    L = int(orc.svec_block_offsets(blk)[-1])
+    return rng.standard_normal(L) * scale
+
+
+@pytest.mark.parametrize("blk", [
+    [1], [2], [3], [4], [5], [8], [9], [16], [17], [31], [32],
+    [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32],
+    [32] * 7, [6] * 37 + [4], [1] * 100 + [2] * 33,
+])
+def test_project_small_blocks(blk):
+    blk = np.array(blk, dtype=np.int32)
+    x = _rand_svec(blk, 11)
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(orc.BlockIndex(blk), x)
+    assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(x)) * 32)
+
+
+@pytest.mark.parametrize("blk", [[33], [55], [64], [65], [91], [120], [128], [130], [33, 40, 64, 100]])
+def test_project_mid_blocks(blk):
+    blk = np.array(blk, dtype=np.int32)
+    x = _rand_svec(blk, 12)
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(orc.BlockIndex(blk), x)
+    assert np.max(np.abs(got - ref)) <= 2e-12 * max(1.0, np.max(np.abs(x)) * blk.max())
+
+
+@pytest.mark.parametrize("n", [150, 300])
+def test_project_large_block_hbm_path(n):
+    blk = np.array([n], dtype=np.int32)
+    x = _rand_svec(blk, 13)
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(orc.BlockIndex(blk), x)
+    assert np.max(np.abs(got - ref)) <= 5e-12 * n
+
+
+def test_project_mixed_planarhand_sizes():
+    blk = np.array([7] * 5 + [10] * 12 + [11] * 26 + [13] * 14 + [15] * 51 + [28] * 3 + [55] * 2 + [66] * 3 + [91] * 3 + [120] * 3,
+                   dtype=np.int32)
+    rng = np.random.default_rng(3)
+    blk = blk[rng.permutation(blk.size)]
+    x = _rand_svec(blk, 14)
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(orc.BlockIndex(blk), x)
+    assert np.max(np.abs(got - ref)) <= 2e-12 * 120
+
+
+def test_project_properties_full_size():
+    """BASELINE config 2 size (10 000 blocks of 32): idempotence, PSD inputs fixed, NSD inputs -> 0."""
+    blk = np.full(10000, 32, dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = _rand_svec(blk, 15)
+    p1 = psd_project_gpu(x, blk)
+    p2 = psd_project_gpu(p1, blk)
+    scale = np.max(np.abs(x)) * 32
+    assert np.max(np.abs(p2 - p1)) <= 1e-12 * scale                     # idempotent
+    # Moreau: x = P+(x) - P+(-x)
+    pm = psd_project_gpu(-x, blk)
+    assert np.max(np.abs((p1 - pm) - x)) <= 1e-12 * scale
+    # <P+(x), P+(-x)> = 0 per block (complementarity), checked in aggregate
+    assert abs(np.dot(p1, pm)) <= 1e-10 * np.dot(x, x)
+    # spot-check 64 random blocks against the oracle
+    sel = np.random.default_rng(0).choice(10000, 64, replace=False)
+    for k in sel:
+        sl = slice(int(bidx.off[k]), int(bidx.off[k + 1]))
+        ref = orc.psd_project_svec(orc.BlockIndex([32]), x[sl])
+        assert np.max(np.abs(p1[sl] - ref)) <= 1e-12 * scale
+
+
+def test_project_edge_inputs():
+    blk = np.array([32, 32, 16, 5, 32, 1, 1], dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    L = int(bidx.off[-1])
+    x = np.zeros(L)
+    rng = np.random.default_rng(5)
+    # block 0: zero matrix; block 1: identity (already diagonal); block 2: diagonal with mixed signs;
+    # block 3: rank one; block 4: repeated eigenvalues; blocks 5,6: scalars +/-.
+    mats = [np.zeros((32, 32)), np.eye(32), np.diag(rng.standard_normal(16))]
+    v = rng.standard_normal(5); mats.append(np.outer(v, v))
+    Q, _ = np.linalg.qr(rng.standard_normal((32, 32)))
+    lam = np.repeat([-2.0, 0.0, 3.0, 3.0], 8)
+    mats.append((Q * lam) @ Q.T)
+    mats += [np.array([[2.5]]), np.array([[-1.5]])]
+    for k, M in enumerate(mats):
+        x[int(bidx.off[k]):int(bidx.off[k + 1])] = orc.BlockIndex([M.shape[0]]).pack([M[None]])
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(bidx, x)
+    assert np.max(np.abs(got - ref)) <= 1e-12 * 10
+    assert np.all(got[:int(bidx.off[1])] == 0.0)                         # zero block stays exactly zero
+    assert got[-1] == 0.0 and got[-2] == 2.5
+
+
+@pytest.mark.parametrize("n,count", [(2, 5), (3, 4), (4, 3), (6, 100), (10, 33), (16, 17), (32, 64), (45, 5), (105, 2), (200, 1)])
+def test_batch_eig_vs_lapack(n, count):
+    rng = np.random.default_rng(n * 1000 + count)
+    A = rng.standard_normal((count, n, n))
+    A = (A + np.swapaxes(A, 1, 2)) / 2
+    W, V, info = batch_eig_gpu(A)
+    assert np.all(info == 0)
+    w_ref = np.linalg.eigvalsh(A)
+    nrm = np.max(np.abs(w_ref))
+    assert np.max(np.abs(W - w_ref)) <= 1e-12 * nrm * max(1, n / 8)
+    assert np.all(np.diff(W, axis=1) >= 0)                               # ascending (sort_eig=1, cusolver.h:112-123)
+    rec = np.einsum("bik,bk,bjk->bij", V, W, V)
+    assert np.max(np.abs(rec - A)) <= 5e-13 * nrm * n
+    orth = np.einsum("bki,bkj->bij", V, V) - np.eye(n)
+    assert np.max(np.abs(orth)) <= 5e-13 * n
+
+
+def test_batch_eig_reference_kats():
+    """Spectra hard-coded in the reference tests (test/cusolver_test.hpp:60-63,117-126,178-182)."""
+    A4 = np.array([[4, 1, 2, 2], [1, 4, 1, 2], [2, 1, 4, 1], [2, 2, 1, 4]], dtype=float)
+    W, V, info = batch_eig_gpu(A4[None])
+    assert np.allclose(W[0], [1.38197, 2.45862, 3.61803, 8.54138], atol=1e-5)
+    exp = np.array([[-1.0, -0.618034, 0.618034, 1.0], [1.0, -1.18046, -1.18046, 1.0],
+                    [-1.0, 1.61803, -1.61803, 1.0], [1.0, 0.847127, 0.847127, 1.0]])
+    exp /= np.linalg.norm(exp, axis=1, keepdims=True)
+    assert np.allclose(np.abs(V[0].T), np.abs(exp), atol=1e-5)
+    W2, _, _ = batch_eig_gpu(np.array([[[2.0, 1.0], [1.0, 3.0]]]))
+    assert np.allclose(W2[0], [0.5 * (5 - 5 ** 0.5), 0.5 * (5 + 5 ** 0.5)], atol=1e-12)
+    W3, _, _ = batch_eig_gpu(np.array([[[3.0, 1, 2], [1, 3, 1], [2, 1, 3]]]))
+    assert np.allclose(W3[0], [1.0, 4 - 3 ** 0.5, 4 + 3 ** 0.5], atol=1e-12)

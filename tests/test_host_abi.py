@@ -1,0 +1,200 @@
+"""CPU tests of the C-ABI shared library: it loads, exports every symbol declared in
+include/cuadmm_amd.h, and its host-side entry points (loader, block bookkeeping, AA^T factor)
+agree with the oracle and with the reference's unit-test vectors.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cuadmm_amd
+from cuadmm_amd._lib import PROTOTYPES, check
+from oracle import cuadmm_oracle as orc
+from tests.conftest import GOLDEN, ROOT
+
+lib = cuadmm_amd.load()
+P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cuadmm_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(cuadmm_[a-z0-9_A-Z]+)\s*\(", hdr)) - {"cuadmm_allreduce_fn"}
+    assert len(names) > 50
+    raw = C.CDLL(cuadmm_amd.LIB_PATH)
+    for n in sorted(names):
+        getattr(raw, n)
+    assert names == set(PROTOTYPES)                                        # the Python binding covers the header
+
+
+def test_no_device_is_a_loud_error():
+    if lib.cuadmm_device_count() > 0:
+        pytest.skip("GPU present")
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    with pytest.raises(cuadmm_amd.CuadmmError) as e:
+        s.init(15, 30, 1, 1, [0, 1], [0], [1.0], 1, [0], [1.0], 1, [0], [1.0], 1, [1], 1)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    p = C.c_void_p()
+    assert lib.cuadmm_dev_malloc(C.byref(p), 64) == -2
+
+
+def test_maps_match_reference_kats():
+    blk = np.array([5, 4], np.int32)
+    mB, m1, m2 = (np.zeros(25, np.int32) for _ in range(3))
+    check(lib.cuadmm_get_maps_duo(P(blk), 2, 5, 4, 25, P(mB), P(m1), P(m2)))
+    oB, o1, o2 = orc.get_maps_duo([5, 4], 5, 4)
+    assert mB.tolist() == oB.tolist() and m1.tolist() == o1.tolist() and m2.tolist() == o2.tolist()
+    assert m1.tolist()[:6] == [0, 5, 6, 10, 11, 12] and m2.tolist()[:6] == [0, 1, 6, 2, 7, 12]   # utils_test.hpp:36-61
+
+
+@pytest.mark.parametrize("blk", [[2, 4], [6] * 40 + [4], [7] * 5 + [10] * 12 + [28] * 3 + [55] * 2 + [120], [3, 45, 3, 45, 10],
+                                 [1] * 30 + [2] * 5 + [33]])
+def test_get_maps_vs_oracle(blk):
+    blk = np.array(blk, np.int32)
+    L = int(orc.svec_block_offsets(blk)[-1])
+    mB, m1, m2 = (np.zeros(L, np.int32) for _ in range(3))
+    check(lib.cuadmm_get_maps(P(blk), blk.size, L, P(mB), P(m1), P(m2)))
+    sizes, nums = orc.analyze_blk(blk)
+    oB, o1, o2 = orc.get_maps(blk, orc.MatrixSizes(sizes, nums))
+    assert np.array_equal(mB, oB) and np.array_equal(m1, o1) and np.array_equal(m2, o2)    # bit-exact indexing
+    s_out, n_out = np.zeros(64, np.int32), np.zeros(64, np.int32)
+    k = lib.cuadmm_analyze_blk(P(blk), blk.size, P(s_out), P(n_out), 64)
+    assert s_out[:k].tolist() == sizes and n_out[:k].tolist() == nums
+    for s_, n_ in zip(sizes, nums):
+        assert bool(lib.cuadmm_is_large_mat(s_, n_)) == orc.is_large_mat(s_, n_)
+
+
+def test_get_maps_kat_two_sizes():
+    # test/kernels_test.hpp:339-341: blk = {2,4} -> 2 is "small", 4 is "small" too under the heuristic, so use
+    # the duo variant that the KAT was generated with (LARGE=4, SMALL=2)
+    blk = np.array([2, 4], np.int32)
+    mB, m1, m2 = (np.zeros(13, np.int32) for _ in range(3))
+    check(lib.cuadmm_get_maps_duo(P(blk), 2, 4, 2, 13, P(mB), P(m1), P(m2)))
+    assert mB.tolist() == [1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    assert m1.tolist() == [0, 2, 3, 0, 4, 5, 8, 9, 10, 12, 13, 14, 15]
+    assert m2.tolist() == [0, 1, 3, 0, 1, 5, 2, 6, 10, 3, 7, 11, 15]
+
+
+def test_inverse_permutation_kat():
+    perm = np.array([10, 6, 2, 4, 0, 8, 1, 3, 5, 7, 9], np.int32)              # test/utils_test.hpp:8-17
+    inv = np.zeros(11, np.int32)
+    check(lib.cuadmm_inverse_permutation(P(perm), 11, P(inv)))
+    assert all(perm[inv[i]] == i for i in range(11))
+    bad = np.array([0, 5], np.int32)
+    assert lib.cuadmm_inverse_permutation(P(bad), 2, P(inv)) == -1
+
+
+def test_coo_to_csc_and_blk_files():
+    r, c, v = orc.read_coo(os.path.join(GOLDEN, "io", "sparse_matrix_coo.txt"))
+    cp = np.zeros(5, np.int32)
+    check(lib.cuadmm_coo_to_csc(P(cp), P(c), P(r), P(v), 6, 4))
+    assert cp.tolist() == [0, 2, 4, 5, 6] and r.tolist() == [0, 2, 1, 3, 2, 2] and v.tolist() == [10, 30, 20, 60, 40, 50]
+    # empty leading column (the case the reference conversion gets wrong)
+    r2, c2, v2 = np.array([0, 1], np.int32), np.array([2, 1], np.int32), np.array([1.0, 2.0])
+    cp2 = np.zeros(4, np.int32)
+    check(lib.cuadmm_coo_to_csc(P(cp2), P(c2), P(r2), P(v2), 2, 3))
+    assert cp2.tolist() == [0, 0, 1, 2] and r2.tolist() == [1, 0]
+    types, sizes = (C.c_char * 8)(), np.zeros(8, np.int32)
+    n = lib.cuadmm_read_blk(os.path.join(GOLDEN, "io", "blk_types.txt").encode(), types, P(sizes), 8)
+    assert n == 3 and bytes(types[:3]) == b"abc" and sizes[:3].tolist() == [10, 20, 30]
+    n = lib.cuadmm_read_blk(os.path.join(GOLDEN, "io", "blk_normal.txt").encode(), types, P(sizes), 8)
+    assert n == 3 and bytes(types[:3]) == b"sss"
+    assert lib.cuadmm_read_blk(b"/nonexistent/blk.txt", types, P(sizes), 8) == -3
+
+
+@pytest.mark.parametrize("name", ["hinf12", "truss5", "rose13", "ros_2000", "cnhil10"])
+def test_problem_from_txt_matches_oracle_loader(name, problem_dirs, capfd):
+    p = cuadmm_amd.Problem.from_txt(problem_dirs[name])
+    o = orc.load_problem_txt(problem_dirs[name])
+    assert (p.vec_len, p.con_num, p.mat_num, p.At_nnz) == (o.vec_len, o.con_num, o.blk.size, o.At_nnz)
+    assert np.array_equal(p.At_csc_col_ptrs, o.At_col_ptrs) and np.array_equal(p.At_csc_row_ids, o.At_row_ids)
+    assert np.array_equal(p.At_csc_vals, o.At_vals)
+    assert np.array_equal(p.b_indices, o.b_idx) and np.array_equal(p.b_vals, o.b_vals)
+    assert np.array_equal(p.C_indices, o.C_idx) and np.array_equal(p.C_vals, o.C_vals)
+    out = capfd.readouterr().out
+    assert "Loaded problem from" in out and ("vector length: %d" % o.vec_len) in out     # problem.cu:74-80
+
+
+def test_problem_from_txt_errors(tmp_path):
+    with pytest.raises(cuadmm_amd.CuadmmError) as e:
+        cuadmm_amd.Problem.from_txt(str(tmp_path) + "/")
+    assert e.value.code == -3
+    d = tmp_path / "p"; d.mkdir()
+    (d / "blk.txt").write_text("u 3\n"); (d / "con_num.txt").write_text("1\n")
+    for f in ("At.txt", "b.txt", "C.txt"):
+        (d / f).write_text("")
+    with pytest.raises(cuadmm_amd.CuadmmError) as e:
+        cuadmm_amd.Problem.from_txt(str(d) + "/")
+    assert "unknown block type 'u'" in str(e.value)                               # problem.cu:33-35
+
+
+def _aat(p):
+    At = sp.csc_matrix((p.At_vals, p.At_row_ids, p.At_col_ptrs), shape=(p.vec_len, p.con_num))
+    A = At.T.tocsc(); A.sort_indices()
+    h = C.c_void_p()
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    check(lib.cuadmm_aat_create(p.con_num, p.vec_len, P(cp), P(ri), P(vx), 1e-15, C.byref(h)))
+    return h, A
+
+
+@pytest.mark.parametrize("name", ["hinf12", "truss5", "rose13", "ros_2000"])
+def test_aat_factor_and_permuted_solve(name, problem_dirs):
+    p = orc.load_problem_txt(problem_dirs[name])
+    m = p.con_num
+    h, A = _aat(p)
+    perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)).copy()
+    assert sorted(perm.tolist()) == list(range(m))
+    rng = np.random.default_rng(0)
+    rhs = A @ rng.standard_normal(p.vec_len)                                       # consistent right-hand side
+    # contract of cholmod_solve2(CHOLMOD_LDLt): rhs_perm[i] = rhs[perm[i]], y[perm[i]] = sol_perm[i]
+    rp = np.ascontiguousarray(rhs[perm]); sol = np.empty(m)
+    check(lib.cuadmm_aat_solve_permuted(h, P(rp), P(sol)))
+    y = np.empty(m); y[perm] = sol
+    B = (A @ A.T) + 1e-15 * sp.identity(m)
+    assert np.linalg.norm(B @ y - rhs) <= 1e-10 * np.linalg.norm(rhs)
+    # without the permutation the answer is wrong (documents the contract, cholesky_cpu_test.hpp:57-100)
+    if name != "ros_2000" and not np.array_equal(perm, np.arange(m)):
+        sol2 = np.empty(m)
+        check(lib.cuadmm_aat_solve_permuted(h, P(np.ascontiguousarray(rhs)), P(sol2)))
+        assert np.linalg.norm(B @ sol2 - rhs) > 1e-6 * np.linalg.norm(rhs)
+    assert lib.cuadmm_aat_factor_nnz(h) >= 0
+    lib.cuadmm_aat_free(h)
+
+
+def test_aat_all_ones_solution():
+    # test/cholesky_cpu_test.hpp:3-55 style: A = I (4x4) scaled, solution of (AA^T) x = AA^T 1 is all ones
+    A = sp.random(30, 80, density=0.15, random_state=3, format="csc") + sp.eye(30, 80, format="csc")
+    A = A.tocsc(); A.sort_indices()
+    h = C.c_void_p()
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    check(lib.cuadmm_aat_create(30, 80, P(cp), P(ri), P(vx), 1e-16, C.byref(h)))
+    perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(30,)).copy()
+    rhs = (A @ A.T) @ np.ones(30)
+    sol = np.empty(30)
+    check(lib.cuadmm_aat_solve_permuted(h, P(np.ascontiguousarray(rhs[perm])), P(sol)))
+    assert np.max(np.abs(sol - 1.0)) <= 1e-5                                       # the reference's tolerance
+    lib.cuadmm_aat_free(h)
+
+
+def test_partition_blocks_balanced_and_contiguous():
+    rng = np.random.default_rng(0)
+    blk = rng.choice([3, 6, 10, 15, 28, 45], size=1000).astype(np.int32)
+    for world in (1, 2, 4, 8):
+        first = np.zeros(world + 1, np.int32)
+        check(lib.cuadmm_partition_blocks(P(blk), blk.size, world, P(first)))
+        assert first[0] == 0 and first[-1] == blk.size and np.all(np.diff(first) >= 0)
+        cost = np.array([np.sum(blk[first[r]:first[r + 1]].astype(float) ** 3) for r in range(world)])
+        assert cost.max() <= cost.sum() / world + 45.0 ** 3 + 1
+    first = np.zeros(9, np.int32)
+    check(lib.cuadmm_partition_blocks(P(np.array([5, 5], np.int32)), 2, 8, P(first)))     # more ranks than blocks
+    assert first[-1] == 2 and np.all(np.diff(first) >= 0)
+
+
+def test_write_dense_txt_format(tmp_path):
+    v = np.array([1.0, -0.5, 1e-3])
+    fn = str(tmp_path / "X_opt.txt")
+    check(lib.cuadmm_write_dense_txt(fn.encode(), P(v), 3))
+    lines = open(fn).read().splitlines()
+    assert lines == ["%.32f" % x for x in v]                                        # memory.h:278-294

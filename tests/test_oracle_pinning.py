@@ -1,0 +1,188 @@
+"""Pins the oracle (oracle/cuadmm_oracle.py) to the reference's own known answers:
+hard-coded unit-test vectors (test/*.hpp) and the printed iteration tables of the shipped logs."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cuadmm_oracle as orc
+from tests.conftest import GOLDEN, ROOT, load_npz_problem
+
+
+# ---- constants (include/cuadmm/kernels.h:173-181; test/kernels_test.hpp:218-222) ---------------
+def test_sqrt2_constants():
+    assert orc.SQRT2.hex() == "0x1.6a09e667f3bccp+0"
+    assert orc.SQRT2INV.hex() == "0x1.6a09e667f3bcdp-1"
+    assert abs(orc.SQRT2 - 2 ** 0.5) <= 4 * np.finfo(float).eps            # EXPECT_DOUBLE_EQ
+    # the unpack/pack factor is exactly 1.0 on diagonals (vec_mat_conversion.cu:26,51)
+    assert orc.SQRT2INV + 1 * (1 - orc.SQRT2INV) == 1.0 and orc.SQRT2 + 1 * (1 - orc.SQRT2) == 1.0
+
+
+# ---- svec maps (test/utils_test.hpp:19-63, test/kernels_test.hpp:339-341,421-423) --------------
+def test_get_maps_duo_kat():
+    mB, m1, m2 = orc.get_maps_duo([5, 4], 5, 4)
+    assert mB.tolist() == [0] * 15 + [1] * 10
+    assert m1.tolist() == [0, 5, 6, 10, 11, 12, 15, 16, 17, 18, 20, 21, 22, 23, 24, 0, 4, 5, 8, 9, 10, 12, 13, 14, 15]
+    assert m2.tolist() == [0, 1, 6, 2, 7, 12, 3, 8, 13, 18, 4, 9, 14, 19, 24, 0, 1, 5, 2, 6, 10, 3, 7, 11, 15]
+
+
+def test_get_maps_multi_kat():
+    # blk {1,2,3,4}: sizes 1,2 small; 3,4 large (1 copy each: n-17 > 1.4 false -> small?).  The KAT at
+    # kernels_test.hpp:421-423 was built for a 'large'={3,4}, 'small'={1,2} split with blk order 3,4,1,2
+    mB = [0] * 16 + [1] * 4
+    m1 = [0, 3, 4, 6, 7, 8, 9, 13, 14, 17, 18, 19, 21, 22, 23, 24, 0, 1, 3, 4]
+    m2 = [0, 1, 4, 2, 5, 8, 9, 10, 14, 11, 15, 19, 12, 16, 20, 24, 0, 1, 2, 4]
+    # restate with explicit class membership (MatrixSizes fields, matrix_sizes.cu:22-69)
+    ms = orc.MatrixSizes([], [])
+    ms.is_large_map = {1: False, 2: False, 3: True, 4: True}
+    ms.large_mat_sizes, ms.large_mat_nums, ms.large_mat_start_indices = [3, 4], [1, 1], [0, 9, 25]
+    ms.small_mat_sizes, ms.small_mat_nums, ms.small_mat_start_indices = [1, 2], [1, 1], [0, 1, 5]
+    gB, g1, g2 = orc.get_maps([3, 4, 1, 2], ms)
+    assert gB.tolist() == mB and g1.tolist() == m1 and g2.tolist() == m2
+
+
+def test_vec_mat_roundtrip_kat():
+    # test/kernels_test.hpp:224-308: two 4x4 matrices -> svec with sqrt2 on off-diagonals
+    mom = np.array([1, 2, 3, 4, 2, 5, 6, 7, 3, 6, 8, 9, 4, 7, 9, 10], float)
+    loc = np.array([2, 3, 4, 5, 3, 6, 7, 8, 4, 7, 9, 10, 5, 8, 10, 11], float)
+    m1 = [0, 1, 2, 3, 5, 6, 7, 10, 11, 15]
+    m2 = [0, 4, 8, 12, 5, 9, 13, 10, 14, 15]
+    mB = np.array([0] * 10 + [1] * 10, np.int32)
+    M1 = np.array(m1 + m1, np.int32); M2 = np.array(m2 + m2, np.int32)
+    x = orc.matrices_to_vector(mom, loc, mB, M1, M2)
+    s = orc.SQRT2
+    want = [1, 2 * s, 3 * s, 4 * s, 5, 6 * s, 7 * s, 8, 9 * s, 10, 2, 3 * s, 4 * s, 5 * s, 6, 7 * s, 8 * s, 9, 10 * s, 11]
+    assert x.tolist() == want                                               # EXPECT_EQ: bit exact
+    lm, sm = np.zeros(16), np.zeros(16)
+    orc.vector_to_matrices(x, lm, sm, mB, M1, M2)
+    assert np.max(np.abs(lm - mom)) <= 4e-16 * 10 and np.max(np.abs(sm - loc)) <= 4e-16 * 11
+
+
+def test_is_large_heuristic():
+    # matrix_sizes.cu:14-19 and the census lines of the shipped logs
+    assert orc.is_large_mat(33, 10 ** 6) and not orc.is_large_mat(32, 10000)
+    assert orc.is_large_mat(28, 3) and not orc.is_large_mat(15, 51)          # PlanarHand cuADMM.log:10-19
+    assert not orc.is_large_mat(6, 1998) and not orc.is_large_mat(4, 1)      # ros_2000 cuADMM.log:10-11
+    assert orc.is_large_mat(45, 16667)
+
+
+# ---- IO (test/io_test.hpp:92-109, test/data/*) ------------------------------------------------
+def test_coo_to_csc_kat():
+    r, c, v = orc.read_coo(os.path.join(GOLDEN, "io", "sparse_matrix_coo.txt"))
+    cp, ri, vv = orc.coo_to_csc(c, r, v, 4)
+    assert cp.tolist() == [0, 2, 4, 5, 6] and ri.tolist() == [0, 2, 1, 3, 2, 2]
+    assert vv.tolist() == [10.0, 30.0, 20.0, 60.0, 40.0, 50.0]
+
+
+def test_read_blk_grammar():
+    assert orc.read_blk(os.path.join(GOLDEN, "io", "blk_normal.txt")) == [("s", 10), ("s", 20), ("s", 30)]
+    assert orc.read_blk(os.path.join(GOLDEN, "io", "blk_types.txt")) == [("a", 10), ("b", 20), ("c", 30)]
+
+
+def test_normA_kat():
+    # test/kernels_test.hpp:35-83
+    r, c, v = orc.read_coo(os.path.join(GOLDEN, "io", "sparse_matrix_coo.txt"))
+    cp, ri, vv = orc.coo_to_csc(c, r, v, 4)
+    s = orc.OracleSolver().init(4, 4, cp, ri, vv, [0], [1.0], [0], [1.0], [2, 1])   # vec_len 4 = svec(2)+svec(1)
+    assert s.normA.tolist() == [np.sqrt(1000.0), np.sqrt(4000.0), 40.0, 50.0]
+
+
+# ---- eigen spectra the reference asserts (test/cusolver_test.hpp:60-63,178-182; eig_cpu_test.hpp) ---
+def test_eig_spectra_kat():
+    A4 = np.array([[4, 1, 2, 2], [1, 4, 1, 2], [2, 1, 4, 1], [2, 2, 1, 4]], float)
+    w = np.linalg.eigvalsh(A4)
+    assert np.allclose(w, [1.38197, 2.45862, 3.61803, 8.54138], atol=1e-5)
+    assert np.allclose(w, [0.5 * (5 - 5 ** .5), 0.5 * (11 - 37 ** .5), 0.5 * (5 + 5 ** .5), 0.5 * (11 + 37 ** .5)], atol=1e-12)
+    x = orc.BlockIndex([4]).pack([A4[None]])
+    assert np.allclose(orc.psd_project_svec(orc.BlockIndex([4]), x), x, atol=1e-13)   # A4 is PD
+
+
+# ---- C twin of the kernel arithmetic vs LAPACK ---------------------------------------------------
+@pytest.fixture(scope="module")
+def twin():
+    out = os.path.join(ROOT, "oracle", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libeigproj_twin.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "oracle", "eigproj_twin.c"), "-o", so, "-lm"])
+    return C.CDLL(so)
+
+
+def test_twin_eig_vs_lapack(twin):
+    rng = np.random.default_rng(1)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    for n in [1, 2, 3, 4, 5, 8, 17, 32, 33, 64, 120]:
+        for kind in range(3):
+            A = rng.standard_normal((n, n)); A = (A + A.T) / 2
+            if kind == 1:
+                Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+                A = (Q * np.concatenate([np.zeros(n // 2), np.ones(n - n // 2)])) @ Q.T
+            if kind == 2:
+                A = np.diag(rng.standard_normal(n))
+            Af = np.asfortranarray(A.copy()); W = np.zeros(n)
+            assert twin.twin_eig_dense(P(Af), P(W), n) == 0
+            w = np.linalg.eigvalsh(A)
+            assert np.max(np.abs(W - w)) <= 1e-13 * max(1, np.max(np.abs(w))) * max(1, n / 8)
+            assert np.max(np.abs((Af * W) @ Af.T - A)) <= 1e-12 * max(1, n / 8)
+
+
+def test_twin_projection_vs_oracle(twin):
+    rng = np.random.default_rng(2)
+    blk = np.array([1, 2, 3, 32, 32, 7, 15, 32, 64, 5], dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = rng.standard_normal(int(bidx.off[-1])); out = np.zeros_like(x)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert twin.twin_psd_project(P(x), P(out), P(blk), len(blk)) == 0
+    assert np.max(np.abs(out - orc.psd_project_svec(bidx, x))) <= 1e-13 * 64
+
+
+# ---- trajectory KATs: the shipped console logs ---------------------------------------------------
+def _check_log(lg, p, iters):
+    s = orc.OracleSolver().init_problem(p)
+    info = s.solve(iters, lg["params"]["stop_tol"], 0, 50, 100, lg["params"]["switch_admm"], 1.05)
+    assert ("%2.1e" % s.norm_Corg) == lg["header"]["norm_C"] and ("%2.1e" % s.norm_borg) == lg["header"]["norm_b"]
+    rows = {r[0]: r for r in info.log_rows}
+    checked = 0
+    for row in lg["rows"]:
+        it = int(row[0])
+        if it > iters:
+            continue
+        o = rows[it]
+        got = (orc.LOG_ROW_FMT % (o[0], o[1], o[2], o[3], o[4], o[5], 0.0, o[6]))
+        g = got.split("|"); gnum = g[1].split() + g[2].split() + [g[4].strip()]
+        want = [row[1], row[2], row[3], row[4], row[5], row[7]]
+        for a, b in zip(gnum, want):
+            fb = float(b)
+            if fb != 0 and abs(fb) < 1e-9:
+                continue            # quantities at the roundoff floor (errRp ~1e-15 in sGS) are not digits-stable
+            assert a == b or abs(float(a) - fb) <= 2e-4 * abs(fb), (it, gnum, want)
+        checked += 1
+    assert checked >= 3
+
+
+@pytest.mark.parametrize("key,iters", [("ros_2000/cuADMM", 300), ("ros_2000/sGS", 300), ("rose13/sGS", 300),
+                                       ("cnhil10/sGS", 100), ("PushT_N=10_MOMENT/cuADMM", 100),
+                                       ("PushT_N=10_MOMENT/sGS", 100)])
+def test_oracle_reproduces_shipped_logs(key, iters, ref_logs, problem_dirs):
+    lg = ref_logs[key]
+    p = orc.load_problem_txt(problem_dirs[lg["problem"]])
+    assert (p.vec_len, p.con_num, p.blk.size, p.At_nnz) == (lg["header"]["vec_len"], lg["header"]["con_num"],
+                                                            lg["header"]["mat_num"], lg["header"]["At_nnz"])
+    _check_log(lg, p, iters)
+
+
+@pytest.mark.slow
+def test_oracle_reproduces_pendulum_log(ref_logs):
+    lg = ref_logs["pendulum_N=80/sGS"]
+    p = load_npz_problem("pendulum_N=80")
+    assert (p.vec_len, p.con_num, p.At_nnz) == (131945, 112028, 278569)
+    _check_log(lg, p, 100)
+
+
+def test_synthetic_generator_is_feasible():
+    p = orc.make_synthetic([32] * 20, seed=7)
+    assert p.vec_len == 20 * 528 and p.con_num == 100 and p.At_nnz == 800
+    s = orc.OracleSolver().init_problem(p)
+    s.solve(60, 0.0, 0, 50, 100, 0, 1.05)
+    assert s.errRp < 5e-2 and s.errRd < 5e-2
