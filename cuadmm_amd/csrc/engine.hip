@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <iostream>
@@ -609,6 +610,19 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     if ((rc = s->upload_y())) return rc;
     if ((rc = s->launch_aty(true))) return rc;
     if ((rc = s->launch_project())) return rc;
+    if (getenv("CUADMM_DEBUG_EIG")) {   // developer aid: dump the projection input when a block hits the QL cap
+      int f = s->plan.fail_count(s->st);
+      if (f != s->eig_fail_total) {
+        fprintf(stderr, "[cuadmm debug] iter %d: QL cap hits %d -> %d\n", iter, s->eig_fail_total, f);
+        std::vector<double> h((size_t)L);
+        if (hipMemcpy(h.data(), s->Xb.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost) == hipSuccess) {
+          char fn[256];
+          snprintf(fn, sizeof fn, "%s/xb_fail_iter%d.bin", getenv("CUADMM_DEBUG_EIG"), iter);
+          if (FILE* fp = fopen(fn, "wb")) { fwrite(h.data(), sizeof(double), (size_t)L, fp); fclose(fp); }
+        }
+        s->eig_fail_total = f;
+      }
+    }
 
     double tau = (iter < switch_admm) ? 1.95 : 1.618;                    // solver.cu:747-754
     if (s->errRd < stop_tol) tau = std::max(1.618, tau / 1.1);

@@ -166,6 +166,13 @@ __device__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n
     esh[n - 1] = 0.0;
   }
   Gp::sync();
+  // Deflation threshold relative to the norm of the whole tridiagonal matrix (as EISPACK tql2 does
+  // with its running max): rotations against the largest entries leave absolute noise ~eps*||T||
+  // in every off-diagonal, so on strongly graded / rank-deficient blocks (moment matrices: one
+  // eigenvalue O(1), the rest ~1e-15) a purely local relative test is never met.
+  double tpart = 0.0;
+  for (int r = rank; r < n; r += GS) { const double dv = dsh[r], ev = esh[r]; tpart += dv * dv + 2.0 * ev * ev; }
+  const double eps_abs = sqrt(Gp::sum(tpart, scratch)) * 0x1p-53;
 
   // ---- form Q in place ------------------------------------------------------------------
   if (rank == 0) M[(n - 1) * ld + (n - 1)] = 1.0;
@@ -216,8 +223,9 @@ __device__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n
     if (i < l) {  // start a sweep: find the first negligible off-diagonal at or after l
       m = Gp::first_true(l, n, [&](int idx) {
         if (idx >= n - 1) return true;
-        double dd = fabs(dq[idx]) + fabs(dq[idx + 1]);
-        return fabs(eq[idx]) + dd == dd;
+        const double ae = fabs(eq[idx]);
+        const double dd = fabs(dq[idx]) + fabs(dq[idx + 1]);
+        return ae <= eps_abs || ae + dd == dd;
       });
       if (m >= n) m = n - 1;
       if (m == l) {

@@ -87,12 +87,15 @@ int twin_sym_eig(double* M, int ld, int n, double* d, double* e, double* tau, do
   }
   /* ---- implicit QL ---- */
   int fail = 0;
+  double tn = 0.0; /* deflation threshold relative to ||T||_F (see psd_device.h) */
+  for (r = 0; r < n; ++r) tn += d[r] * d[r] + 2.0 * e[r] * e[r];
+  const double eps_abs = sqrt(tn) * 0x1p-53;
   for (int l = 0; l < n; ++l) {
     int iter = 0, m;
     do {
       for (m = l; m < n - 1; ++m) {
         double dd = fabs(d[m]) + fabs(d[m + 1]);
-        if (fabs(e[m]) + dd == dd) break;
+        if (fabs(e[m]) <= eps_abs || fabs(e[m]) + dd == dd) break;
       }
       if (m != l) {
         if (iter++ == 60) { fail = 1; break; }

@@ -105,6 +105,25 @@ def test_project_edge_inputs():
     assert got[-1] == 0.0 and got[-2] == 2.5
 
 
+@pytest.mark.parametrize("n", [5, 16, 28, 32, 55, 91, 120])
+def test_project_rank_deficient_and_graded(n):
+    """Moment-matrix-like inputs: rank one (one O(1) eigenvalue, the rest at roundoff level), rank two shifted
+    slightly negative, and a spectrum graded over 20 decades -- the cases where a purely local QL
+    deflation test stagnates (seen on PlanarHand_N=1 block 0, n=91, iteration 2)."""
+    rng = np.random.default_rng(n)
+    mats = []
+    v = rng.standard_normal(n); mats.append(np.outer(v, v))
+    u = rng.standard_normal((n, 2)); mats.append(u @ u.T - 1e-9 * np.eye(n))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n))); mats.append((Q * np.logspace(-18, 2, n)) @ Q.T)
+    mats.append(-mats[0])
+    blk = np.full(len(mats), n, dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = bidx.pack([np.stack(mats)])
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(bidx, x)
+    assert np.max(np.abs(got - ref)) <= 1e-13 * n * max(1.0, np.max(np.abs(x)))
+
+
 @pytest.mark.parametrize("n,count", [(2, 5), (3, 4), (4, 3), (6, 100), (10, 33), (16, 17), (32, 64), (45, 5), (105, 2), (200, 1)])
 def test_batch_eig_vs_lapack(n, count):
     rng = np.random.default_rng(n * 1000 + count)

@@ -85,18 +85,22 @@ def test_printed_log_digits(key, iters, ref_logs, problem_dirs):
 
 
 def test_warm_restart_if_first_false(problem_dirs):
-    """solve(K1) then solve(K2, if_first=false) continues the same trajectory as one solve(K1+K2)
-    up to the unscale/rescale roundoff (solver.cu:385-409)."""
+    """solve(K1) then solve(K2, if_first=false) (solver.cu:385-409: the iterate is re-scaled, residual
+    vectors rebuilt, the iteration counter and hence the sigma schedule restart) -- same two calls on the oracle."""
     p = orc.load_problem_txt(problem_dirs["hinf12"])
-    a = _run(p, 30, 11000)
+    o = orc.OracleSolver().init_problem(p)
+    o.solve(12, 0.0, 0, 50, 100, 11000, 1.05)
+    o.solve(18, 0.0, 0, 50, 100, 11000, 1.05, if_first=False)
     b = cuadmm_amd.SDPSolver(verbose=False)
     b.init_problem(problem_to_amd(p))
     b.solve(12, 0.0, 0, 50, 100, 11000, 1.05)
     b.solve(18, 0.0, 0, 50, 100, 11000, 1.05, if_first=False)
-    full = a.info_arr("pobj")
-    two = b.info_arr("pobj")
-    assert two.size == 30
-    assert np.max(np.abs(two - full) / (1e-9 + np.abs(full))) <= 1e-6
+    assert b.info_arr("pobj").size == 30 and b.info_iter_num == 18
+    for nm, ref in (("pobj", o.info.pobj), ("dobj", o.info.dobj), ("errRp", o.info.errRp), ("errRd", o.info.errRd)):
+        _cmp("restart:" + nm, b.info_arr(nm), np.array(ref), rtol=1e-8, atol=1e-11)
+    assert np.array_equal(b.info_arr("sig"), np.array(o.info.sig))
+    assert np.max(np.abs(b.X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))
+    assert np.max(np.abs(b.S - o.S)) <= 1e-8 * (1 + np.max(np.abs(o.S)))
 
 
 def test_init_rejects_bad_input():

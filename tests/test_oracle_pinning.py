@@ -127,6 +127,19 @@ def test_twin_eig_vs_lapack(twin):
             assert np.max(np.abs((Af * W) @ Af.T - A)) <= 1e-12 * max(1, n / 8)
 
 
+def test_twin_rank_deficient_and_graded(twin):
+    rng = np.random.default_rng(4)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    for n in [5, 16, 32, 91, 120]:
+        v = rng.standard_normal(n)
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        for A in (np.outer(v, v), -np.outer(v, v), (Q * np.logspace(-18, 2, n)) @ Q.T):
+            x = orc.BlockIndex([n]).pack([A[None]]); out = np.empty_like(x)
+            assert twin.twin_psd_project_block(P(x), P(out), n) == 0
+            ref = orc.psd_project_svec(orc.BlockIndex([n]), x)
+            assert np.max(np.abs(out - ref)) <= 1e-13 * n * max(1.0, np.abs(A).max())
+
+
 def test_twin_projection_vs_oracle(twin):
     rng = np.random.default_rng(2)
     blk = np.array([1, 2, 3, 32, 32, 7, 15, 32, 64, 5], dtype=np.int32)
