@@ -165,12 +165,13 @@ struct cuadmm_solver {
     if (st) { hipError_t e = hipStreamDestroy(st); (void)e; }
   }
 
+  bool prof_on(int k) const { return profile == 1 || (profile == 2 && k == K_PSD); }
   void prof_begin(int k) {
-    if (!profile || ev_used[k] >= 2) return;
+    if (!prof_on(k) || ev_used[k] >= 2) return;
     hipError_t e = hipEventRecord(ev0[k][ev_used[k]], st); (void)e;
   }
   void prof_end(int k, double bytes) {
-    if (!profile || ev_used[k] >= 2) return;
+    if (!prof_on(k) || ev_used[k] >= 2) return;
     hipError_t e = hipEventRecord(ev1[k][ev_used[k]], st); (void)e;
     ev_used[k]++;
     prof_bytes[k] = bytes;
@@ -186,7 +187,7 @@ struct cuadmm_solver {
     }
   }
   void prof_host(int k, double seconds) {
-    if (!profile) return;
+    if (profile != 1) return;
     prof_ms[k] += seconds * 1e3; prof_count[k] += 1;
   }
 

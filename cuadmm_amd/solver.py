@@ -79,7 +79,7 @@ class SDPSolver:
         self._h = C.c_void_p()
         check(self._lib.cuadmm_create(C.byref(self._h)))
         for k, v in (("device", device), ("verbose", int(bool(verbose))), ("rank", rank), ("world", world),
-                     ("profile", int(bool(profile)))):
+                     ("profile", int(profile))):
             check(self._lib.cuadmm_set_option(self._h, k.encode(), float(v)))
         self._cb = None
         self.vec_len = self.con_num = 0

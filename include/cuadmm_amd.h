@@ -49,7 +49,8 @@ void cuadmm_destroy(cuadmm_solver* s);
  *   "verbose"       1 = print the reference's census + iteration table to stdout (default 1)
  *   "rank","world"  shard blocks by index over `world` engines (default 0,1); see
  *                   cuadmm_set_allreduce
- *   "profile"       1 = time every kernel class with HIP events on the engine stream
+ *   "profile"       1 = time every kernel class with HIP events on the engine stream;
+ *                   2 = time only the dominant kernel (psd_project)
  *   "graph"         reserved
  */
 int cuadmm_set_option(cuadmm_solver* s, const char* key, double value);

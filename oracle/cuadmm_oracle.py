@@ -6,7 +6,7 @@ the body of ``SDPSolver::init`` / ``SDPSolver::solve`` and the helpers it calls.
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py`` may import this module, and only as the checker.
 
-Parity status: PINNED.  ``tests/test_oracle_logs.py`` checks this restatement
+Parity status: PINNED.  ``tests/test_oracle_pinning.py`` checks this restatement
 against the reference's own known answers:
   * unit KATs hard-coded in the reference tests (svec maps, sqrt(2) scaling,
     COO->CSC ordering, eigen spectra, permutation scatter, normA), and
@@ -580,57 +580,3 @@ class OracleSolver:
 
 def format_log_row(row, seconds=0.0):
     return LOG_ROW_FMT % (row[0], row[1], row[2], row[3], row[4], row[5], seconds, row[6])
-
-
-# --------------------------------------------------------------------------------------
-# synthetic problem generators -- shared by tests and bench.py
-# --------------------------------------------------------------------------------------
-def make_synthetic(blk, cons_per_block=5, nnz_per_con=8, seed=20240601, dense_C=True):
-    """Strictly feasible random SDP over the given block sizes.
-
-    Draw order (PCG64, seed): for each size group in blk order: G, H (standard normal);
-    then constraint slots, constraint values, y0.
-    """
-    rng = np.random.Generator(np.random.PCG64(seed))
-    blk = np.asarray(blk, dtype=np.int64)
-    bidx = BlockIndex(blk)
-    nb = blk.size
-    L = int(bidx.off[-1])
-    X0m, S0m = [], []
-    for n, ids, ii, jj, gather in bidx.groups:
-        G = rng.standard_normal((ids.size, n, n))
-        H = rng.standard_normal((ids.size, n, n))
-        X0m.append(G @ np.swapaxes(G, 1, 2) / n + np.eye(n)[None])
-        S0m.append(H @ np.swapaxes(H, 1, 2) / n + np.eye(n)[None])
-    x0 = bidx.pack(X0m)
-    s0 = bidx.pack(S0m)
-    m = cons_per_block * nb
-    seglen = blk * (blk + 1) // 2
-    con_blk = np.arange(m) % nb
-    r_eff = np.minimum(nnz_per_con, seglen[con_blk])
-    rows_l, cols_l, vals_l = [], [], []
-    # distinct slots per constraint: argsort of uniforms, first r entries
-    for r in sorted(set(int(x) for x in r_eff)):
-        cons = np.nonzero(r_eff == r)[0]
-        for sl in sorted(set(int(x) for x in seglen[con_blk[cons]])):
-            cc = cons[seglen[con_blk[cons]] == sl]
-            u = rng.random((cc.size, sl))
-            slots = np.argsort(u, axis=1)[:, :r]
-            rows_l.append((bidx.off[con_blk[cc]][:, None] + slots).ravel())
-            cols_l.append(np.repeat(cc, r))
-            vals_l.append(rng.standard_normal(cc.size * r))
-    rows = np.concatenate(rows_l).astype(np.int32)
-    cols = np.concatenate(cols_l).astype(np.int32)
-    vals = np.concatenate(vals_l)
-    cp, ri, v = coo_to_csc(cols, rows, vals, m)
-    At = sp.csc_matrix((v, ri, cp), shape=(L, m))
-    y0 = rng.standard_normal(m)
-    b = At.T @ x0
-    if dense_C:
-        C = s0 + At @ y0
-    else:
-        eye_svec = bidx.pack([np.broadcast_to(np.eye(n), (ids.size, n, n)) for n, ids, *_ in bidx.groups])
-        C = At @ y0 + eye_svec
-    b_idx = np.nonzero(b)[0].astype(np.int32)
-    C_idx = np.nonzero(C)[0].astype(np.int32)
-    return Problem(L, m, blk.astype(np.int32), cp, ri, v, b_idx, b[b_idx], C_idx, C[C_idx])

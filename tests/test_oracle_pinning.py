@@ -194,8 +194,10 @@ def test_oracle_reproduces_pendulum_log(ref_logs):
 
 
 def test_synthetic_generator_is_feasible():
-    p = orc.make_synthetic([32] * 20, seed=7)
+    from cuadmm_amd.synthetic import make_synthetic
+    p = make_synthetic([32] * 20, seed=7)
     assert p.vec_len == 20 * 528 and p.con_num == 100 and p.At_nnz == 800
     s = orc.OracleSolver().init_problem(p)
     s.solve(60, 0.0, 0, 50, 100, 0, 1.05)
+    print(s.errRp, s.errRd)
     assert s.errRp < 5e-2 and s.errRd < 5e-2
