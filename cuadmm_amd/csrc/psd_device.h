@@ -28,6 +28,29 @@ __device__ __forceinline__ void wave_fence() {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// sqrt(h) and 1/sqrt(h) together from one v_rsq_f64 + two Goldschmidt steps (h > 0, normal range).
+// ~1-2 ulp; replaces an IEEE sqrt followed by an IEEE divide (about 45 dependent instructions) on the
+// serial critical path of the QL recurrence.
+__device__ __forceinline__ void fast_sqrt_rsqrt(double h, double& root, double& inv_root) {
+  const double y = __builtin_amdgcn_rsq(h);
+  double g = h * y, hh = 0.5 * y;
+  double r = fma(-hh, g, 0.5);
+  g = fma(g, r, g); hh = fma(hh, r, hh);
+  r = fma(-hh, g, 0.5);
+  g = fma(g, r, g); hh = fma(hh, r, hh);
+  root = g;
+  inv_root = hh + hh;
+}
+
+// 1/x from v_rcp_f64 + two Newton steps (x finite, non-zero, normal range); ~1 ulp
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
 // svec slot e (0-based, within a block) -> (col i, row j), j<=i, e = i(i+1)/2 + j
 __device__ __forceinline__ void tri_decode(int e, int& i, int& j) {
   int t = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);

@@ -12,11 +12,14 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "device_util.h"
 #include "psd_device.h"
 #include "psd_plan.h"
+#include "psd_small_reg.h"
 
 namespace cuadmm {
 
@@ -32,6 +35,7 @@ struct PsdArgs {
   int n_uniform;           // MODE 1
   double* workspace;       // GLOBAL variant
   const long long* ws_off; // GLOBAL variant: workspace offset per member
+  long long* dbg;          // developer aid: per-workgroup phase timestamps (CUADMM_PSD_DEBUG)
 };
 
 template <int LPB, int MODE>
@@ -95,6 +99,17 @@ __global__ __launch_bounds__(64) void psd_small_kernel(PsdArgs a) {
   } else {
     write_sorted_eig<Gp>(M, LD, n, d, a.out + (long long)bi * n * n, a.Wout + (long long)bi * n);
     if (Gp::rank() == 0 && a.info) a.info[bi] = fail;
+  }
+}
+
+// register-resident variant (psd_small_reg.h): the production path for n <= 32
+template <int NMAX, int MODE>
+__global__ __launch_bounds__(64) void psd_small_reg_kernel(PsdArgs a) {
+  __shared__ double smem[(64 / NMAX) * RegLayout<NMAX>::kPer];
+  psd_small_reg_body<NMAX, MODE>(a, smem);
+  if (MODE == 0) {
+    wave_fence();
+    psd_small_reg_store<NMAX>(a, smem);
   }
 }
 
@@ -248,9 +263,26 @@ static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
   return CUADMM_OK;
 }
 
+// CUADMM_PSD_SMALL=lds selects the LDS-resident small-block kernel (kept for A/B measurements)
+static bool use_reg_kernel() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CUADMM_PSD_SMALL"); v = (e && std::string(e) == "lds") ? 0 : 1; }
+  return v == 1;
+}
+
 template <int MODE>
 static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
   if (a.count <= 0) return CUADMM_OK;
+  if (c <= 3 && use_reg_kernel()) {
+    switch (c) {
+      case 0: hipLaunchKernelGGL((psd_small_reg_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
+      case 1: hipLaunchKernelGGL((psd_small_reg_kernel<8, MODE>), dim3((a.count + 7) / 8), dim3(64), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((psd_small_reg_kernel<16, MODE>), dim3((a.count + 3) / 4), dim3(64), 0, st, a); break;
+      default: hipLaunchKernelGGL((psd_small_reg_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
+    }
+    CUADMM_HIP_TRY(hipGetLastError());
+    return CUADMM_OK;
+  }
   switch (c) {
     case 0: hipLaunchKernelGGL((psd_small_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
     case 1: hipLaunchKernelGGL((psd_small_kernel<8, MODE>), dim3((a.count + 7) / 8), dim3(64), 0, st, a); break;
@@ -277,8 +309,31 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
     a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff;
+    long long* dbg = nullptr;
+    const int nwg = (cls_count[c] + 1) / 2;
+    if (c == 3 && getenv("CUADMM_PSD_DEBUG")) {
+      CUADMM_HIP_TRY(hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)nwg));
+      CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));
+      a.dbg = dbg;
+    }
     int rc = launch_class<0>(c, a, cls_maxn[c], st);
     if (rc) return rc;
+    if (dbg) {
+      std::vector<long long> h((size_t)nwg * 8);
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      CUADMM_HIP_TRY(hipMemcpy(h.data(), dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      double ph[6] = {0, 0, 0, 0, 0, 0}, its = 0, slots = 0;
+      long long tmin = h[0], tmax = 0;
+      for (int w = 0; w < nwg; ++w) {
+        for (int i = 0; i < 5; ++i) ph[i] += (double)(h[w * 8 + i + 1] - h[w * 8 + i]);
+        tmin = std::min(tmin, h[w * 8]); tmax = std::max(tmax, h[w * 8 + 5]);
+        its += (double)h[w * 8 + 6]; slots += (double)h[w * 8 + 7];
+      }
+      fprintf(stderr, "[psd debug] %d waves: cycles/wave load %.0f tridiag %.0f ql %.0f rebuild %.0f store %.0f | span %lld cycles\n",
+              nwg, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, tmax - tmin);
+      (void)its; (void)slots;
+      hipFree(dbg);
+    }
   }
   return CUADMM_OK;
 }
