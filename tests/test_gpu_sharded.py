@@ -1,0 +1,91 @@
+"""Block-sharded engine (world=2) on ONE GPU: two engines in two host threads, the all-reduce hook
+implemented through a host staging buffer.  Checks the sharding arithmetic of SURVEY.md section 8e
+(contiguous block ranges, partial A*v summed before the replicated host solve) against the
+single-engine run.  The RCCL transport itself is exercised by bench.py --gpus N on multi-GPU nodes."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import cuadmm_amd
+from cuadmm_amd._lib import check
+from cuadmm_amd.synthetic import make_synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _amd(p):
+    return cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals,
+                              p.b_idx, p.b_vals, p.C_idx, p.C_vals)
+
+
+class HostAllReduce:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.bufs = [None] * world
+        self.lib = cuadmm_amd.load()
+
+    def hook(self, rank):
+        def fn(ptr, count, stream):
+            check(self.lib.cuadmm_dev_sync())
+            mine = np.empty(count)
+            check(self.lib.cuadmm_memcpy_d2h(mine.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), count * 8))
+            self.bufs[rank] = mine
+            self.barrier.wait()
+            total = np.zeros(count)
+            for r in range(self.world):            # fixed order: every rank gets bit-identical sums
+                total += self.bufs[r]
+            self.barrier.wait()
+            check(self.lib.cuadmm_memcpy_h2d(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), count * 8))
+        return fn
+
+
+@pytest.mark.parametrize("sw,iters", [(0, 25), (10 ** 9, 12), (8, 20)])
+def test_two_shards_match_single_engine(sw, iters):
+    blk = [32] * 40 + [7] * 30 + [15] * 21 + [40, 3, 3, 28]
+    rng = np.random.default_rng(2)
+    blk = list(np.array(blk)[rng.permutation(len(blk))])
+    p = make_synthetic(blk, cons_per_block=3, seed=11)
+    ref = cuadmm_amd.SDPSolver(verbose=False)
+    ref.init_problem(_amd(p))
+    ref.solve(iters, 0.0, 0, 50, 100, sw, 1.05)
+
+    world = 2
+    ar = HostAllReduce(world)
+    solvers = [cuadmm_amd.SDPSolver(verbose=False, rank=r, world=world) for r in range(world)]
+    errs = []
+
+    def run(r):
+        try:
+            solvers[r].set_allreduce(ar.hook(r))
+            solvers[r].init_problem(_amd(p))
+            solvers[r].solve(iters, 0.0, 0, 50, 100, sw, 1.05)
+        except Exception as e:          # pragma: no cover
+            errs.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    shards = [s.shard() for s in solvers]
+    assert shards[0][0] == 0 and shards[0][1] == shards[1][0] and shards[1][1] == p.vec_len
+    assert shards[0][3] == shards[1][2] and 0 < shards[0][3] < len(blk)
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig"):
+        a, b0, b1 = ref.info_arr(nm), solvers[0].info_arr(nm), solvers[1].info_arr(nm)
+        assert np.array_equal(b0, b1), nm                                   # replicated host state is identical
+        assert np.max(np.abs(a - b0) / (1e-12 + np.abs(a))) <= 1e-9, nm     # only the summation order differs
+    X = np.concatenate([s.X for s in solvers])
+    S = np.concatenate([s.S for s in solvers])
+    assert np.max(np.abs(X - ref.X)) <= 1e-9 * (1 + np.max(np.abs(ref.X)))
+    assert np.max(np.abs(S - ref.S)) <= 1e-9 * (1 + np.max(np.abs(ref.S)))
+    assert np.max(np.abs(solvers[0].y - ref.y)) <= 1e-8 * (1 + np.max(np.abs(ref.y)))
+
+
+def test_world_without_hook_is_an_error():
+    p = make_synthetic([8] * 6, seed=1)
+    s = cuadmm_amd.SDPSolver(verbose=False, rank=0, world=2)
+    with pytest.raises(cuadmm_amd.CuadmmError) as e:
+        s.init_problem(_amd(p))
+    assert e.value.code == -6
