@@ -196,29 +196,32 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
 #pragma unroll
     for (int i = NMAX - 2; i >= 0; --i) {
       if (i < m && i >= l && !broke) {
+        // straight-line fast path; the textbook's r == 0 underflow recovery is a rare branch at the end
         double e_n = 0.0, d_n = 0.0;
         if (i > 0) { e_n = E[i - 1]; d_n = D[i - 1]; }          // prefetch for slot i-1 (not yet touched this sweep)
         const double f = s * e_c, b = c * e_c;
         const double h = fma(f, f, gq * gq);
-        if (h == 0.0) {                                            // underflow recovery of the textbook recurrence
-          if (writer) { E[i + 1] = 0.0; D[i + 1] = d1_c - p; E[m] = 0.0; }
+        const bool hz = (h == 0.0);
+        double rr, rinv;
+        fast_sqrt_rsqrt(hz ? 1.0 : h, rr, rinv);
+        const double p_old = p;
+        s = f * rinv; c = gq * rinv;
+        gq = d1_c - p;
+        const double cb = c * b;
+        const double r2 = fma(d_c - gq, s, cb + cb);
+        p = s * r2;
+        const double dnew = gq + p;
+        gq = fma(c, r2, -b);
+        const double z0 = q[i], z1 = q[i + 1];
+        q[i + 1] = fma(s, z0, c * z1);
+        q[i] = fma(c, z0, -(s * z1));
+        if (writer) { E[i + 1] = rr; D[i + 1] = dnew; }
+        if (hz) {                                                  // f == g == 0: s = c = 0 above, Z columns must be restored
+          q[i + 1] = z1; q[i] = z0;
+          if (writer) { E[i + 1] = 0.0; D[i + 1] = d1_c - p_old; E[m] = 0.0; }
           broke = true;
-        } else {
-          double rr, rinv;
-          fast_sqrt_rsqrt(h, rr, rinv);
-          if (writer) E[i + 1] = rr;
-          s = f * rinv; c = gq * rinv;
-          gq = d1_c - p;
-          const double cb = c * b;
-          const double r2 = fma(d_c - gq, s, cb + cb);
-          p = s * r2;
-          if (writer) D[i + 1] = gq + p;
-          gq = fma(c, r2, -b);
-          const double z0 = q[i], z1 = q[i + 1];
-          q[i + 1] = fma(s, z0, c * z1);
-          q[i] = fma(c, z0, -(s * z1));
-          d1_c = d_c; e_c = e_n; d_c = d_n;
         }
+        d1_c = d_c; e_c = e_n; d_c = d_n;
       }
     }
     if (!broke && writer) { D[l] = D[l] - p; E[l] = gq; E[m] = 0.0; }

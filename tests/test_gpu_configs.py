@@ -1,0 +1,72 @@
+"""BASELINE.json configurations other than the bench line, as parity-test cases.
+
+C3 max-cut (single large block, k=2 formulation examples/max-cut/genMAXCUT.m:28-31) at a size the oracle
+finishes in seconds; C4 mixed moment-SOS sizes {3,6,10,15,28,45}; C5 pendulum N=80 (recovered inputs) vs its log."""
+import numpy as np
+import pytest
+
+import cuadmm_amd
+from cuadmm_amd.synthetic import config_c4
+from oracle import cuadmm_oracle as orc
+from tests.conftest import load_npz_problem
+from tests.helpers import problem_to_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _maxcut_problem(n, p_edge, seed):
+    rng = np.random.default_rng(seed)
+    W = np.triu((rng.random((n, n)) < p_edge).astype(float), 1)
+    W = W + W.T
+    Lg = np.diag(W.sum(1)) - W
+    Cm = -0.25 * Lg
+    bidx = orc.BlockIndex([n])
+    c = bidx.pack([Cm[None]])
+    c_idx = np.nonzero(c)[0].astype(np.int32)
+    diag_slots = np.array([i * (i + 1) // 2 + i for i in range(n)], dtype=np.int32)     # X_ii = 1
+    cp = np.arange(n + 1, dtype=np.int32)
+    return orc.Problem(n * (n + 1) // 2, n, np.array([n], np.int32), cp, diag_slots, np.ones(n),
+                       np.arange(n, dtype=np.int32), np.ones(n), c_idx, c[c_idx])
+
+
+def _compare(p, iters, sw, rtol=1e-8):
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.init_problem(problem_to_amd(p))
+    s.solve(iters, 0.0, 0, 50, 100, sw, 1.05)
+    o = orc.OracleSolver().init_problem(p)
+    info = o.solve(iters, 0.0, 0, 50, 100, sw, 1.05)
+    for nm, ref in (("errRp", info.errRp), ("errRd", info.errRd), ("pobj", info.pobj), ("dobj", info.dobj)):
+        got, ref = s.info_arr(nm), np.array(ref)
+        assert np.max(np.abs(got - ref) / (1e-9 + np.abs(ref))) <= rtol, nm
+    assert np.max(np.abs(s.X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))
+    return s, o
+
+
+def test_c3_maxcut_single_large_block_lds_path():
+    _compare(_maxcut_problem(120, 0.1, 1), 25, 10 ** 9)
+
+
+def test_c3_maxcut_single_large_block_hbm_path():
+    _compare(_maxcut_problem(200, 0.05, 2), 12, 10 ** 9)
+
+
+def test_c4_mixed_moment_sos_sizes():
+    p = config_c4(n_blocks=600, seed=3)
+    assert sorted(set(p.blk.tolist())) == [3, 6, 10, 15, 28, 45]
+    _compare(p, 20, 0)
+    _compare(p, 10, 10 ** 9)
+
+
+def test_c5_pendulum_first_log_rows(ref_logs):
+    """examples/pendulum/N=80_licols.log rows at it 50 and 100 (inputs rebuilt from the shipped .mat)."""
+    lg = ref_logs["pendulum_N=80/sGS"]
+    p = load_npz_problem("pendulum_N=80")
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.init_problem(problem_to_amd(p))
+    s.solve(100, 1e-3, 0, 50, 100, 11000, 1.05)
+    for row in lg["rows"]:
+        it = int(row[0])
+        if it in (50, 100):
+            got = [s.info_arr(n)[it - 1] for n in ("errRp", "errRd", "pobj", "dobj", "relgap")]
+            for g, w in zip(got, [float(x) for x in row[1:6]]):
+                assert abs(g - w) <= 6e-3 * abs(w) + 1e-12, (it, got, row)

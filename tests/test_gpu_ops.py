@@ -1,0 +1,157 @@
+"""GPU parity of the op-level entry points, one per reference kernel / library wrapper,
+against the oracle and the reference's own unit-test vectors.  Integer/index work is bit-exact."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cuadmm_amd
+from cuadmm_amd._lib import check
+from oracle import cuadmm_oracle as orc
+from tests.conftest import GOLDEN
+from tests.helpers import Dev
+
+pytestmark = pytest.mark.gpu
+lib = cuadmm_amd.load()
+
+
+def test_matrices_to_vector_reference_kat():
+    # test/kernels_test.hpp:224-308
+    mom = np.array([1, 2, 3, 4, 2, 5, 6, 7, 3, 6, 8, 9, 4, 7, 9, 10], float)
+    loc = np.array([2, 3, 4, 5, 3, 6, 7, 8, 4, 7, 9, 10, 5, 8, 10, 11], float)
+    m1 = [0, 1, 2, 3, 5, 6, 7, 10, 11, 15]; m2 = [0, 4, 8, 12, 5, 9, 13, 10, 14, 15]
+    mB = np.array([0] * 10 + [1] * 10, np.int32); M1 = np.array(m1 + m1, np.int32); M2 = np.array(m2 + m2, np.int32)
+    dX = Dev(shape=(20,)); dm, dl = Dev(mom), Dev(loc)
+    dB, d1, d2 = Dev(mB), Dev(M1), Dev(M2)
+    check(lib.cuadmm_op_matrices_to_vector(dX.ptr, dm.ptr, dl.ptr, dB.ptr, d1.ptr, d2.ptr, 20, None))
+    s = orc.SQRT2
+    want = [1, 2 * s, 3 * s, 4 * s, 5, 6 * s, 7 * s, 8, 9 * s, 10, 2, 3 * s, 4 * s, 5 * s, 6, 7 * s, 8 * s, 9, 10 * s, 11]
+    assert dX.get().tolist() == want                                   # EXPECT_EQ in the reference: bit exact
+
+
+@pytest.mark.parametrize("blk", [[2, 4], [1, 2, 3, 4], [6] * 50 + [4], [7, 10, 28, 55, 3, 28, 120]])
+def test_vec_mat_roundtrip_with_reference_maps(blk):
+    """vector_to_matrices -> matrices_to_vector with the maps of get_maps (bit-exact vs the oracle)."""
+    blk = np.array(blk, np.int32)
+    L = int(orc.svec_block_offsets(blk)[-1])
+    mB, m1, m2 = (np.zeros(L, np.int32) for _ in range(3))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.cuadmm_get_maps(P(blk), blk.size, L, P(mB), P(m1), P(m2)))
+    sizes, nums = orc.analyze_blk(blk)
+    ms = orc.MatrixSizes(sizes, nums)
+    x = np.random.default_rng(0).standard_normal(L)
+    lg, smm = np.zeros(max(ms.total_large_mat_size, 1)), np.zeros(max(ms.total_small_mat_size, 1))
+    orc.vector_to_matrices(x, lg, smm, mB, m1, m2)
+    dx, dlg, dsm = Dev(x), Dev(np.zeros_like(lg)), Dev(np.zeros_like(smm))
+    dB, d1, d2 = Dev(mB), Dev(m1), Dev(m2)
+    check(lib.cuadmm_op_vector_to_matrices(dx.ptr, dlg.ptr, dsm.ptr, dB.ptr, d1.ptr, d2.ptr, L, None))
+    assert np.array_equal(dlg.get(), lg) and np.array_equal(dsm.get(), smm)
+    dback = Dev(shape=(L,))
+    check(lib.cuadmm_op_matrices_to_vector(dback.ptr, dlg.ptr, dsm.ptr, dB.ptr, d1.ptr, d2.ptr, L, None))
+    assert np.array_equal(dback.get(), orc.matrices_to_vector(lg, smm, mB, m1, m2))
+    assert np.max(np.abs(dback.get() - x)) <= 4e-16 * np.max(np.abs(x))     # sqrt2*sqrt2inv round trip
+
+
+def test_permutation_scatter_kat():
+    # test/kernels_test.hpp:4-33: v1[perm[i]] = v2[i]
+    v2 = np.arange(10, dtype=float); perm = np.array([6, 4, 1, 3, 0, 5, 2, 8, 7, 9], np.int32)
+    d1, d2, dp = Dev(np.zeros(10)), Dev(v2), Dev(perm)
+    check(lib.cuadmm_op_permute(d1.ptr, d2.ptr, dp.ptr, 10, None))
+    out = d1.get()
+    assert all(out[perm[i]] == v2[i] for i in range(10))
+
+
+def test_normA_kat():
+    # test/kernels_test.hpp:35-83 with test/data/sparse_matrix_coo.txt
+    r, c, v = orc.read_coo(os.path.join(GOLDEN, "io", "sparse_matrix_coo.txt"))
+    cp, ri, vv = orc.coo_to_csc(c, r, v, 4)
+    dcp, dv, dn = Dev(cp), Dev(vv), Dev(shape=(4,))
+    check(lib.cuadmm_op_get_normA(dcp.ptr, dv.ptr, dn.ptr, 4, None))
+    assert dn.get().tolist() == [np.sqrt(1000.0), np.sqrt(4000.0), 40.0, 50.0]
+    assert np.allclose(dv.get(), [10 / np.sqrt(1000), 30 / np.sqrt(1000), 20 / np.sqrt(4000), 60 / np.sqrt(4000), 1, 1], rtol=1e-15)
+
+
+def test_max_zero_and_mul_diag_batch():
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal(1000)
+    dw = Dev(w)
+    check(lib.cuadmm_op_max_zero(dw.ptr, 1000, None))
+    assert np.array_equal(dw.get(), np.maximum(w, 0.0))
+    n, cnt = 5, 7                                                        # diagonal_batch.cu:11-23: scales COLUMN j
+    V = rng.standard_normal((cnt, n, n)); lam = rng.standard_normal((cnt, n))
+    colmajor = np.ascontiguousarray(np.swapaxes(V, 1, 2))
+    din, dout, dl = Dev(colmajor), Dev(shape=(cnt, n, n)), Dev(lam)
+    check(lib.cuadmm_op_mul_diag_batch(dout.ptr, din.ptr, dl.ptr, n, cnt, None))
+    got = np.swapaxes(dout.get(), 1, 2)
+    assert np.array_equal(got, V * lam[:, None, :])
+
+
+@pytest.mark.parametrize("n,cnt", [(2, 3), (16, 5), (32, 40), (45, 3), (100, 2), (7, 11)])
+def test_mul_trans_batch_mfma(n, cnt):
+    """P = T * V^T on the fp64 matrix cores (cublasDgemmStridedBatched(N,T), cublas.h:18-35), asymmetric inputs."""
+    rng = np.random.default_rng(n)
+    T = rng.standard_normal((cnt, n, n)); V = rng.standard_normal((cnt, n, n))
+    cm = lambda a: np.ascontiguousarray(np.swapaxes(a, 1, 2))
+    dT, dV, dP = Dev(cm(T)), Dev(cm(V)), Dev(shape=(cnt, n, n))
+    check(lib.cuadmm_op_mul_trans_batch(dP.ptr, dT.ptr, dV.ptr, n, cnt, None))
+    got = np.swapaxes(dP.get(), 1, 2)
+    ref = T @ np.swapaxes(V, 1, 2)
+    assert np.max(np.abs(got - ref)) <= 1e-13 * n * max(1, np.abs(ref).max())
+    if n == 2:                                                            # test/cublas_test.hpp:3-40 style: M*M^T
+        M = np.array([[1.0, 2.0], [3.0, 4.0]])
+        dM, dQ = Dev(cm(M[None])), Dev(shape=(1, 2, 2))
+        check(lib.cuadmm_op_mul_trans_batch(dQ.ptr, dM.ptr, dM.ptr, 2, 1, None))
+        assert np.array_equal(np.swapaxes(dQ.get(), 1, 2)[0], M @ M.T)
+
+
+def test_spmv_csr_and_axpby_and_norm():
+    rng = np.random.default_rng(3)
+    A = sp.random(300, 500, density=0.03, random_state=4, format="csr")
+    x, y = rng.standard_normal(500), rng.standard_normal(300)
+    drp, dci, dv = Dev(A.indptr.astype(np.int32)), Dev(A.indices.astype(np.int32)), Dev(A.data)
+    dx, dy = Dev(x), Dev(y)
+    check(lib.cuadmm_op_spmv_csr(300, drp.ptr, dci.ptr, dv.ptr, dx.ptr, dy.ptr, -1.0, 0.0, None))   # solver.cu:478
+    assert np.max(np.abs(dy.get() + A @ x)) <= 1e-13
+    dy = Dev(y)
+    check(lib.cuadmm_op_spmv_csr(300, drp.ptr, dci.ptr, dv.ptr, dx.ptr, dy.ptr, 2.0, 0.5, None))
+    assert np.max(np.abs(dy.get() - (2 * (A @ x) + 0.5 * y))) <= 1e-13
+    a, b = rng.standard_normal(10001), rng.standard_normal(10001)
+    da, db = Dev(a), Dev(b)
+    check(lib.cuadmm_op_axpby2(da.ptr, db.ptr, 1.0, 0.7, a.size, None))          # X = X + tau*sig*Rd, solver.cu:758
+    assert np.max(np.abs(da.get() - (a + 0.7 * b))) <= 1e-15 * 4
+    dc = Dev(shape=(a.size,))
+    check(lib.cuadmm_op_axpby3(dc.ptr, da.ptr, db.ptr, 0.25, -1.0, a.size, None))  # S = Xdiff/sig - Rd1, solver.cu:656
+    assert np.max(np.abs(dc.get() - (0.25 * da.get() - b))) <= 1e-15 * 4
+    nrm = C.c_double()
+    check(lib.cuadmm_op_norm2(db.ptr, b.size, C.byref(nrm), None))
+    assert abs(nrm.value - np.linalg.norm(b)) <= 1e-13 * np.linalg.norm(b)
+
+
+def test_cli_matches_engine_and_reference_format(problem_dirs, ref_logs):
+    """cuadmm_exe <dir/> (src/main.cu:8-44): console census/table and X_opt.txt."""
+    exe = os.path.join(os.path.dirname(cuadmm_amd.LIB_PATH), "cuadmm_exe")
+    d = problem_dirs["hinf12"]
+    r = subprocess.run([exe, d, "--max_iter=60", "--switch_admm=5000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "Loaded problem from " + d in out and "Analysis of the blk vector:" in out
+    assert "  it. | p infeas d infeas | primal obj.   dual obj. rel. gap |  time |   sigma | " in out
+    assert "Solver ended: maximum iteration reached" in out and "time per iteration" in out
+    rows = [ln for ln in out.splitlines() if ln.startswith("    0 |") or ln.startswith("   50 |") or ln.startswith("   60 |")]
+    assert len(rows) == 3
+    p = orc.load_problem_txt(d)
+    o = orc.OracleSolver().init_problem(p)
+    o.solve(60, 1e-3, 0, 50, 100, 5000, 1.05)
+    want50 = orc.LOG_ROW_FMT % (50, o.info.errRp[49], o.info.errRd[49], o.info.pobj[49], o.info.dobj[49], o.info.relgap[49], 0.0, o.info.sig[49])
+    got = [ln for ln in rows if ln.startswith("   50 |")][0]
+    assert got.split("|")[1:3] == want50.split("|")[1:3] and got.split("|")[4] == want50.split("|")[4]
+    X = np.array([float(x) for x in open(d + "X_opt.txt").read().split()])
+    assert X.size == p.vec_len and np.max(np.abs(X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))
+    first = open(d + "X_opt.txt").readline().rstrip("\n")
+    assert len(first.split(".")[1]) == 32                                           # "%.32f"
+    # unreadable directory -> exit(1) like the reference (io.cu:30-33)
+    r2 = subprocess.run([exe, "/nonexistent/"], capture_output=True, text=True)
+    assert r2.returncode == 1
