@@ -109,6 +109,11 @@ __global__ __launch_bounds__(64) void psd_small_reg_kernel(PsdArgs a) {
   psd_small_reg_body<NMAX, MODE>(a, smem);
   if (MODE == 0) {
     wave_fence();
+    if constexpr (NMAX >= 16) {
+      const long long t0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+      psd_small_reg_rebuild_mfma<NMAX>(a, smem);
+      if (a.dbg && lane_id() == 0) a.dbg[(long long)blockIdx.x * 8 + 6] = (long long)__builtin_readcyclecounter() - t0;
+    }
     psd_small_reg_store<NMAX>(a, smem);
   }
 }
@@ -329,9 +334,10 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
         tmin = std::min(tmin, h[w * 8]); tmax = std::max(tmax, h[w * 8 + 5]);
         its += (double)h[w * 8 + 6]; slots += (double)h[w * 8 + 7];
       }
-      fprintf(stderr, "[psd debug] %d waves: cycles/wave load %.0f tridiag %.0f ql %.0f rebuild %.0f store %.0f | span %lld cycles\n",
-              nwg, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, tmax - tmin);
-      (void)its; (void)slots;
+      // MFMA utilisation of the rebuild: 2 blocks x 3 upper tiles x 8 k-steps x 64 cycles per v_mfma_f64_16x16x4
+      fprintf(stderr, "[psd debug] %d waves: cycles/wave load %.0f tridiag %.0f ql %.0f handoff %.0f tail %.0f | mfma rebuild %.0f cycles/wave -> MFMA busy %.1f%%\n",
+              nwg, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, its / nwg, 100.0 * (2 * 3 * 8 * 64.0) / (its / nwg));
+      (void)slots; (void)tmin; (void)tmax;
       hipFree(dbg);
     }
   }

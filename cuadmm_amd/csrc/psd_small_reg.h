@@ -231,20 +231,27 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
   CUADMM_STAMP(3);
   // ---- output ------------------------------------------------------------------------------------------
   if (MODE == 0) {
-    // T = Z * diag(max(d,0))   (dense_scalar.cu:41-47, diagonal_batch.cu:11-23)
+    if constexpr (NMAX >= 16) {
+      // hand Z (unscaled) and max(d,0) to the matrix-core rebuild that follows (psd_small_reg_rebuild_mfma)
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      const double lam = (k < n) ? D[k] : 0.0;
-      T[rank * LD + k] = q[k] * (lam > 0.0 ? lam : 0.0);
-    }
-    wave_fence();
-    // P = T * Z^T, upper triangle, row a at a time; row a of T is dead once it has been used
-    for (int aa = 0; aa < n; ++aa) {
-      const double* ta = T + aa * LD;
-      double acc0 = 0.0, acc1 = 0.0;
+      for (int k = 0; k < NMAX; ++k) T[rank * LD + k] = q[k];
+      { const double lam = rank < n ? D[rank] : 0.0; vv[rank] = lam > 0.0 ? lam : 0.0; }   // dense_scalar.cu:41-47
+    } else {
+      // T = Z * diag(max(d,0))   (dense_scalar.cu:41-47, diagonal_batch.cu:11-23)
 #pragma unroll
-      for (int k = 0; k < NMAX; k += 2) { acc0 += ta[k] * q[k]; acc1 += ta[k + 1] * q[k + 1]; }
-      T[aa * LD + rank] = acc0 + acc1;                      // P[aa][rank]
+      for (int k = 0; k < NMAX; ++k) {
+        const double lam = (k < n) ? D[k] : 0.0;
+        T[rank * LD + k] = q[k] * (lam > 0.0 ? lam : 0.0);
+      }
+      wave_fence();
+      // P = T * Z^T, upper triangle, row a at a time; row a of T is dead once it has been used
+      for (int aa = 0; aa < n; ++aa) {
+        const double* ta = T + aa * LD;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NMAX; k += 2) { acc0 += ta[k] * q[k]; acc1 += ta[k + 1] * q[k + 1]; }
+        T[aa * LD + rank] = acc0 + acc1;                      // P[aa][rank]
+      }
     }
     wave_fence();
     if (fail && rank == 0 && a.info) atomicAdd(a.info, 1);
@@ -273,6 +280,55 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
   CUADMM_STAMP(4);
   }  // slot < count
 #undef CUADMM_STAMP
+}
+
+// P = (Z diag(l+)) Z^T on the fp64 matrix cores for the blocks of one wavefront (NMAX = 16 or 32), executed
+// by the whole wavefront in uniform control flow after every group has left the eigen-solver.
+// v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the four results of
+// a lane are D[row = (l>>4) + 4*reg][col = l&15].  A = Z*diag(l+) is formed on the fly from the LDS tile
+// (the reference's diagonal_batch.cu:11-23 + cublas.h:18-35 in one step).  Only the tiles of the upper
+// triangle are computed (svec stores the upper triangle).
+typedef double psd_v4f64 __attribute__((ext_vector_type(4)));
+template <int NMAX, class Args>
+__device__ __forceinline__ void psd_small_reg_rebuild_mfma(const Args& a, double* smem) {
+  using Lay = RegLayout<NMAX>;
+  constexpr int LD = Lay::LD;
+  constexpr int BPW = 64 / NMAX;
+  constexpr int NT = NMAX >= 16 ? NMAX / 16 : 1;  // tiles per dimension
+  const int lane = lane_id();
+  const int slot0 = (int)blockIdx.x * BPW;
+  const int r16 = lane & 15, kk = lane >> 4;
+  for (int gg = 0; gg < BPW; ++gg) {
+    if (slot0 + gg >= a.count) break;
+    double* T = smem + gg * Lay::kPer;
+    const double* lam = T + Lay::kTile;         // vv: max(d,0)
+    psd_v4f64 acc[NT * (NT + 1) / 2];
+#pragma unroll
+    for (int t = 0; t < NT * (NT + 1) / 2; ++t) acc[t] = psd_v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < NMAX; k0 += 4) {
+      const int k = k0 + kk;
+      const double lk = lam[k];
+      double zf[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) zf[t] = T[(16 * t + r16) * LD + k];
+      int idx = 0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < NT; ++tj, ++idx)
+          acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[ti] * lk, zf[tj], acc[idx], 0, 0, 0);
+    }
+    wave_fence();                               // every lane has finished reading Z
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < NT; ++tj, ++idx)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * ti + kk + 4 * r) * LD + 16 * tj + r16] = acc[idx][r];
+  }
+  wave_fence();
 }
 
 // store phase, executed by the whole wavefront after every group has finished
