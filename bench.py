@@ -97,6 +97,20 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
+    # CUADMM_BENCH_FORCE_DIST=1 exercises the torch.distributed/RCCL hook with a single rank (transport check)
+    force_dist = os.environ.get("CUADMM_BENCH_FORCE_DIST") == "1"
+    dist = None
+    torch = None
+    if world > 1 or force_dist:
+        # import torch BEFORE loading the engine so that both share one HIP runtime (same soname, first one wins)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
     import cuadmm_amd
     from cuadmm_amd.synthetic import config_c2
 
@@ -104,19 +118,11 @@ def main():
     if lib.cuadmm_device_count() < 1:
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
     prob = config_c2(args.blocks_per_gpu * world, BLOCK_N)
-    solver = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=rank, world=world, profile=2)
+    solver = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=rank, world=world, profile=2, force_comm=force_dist)
 
     keep = []
-    if world > 1:
+    if world > 1 or force_dist:
         if args.comm == "rccl":
             uid = ctypes.create_string_buffer(128)
             if rank == 0:

@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in HEADERS]
-    common = ["-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wno-unused-result"]
+    common = (["-DCUADMM_QL_CHECKS"] if os.environ.get("CUADMM_QL_CHECKS") else []) + ["-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wno-unused-result"]
     jobs = []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)

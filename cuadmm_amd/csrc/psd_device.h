@@ -21,18 +21,34 @@ constexpr double kSqrt2 = 0x1.6a09e667f3bccp+0;     // reference SQRT2    (inclu
 constexpr double kSqrt2Inv = 0x1.6a09e667f3bcdp-1;  // reference SQRT2INV (include/cuadmm/kernels.h:181)
 constexpr int kQlMaxSweepsPerEig = 60;
 
-__device__ __forceinline__ void wave_fence() {
+// The eigen-solver below is also compiled for the host with a one-thread group policy
+// (tools/host_check_eig.cpp) so that its control flow can be debugged without a GPU.
+#define CUADMM_HD __host__ __device__
+
+CUADMM_HD __forceinline__ void wave_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+#endif
 }
 
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+CUADMM_HD __forceinline__ int lane_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)(threadIdx.x & 63u);
+#else
+  return 0;
+#endif
+}
 
 // sqrt(h) and 1/sqrt(h) together from one v_rsq_f64 + two Goldschmidt steps (h > 0, normal range).
 // ~1-2 ulp; replaces an IEEE sqrt followed by an IEEE divide (about 45 dependent instructions) on the
 // serial critical path of the QL recurrence.
-__device__ __forceinline__ void fast_sqrt_rsqrt(double h, double& root, double& inv_root) {
+CUADMM_HD __forceinline__ void fast_sqrt_rsqrt(double h, double& root, double& inv_root) {
+#if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(h);
+#else
+  const double y = (double)(1.0f / sqrtf((float)h));   // host twin: a low-precision seed, like v_rsq_f64
+#endif
   double g = h * y, hh = 0.5 * y;
   double r = fma(-hh, g, 0.5);
   g = fma(g, r, g); hh = fma(hh, r, hh);
@@ -43,8 +59,12 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double h, double& root, double& 
 }
 
 // 1/x from v_rcp_f64 + two Newton steps (x finite, non-zero, normal range); ~1 ulp
-__device__ __forceinline__ double fast_rcp(double x) {
+CUADMM_HD __forceinline__ double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
   double y = __builtin_amdgcn_rcp(x);
+#else
+  double y = (double)(1.0f / (float)x);
+#endif
   double e = fma(-x, y, 1.0);
   y = fma(y, e, y);
   e = fma(-x, y, 1.0);
@@ -129,7 +149,7 @@ struct WgGroup {
 // Returns 0, or 1 when QL exceeded its sweep cap (eigenvalues in dq either way).
 // ---------------------------------------------------------------------------------------
 template <class Gp>
-__device__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n, double* dsh, double* esh,
+CUADMM_HD __forceinline__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n, double* dsh, double* esh,
                                double* tau, double* vv, double* ww, double* dq, double* eq, double* scratch) {
   constexpr int GS = Gp::kSize;
   const int rank = Gp::rank();
@@ -239,11 +259,11 @@ __device__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n
     wave_fence();
   }
   const bool writer = Gp::kMultiWave ? (lane_id() == 0) : (rank == 0);
-  int l = 0, m = 0, i = -1, sweeps = 0, fail = 0;
+  int l = 0, m = 0, sweeps = 0, fail = 0;
   bool done = (n <= 1);
-  double c = 1.0, s = 1.0, p = 0.0, g = 0.0;
   while (!done) {
-    if (i < l) {  // start a sweep: find the first negligible off-diagonal at or after l
+    // find the first negligible off-diagonal at or after l; deflate converged eigenvalues
+    for (;;) {
       m = Gp::first_true(l, n, [&](int idx) {
         if (idx >= n - 1) return true;
         const double ae = fabs(eq[idx]);
@@ -251,48 +271,67 @@ __device__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n
         return ae <= eps_abs || ae + dd == dd;
       });
       if (m >= n) m = n - 1;
-      if (m == l) {
-        ++l; sweeps = 0; i = l - 1;
-        if (l >= n) done = true;
-      } else if (sweeps++ >= kQlMaxSweepsPerEig) {
-        fail = 1; done = true;
-      } else {
-        const double dl = dq[l], el = eq[l];
-        g = (dq[l + 1] - dl) / (2.0 * el);
-        const double rr = sqrt(g * g + 1.0);
-        g = dq[m] - dl + el / (g + copysign(rr, g));
-        s = 1.0; c = 1.0; p = 0.0;
-        i = m - 1;
-      }
+      if (m > l) break;
+      ++l; sweeps = 0;
+      if (l >= n) { done = true; break; }
     }
-    if (!done && i >= l) {  // one plane rotation at (i, i+1)
-      const double ei = eq[i];
-      const double f = s * ei, b = c * ei;
-      double rr = sqrt(f * f + g * g);
-      if (writer) eq[i + 1] = rr;
-      if (rr == 0.0) {
-        if (writer) { dq[i + 1] -= p; eq[m] = 0.0; }
-        i = l - 1;  // abandon the sweep, re-scan
-      } else {
-        const double rinv = 1.0 / rr;
-        s = f * rinv; c = g * rinv;
-        const double di1 = dq[i + 1];
-        g = di1 - p;
-        rr = (dq[i] - g) * s + 2.0 * c * b;
-        p = s * rr;
-        if (writer) dq[i + 1] = g + p;
-        g = c * rr - b;
-        for (int r = rank; r < n; r += GS) {
-          double* z = M + r * ld + i;
-          const double z0 = z[0], z1 = z[1];
-          z[1] = s * z0 + c * z1;
-          z[0] = c * z0 - s * z1;
-        }
-        --i;
-        if (i < l && writer) { dq[l] -= p; eq[l] = g; eq[m] = 0.0; }
+    if (done) break;
+    if (sweeps++ >= kQlMaxSweepsPerEig) { fail = 1; break; }
+#ifdef CUADMM_QL_CHECKS
+    if (l < 0 || m <= l || m >= n) { fail = 1000 + m * 10000 + l * 10; break; }
+#endif
+    // Wilkinson shift
+    const double dl = dq[l], el = eq[l];
+    double g = (dq[l + 1] - dl) * fast_rcp(el + el);
+    double r0, r0i;
+    fast_sqrt_rsqrt(fma(g, g, 1.0), r0, r0i);
+    g = dq[m] - dl + el * fast_rcp(g + copysign(r0, g));
+    double s = 1.0, c = 1.0, p = 0.0;
+    // one sweep: rotations (i, i+1) for i = m-1 .. l.  Slot i writes d[i+1], e[i+1] and slot i-1 reads
+    // d[i-1], e[i-1], d[i]: no hazard between slots, so the only fence is at the end of the sweep.
+    // Z is streamed: the current column i+1 of the thread's first row is carried in a register.
+    double e_c = eq[m - 1], d_c = dq[m - 1], d1_c = dq[m];
+    const bool own = rank < n;
+    double* zrow = M + (size_t)(own ? rank : 0) * ld;   // non-owners point at a valid row: the compiler may speculate the loads
+    double carry = own ? zrow[m] : 0.0;
+    double z_c = own ? zrow[m - 1] : 0.0;
+    int i = m - 1;
+    bool broke = false;
+    for (; i >= l; --i) {
+      double e_n = 0.0, d_n = 0.0, z_n = 0.0;
+      if (i > l) { e_n = eq[i - 1]; d_n = dq[i - 1]; if (own) z_n = zrow[i - 1]; }   // prefetch for slot i-1
+      const double f = s * e_c, b = c * e_c;
+      const double h = fma(f, f, g * g);
+      if (h == 0.0) {                                   // underflow recovery of the textbook recurrence
+        if (writer) { eq[i + 1] = 0.0; dq[i + 1] = d1_c - p; eq[m] = 0.0; }
+        broke = true;
+        break;
       }
-      wave_fence();
+      double rr, rinv;
+      fast_sqrt_rsqrt(h, rr, rinv);
+      s = f * rinv; c = g * rinv;
+      g = d1_c - p;
+      const double cb = c * b;
+      const double r2 = fma(d_c - g, s, cb + cb);
+      p = s * r2;
+      if (writer) { eq[i + 1] = rr; dq[i + 1] = g + p; }
+      g = fma(c, r2, -b);
+      if (own) {
+        zrow[i + 1] = fma(s, z_c, c * carry);
+        carry = fma(c, z_c, -(s * carry));
+      }
+      for (int r = rank + GS; r < n; r += GS) {         // further rows of this thread (large blocks only)
+        double* z = M + (size_t)r * ld + i;
+        const double z0 = z[0], z1 = z[1];
+        z[1] = fma(s, z0, c * z1);
+        z[0] = fma(c, z0, -(s * z1));
+      }
+      d1_c = d_c; e_c = e_n; d_c = d_n; z_c = z_n;
     }
+    // column i+1 of the first row is still in the register (i = l-1 after a full sweep)
+    if (own) zrow[i + 1] = carry;
+    if (!broke && writer) { dq[l] = dq[l] - p; eq[l] = g; eq[m] = 0.0; }
+    wave_fence();
   }
   Gp::sync();
   return fail;
@@ -303,7 +342,7 @@ __device__ int sym_eig_inplace(double* __restrict__ M, const int ld, const int n
 // (cublas.h:18-35), so that e.g. a 1x1 block returns max(x,0) exactly.  Only the upper triangle
 // that svec stores is computed.
 template <class Gp>
-__device__ void reconstruct_to_svec(const double* __restrict__ M, const int ld, const int n, const double* dq, double* vv,
+CUADMM_HD __forceinline__ void reconstruct_to_svec(const double* __restrict__ M, const int ld, const int n, const double* dq, double* vv,
                                     double* __restrict__ out) {
   constexpr int GS = Gp::kSize;
   const int rank = Gp::rank();
@@ -329,7 +368,7 @@ __device__ void reconstruct_to_svec(const double* __restrict__ M, const int ld, 
 
 // Eigenpairs sorted ascending, eigenvectors column-major (the contract of cusolver.h:76-95).
 template <class Gp>
-__device__ void write_sorted_eig(const double* __restrict__ M, const int ld, const int n, const double* dq,
+__device__ __forceinline__ void write_sorted_eig(const double* __restrict__ M, const int ld, const int n, const double* dq,
                                  double* __restrict__ Vout, double* __restrict__ Wout) {
   constexpr int GS = Gp::kSize;
   for (int k = Gp::rank(); k < n; k += GS) {

@@ -196,8 +196,9 @@ int psd_class_of(int n) {
   if (n <= 8) return 1;
   if (n <= 16) return 2;
   if (n <= 32) return 3;
-  if (wg_lds_bytes(n, wg_threads_lds(n), false) <= kMaxLdsBytes) return 4;
-  return 5;
+  if (n <= 64) return 4;
+  if (wg_lds_bytes(n, wg_threads_lds(n), false) <= kMaxLdsBytes) return 5;
+  return 6;
 }
 
 int PsdPlan::build(const int* blk, int mat_num) {
@@ -221,7 +222,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return blk[x] > blk[y]; });
     for (int k : members) {
       ids.push_back(k);
-      if (c == 5) { wsoff.push_back(ws_total); ws_total += (long long)blk[k] * (blk[k] | 1); }
+      if (c == 6) { wsoff.push_back(ws_total); ws_total += (long long)blk[k] * (blk[k] | 1); }
       if (c >= 4) cls_maxn[c] = std::max(cls_maxn[c], blk[k]);
     }
     cls_count[c] = (int)ids.size() - cls_begin[c];
@@ -294,10 +295,17 @@ static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
     case 2: hipLaunchKernelGGL((psd_small_kernel<16, MODE>), dim3((a.count + 3) / 4), dim3(64), 0, st, a); break;
     case 3: hipLaunchKernelGGL((psd_small_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
     case 4:
+      if (use_reg_kernel() && !getenv("CUADMM_PSD_NO_REG64")) {
+        hipLaunchKernelGGL((psd_small_reg_kernel<64, MODE>), dim3(a.count), dim3(64), 0, st, a);
+        CUADMM_HIP_TRY(hipGetLastError());
+        return CUADMM_OK;
+      }
+      return launch_wg<64, MODE, false>(a, maxn, st);
+    case 5:
       if (maxn <= 64) return launch_wg<64, MODE, false>(a, maxn, st);
       if (maxn <= 128) return launch_wg<128, MODE, false>(a, maxn, st);
       return launch_wg<256, MODE, false>(a, maxn, st);
-    case 5:
+    case 6:
       if (wg_lds_bytes(maxn, 256, true) <= kMaxLdsBytes) return launch_wg<256, MODE, true>(a, maxn, st);
       return launch_wg<64, MODE, true>(a, maxn, st);
     default: break;
@@ -363,7 +371,7 @@ int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream
   a.count = count; a.n_uniform = n;
   double* ws = nullptr;
   long long* wsoff = nullptr;
-  if (c == 5) {
+  if (c == 6) {
     std::vector<long long> off((size_t)count);
     for (int i = 0; i < count; ++i) off[i] = (long long)i * n * (n | 1);
     CUADMM_HIP_TRY(hipMalloc(&ws, sizeof(double) * (size_t)count * n * (n | 1)));
@@ -372,7 +380,7 @@ int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream
     a.workspace = ws; a.ws_off = wsoff;
   }
   int rc = launch_class<1>(c, a, n, st);
-  if (c == 5) {
+  if (c == 6) {
     hipStreamSynchronize(st);
     hipFree(ws);
     hipFree(wsoff);

@@ -6,7 +6,7 @@
 
 namespace cuadmm {
 
-constexpr int kNumPsdClasses = 6;
+constexpr int kNumPsdClasses = 7;   // n<=4, <=8, <=16, <=32, <=64 (register kernels) | LDS workgroup | HBM workgroup
 int psd_class_of(int n);
 
 struct PsdPlan {

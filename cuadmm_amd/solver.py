@@ -74,12 +74,12 @@ class Problem:
 class SDPSolver:
     """Mirror of class SDPSolver (include/cuadmm/solver.h:30-248)."""
 
-    def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False):
+    def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False, force_comm=False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.cuadmm_create(C.byref(self._h)))
         for k, v in (("device", device), ("verbose", int(bool(verbose))), ("rank", rank), ("world", world),
-                     ("profile", int(profile))):
+                     ("profile", int(profile)), ("force_comm", int(bool(force_comm)))):
             check(self._lib.cuadmm_set_option(self._h, k.encode(), float(v)))
         self._cb = None
         self.vec_len = self.con_num = 0

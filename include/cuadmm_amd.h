@@ -51,6 +51,7 @@ void cuadmm_destroy(cuadmm_solver* s);
  *                   cuadmm_set_allreduce
  *   "profile"       1 = time every kernel class with HIP events on the engine stream;
  *                   2 = time only the dominant kernel (psd_project)
+ *   "force_comm"    1 = call the collective hook even when world == 1 (transport tests on one GPU)
  *   "graph"         reserved
  */
 int cuadmm_set_option(cuadmm_solver* s, const char* key, double value);
