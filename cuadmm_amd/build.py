@@ -22,7 +22,7 @@ EXE = os.path.join(LIBDIR, "cuadmm_exe")
 
 HIP_SOURCES = ["psd_kernels.hip", "vec_kernels.hip", "engine.hip"]
 CPP_SOURCES = ["io.cpp", "blocks.cpp", "aat_ldlt.cpp"]
-HEADERS = ["common.h", "device_util.h", "psd_device.h", "psd_plan.h", "vec_kernels.h", "../../include/cuadmm_amd.h"]
+HEADERS = None   # every header under csrc/ plus the public C header (computed in build())
 ARCH = "gfx950"
 
 
@@ -50,7 +50,8 @@ def _run(cmd):
 def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "cuadmm_amd.h"))
     common = (["-DCUADMM_QL_CHECKS"] if os.environ.get("CUADMM_QL_CHECKS") else []) + ["-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wno-unused-result"]
     jobs = []
     for src in HIP_SOURCES:

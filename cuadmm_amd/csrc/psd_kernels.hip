@@ -20,6 +20,7 @@
 #include "psd_device.h"
 #include "psd_plan.h"
 #include "psd_small_reg.h"
+#include "psd_small_pc.h"
 
 namespace cuadmm {
 
@@ -109,12 +110,36 @@ __global__ __launch_bounds__(64) void psd_small_reg_kernel(PsdArgs a) {
   psd_small_reg_body<NMAX, MODE>(a, smem);
   if (MODE == 0) {
     wave_fence();
+    const int slot0 = (int)blockIdx.x * (64 / NMAX);
+    long long* dbg = a.dbg ? a.dbg + (long long)blockIdx.x * 8 : nullptr;
     if constexpr (NMAX >= 16) {
-      const long long t0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-      psd_small_reg_rebuild_mfma<NMAX>(a, smem);
-      if (a.dbg && lane_id() == 0) a.dbg[(long long)blockIdx.x * 8 + 6] = (long long)__builtin_readcyclecounter() - t0;
+      const long long t0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
+      psd_small_reg_rebuild_mfma<NMAX, RegLayout<NMAX>>(a, smem, slot0);
+      if (dbg && lane_id() == 0) dbg[6] = (long long)__builtin_readcyclecounter() - t0;
     }
-    psd_small_reg_store<NMAX>(a, smem);
+    psd_small_reg_store<NMAX, RegLayout<NMAX>>(a, smem, slot0, dbg);
+  }
+}
+
+// producer/consumer variant (psd_small_pc.h): WAVES wavefronts per workgroup, the last one also produces
+// the QL rotations of all the workgroup's blocks
+template <int NMAX, int WAVES, int MODE>
+__global__ __launch_bounds__(64 * WAVES, 2) void psd_small_pc_kernel(PsdArgs a) {
+  __shared__ double smem[WAVES * (64 / NMAX) * PcLayout<NMAX>::kPer];
+  __shared__ int flags[2];
+  psd_small_pc_body<NMAX, WAVES, MODE>(a, smem, flags);
+  if (MODE == 0) {
+    wave_fence();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int slot0 = ((int)blockIdx.x * WAVES + wave) * (64 / NMAX);
+    double* wsm = smem + wave * (64 / NMAX) * PcLayout<NMAX>::kPer;
+    long long* dbg = a.dbg ? a.dbg + ((long long)blockIdx.x * WAVES + wave) * 8 : nullptr;
+    if constexpr (NMAX >= 16) {
+      const long long t0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
+      psd_small_reg_rebuild_mfma<NMAX, PcLayout<NMAX>>(a, wsm, slot0);
+      if (dbg && lane_id() == 0) dbg[6] = (long long)__builtin_readcyclecounter() - t0;
+    }
+    psd_small_reg_store<NMAX, PcLayout<NMAX>>(a, wsm, slot0, dbg);
   }
 }
 
@@ -270,15 +295,26 @@ static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
 }
 
 // CUADMM_PSD_SMALL=lds selects the LDS-resident small-block kernel (kept for A/B measurements)
-static bool use_reg_kernel() {
+// CUADMM_PSD_SMALL = lds | reg | pc selects the small-block kernel (default pc; the others are kept for A/B runs)
+static int small_kernel_kind() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CUADMM_PSD_SMALL"); v = (e && std::string(e) == "lds") ? 0 : 1; }
-  return v == 1;
+  if (v < 0) {
+    const char* e = getenv("CUADMM_PSD_SMALL");
+    v = !e ? 2 : (std::string(e) == "lds" ? 0 : (std::string(e) == "reg" ? 1 : 2));
+  }
+  return v;
 }
+static bool use_reg_kernel() { return small_kernel_kind() >= 1; }
 
 template <int MODE>
 static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
   if (a.count <= 0) return CUADMM_OK;
+  if (c == 3 && small_kernel_kind() == 2) {
+    constexpr int W = 4, NB = W * 2;
+    hipLaunchKernelGGL((psd_small_pc_kernel<32, W, MODE>), dim3((a.count + NB - 1) / NB), dim3(64 * W), 0, st, a);
+    CUADMM_HIP_TRY(hipGetLastError());
+    return CUADMM_OK;
+  }
   if (c <= 3 && use_reg_kernel()) {
     switch (c) {
       case 0: hipLaunchKernelGGL((psd_small_reg_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
@@ -323,7 +359,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
     a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff;
     long long* dbg = nullptr;
-    const int nwg = (cls_count[c] + 1) / 2;
+    const int nwg = (cls_count[c] + 1) / 2 + 4;
     if (c == 3 && getenv("CUADMM_PSD_DEBUG")) {
       CUADMM_HIP_TRY(hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)nwg));
       CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));
@@ -345,6 +381,19 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
       // MFMA utilisation of the rebuild: 2 blocks x 3 upper tiles x 8 k-steps x 64 cycles per v_mfma_f64_16x16x4
       fprintf(stderr, "[psd debug] %d waves: cycles/wave load %.0f tridiag %.0f ql %.0f handoff %.0f tail %.0f | mfma rebuild %.0f cycles/wave -> MFMA busy %.1f%%\n",
               nwg, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, its / nwg, 100.0 * (2 * 3 * 8 * 64.0) / (its / nwg));
+      if (small_kernel_kind() == 2) {   // producer/consumer split of the QL phase: wave 3 of each workgroup produces
+        double pp = 0, pc = 0, pbr = 0, cp = 0, cc = 0, cb = 0, st = 0; int np = 0, nc = 0;
+        for (int w = 0; w < nwg; ++w) {
+          const long long v = h[w * 8 + 7];
+          const double a1 = (double)(v >> 40), a2 = (double)((v >> 20) & 0xFFFFF), a3 = (double)(v & 0xFFFFF) * 16;
+          if (w % 4 == 3) { pp += a1; pc += a2; pbr += a3; ++np; st += (double)h[w * 8 + 6]; } else { cp += a1; cc += a2; cb += a3; ++nc; }
+        }
+        double sc = 0, lp = 0, sl = 0, stp = 0;
+        for (int w = 3; w < nwg; w += 4) { sc += -(double)h[w * 8 + 1]; lp += -(double)h[w * 8 + 2]; sl += -(double)h[w * 8 + 3]; stp += -(double)h[w * 8 + 4]; }
+        if (np) fprintf(stderr, "[psd debug] producer lane0 per wg: steps %.1f scan %.0f loop %.0f cycles, slots(block0) %.0f -> %.0f cycles/slot-iteration\n", stp / np, sc / np, lp / np, sl / np, lp / (sl > 0 ? sl : 1));
+        if (np && nc) fprintf(stderr, "[psd debug] QL steps/wg %.1f | producer wave: produce %.0f consume %.0f barrier %.0f | consumer waves: consume %.0f barrier %.0f cycles\n",
+                              st / np, pp / np, pc / np, pbr / np, cc / nc, cb / nc);
+      }
       (void)slots; (void)tmin; (void)tmax;
       hipFree(dbg);
     }

@@ -289,14 +289,12 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
 // (the reference's diagonal_batch.cu:11-23 + cublas.h:18-35 in one step).  Only the tiles of the upper
 // triangle are computed (svec stores the upper triangle).
 typedef double psd_v4f64 __attribute__((ext_vector_type(4)));
-template <int NMAX, class Args>
-__device__ __forceinline__ void psd_small_reg_rebuild_mfma(const Args& a, double* smem) {
-  using Lay = RegLayout<NMAX>;
+template <int NMAX, class Lay, class Args>
+__device__ __forceinline__ void psd_small_reg_rebuild_mfma(const Args& a, double* smem, const int slot0) {
   constexpr int LD = Lay::LD;
   constexpr int BPW = 64 / NMAX;
   constexpr int NT = NMAX >= 16 ? NMAX / 16 : 1;  // tiles per dimension
   const int lane = lane_id();
-  const int slot0 = (int)blockIdx.x * BPW;
   const int r16 = lane & 15, kk = lane >> 4;
   for (int gg = 0; gg < BPW; ++gg) {
     if (slot0 + gg >= a.count) break;
@@ -332,13 +330,11 @@ __device__ __forceinline__ void psd_small_reg_rebuild_mfma(const Args& a, double
 }
 
 // store phase, executed by the whole wavefront after every group has finished
-template <int NMAX, class Args>
-__device__ __forceinline__ void psd_small_reg_store(const Args& a, const double* smem) {
-  using Lay = RegLayout<NMAX>;
+template <int NMAX, class Lay, class Args>
+__device__ __forceinline__ void psd_small_reg_store(const Args& a, const double* smem, const int slot0, long long* dbg) {
   constexpr int LD = Lay::LD;
   constexpr int BPW = 64 / NMAX;
   const int lane = lane_id();
-  const int slot0 = (int)blockIdx.x * BPW;
   for (int gg = 0; gg < BPW; ++gg) {
     const int slot = slot0 + gg;
     if (slot >= a.count) break;
@@ -354,7 +350,7 @@ __device__ __forceinline__ void psd_small_reg_store(const Args& a, const double*
       dst[e] = (i == j) ? v : v * kSqrt2;
     }
   }
-  if (a.dbg && lane == 0) a.dbg[(long long)blockIdx.x * 8 + 5] = (long long)__builtin_readcyclecounter();
+  if (dbg && lane == 0) dbg[5] = (long long)__builtin_readcyclecounter();
 }
 
 }  // namespace cuadmm
