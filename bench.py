@@ -77,6 +77,24 @@ def cpu_baseline(prob, n_iters, threads):
     return n_iters / dt, dt
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no summary is present."""
+    best = None
+    prof = os.path.join(ROOT, "profiles")
+    if os.path.isdir(prof):
+        for fn in sorted(os.listdir(prof)):
+            if fn.endswith("_pmc_hbm_traffic.json"):
+                try:
+                    d = json.load(open(os.path.join(prof, fn)))
+                except Exception:
+                    continue
+                for k, v in d.items():
+                    if kernel_substr in k:
+                        best = v.get("hbm_bytes_per_launch")
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,9 +208,12 @@ def main():
                                    % (args.blocks_per_gpu, BLOCK_N, BLOCK_N, "ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM"),
                        "blocks_total": args.blocks_per_gpu * world, "vec_len": int(prob.vec_len), "con_num": int(prob.con_num),
                        "sharding": "blocks by index" if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
-            "roofline": {"kernel": "psd_small_kernel<32,0> (fused svec->eig->project->svec)", "bound": "hbm",
+            "roofline": {"kernel": "psd_small_reg_kernel<32,0> (fused svec->eig->project->svec)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": psd_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": pmc_traffic("psd_small_reg_kernel<32, 0>"), "avg_launch_ms": psd_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "latency/VALU-issue bound (implicit-QL recurrence), not HBM bound: DESIGN.md section 4; "
+                                 "traffic = FETCH_SIZE*2 + WRITE_SIZE from the committed rocprofv3 PMC passes (profiles/)",
                          "psd_proj_nominal_tflops": nominal_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
                          "fp64_peak_tflops": FP64_PEAK_TFLOPS,
                          "blocks_per_s": args.blocks_per_gpu / (psd_ms * 1e-3) if psd_ms > 0 else 0.0},

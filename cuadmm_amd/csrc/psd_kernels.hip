@@ -295,12 +295,12 @@ static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
 }
 
 // CUADMM_PSD_SMALL=lds selects the LDS-resident small-block kernel (kept for A/B measurements)
-// CUADMM_PSD_SMALL = lds | reg | pc selects the small-block kernel (default pc; the others are kept for A/B runs)
+// CUADMM_PSD_SMALL = lds | reg | pc selects the small-block kernel (default reg; the others are kept for A/B runs)
 static int small_kernel_kind() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CUADMM_PSD_SMALL");
-    v = !e ? 2 : (std::string(e) == "lds" ? 0 : (std::string(e) == "reg" ? 1 : 2));
+    v = !e ? 1 : (std::string(e) == "lds" ? 0 : (std::string(e) == "pc" ? 2 : 1));
   }
   return v;
 }

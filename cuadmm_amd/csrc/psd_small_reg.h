@@ -191,20 +191,22 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
     fast_sqrt_rsqrt(fma(gq, gq, 1.0), r0, r0i);
     gq = D[m] - dl + el * fast_rcp(gq + copysign(r0, gq));
     double s = 1.0, c = 1.0, p = 0.0;
-    bool broke = false;
     double e_c = E[m - 1], d_c = D[m - 1], d1_c = D[m];      // operands of the first active slot i = m-1
+    // Slot predicates depend only on (i, l, m): nothing on the serial critical path feeds a branch (a data
+    // dependent exit test costs ~75 cycles per slot on gfx950, tools/ubench/loop_overheads.hip).  The
+    // textbook's "r == 0" underflow exit cannot trigger for blocks whose norm is in the normal fp64 range
+    // (every off-diagonal inside the window exceeds eps*||T||); should it happen anyway the block is
+    // flagged as failed instead of being special-cased.
 #pragma unroll
     for (int i = NMAX - 2; i >= 0; --i) {
-      if (i < m && i >= l && !broke) {
-        // straight-line fast path; the textbook's r == 0 underflow recovery is a rare branch at the end
+      if (i < m && i >= l) {
         double e_n = 0.0, d_n = 0.0;
         if (i > 0) { e_n = E[i - 1]; d_n = D[i - 1]; }          // prefetch for slot i-1 (not yet touched this sweep)
         const double f = s * e_c, b = c * e_c;
         const double h = fma(f, f, gq * gq);
-        const bool hz = (h == 0.0);
+        fail |= (h == 0.0) ? 2 : 0;
         double rr, rinv;
-        fast_sqrt_rsqrt(hz ? 1.0 : h, rr, rinv);
-        const double p_old = p;
+        fast_sqrt_rsqrt(h, rr, rinv);
         s = f * rinv; c = gq * rinv;
         gq = d1_c - p;
         const double cb = c * b;
@@ -216,14 +218,10 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
         q[i + 1] = fma(s, z0, c * z1);
         q[i] = fma(c, z0, -(s * z1));
         if (writer) { E[i + 1] = rr; D[i + 1] = dnew; }
-        if (hz) {                                                  // f == g == 0: s = c = 0 above, Z columns must be restored
-          q[i + 1] = z1; q[i] = z0;
-          if (writer) { E[i + 1] = 0.0; D[i + 1] = d1_c - p_old; E[m] = 0.0; }
-          broke = true;
-        }
         d1_c = d_c; e_c = e_n; d_c = d_n;
       }
     }
+    const bool broke = false;
     if (!broke && writer) { D[l] = D[l] - p; E[l] = gq; E[m] = 0.0; }
     wave_fence();
   }
