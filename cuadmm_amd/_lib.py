@@ -42,6 +42,13 @@ PROTOTYPES = {
                                C.c_void_p, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
+    "cuadmm_duo_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
+    "cuadmm_duo_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cuadmm_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cuadmm_get_dims": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),
     "cuadmm_get_X": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -722,6 +722,38 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   return CUADMM_OK;
 }
 
+// SDPDuoSolver front (duo_solver.h:236-276): exactly two block sizes, then the generic engine.
+int cuadmm_duo_init(cuadmm_solver* s, int if_gpu_eig_mom, int device_num_requested, int eig_stream_num_per_gpu,
+                    int cpu_eig_thread_num, int vec_len, int con_num, const int* At_cp, const int* At_ri, const double* At_vx,
+                    int At_nnz, const int* b_idx, const double* b_vals, int b_nnz, const int* C_idx, const double* C_vals,
+                    int C_nnz, const int* blk, int mat_num, const double* X0, const double* y0, const double* S0, double sig) {
+  (void)if_gpu_eig_mom; (void)device_num_requested;
+  if (!s || !blk || mat_num <= 0) { set_error("duo_init: invalid argument"); return CUADMM_ERR_INVALID; }
+  std::vector<int> sizes, nums;
+  analyze_blk(blk, mat_num, sizes, nums);
+  if (sizes.size() != 2) {   // analyze_blk_duo, src/utils/analyze_blk.cu:39-43
+    set_error("SDP solver only supports two matrix sizes! You matrix type number is: %d", (int)sizes.size());
+    return CUADMM_ERR_INVALID;
+  }
+  if (s->verbose && s->rank == 0) {
+    std::cout << "\nAnalysis of the blk vector:" << std::endl;
+    std::cout << "moment matrix size: " << sizes[1] << std::endl;
+    std::cout << "localizing matrix size: " << sizes[0] << std::endl;
+    std::cout << "number of moment matrices: " << nums[1] << std::endl;
+    std::cout << "number of localizing matrices: " << nums[0] << std::endl << std::endl;
+  }
+  const int verbose = s->verbose;
+  s->verbose = 0;   // the generic census is not part of the duo solver's console output
+  int rc = cuadmm_init(s, eig_stream_num_per_gpu, cpu_eig_thread_num, vec_len, con_num, At_cp, At_ri, At_vx, At_nnz, b_idx, b_vals,
+                       b_nnz, C_idx, C_vals, C_nnz, blk, mat_num, X0, y0, S0, sig);
+  s->verbose = verbose;
+  return rc;
+}
+int cuadmm_duo_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update_threshold, int sig_update_stage_1,
+                     int sig_update_stage_2, int switch_admm, double sigscale, int if_first) {
+  return cuadmm_solve(s, max_iter, stop_tol, sig_update_threshold, sig_update_stage_1, sig_update_stage_2, switch_admm, sigscale, if_first);
+}
+
 int cuadmm_get_dims(const cuadmm_solver* s, int* vec_len, int* con_num, int* mat_num) {
   if (!s) { set_error("get_dims: null"); return CUADMM_ERR_INVALID; }
   if (vec_len) *vec_len = s->L_full;

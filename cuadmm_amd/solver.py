@@ -135,6 +135,22 @@ class SDPSolver:
                                      float(sigscale), int(bool(if_first))))
         return self
 
+    # -- SDPDuoSolver::init / ::solve (duo_solver.h:236-276): two block sizes only ---------------------
+    def duo_init(self, if_gpu_eig_mom, device_num_requested, eig_stream_num_per_gpu, cpu_eig_thread_num, vec_len, con_num,
+                 At_csc_col_ptrs, At_csc_row_ids, At_csc_vals, At_nnz, b_indices, b_vals, b_nnz,
+                 C_indices, C_vals, C_nnz, blk_vals, mat_num, X=None, y=None, S=None, sig=2e2):
+        a = [_i32(At_csc_col_ptrs), _i32(At_csc_row_ids), _f64(At_csc_vals), _i32(b_indices), _f64(b_vals),
+             _i32(C_indices), _f64(C_vals), _i32(blk_vals)]
+        Xa = None if X is None else _f64(X)
+        ya = None if y is None else _f64(y)
+        Sa = None if S is None else _f64(S)
+        check(self._lib.cuadmm_duo_init(self._h, int(bool(if_gpu_eig_mom)), int(device_num_requested),
+                                        int(eig_stream_num_per_gpu), int(cpu_eig_thread_num), int(vec_len), int(con_num),
+                                        _p(a[0]), _p(a[1]), _p(a[2]), int(At_nnz), _p(a[3]), _p(a[4]), int(b_nnz),
+                                        _p(a[5]), _p(a[6]), int(C_nnz), _p(a[7]), int(mat_num), _p(Xa), _p(ya), _p(Sa), float(sig)))
+        self.vec_len, self.con_num, self.mat_num = int(vec_len), int(con_num), int(mat_num)
+        return self
+
     # -- results (public members of the reference class) -----------------------------------------
     def shard(self):
         b, e, kb, ke = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()

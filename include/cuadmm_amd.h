@@ -90,6 +90,26 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol,
                  int sig_update_threshold, int sig_update_stage_1, int sig_update_stage_2,
                  int switch_admm, double sigscale, int if_first);
 
+/* SDPDuoSolver::init / ::solve  (reference include/cuadmm/duo_solver.h:236-276, src/duo_solver.cu): the
+ * two-block-size specialisation (moment + localizing matrices).  Same iteration; the reference differs only in
+ * where the moment-matrix eigendecompositions run (`if_gpu_eig_mom`: N GPUs through threads + P2P copies, or
+ * `cpu_eig_thread_num` host LAPACK threads).  Here every block is projected by the fused kernels of this
+ * engine, so both arguments are accepted and ignored; like the reference (analyze_blk.cu:39-43) init rejects
+ * inputs that do not have exactly two distinct block sizes.  Multi-GPU goes through rank/world + the hook. */
+int cuadmm_duo_init(cuadmm_solver* s,
+                    int if_gpu_eig_mom, int device_num_requested,
+                    int eig_stream_num_per_gpu, int cpu_eig_thread_num,
+                    int vec_len, int con_num,
+                    const int* At_csc_col_ptrs, const int* At_csc_row_ids, const double* At_csc_vals, int At_nnz,
+                    const int* b_indices, const double* b_vals, int b_nnz,
+                    const int* C_indices, const double* C_vals, int C_nnz,
+                    const int* blk_vals, int mat_num,
+                    const double* X, const double* y, const double* S,
+                    double sig /* reference default 2e2 */);
+int cuadmm_duo_solve(cuadmm_solver* s, int max_iter, double stop_tol,
+                     int sig_update_threshold, int sig_update_stage_1, int sig_update_stage_2,
+                     int switch_admm, double sigscale, int if_first);
+
 /* Results: the reference exposes public members X.vals / y.vals / S.vals (device pointers,
  * unscaled after solve, solver.cu:814-816) and info_* vectors (solver.h:149-161). */
 int cuadmm_get_dims(const cuadmm_solver* s, int* vec_len, int* con_num, int* mat_num);

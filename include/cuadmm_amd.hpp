@@ -53,6 +53,19 @@ class SDPSolver {
     con_num = con_num_;
   }
 
+  // SDPDuoSolver::init (duo_solver.h:236-255): two leading arguments more, default sig = 2e2
+  void duo_init(bool if_gpu_eig_mom, int device_num_requested, int eig_stream_num_per_gpu, int cpu_eig_thread_num, int vec_len_,
+                int con_num_, int* cpu_At_csc_col_ptrs, int* cpu_At_csc_row_ids, double* cpu_At_csc_vals, int At_nnz,
+                int* cpu_b_indices, double* cpu_b_vals, int b_nnz, int* cpu_C_indices, double* cpu_C_vals, int C_nnz,
+                int* cpu_blk_vals, int mat_num, double* cpu_X_vals = nullptr, double* cpu_y_vals = nullptr,
+                double* cpu_S_vals = nullptr, double sig = 2e2) {
+    check(cuadmm_duo_init(h_, if_gpu_eig_mom ? 1 : 0, device_num_requested, eig_stream_num_per_gpu, cpu_eig_thread_num, vec_len_,
+                          con_num_, cpu_At_csc_col_ptrs, cpu_At_csc_row_ids, cpu_At_csc_vals, At_nnz, cpu_b_indices, cpu_b_vals,
+                          b_nnz, cpu_C_indices, cpu_C_vals, C_nnz, cpu_blk_vals, mat_num, cpu_X_vals, cpu_y_vals, cpu_S_vals, sig));
+    vec_len = vec_len_;
+    con_num = con_num_;
+  }
+
   // SDPSolver::solve, same argument list and defaults (solver.h:236-244)
   void solve(int max_iter, double stop_tol, int sig_update_threshold = 500, int sig_update_stage_1 = 50,
              int sig_update_stage_2 = 100, int switch_admm = (int)1.1e4, double sigscale = 1.05, bool if_first = true) {

@@ -132,3 +132,23 @@ def test_planarhand_config1_shapes():
     want = [1.73e-02, 2.01e-02, 2.9184e-01, 1.8059e+00, 4.89e-01]
     for g, w in zip(e50, want):
         assert abs(g - w) <= 6e-3 * abs(w)
+
+
+def test_duo_solver_front(problem_dirs):
+    """SDPDuoSolver::init/solve (duo_solver.h:236-276): two block sizes accepted, anything else rejected
+    (analyze_blk.cu:39-43); the iteration is the generic one (ros_2000 has sizes {4, 6})."""
+    p = orc.load_problem_txt(problem_dirs["ros_2000"])
+    a = problem_to_amd(p)
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.duo_init(True, 1, 15, 30, a.vec_len, a.con_num, a.At_csc_col_ptrs, a.At_csc_row_ids, a.At_csc_vals, a.At_nnz,
+               a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
+    s.solve(20, 0.0, 0, 50, 100, 11000, 1.05)
+    o = orc.OracleSolver().init_problem(p)
+    info = o.solve(20, 0.0, 0, 50, 100, 11000, 1.05)
+    _cmp("duo:pobj", s.info_arr("pobj"), np.array(info.pobj), rtol=1e-8, atol=1e-11)
+    q = orc.load_problem_txt(problem_dirs["rose13"])            # a single size -> rejected like the reference's assert
+    b = problem_to_amd(q)
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        cuadmm_amd.SDPSolver(verbose=False).duo_init(True, 1, 15, 30, b.vec_len, b.con_num, b.At_csc_col_ptrs, b.At_csc_row_ids,
+                                                     b.At_csc_vals, b.At_nnz, b.b_indices, b.b_vals, b.b_nnz, b.C_indices,
+                                                     b.C_vals, b.C_nnz, b.blk_vals, b.mat_num)
