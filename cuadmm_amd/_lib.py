@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cuadmm_aat_free": (None, [C.c_void_p]),
     "cuadmm_op_vector_to_matrices": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "cuadmm_op_matrices_to_vector": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    "cuadmm_op_gemm_sym": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cuadmm_op_batch_eig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cuadmm_op_max_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "cuadmm_op_mul_diag_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -842,6 +842,11 @@ int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, voi
   return psd_batch_eig(mat, W, info, n, count, (hipStream_t)stream);
 }
 
+int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, double beta, const double* E, double* Cout, void* stream) {
+  if (n < 64 || n % 64 != 0 || !A || !B || !Cout) { set_error("gemm_sym: n must be a positive multiple of 64 and pointers non-null"); return CUADMM_ERR_INVALID; }
+  return large_gemm_sym(n, A, B, alpha, beta, E, Cout, (hipStream_t)stream);
+}
+
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream) {
   if (!blk_host || mat_num < 0) { set_error("psd_project: bad arguments"); return CUADMM_ERR_INVALID; }
   PsdPlan plan;

@@ -236,6 +236,10 @@ int PsdPlan::build(const int* blk, int mat_num) {
     off[k + 1] = off[k] + (long long)blk[k] * (blk[k] + 1) / 2;
   }
   vec_len = off[mat_num];
+  if (const char* e = getenv("CUADMM_PSD_SIGN_MIN")) sign_min = std::max(65, atoi(e));
+  std::vector<int> sign_members;
+  for (int k = 0; k < mat_num; ++k)
+    if (blk[k] >= sign_min) sign_members.push_back(k);
   std::vector<int> ids;
   std::vector<long long> wsoff;
   long long ws_total = 0;
@@ -243,7 +247,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     cls_begin[c] = (int)ids.size();
     std::vector<int> members;
     for (int k = 0; k < mat_num; ++k)
-      if (psd_class_of(blk[k]) == c) members.push_back(k);
+      if (psd_class_of(blk[k]) == c && blk[k] < sign_min) members.push_back(k);
     std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return blk[x] > blk[y]; });
     for (int k : members) {
       ids.push_back(k);
@@ -258,7 +262,11 @@ int PsdPlan::build(const int* blk, int mat_num) {
   CUADMM_HIP_TRY(hipMalloc(&d_fail, sizeof(int)));
   CUADMM_HIP_TRY(hipMemcpy(d_off, off.data(), sizeof(long long) * ((size_t)mat_num + 1), hipMemcpyHostToDevice));
   CUADMM_HIP_TRY(hipMemcpy(d_n, blk, sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
-  CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
+  if (!ids.empty()) CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
+  {
+    int rc = sign.build(blk, sign_members);
+    if (rc) return rc;
+  }
   CUADMM_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
   if (ws_total > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_ws, sizeof(double) * (size_t)ws_total));
@@ -279,6 +287,7 @@ void PsdPlan::release() {
   if (d_ws) hipFree(d_ws);
   if (d_wsoff) hipFree(d_wsoff);
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
+  sign.release();
   for (int c = 0; c < kNumPsdClasses; ++c) { cls_begin[c] = cls_count[c] = 0; cls_maxn[c] = 0; }
 }
 
@@ -398,6 +407,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
       hipFree(dbg);
     }
   }
+  if (!sign.empty()) return sign.project(Xb, Xproj, d_off, d_n, d_fail, st);
   return CUADMM_OK;
 }
 

@@ -1,0 +1,368 @@
+// PSD-cone projection of blocks with n > 64 on the fp64 matrix cores, WITHOUT an eigendecomposition.
+//
+// The reference sends large blocks one by one to cusolverDnXsyevd and small ones to the batched Jacobi solver, then
+// forms V max(L,0) V^T with DGEMMs (src/solver.cu:534-647).  Here, for every block that does not fit the
+// register-resident eigensolver (psd_small_reg.h, n <= 64):
+//
+//     P_+(X) = (X + |X|) / 2,   |X| = X * sign(X),
+//
+// with the matrix sign function from the Newton-Schulz iteration  S <- p(mu S),  p(x) = 1.5 x - 0.5 x^3,  started
+// from S_0 = X / ||X||_1 (all eigenvalues in [-1, 1]; zero eigenvalues stay zero).  Everything is GEMM on
+// v_mfma_f64_16x16x4_f64: that is what CDNA4 is good at, while the sequential rotation chains of a tridiagonal
+// eigensolver (5 million dependent rotations at n = 2000) are what it is bad at.
+//
+// Schedule (fixed, no host synchronisation, so the whole projection is asynchronous on the stream):
+//   * kLiftSteps = 36 steps with mu = 1.53: eigenvalues in (0, 1] stay in (0, 1] and never fall below p(1.53) = 0.5
+//     once they are there (the gap between the + and - invariant subspaces stays wide: stable), while small ones
+//     grow by 1.5 mu = 2.3 per step instead of 1.5, so |lambda| >= 1e-13 ||X||_1 is resolved after 36 steps;
+//   * kPolishSteps = 8 plain steps (mu = 1): quadratic convergence from [0.5, 1] to 1 within roundoff.
+//   An eigenvalue still below resolution contributes an error <= |lambda| <= 1e-13 ||X||_1 to the projection.
+//
+// Every iterate is a polynomial in X, hence symmetric, and all products are of commuting symmetric matrices.  The
+// GEMM kernel uses that twice: the left operand is read transposed (row tile of A = rows k of A, coalesced, no LDS
+// transpose), and only the tiles on or above the diagonal are computed and MIRRORED on store.  Mirroring halves the
+// flops and keeps the iterate EXACTLY symmetric -- with an independently computed lower triangle the skew-symmetric
+// rounding error doubles every step (measured: divergence after ~60 steps).
+//
+// Batching: blocks are grouped by padded size N (multiple of 64); one launch covers a whole group (blockIdx.y =
+// member), so many mid-size blocks (n = 65..200) fill the chip the same way one n = 2000 block does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "common.h"
+#include "device_util.h"
+#include "psd_device.h"
+#include "psd_large.h"
+
+namespace cuadmm {
+
+typedef double lg_v4f64 __attribute__((ext_vector_type(4)));
+constexpr int LG_BK = 16;
+constexpr int LG_TM = 64;   // measured on MI355X: 64x64 tiles (4 workgroups per CU) beat 128x128 at every N (48 vs 41 TFLOP/s at 2048)
+
+// C = alpha * A*B + beta * E over a batch (blockIdx.y = matrix, stride N*N).  A (and, when MIRROR, the product) symmetric.
+// MIRROR: blockIdx.x enumerates the tiles (by <= bx) of the upper triangle; C[row][col] and C[col][row] are both written.
+template <bool MIRROR>
+__global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
+                                                          double alpha, double beta, const double* __restrict__ Eb,
+                                                          double* __restrict__ Cb, int sb) {
+  constexpr int TM = LG_TM;
+  constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
+  constexpr int WT = TM / 2;        // rows / cols per wave
+  constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
+  constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * LG_BK * LDS ? TM * (TM + 1) : 2 * LG_BK * LDS) : 2 * LG_BK * LDS;
+  __shared__ double smem[SMEM];
+  double* As = smem;
+  double* Bs = smem + LG_BK * LDS;
+  double* Ct = smem;                // TM x (TM+1) transposed output tile (MIRROR), after the k loop
+  const size_t mat = (size_t)blockIdx.y * (size_t)N * (size_t)N;
+  const double* A = Ab + mat;
+  const double* B = Bb + mat;
+  const double* E = Eb ? Eb + mat : nullptr;
+  double* C = Cb + mat;
+  int by, bx;
+  if (MIRROR) {
+    if (sb > 0) {
+      // XCD-aware order for one big matrix: workgroup i runs on XCD i % 8 (round-robin dispatch); give every XCD a
+      // contiguous range of the tile sequence, and let the sequence walk 8x8-tile super-blocks of the upper triangle,
+      // so that the ~128 tiles resident on an XCD share ~16 row/column strips in its private L2.
+      const int per_xcd = (int)gridDim.x / 8;
+      const int L = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+      int sbx, sby;
+      tri_decode(L / 64, sbx, sby);
+      by = sby * 8 + (L % 64) / 8;
+      bx = sbx * 8 + (L % 64) % 8;
+      if (sbx >= sb || bx < by || bx >= N / TM) return;   // whole workgroup leaves before any barrier
+    } else {
+      tri_decode((int)blockIdx.x, bx, by);   // bx >= by
+    }
+  } else {
+    const int nb = N / TM;
+    by = (int)blockIdx.x / nb;
+    bx = (int)blockIdx.x % nb;
+  }
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int row0 = by * TM, col0 = bx * TM;
+  const int r16 = lane & 15, kk = lane >> 4;
+
+  lg_v4f64 acc[NTW][NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = lg_v4f64{0.0, 0.0, 0.0, 0.0};
+
+  // staging: tile[k][0..TM-1] = M[k0 + k][c0 .. c0+TM-1]; thread t loads row k = t/16, 4 doubles at column (t%16)*4
+  const int lk = tid >> 4, lc = (tid & 15) * 4;
+  // register prefetch two k-tiles ahead (an L2 miss costs several k-tiles of MFMA work); scalars, not arrays (scratch)
+  double2 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+  const double2* ap = reinterpret_cast<const double2*>(A + (size_t)lk * N + row0 + lc);   // A symmetric: A[row][k] = A[k][row]
+  const double2* bp = reinterpret_cast<const double2*>(B + (size_t)lk * N + col0 + lc);
+  const size_t kstep = (size_t)LG_BK * N / 2;
+  pa0 = ap[0]; pa1 = ap[1]; pb0 = bp[0]; pb1 = bp[1];
+  ap += kstep; bp += kstep;
+  qa0 = ap[0]; qa1 = ap[1]; qb0 = bp[0]; qb1 = bp[1];     // N / LG_BK is a multiple of 4
+  double2* sa = reinterpret_cast<double2*>(As + lk * LDS + lc);
+  double2* sb2 = reinterpret_cast<double2*>(Bs + lk * LDS + lc);
+#define LG_COMPUTE()                                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < LG_BK; ks += 4) {                                                       \
+    double af[NTW], bf[NTW];                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                             \
+      af[t] = As[(ks + kk) * LDS + wy * WT + t * 16 + r16];                                                       \
+      bf[t] = Bs[(ks + kk) * LDS + wx * WT + t * 16 + r16];                                                       \
+    }                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NTW; ++i)                                                               \
+      _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                       \
+  }
+  for (int k0 = 0; k0 < N; k0 += 2 * LG_BK) {
+    __syncthreads();
+    sa[0] = pa0; sa[1] = pa1; sb2[0] = pb0; sb2[1] = pb1;
+    __syncthreads();
+    if (k0 + 2 * LG_BK < N) { ap += kstep; bp += kstep; pa0 = ap[0]; pa1 = ap[1]; pb0 = bp[0]; pb1 = bp[1]; }
+    LG_COMPUTE();
+    __syncthreads();
+    sa[0] = qa0; sa[1] = qa1; sb2[0] = qb0; sb2[1] = qb1;
+    __syncthreads();
+    if (k0 + 3 * LG_BK < N) { ap += kstep; bp += kstep; qa0 = ap[0]; qa1 = ap[1]; qb0 = bp[0]; qb1 = bp[1]; }
+    LG_COMPUTE();
+  }
+#undef LG_COMPUTE
+  // epilogue: D[row = (l>>4) + 4*reg][col = l&15] per 16x16 tile.  The mirrored copy goes through LDS so that it is
+  // stored row-wise too (a direct transposed store puts the 16 lanes of a fragment 8N bytes apart: one L2 channel).
+  if (MIRROR) __syncthreads();   // everyone is done with As / Bs: Ct overlays them
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = wy * WT + i * 16 + kk + 4 * r, lcol = wx * WT + j * 16 + r16;
+        const int row = row0 + lrow, col = col0 + lcol;
+        const size_t idx = (size_t)row * N + col;
+        double c = alpha * acc[i][j][r];
+        if (E) c += beta * E[idx];
+        if (!MIRROR || col >= row) C[idx] = c;        // diagonal tiles: the upper triangle decides
+        if (MIRROR) Ct[lcol * (TM + 1) + lrow] = c;
+      }
+  if (MIRROR) {
+    __syncthreads();
+    const int q = tid & 63;                           // original row   -> column of the mirrored tile
+#pragma unroll 4
+    for (int p = tid >> 6; p < TM; p += 4)            // original column -> row of the mirrored tile
+      if (by != bx || q < p) C[(size_t)(col0 + p) * N + row0 + q] = Ct[p * (TM + 1) + q];
+  }
+}
+
+// Group descriptors: member m of the group is block ids[m]; n = bn[id], svec offset boff[id].
+// svec (upper triangle, column by column, sqrt2 on off-diagonals) -> dense N x N (padding pre-zeroed)
+__global__ void lg_unpack_kernel(const double* __restrict__ src, const int* __restrict__ ids, const long long* __restrict__ boff,
+                                 const int* __restrict__ bn, int N, double* __restrict__ dst) {
+  const int id = ids[blockIdx.y];
+  const int n = bn[id];
+  const int len = n * (n + 1) / 2;
+  const double* s = src + boff[id];
+  double* d = dst + (size_t)blockIdx.y * N * N;
+  for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < len; e += (int)(gridDim.x * blockDim.x)) {
+    int i, j;
+    tri_decode(e, i, j);
+    double v = s[e];
+    if (i != j) v *= kSqrt2Inv;
+    d[(size_t)j * N + i] = v;
+    d[(size_t)i * N + j] = v;
+  }
+}
+__global__ void lg_pack_kernel(const double* __restrict__ src, const int* __restrict__ ids, const long long* __restrict__ boff,
+                               const int* __restrict__ bn, int N, double* __restrict__ dst, int* __restrict__ fail) {
+  const int id = ids[blockIdx.y];
+  const int n = bn[id];
+  const int len = n * (n + 1) / 2;
+  const double* s = src + (size_t)blockIdx.y * N * N;
+  double* d = dst + boff[id];
+  bool bad = false;
+  for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < len; e += (int)(gridDim.x * blockDim.x)) {
+    int i, j;
+    tri_decode(e, i, j);
+    const double v = s[(size_t)j * N + i];
+    bad |= !(fabs(v) <= 1.7976931348623157e308);
+    d[e] = (i == j) ? v : v * kSqrt2;
+  }
+  if (bad && fail) atomicAdd(fail, 1);   // non-finite input: same counter as the QL sweep cap of the eigensolver kernels
+}
+// column sums of |X| (X symmetric: = row sums), then scale[m] = 1 / max_c colsum (0 for a zero block)
+__global__ __launch_bounds__(256) void lg_colsum_kernel(const double* __restrict__ Mb, int N, double* __restrict__ colsum) {
+  const double* M = Mb + (size_t)blockIdx.y * N * N;
+  const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (col < N) {
+    double s = 0.0;
+    for (int r = 0; r < N; ++r) s += fabs(M[(size_t)r * N + col]);
+    colsum[(size_t)blockIdx.y * N + col] = s;
+  }
+}
+__global__ __launch_bounds__(256) void lg_scale_kernel(const double* __restrict__ colsum, int N, double* __restrict__ scale) {
+  __shared__ double red[256];
+  double m = 0.0;
+  for (int c = (int)threadIdx.x; c < N; c += 256) {
+    const double v = colsum[(size_t)blockIdx.x * N + c];
+    m = (v > m || !(v == v)) ? v : m;   // NaN propagates (flagged by the pack kernel)
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double v = red[threadIdx.x + s];
+      if (v > red[threadIdx.x] || !(v == v)) red[threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale[blockIdx.x] = red[0] > 0.0 ? 1.0 / red[0] : (red[0] == 0.0 ? 0.0 : red[0]);
+}
+__global__ void lg_scaled_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t per_mat,
+                                      const double* __restrict__ scale) {
+  const double s = scale[blockIdx.y];
+  const double* a = src + (size_t)blockIdx.y * per_mat;
+  double* b = dst + (size_t)blockIdx.y * per_mat;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_mat; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i] * s;
+}
+// debug only: sum (A - B)^2 per matrix
+__global__ __launch_bounds__(256) void lg_diff_kernel(const double* __restrict__ A, const double* __restrict__ B, size_t per_mat,
+                                                      double* __restrict__ out) {
+  __shared__ double red[256];
+  const double* a = A + (size_t)blockIdx.x * per_mat;
+  const double* b = B + (size_t)blockIdx.x * per_mat;
+  double s = 0.0;
+  for (size_t i = threadIdx.x; i < per_mat; i += 256) { const double d = a[i] - b[i]; s += d * d; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+static int lg_pad(int n) { return (n + LG_TM - 1) / LG_TM * LG_TM; }
+
+static int lg_gemm(bool mirror, int N, int count, const double* A, const double* B, double alpha, double beta, const double* E,
+                   double* C, hipStream_t st) {
+  const int nb = N / LG_TM;
+  if (mirror && count == 1 && nb >= 16) {
+    const int sb = (nb + 7) / 8;                               // 8x8-tile super-blocks per direction
+    hipLaunchKernelGGL(lg_gemm_sym_kernel<true>, dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
+  } else if (mirror) {
+    hipLaunchKernelGGL(lg_gemm_sym_kernel<true>, dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+  } else {
+    hipLaunchKernelGGL(lg_gemm_sym_kernel<false>, dim3(nb * nb, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+  }
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+int large_gemm_sym(int N, const double* A, const double* B, double alpha, double beta, const double* E, double* C, hipStream_t st) {
+  return lg_gemm(false, N, 1, A, B, alpha, beta, E, C, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// Planner: groups by padded size, chunks of bounded workspace
+// ------------------------------------------------------------------------------------------
+int SignPsd::build(const int* blk, const std::vector<int>& members) {
+  release();
+  if (members.empty()) return CUADMM_OK;
+  size_t ws_cap = (size_t)8 << 30;   // bytes of workspace (4 matrices per member); 288 GB of HBM make this generous
+  if (const char* e = getenv("CUADMM_PSD_SIGN_WS_MB")) ws_cap = (size_t)std::max(1, atoi(e)) << 20;
+  std::map<int, std::vector<int>> by_pad;
+  for (int k : members) by_pad[lg_pad(blk[k])].push_back(k);
+  std::vector<int> ids;
+  size_t max_elems = 0, max_cols = 0;
+  int max_count = 0;
+  for (auto& kv : by_pad) {
+    const int N = kv.first;
+    const size_t per = (size_t)N * N * sizeof(double) * 4;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(ws_cap / per, 65535));
+    for (size_t b = 0; b < kv.second.size(); b += (size_t)chunk) {
+      Group g;
+      g.N = N;
+      g.begin = (int)ids.size();
+      g.count = (int)std::min<size_t>((size_t)chunk, kv.second.size() - b);
+      for (int i = 0; i < g.count; ++i) ids.push_back(kv.second[b + i]);
+      max_elems = std::max(max_elems, (size_t)g.count * N * N);
+      max_cols = std::max(max_cols, (size_t)g.count * N);
+      max_count = std::max(max_count, g.count);
+      groups.push_back(g);
+    }
+  }
+  CUADMM_HIP_TRY(hipMalloc(&d_ids, sizeof(int) * ids.size()));
+  CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMalloc(&X0, sizeof(double) * max_elems));
+  CUADMM_HIP_TRY(hipMalloc(&S, sizeof(double) * max_elems));
+  CUADMM_HIP_TRY(hipMalloc(&Y, sizeof(double) * max_elems));
+  CUADMM_HIP_TRY(hipMalloc(&T, sizeof(double) * max_elems));
+  CUADMM_HIP_TRY(hipMalloc(&colsum, sizeof(double) * max_cols));
+  CUADMM_HIP_TRY(hipMalloc(&scale, sizeof(double) * (size_t)max_count));
+  return CUADMM_OK;
+}
+
+void SignPsd::release() {
+  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale})
+    if (p) { hipError_t e = hipFree(p); (void)e; }
+  d_ids = nullptr;
+  X0 = S = Y = T = colsum = scale = nullptr;
+  groups.clear();
+}
+
+// out = svec(P_+(smat(in))) for every member block; boff / bn are the plan's device arrays (all blocks).  Asynchronous.
+int SignPsd::project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
+  static const int debug = getenv("CUADMM_PSD_DEBUG") ? std::max(1, atoi(getenv("CUADMM_PSD_DEBUG"))) : 0;   // 2: per-step updates
+  for (const Group& g : groups) {
+    const int N = g.N, cnt = g.count;
+    const size_t per = (size_t)N * N;
+    const int* ids = d_ids + g.begin;
+    const unsigned gx = (unsigned)std::min<size_t>((per / 2 + 255) / 256, 1024);
+    const auto t0 = std::chrono::steady_clock::now();
+    CUADMM_HIP_TRY(hipMemsetAsync(X0, 0, sizeof(double) * per * (size_t)cnt, st));
+    hipLaunchKernelGGL(lg_unpack_kernel, dim3(gx, cnt), dim3(256), 0, st, in, ids, boff, bn, N, X0);
+    hipLaunchKernelGGL(lg_colsum_kernel, dim3((N + 255) / 256, cnt), dim3(256), 0, st, X0, N, colsum);
+    hipLaunchKernelGGL(lg_scale_kernel, dim3(cnt), dim3(256), 0, st, colsum, N, scale);
+    hipLaunchKernelGGL(lg_scaled_copy_kernel, dim3(gx, cnt), dim3(256), 0, st, X0, S, per, scale);
+    CUADMM_HIP_TRY(hipGetLastError());
+    double* s = S;
+    double* t = T;
+    int rc;
+    for (int it = 0; it < kLiftSteps + kPolishSteps; ++it) {
+      const double mu = it < kLiftSteps ? kLiftMu : 1.0;
+      // Y = S*S ; T = 1.5 mu S - 0.5 mu^3 S*Y
+      if ((rc = lg_gemm(true, N, cnt, s, s, 1.0, 0.0, nullptr, Y, st))) return rc;
+      if ((rc = lg_gemm(true, N, cnt, s, Y, -0.5 * mu * mu * mu, 1.5 * mu, s, t, st))) return rc;
+      if (debug >= 2 && it >= kLiftSteps) {
+        hipLaunchKernelGGL(lg_diff_kernel, dim3(cnt), dim3(256), 0, st, s, t, per, colsum);
+        std::vector<double> h((size_t)cnt);
+        CUADMM_HIP_TRY(hipMemcpyAsync(h.data(), colsum, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+        CUADMM_HIP_TRY(hipStreamSynchronize(st));
+        double mx = 0;
+        for (double v : h) mx = std::max(mx, std::sqrt(v));
+        fprintf(stderr, "[psd debug]   N=%d step %d  max ||S_new - S||_F = %.3e\n", N, it + 1, mx);
+      }
+      std::swap(s, t);
+    }
+    // P = 0.5 * (X0 + X0 * S)
+    if ((rc = lg_gemm(true, N, cnt, X0, s, 0.5, 0.5, X0, Y, st))) return rc;
+    hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
+    CUADMM_HIP_TRY(hipGetLastError());
+    if (debug) {
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      const int steps = kLiftSteps + kPolishSteps;
+      const int nb = N / LG_TM;
+      const double flops = (2.0 * steps + 1.0) * 2.0 * (double)N * LG_TM * LG_TM * (nb * (nb + 1) / 2) * cnt;
+      fprintf(stderr, "[psd debug] sign path: %d blocks padded to N=%d: %d steps, %.2f ms, %.1f TFLOP/s fp64 MFMA (upper-triangle tiles)\n",
+              cnt, N, steps, ms, flops / ms * 1e-9);
+    }
+  }
+  return CUADMM_OK;
+}
+
+}  // namespace cuadmm

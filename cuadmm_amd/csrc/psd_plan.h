@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_util.h"
+#include "psd_large.h"
 
 namespace cuadmm {
 
@@ -19,6 +20,11 @@ struct PsdPlan {
   int* d_fail = nullptr;       // number of blocks whose QL iteration hit its cap (cumulative)
   double* d_ws = nullptr;      // HBM workspace of the large-block path
   long long* d_wsoff = nullptr;
+  // blocks with n >= sign_min (default 65: everything beyond the register kernels) take the GEMM-only matrix-sign
+  // path (psd_large.hip); the workgroup eigensolver kernels (classes 5, 6) then only serve cuadmm_op_batch_eig.
+  // CUADMM_PSD_SIGN_MIN=<n> moves the boundary (A/B measurements).
+  int sign_min = 65;
+  mutable SignPsd sign;
   int cls_begin[kNumPsdClasses] = {0}, cls_count[kNumPsdClasses] = {0}, cls_maxn[kNumPsdClasses] = {0};
 
   int build(const int* blk, int mat_num);

@@ -228,6 +228,11 @@ int cuadmm_op_matrices_to_vector(double* Xb, const double* large_mat, const doub
  * `count` contiguous n x n column-major symmetric matrices, overwritten by eigenvectors
  * (column-major, column k <-> W[k]); W ascending; info[i] = 0 or 1 (iteration cap hit). */
 int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, void* stream);
+/* The DGEMM of the large-block rebuild (the reference calls cublasDgemm on large_mat, src/solver.cu:630-644).
+ * C = alpha * A * B + beta * E for n x n row-major SYMMETRIC A and B (device pointers, n a multiple of 64,
+ * E may be null); this is the fp64 matrix-core kernel behind the large-block projection (psd_large.hip). */
+int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, double beta, const double* E,
+                       double* C, void* stream);
 /* max_dense_vector_zero (src/kernels/dense_scalar.cu:41-47,93-97) */
 int cuadmm_op_max_zero(double* w, int64_t n, void* stream);
 /* dense_matrix_mul_diag_batch (src/kernels/diagonal_batch.cu:11-62): out = in * diag(w) per matrix */
