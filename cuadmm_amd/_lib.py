@@ -78,11 +78,17 @@ PROTOTYPES = {
     "cuadmm_aat_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
     "cuadmm_aat_perm": (c_int_p, [C.c_void_p]),
     "cuadmm_aat_factor_nnz": (C.c_int64, [C.c_void_p]),
+    "cuadmm_aat_factor_colptr": (C.POINTER(C.c_int64), [C.c_void_p]),
     "cuadmm_aat_solve_permuted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cuadmm_aat_tail_plan": (C.c_int, [C.c_void_p, C.c_int]),
+    "cuadmm_aat_tail_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cuadmm_aat_solve_leading_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cuadmm_aat_solve_leading_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "cuadmm_aat_free": (None, [C.c_void_p]),
     "cuadmm_op_vector_to_matrices": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "cuadmm_op_matrices_to_vector": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "cuadmm_op_gemm_sym": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cuadmm_op_tail_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cuadmm_op_batch_eig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cuadmm_op_max_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "cuadmm_op_mul_diag_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

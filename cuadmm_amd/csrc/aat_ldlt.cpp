@@ -291,6 +291,7 @@ int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double
 
 const int* cuadmm_aat_perm(const cuadmm_aat* f) { return f ? f->perm.data() : nullptr; }
 int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f) { return f ? f->Lp[f->m] : 0; }
+const int64_t* cuadmm_aat_factor_colptr(const cuadmm_aat* f) { return f ? f->Lp.data() : nullptr; }
 
 int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x) {
   if (!f || !rhs || !x) { set_error("aat_solve: null argument"); return CUADMM_ERR_INVALID; }
@@ -307,6 +308,76 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x)
   }
   for (int j = 0; j < m; ++j) x[j] /= D[j];
   for (int j = m - 1; j >= 0; --j) {  // L^T x = z
+    double s = x[j];
+    for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
+    x[j] = s;
+  }
+  return CUADMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Dense-tail split.  With a fill-reducing ordering the last k columns of L form an (almost) dense triangle that
+// holds most of nnz(L) (PlanarHand_N=1: last 12 000 of 66 008 columns = 92 % of 13.5 M).  The engine keeps
+// inv(L22) in HBM and runs that part of both triangular solves as two GEMVs on the GPU (tail_solve.hip); the host
+// keeps the sparse leading columns:
+//   forward  : columns j < m-k  (updates rows of both parts),           host
+//   tail     : x2 = L22^-T D2^-1 L22^-1 z2,                             GPU
+//   backward : columns j < m-k  (reads x2),                             host
+// ---------------------------------------------------------------------------------------
+// Cost model: host 1.2 ns per nonzero of the leading columns (both sweeps, measured), GPU 60 us + k^2 * 8 B at 4 TB/s.
+int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k) {
+  if (!f) return 0;
+  const int m = f->m;
+  const int64_t* Lp = f->Lp.data();
+  const double host_ns = 1.2, total = host_ns * (double)Lp[m];
+  double best = total;
+  int best_k = 0;
+  for (int k = 256; k <= std::min(m, max_k); k += 256) {
+    const double cost = host_ns * (double)Lp[m - k] + 60e3 + (double)k * k * 8.0 / 4000.0;
+    if (cost < best) { best = cost; best_k = k; }
+  }
+  if (best_k == 0 || best > 0.7 * total || total < 300e3) return 0;   // not worth a PCIe round trip per solve
+  return best_k;
+}
+
+// dense (k x ld, row-major, unit lower triangular, ld >= k) copy of the trailing k x k block of L, and its D
+int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, double* D2) {
+  if (!f || !L22 || !D2 || k < 1 || k > f->m || ld < k) { set_error("aat_tail_dense: bad arguments"); return CUADMM_ERR_INVALID; }
+  const int m = f->m, n1 = m - k;
+  for (int i = 0; i < k; ++i) {
+    std::memset(L22 + (size_t)i * ld, 0, sizeof(double) * (size_t)ld);
+    L22[(size_t)i * ld + i] = 1.0;
+    D2[i] = f->D[n1 + i];
+  }
+  for (int j = n1; j < m; ++j)
+    for (int64_t p = f->Lp[j]; p < f->Lp[j + 1]; ++p) L22[(size_t)(f->Li[p] - n1) * ld + (j - n1)] = f->Lx[p];
+  return CUADMM_OK;
+}
+
+// forward sweep over the leading m-k columns, then D scaling of the leading part; x[m-k..] holds z2 on return
+int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
+  if (!f || !x || k < 0 || k > f->m) { set_error("aat_solve_leading_forward: bad arguments"); return CUADMM_ERR_INVALID; }
+  const int n1 = f->m - k;
+  const int64_t* Lp = f->Lp.data();
+  const int* Li = f->Li.data();
+  const double* Lx = f->Lx.data();
+  for (int j = 0; j < n1; ++j) {
+    const double xj = x[j];
+    if (xj != 0.0)
+      for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
+  }
+  for (int j = 0; j < n1; ++j) x[j] /= f->D[j];
+  return CUADMM_OK;
+}
+
+// backward sweep over the leading m-k columns; x[m-k..] must hold the solved tail x2
+int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
+  if (!f || !x || k < 0 || k > f->m) { set_error("aat_solve_leading_backward: bad arguments"); return CUADMM_ERR_INVALID; }
+  const int n1 = f->m - k;
+  const int64_t* Lp = f->Lp.data();
+  const int* Li = f->Li.data();
+  const double* Lx = f->Lx.data();
+  for (int j = n1 - 1; j >= 0; --j) {
     double s = x[j];
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
     x[j] = s;

@@ -23,6 +23,7 @@
 
 #include "device_util.h"
 #include "psd_plan.h"
+#include "tail_solve.h"
 #include "vec_kernels.h"
 
 using namespace cuadmm;
@@ -77,7 +78,7 @@ struct PinnedBuf {
   ~PinnedBuf() { release(); }
 };
 
-enum KClass { K_ATY = 0, K_PSD = 1, K_POST = 2, K_SPMV = 3, K_COPY = 4, K_HOST = 5, K_COMM = 6, K_NUM = CUADMM_NUM_KCLASS };
+enum KClass { K_ATY = 0, K_PSD = 1, K_POST = 2, K_SPMV = 3, K_COPY = 4, K_HOST = 5, K_COMM = 6, K_TAIL = 7, K_NUM = CUADMM_NUM_KCLASS };
 
 // direct RCCL binding (symbols resolved at run time so that a process that already loaded an RCCL,
 // e.g. through torch, shares it)
@@ -127,6 +128,7 @@ struct cuadmm_solver {
 
   // host state (constraint space, permuted order unless noted)
   cuadmm_aat* fac = nullptr;
+  TailSolve tail;              // dense trailing triangle of L on the GPU (tail.k == 0: whole solve on the host)
   std::vector<int> perm, perm_inv;
   std::vector<double> normA;      // original order
   std::vector<double> normA_p, b_p, y_p, Rp_p, ASmC_p, rhs_p, y_best_p;
@@ -212,7 +214,19 @@ struct cuadmm_solver {
     double t0 = wall_s();
     const double isig = 1 / sig;
     for (int i = 0; i < m; ++i) rhs_p[i] = -ASmC_p[i] + isig * Rp_p[i];   // solver.cu:478-482
-    int rc = cuadmm_aat_solve_permuted(fac, rhs_p.data(), y_p.data());     // solver.cu:494
+    int rc;
+    if (tail.k == 0) {
+      rc = cuadmm_aat_solve_permuted(fac, rhs_p.data(), y_p.data());     // solver.cu:494
+    } else {   // sparse leading columns here, dense trailing triangle on the GPU
+      y_p = rhs_p;
+      rc = cuadmm_aat_solve_leading_forward(fac, tail.k, y_p.data());
+      double t1 = wall_s();
+      if (!rc) rc = tail.solve(y_p.data() + (m - tail.k), st);
+      double t2 = wall_s();
+      prof_host(K_TAIL, t2 - t1);
+      t0 += t2 - t1;
+      if (!rc) rc = cuadmm_aat_solve_leading_backward(fac, tail.k, y_p.data());
+    }
     prof_host(K_HOST, wall_s() - t0);
     return rc;
   }
@@ -399,6 +413,22 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   // --- host factor of A A^T + 1e-15 I (solver.cu:91-96, cholesky_cpu.h:62-141)
   rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
   if (rc) return rc;
+  // --- dense trailing triangle of L: inverted once on the GPU, two GEMVs per solve (tail_solve.hip)
+  {
+    int tk = 0;
+    const char* e = getenv("CUADMM_TAIL_K");   // 0 disables, >0 forces the tail size (A/B measurements)
+    if (e) tk = std::min(std::max(0, atoi(e)), m);
+    else tk = cuadmm_aat_tail_plan(s->fac, 32768);
+    if (tk > 0) {
+      std::vector<double> L22((size_t)tk * tk), D2((size_t)tk);
+      rc = cuadmm_aat_tail_dense(s->fac, tk, L22.data(), tk, D2.data());
+      if (!rc) rc = s->tail.build(L22.data(), D2.data(), tk, s->st);
+      if (rc) return rc;
+      if (s->verbose) printf("\n A*A^T solve: last %d of %d columns of L (%.1f%% of nnz(L) = %lld) as dense inverse on the GPU (built in %.2fs)\n", tk, m,
+                             100.0 * (double)(cuadmm_aat_factor_nnz(s->fac) - cuadmm_aat_factor_colptr(s->fac)[m - tk]) / (double)std::max<long long>(1, cuadmm_aat_factor_nnz(s->fac)),
+                             (long long)cuadmm_aat_factor_nnz(s->fac), s->tail.build_s);
+    }
+  }
   s->perm.assign(cuadmm_aat_perm(s->fac), cuadmm_aat_perm(s->fac) + m);
   s->perm_inv.assign(m, 0);
   for (int i = 0; i < m; ++i) s->perm_inv[s->perm[i]] = i;
@@ -845,6 +875,14 @@ int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, voi
 int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, double beta, const double* E, double* Cout, void* stream) {
   if (n < 64 || n % 64 != 0 || !A || !B || !Cout) { set_error("gemm_sym: n must be a positive multiple of 64 and pointers non-null"); return CUADMM_ERR_INVALID; }
   return large_gemm_sym(n, A, B, alpha, beta, E, Cout, (hipStream_t)stream);
+}
+
+int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs) {
+  if (!L22_host || !D2_host || !z2_host || k < 1 || nrhs < 0) { set_error("tail_solve: bad arguments"); return CUADMM_ERR_INVALID; }
+  TailSolve t;
+  int rc = t.build(L22_host, D2_host, k, nullptr);
+  for (int r = 0; r < nrhs && !rc; ++r) rc = t.solve(z2_host + (size_t)r * k, nullptr);
+  return rc;
 }
 
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream) {

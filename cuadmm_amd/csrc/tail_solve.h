@@ -1,0 +1,18 @@
+// Dense tail of the A A^T solve on the GPU (tail_solve.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cuadmm {
+
+struct TailSolve {
+  int k = 0, K = 0;            // tail size, padded to a multiple of 64
+  double *W = nullptr, *Wt = nullptr, *dinv = nullptr, *vin = nullptr, *vmid = nullptr;   // device
+  double* h_vec = nullptr;     // pinned staging vector
+  double build_s = 0;
+  int build(const double* L22, const double* D2, int k, hipStream_t st);
+  int solve(double* z2, hipStream_t st);
+  void release();
+  ~TailSolve() { release(); }
+};
+
+}  // namespace cuadmm

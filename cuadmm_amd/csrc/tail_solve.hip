@@ -1,0 +1,246 @@
+// Dense tail of the A A^T solve on the GPU.
+//
+// The reference runs both triangular sweeps of CHOLMOD's LDL^T on the host every iteration (cholesky_cpu.h:146-155,
+// solver.cu:487-500).  With a fill-reducing ordering the last k columns of L are an almost dense triangle L22 that
+// holds most of nnz(L), and sweeping it from host DRAM is what bounds the iteration on moment-relaxation problems
+// (PlanarHand_N=1: 13.5 M nonzeros, 16 ms per solve, 89 % of the iteration).  Here
+//     x2 = L22^-T D2^-1 L22^-1 z2
+// runs on the GPU as two triangular GEMVs with W = inv(L22) resident in HBM (W and W^T, both row-major, so that
+// both GEMVs are row dot products: coalesced, no atomics, bit-reproducible across ranks).  W is computed once at
+// init by recursive doubling on the fp64 matrix cores:
+//     inv([L11 0; L21 L22]) = [W11 0; -W22 L21 W11, W22],
+// 64 x 64 diagonal blocks by forward substitution, then block sizes 64, 128, 256, ... with two batched GEMMs per
+// level (all groups of a level in one launch).  The host keeps the sparse leading columns (aat_ldlt.cpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "device_util.h"
+#include "tail_solve.h"
+
+namespace cuadmm {
+
+typedef double ts_v4f64 __attribute__((ext_vector_type(4)));
+constexpr int TS_BK = 16, TS_TM = 64;
+
+// C = alpha * A * B, general row-major operands with leading dimensions, batched (blockIdx.y) with element strides.
+// M, N, Kd multiples of 64 / 64 / 16.  Same tiling as lg_gemm_sym_kernel (psd_large.hip); A is staged transposed.
+__global__ __launch_bounds__(256) void ts_gemm_nn_kernel(int M, int N, int Kd, double alpha,
+                                                         const double* __restrict__ Ab, long long lda, long long sA,
+                                                         const double* __restrict__ Bb, long long ldb, long long sB,
+                                                         double* __restrict__ Cb, long long ldc, long long sC) {
+  constexpr int LDS = TS_TM + 16, WT = TS_TM / 2, NTW = WT / 16;
+  __shared__ double As[TS_BK * LDS];
+  __shared__ double Bs[TS_BK * LDS];
+  const double* A = Ab + (size_t)blockIdx.y * sA;
+  const double* B = Bb + (size_t)blockIdx.y * sB;
+  double* C = Cb + (size_t)blockIdx.y * sC;
+  const int tn = N / TS_TM;
+  const int by = (int)blockIdx.x / tn, bx = (int)blockIdx.x % tn;
+  (void)M;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int row0 = by * TS_TM, col0 = bx * TS_TM;
+  const int r16 = lane & 15, kk = lane >> 4;
+  ts_v4f64 acc[NTW][NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = ts_v4f64{0.0, 0.0, 0.0, 0.0};
+  // A tile: 64 rows x 16 k; thread t: row t/4, k (t%4)*4 .. +3 (contiguous in memory), stored transposed As[k][row]
+  const int ar = tid >> 2, ak = (tid & 3) * 4;
+  const double2* ap = reinterpret_cast<const double2*>(A + (size_t)(row0 + ar) * lda + ak);
+  // B tile: 16 k x 64 cols; thread t: k t/16, 4 cols at (t%16)*4
+  const int lk = tid >> 4, lc = (tid & 15) * 4;
+  const double2* bp = reinterpret_cast<const double2*>(B + (size_t)lk * ldb + col0 + lc);
+  const size_t bstep = (size_t)TS_BK * ldb / 2;
+  double2 pa0 = ap[0], pa1 = ap[1], pb0 = bp[0], pb1 = bp[1];
+  double2* sb = reinterpret_cast<double2*>(Bs + lk * LDS + lc);
+  for (int k0 = 0; k0 < Kd; k0 += TS_BK) {
+    __syncthreads();
+    As[(ak + 0) * LDS + ar] = pa0.x; As[(ak + 1) * LDS + ar] = pa0.y;
+    As[(ak + 2) * LDS + ar] = pa1.x; As[(ak + 3) * LDS + ar] = pa1.y;
+    sb[0] = pb0; sb[1] = pb1;
+    __syncthreads();
+    if (k0 + TS_BK < Kd) { ap += TS_BK / 2; bp += bstep; pa0 = ap[0]; pa1 = ap[1]; pb0 = bp[0]; pb1 = bp[1]; }
+#pragma unroll
+    for (int ks = 0; ks < TS_BK; ks += 4) {
+      double af[NTW], bf[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        af[t] = As[(ks + kk) * LDS + wy * WT + t * 16 + r16];
+        bf[t] = Bs[(ks + kk) * LDS + wx * WT + t * 16 + r16];
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wy * WT + i * 16 + kk + 4 * r, col = col0 + wx * WT + j * 16 + r16;
+        C[(size_t)row * ldc + col] = alpha * acc[i][j][r];
+      }
+}
+
+// W_bb = inv(L_bb) for every 64 x 64 diagonal block (unit lower triangular): thread c builds column c by forward substitution
+__global__ __launch_bounds__(64) void ts_diag_inverse_kernel(const double* __restrict__ L, double* __restrict__ W, long long ld) {
+  __shared__ double Ls[64 * 65];
+  const size_t base = (size_t)blockIdx.x * 64 * ld + (size_t)blockIdx.x * 64;
+  const int c = (int)threadIdx.x;
+  for (int r = 0; r < 64; ++r) Ls[r * 65 + c] = L[base + (size_t)r * ld + c];
+  __syncthreads();
+  double w[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) w[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= Ls[i * 65 + j] * w[j];   // w[j] = 0 for j < c
+    w[i] = (i >= c) ? s : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 64; ++i) Ls[i * 65 + c] = w[i];
+  __syncthreads();
+  for (int r = 0; r < 64; ++r) W[base + (size_t)r * ld + c] = Ls[r * 65 + c];
+}
+
+__global__ __launch_bounds__(256) void ts_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, long long ld) {
+  __shared__ double t[32][33];
+  const int tx = (int)threadIdx.x & 31, ty = (int)threadIdx.x >> 5;
+  const size_t r0 = (size_t)blockIdx.y * 32, c0 = (size_t)blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = src[(r0 + r) * ld + c0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) dst[(c0 + r) * ld + r0 + tx] = t[tx][r];
+}
+
+// out[i] = scale[i] * sum_{c in range(i)} Mx[i][c] * in[c];  LOWER: c <= i,  else c >= i.  One wavefront per row.
+template <bool LOWER>
+__global__ __launch_bounds__(256) void ts_tri_gemv_kernel(const double* __restrict__ Mx, long long ld, int K,
+                                                          const double* __restrict__ in, const double* __restrict__ scale,
+                                                          double* __restrict__ out) {
+  const int lane = (int)threadIdx.x & 63;
+  // long rows first (they decide the tail of the launch)
+  const int slot = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (slot >= K) return;
+  const int i = LOWER ? K - 1 - slot : slot;
+  const int lo = LOWER ? 0 : (i & ~1), hi = LOWER ? i + 1 : K;   // even start keeps the double2 loads aligned
+  const double* row = Mx + (size_t)i * ld;
+  double s = 0.0;
+  int c = lo + 2 * lane;
+  for (; c + 1 < hi; c += 128) {
+    const double2 mv = *reinterpret_cast<const double2*>(row + c);
+    const double2 xv = *reinterpret_cast<const double2*>(in + c);
+    s += mv.x * xv.x + mv.y * xv.y;      // entries outside the triangle are exact zeros
+  }
+  if (c < hi) s += row[c] * in[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[i] = scale ? s * scale[i] : s;
+}
+
+static int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, long long sA, const double* B, long long ldb,
+                   long long sB, double* C, long long ldc, long long sC, int batch, hipStream_t st) {
+  if (batch <= 0 || M <= 0 || N <= 0) return CUADMM_OK;
+  hipLaunchKernelGGL(ts_gemm_nn_kernel, dim3((M / TS_TM) * (N / TS_TM), batch), dim3(256), 0, st, M, N, Kd, alpha, A, lda, sA, B, ldb, sB,
+                     C, ldc, sC);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+void TailSolve::release() {
+  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
+  W = Wt = dinv = vin = vmid = h_vec = nullptr;
+  k = K = 0;
+}
+
+// L22: k x k dense row-major unit lower triangular (host), D2: k pivots (host)
+int TailSolve::build(const double* L22, const double* D2, int k_, hipStream_t st) {
+  release();
+  k = k_;
+  K = (k + TS_TM - 1) / TS_TM * TS_TM;
+  const long long ld = K;
+  const size_t sz = (size_t)K * K;
+  const auto t0 = std::chrono::steady_clock::now();
+  double *dL = nullptr, *dT = nullptr;
+  CUADMM_HIP_TRY(hipMalloc(&dL, sizeof(double) * sz));
+  CUADMM_HIP_TRY(hipMalloc(&dT, sizeof(double) * sz));
+  CUADMM_HIP_TRY(hipMalloc(&W, sizeof(double) * sz));
+  CUADMM_HIP_TRY(hipMalloc(&Wt, sizeof(double) * sz));
+  CUADMM_HIP_TRY(hipMalloc(&dinv, sizeof(double) * (size_t)K));
+  CUADMM_HIP_TRY(hipMalloc(&vin, sizeof(double) * (size_t)K));
+  CUADMM_HIP_TRY(hipMalloc(&vmid, sizeof(double) * (size_t)K));
+  CUADMM_HIP_TRY(hipHostMalloc(&h_vec, sizeof(double) * (size_t)K, hipHostMallocDefault));
+  // upload: rows of L22 (leading dimension k) into the padded matrix (identity in the padding)
+  CUADMM_HIP_TRY(hipMemsetAsync(dL, 0, sizeof(double) * sz, st));
+  CUADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * sz, st));
+  CUADMM_HIP_TRY(hipMemcpy2DAsync(dL, sizeof(double) * (size_t)ld, L22, sizeof(double) * (size_t)k, sizeof(double) * (size_t)k, (size_t)k,
+                                  hipMemcpyHostToDevice, st));
+  {
+    std::vector<double> di((size_t)K, 1.0), ones((size_t)(K - k), 1.0);
+    for (int i = 0; i < k; ++i) di[i] = 1.0 / D2[i];
+    CUADMM_HIP_TRY(hipMemcpyAsync(dinv, di.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
+    if (K > k)   // unit diagonal of the padding
+      CUADMM_HIP_TRY(hipMemcpy2DAsync(dL + (size_t)k * ld + k, sizeof(double) * (size_t)(ld + 1), ones.data(), sizeof(double), sizeof(double),
+                                      (size_t)(K - k), hipMemcpyHostToDevice, st));
+    CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  }
+  hipLaunchKernelGGL(ts_diag_inverse_kernel, dim3(K / 64), dim3(64), 0, st, dL, W, ld);
+  CUADMM_HIP_TRY(hipGetLastError());
+  int rc = CUADMM_OK;
+  for (long long h = 64; h < K && !rc; h *= 2) {
+    // groups [a, a+2h): W21 = -W22 * (L21 * W11); the second half may be short (h2 < h) in the last group only
+    const int full = (int)(K / (2 * h));
+    const long long gs = 2 * h * (ld + 1);   // element stride between groups (diagonal step)
+    if (full > 0) {
+      rc = ts_gemm((int)h, (int)h, (int)h, 1.0, dL + h * ld, ld, gs, W, ld, gs, dT + h * ld, ld, gs, full, st);
+      if (!rc) rc = ts_gemm((int)h, (int)h, (int)h, -1.0, W + h * (ld + 1), ld, gs, dT + h * ld, ld, gs, W + h * ld, ld, gs, full, st);
+    }
+    const long long a = (long long)full * 2 * h;
+    const long long h2 = K - a - h;
+    if (!rc && h2 > 0) {
+      const size_t o = (size_t)a * (ld + 1);
+      rc = ts_gemm((int)h2, (int)h, (int)h, 1.0, dL + o + h * ld, ld, 0, W + o, ld, 0, dT + o + h * ld, ld, 0, 1, st);
+      if (!rc) rc = ts_gemm((int)h2, (int)h, (int)h2, -1.0, W + o + h * (ld + 1), ld, 0, dT + o + h * ld, ld, 0, W + o + h * ld, ld, 0, 1, st);
+    }
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(ts_transpose_kernel, dim3(K / 32, K / 32), dim3(256), 0, st, W, Wt, ld);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("tail_solve build: %s", hipGetErrorString(e)); rc = CUADMM_ERR_INVALID; }
+  }
+  { hipError_t e = hipFree(dL); (void)e; e = hipFree(dT); (void)e; }
+  build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc) release();
+  return rc;
+}
+
+// x2 = L22^-T D2^-1 L22^-1 z2, host vector in place (k doubles); synchronous on `st`
+int TailSolve::solve(double* z2, hipStream_t st) {
+  if (!W) { set_error("tail_solve: not built"); return CUADMM_ERR_INVALID; }
+  std::copy(z2, z2 + k, h_vec);
+  std::fill(h_vec + k, h_vec + K, 0.0);
+  CUADMM_HIP_TRY(hipMemcpyAsync(vin, h_vec, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
+  CUADMM_HIP_TRY(hipGetLastError());
+  CUADMM_HIP_TRY(hipMemcpyAsync(h_vec, vin, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, st));
+  CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  std::copy(h_vec, h_vec + k, z2);
+  return CUADMM_OK;
+}
+
+}  // namespace cuadmm

@@ -220,7 +220,7 @@ class SDPSolver:
     def profile(self):
         o = np.zeros(24)
         check(self._lib.cuadmm_get_profile(self._h, _p(o)))
-        names = ["aty_xb", "psd_project", "post_proj", "spmv_A", "copies", "host", "allreduce", "reserved"]
+        names = ["aty_xb", "psd_project", "post_proj", "spmv_A", "copies", "host", "allreduce", "tail_solve"]
         return {n: dict(launches=o[3 * i], ms=o[3 * i + 1], bytes_per_launch=o[3 * i + 2]) for i, n in enumerate(names)}
 
     def reset_profile(self):

@@ -143,7 +143,7 @@ int cuadmm_get_state(const cuadmm_solver* s, double out12[12]);
 
 /* Per-kernel-class timing collected when option "profile"=1 (HIP events on the engine
  * stream).  Classes: 0 aty_xb, 1 psd_project, 2 post_proj, 3 spmv_A, 4 copies/h2d/d2h,
- * 5 host_solve (wall), 6 allreduce.  out[3*k+0]=launches, [3*k+1]=total ms, [3*k+2]=bytes
+ * 5 host_solve (wall, without 7), 6 allreduce, 7 GPU part of the A*A^T solve (wall, incl. transfers).  out[3*k+0]=launches, [3*k+1]=total ms, [3*k+2]=bytes
  * (algorithmic HBM bytes per launch).  */
 #define CUADMM_NUM_KCLASS 8
 int cuadmm_get_profile(const cuadmm_solver* s, double out[3 * CUADMM_NUM_KCLASS]);
@@ -208,9 +208,22 @@ int cuadmm_aat_create(int con_num, int vec_len, const int* A_col_ptrs, const int
 /* CHOLMOD L->Perm semantics: row i of the permuted system is original row perm[i] */
 const int* cuadmm_aat_perm(const cuadmm_aat* f);
 int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f);
+/* column pointers (m+1) of the strict lower triangle of L, for diagnostics */
+const int64_t* cuadmm_aat_factor_colptr(const cuadmm_aat* f);
 /* cholmod_solve2(CHOLMOD_LDLt): NO permutation applied inside (cholesky_cpu.h:146-155);
  * caller does rhs_perm[perm_inv[i]] = rhs[i] and y[perm[i]] = sol_perm[i] (solver.cu:487,500) */
 int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs_perm, double* sol_perm);
+/* Dense-tail split of the solve (no reference counterpart: CHOLMOD runs both sweeps on the host).  The last k
+ * columns of L are an almost dense triangle holding most of nnz(L); the engine inverts that triangle once on the GPU
+ * and runs it as two GEMVs per solve, the host keeps the sparse leading columns.
+ *   tail_plan            : k chosen by the cost model (0 = keep everything on the host), k <= max_k
+ *   tail_dense           : trailing k x k block of L as dense row-major unit-lower matrix (leading dimension ld) and D
+ *   solve_leading_forward: forward sweep + D scaling over the leading m-k columns, in place; x[m-k..] then holds z2
+ *   solve_leading_backward: backward sweep over the leading columns, in place; x[m-k..] must hold the solved tail */
+int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k);
+int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, double* D2);
+int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x);
+int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x);
 void cuadmm_aat_free(cuadmm_aat* f);
 
 /* ------------------------------------------------------------------------------------ */
@@ -233,6 +246,9 @@ int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, voi
  * E may be null); this is the fp64 matrix-core kernel behind the large-block projection (psd_large.hip). */
 int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, double beta, const double* E,
                        double* C, void* stream);
+/* The GPU part of the A*A^T solve on its own (tail_solve.hip): z <- L22^-T D2^-1 L22^-1 z for `nrhs` host vectors
+ * of length k (contiguous), L22 dense k x k row-major unit lower triangular and D2 the pivots (host pointers). */
+int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs);
 /* max_dense_vector_zero (src/kernels/dense_scalar.cu:41-47,93-97) */
 int cuadmm_op_max_zero(double* w, int64_t n, void* stream);
 /* dense_matrix_mul_diag_batch (src/kernels/diagonal_batch.cu:11-62): out = in * diag(w) per matrix */
