@@ -70,3 +70,22 @@ def test_c5_pendulum_first_log_rows(ref_logs):
             got = [s.info_arr(n)[it - 1] for n in ("errRp", "errRd", "pobj", "dobj", "relgap")]
             for g, w in zip(got, [float(x) for x in row[1:6]]):
                 assert abs(g - w) <= 6e-3 * abs(w) + 1e-12, (it, got, row)
+
+
+def test_gpu_tail_of_the_aat_solve_matches_host_only_solve(monkeypatch):
+    """pendulum N=80: the cost model moves the dense trailing triangle of L to the GPU (tail_solve.hip); the iterates
+    must agree with the host-only solve (CUADMM_TAIL_K=0) far below the stopping tolerance."""
+    p = load_npz_problem("pendulum_N=80")
+    runs = {}
+    for mode in ("gpu_tail", "host_only"):
+        if mode == "host_only":
+            monkeypatch.setenv("CUADMM_TAIL_K", "0")
+        else:
+            monkeypatch.delenv("CUADMM_TAIL_K", raising=False)
+        s = cuadmm_amd.SDPSolver(verbose=False, profile=1)
+        s.init_problem(problem_to_amd(p))
+        s.solve(60, 1e-3, 0, 50, 100, 11000, 1.05)
+        runs[mode] = (s.X, s.y, s.S, s.profile())
+    assert runs["gpu_tail"][3]["tail_solve"]["launches"] > 0 and runs["host_only"][3]["tail_solve"]["launches"] == 0
+    for a, b in zip(runs["gpu_tail"][:3], runs["host_only"][:3]):
+        assert np.linalg.norm(a - b) <= 1e-9 * max(1.0, np.linalg.norm(b))

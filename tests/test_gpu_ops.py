@@ -155,3 +155,37 @@ def test_cli_matches_engine_and_reference_format(problem_dirs, ref_logs):
     # unreadable directory -> exit(1) like the reference (io.cu:30-33)
     r2 = subprocess.run([exe, "/nonexistent/"], capture_output=True, text=True)
     assert r2.returncode == 1
+
+
+@pytest.mark.parametrize("n", [64, 192, 1024])
+def test_gemm_sym_op_fp64_mfma(n):
+    """The DGEMM behind the large-block projection (psd_large.hip) against numpy; A must be symmetric."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)); A = (A + A.T) / 2
+    B = rng.standard_normal((n, n))
+    E = rng.standard_normal((n, n))
+    dA, dB, dE, dC = Dev(A), Dev(B), Dev(E), Dev(shape=(n, n))
+    check(lib.cuadmm_op_gemm_sym(n, dA.ptr, dB.ptr, 0.75, -1.25, dE.ptr, dC.ptr, None))
+    check(lib.cuadmm_dev_sync())
+    ref = 0.75 * A @ B - 1.25 * E
+    assert np.max(np.abs(dC.get() - ref)) <= 1e-13 * n
+    check(lib.cuadmm_op_gemm_sym(n, dA.ptr, dB.ptr, 1.0, 0.0, None, dC.ptr, None))
+    check(lib.cuadmm_dev_sync())
+    assert np.max(np.abs(dC.get() - A @ B)) <= 1e-13 * n
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        check(lib.cuadmm_op_gemm_sym(100, dA.ptr, dB.ptr, 1.0, 0.0, None, dC.ptr, None))
+
+
+@pytest.mark.parametrize("k", [1, 50, 64, 100, 192, 1000, 2500])
+def test_tail_solve_op_vs_triangular_solves(k):
+    """z <- L^-T D^-1 L^-1 z with inv(L) from recursive doubling on the matrix cores (tail_solve.hip), ragged sizes."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(k)
+    L = np.tril(rng.standard_normal((k, k)) * (0.5 / np.sqrt(k)), -1) + np.eye(k)
+    D = rng.uniform(0.1, 2.0, k) * rng.choice([1.0, 1.0, 1.0, -1.0], k)       # LDL^T pivots may be negative
+    z = rng.standard_normal((3, k))
+    ref = np.stack([sl.solve_triangular(L.T, sl.solve_triangular(L, zi, lower=True, unit_diagonal=True) / D,
+                                        lower=False, unit_diagonal=True) for zi in z])
+    got = z.copy()
+    check(lib.cuadmm_op_tail_solve(L.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p), k, got.ctypes.data_as(C.c_void_p), 3))
+    assert np.linalg.norm(got - ref) <= 1e-13 * np.linalg.norm(ref)

@@ -154,3 +154,82 @@ def test_batch_eig_reference_kats():
     assert np.allclose(W2[0], [0.5 * (5 - 5 ** 0.5), 0.5 * (5 + 5 ** 0.5)], atol=1e-12)
     W3, _, _ = batch_eig_gpu(np.array([[[3.0, 1, 2], [1, 3, 1], [2, 1, 3]]]))
     assert np.allclose(W3[0], [1.0, 4 - 3 ** 0.5, 4 + 3 ** 0.5], atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Blocks with n > 64: GEMM-only projection through the matrix sign function (psd_large.hip).  The oracle is still the
+# LAPACK eigendecomposition; tolerance 1e-12 * ||X||_2-ish per entry (an eigenvalue below 1e-13 ||X||_1 may be
+# treated as zero: its contribution to the projection is at most its own size).
+# ------------------------------------------------------------------------------------------------------------
+def _spectrum_matrix(n, kind, rng):
+    if kind == "randn":
+        M = rng.standard_normal((n, n)); return (M + M.T) / 2
+    if kind == "lowrank":                 # late-ADMM iterate: rank 5 plus indefinite noise at 1e-7
+        U = rng.standard_normal((n, 5)); G = rng.standard_normal((n, n))
+        return U @ U.T + 1e-7 * (G + G.T)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    if kind == "graded":                  # both signs over 14 decades
+        lam = np.concatenate([10.0 ** rng.uniform(-14, 0, n // 2), -10.0 ** rng.uniform(-14, 0, n - n // 2)])
+    elif kind == "psd":
+        lam = rng.uniform(0.1, 3.0, n)
+    elif kind == "nsd":
+        lam = -rng.uniform(0.1, 3.0, n)
+    elif kind == "clustered":             # eigenvalues +-1 (sign function already converged) and a zero cluster
+        lam = np.repeat([1.0, -1.0, 0.0, 2.0], (n + 3) // 4)[:n]
+    M = (Q * lam) @ Q.T
+    return (M + M.T) / 2
+
+
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 500])
+@pytest.mark.parametrize("kind", ["randn", "lowrank", "graded", "psd", "nsd", "clustered"])
+def test_project_sign_path_spectra(n, kind):
+    rng = np.random.default_rng(1000 * n + len(kind))
+    M = _spectrum_matrix(n, kind, rng)
+    blk = np.array([n], dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = bidx.pack([M[None]])
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(bidx, x)
+    nrm = np.linalg.norm(M, 2)
+    assert np.max(np.abs(got - ref)) <= 2e-12 * max(nrm, 1e-300) * np.sqrt(2)
+    if kind == "psd":
+        assert np.max(np.abs(got - x)) <= 2e-12 * nrm * np.sqrt(2)          # P+ is the identity on the cone
+
+
+def test_project_sign_path_batched_groups_and_zero_block():
+    """Several padded sizes in one call (N = 128: n = 65, 100, 128; N = 192: 130, 192; N = 256: 200) mixed with
+    register-kernel blocks; a zero block stays exactly zero."""
+    blk = np.array([100, 32, 65, 130, 128, 8, 100, 200, 192, 100, 64, 70], dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = _rand_svec(blk, 21)
+    zero_k = 6
+    x[int(bidx.off[zero_k]):int(bidx.off[zero_k + 1])] = 0.0
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(bidx, x)
+    assert np.max(np.abs(got - ref)) <= 2e-12 * 200
+    assert np.all(got[int(bidx.off[zero_k]):int(bidx.off[zero_k + 1])] == 0.0)
+
+
+def test_project_sign_path_full_size_properties():
+    """BASELINE config 3 size (one block of n = 2000): oracle parity, idempotence, Moreau decomposition, complementarity."""
+    n = 2000
+    blk = np.array([n], dtype=np.int32)
+    x = _rand_svec(blk, 22)
+    p1 = psd_project_gpu(x, blk)
+    pm = psd_project_gpu(-x, blk)
+    p2 = psd_project_gpu(p1, blk)
+    scale = 70.0                                                            # ||X||_2 of this input ~ 2 sqrt(n) / sqrt(2)
+    assert np.max(np.abs(p2 - p1)) <= 1e-12 * scale
+    assert np.max(np.abs((p1 - pm) - x)) <= 1e-12 * scale
+    assert abs(np.dot(p1, pm)) <= 1e-10 * np.dot(x, x)
+    ref = orc.psd_project_svec(orc.BlockIndex(blk), x)
+    assert np.max(np.abs(p1 - ref)) <= 1e-12 * scale
+
+
+def test_project_sign_path_flags_non_finite_input():
+    import cuadmm_amd
+    blk = np.array([100, 16], dtype=np.int32)
+    x = _rand_svec(blk, 23)
+    x[17] = np.nan
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        psd_project_gpu(x, blk)

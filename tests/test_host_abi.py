@@ -198,3 +198,53 @@ def test_write_dense_txt_format(tmp_path):
     check(lib.cuadmm_write_dense_txt(fn.encode(), P(v), 3))
     lines = open(fn).read().splitlines()
     assert lines == ["%.32f" % x for x in v]                                        # memory.h:278-294
+
+
+@pytest.mark.parametrize("name,frac", [("rose13", 0.3), ("truss5", 0.5), ("hinf12", 1.0)])
+def test_aat_dense_tail_split_matches_full_solve(name, frac, problem_dirs):
+    """The split used by the engine's GPU tail (aat_ldlt.cpp / tail_solve.hip): leading sparse columns on the host,
+    trailing k x k dense unit-lower triangle solved separately (here by scipy), equals the one-piece solve."""
+    import scipy.linalg as sl
+    p = orc.load_problem_txt(problem_dirs[name])
+    m = p.con_num
+    h, A = _aat(p)
+    k = max(1, int(m * frac))
+    rng = np.random.default_rng(1)
+    rhs = rng.standard_normal(m)
+    ref = np.empty(m)
+    check(lib.cuadmm_aat_solve_permuted(h, P(rhs), P(ref)))
+    L22 = np.full((k, k + 3), np.nan); D2 = np.empty(k)                          # leading dimension > k
+    check(lib.cuadmm_aat_tail_dense(h, k, P(L22), k + 3, P(D2)))
+    L22 = L22[:, :k]
+    assert np.all(np.diag(L22) == 1.0) and np.all(np.triu(L22, 1) == 0.0)
+    Lp = np.ctypeslib.as_array(lib.cuadmm_aat_factor_colptr(h), shape=(m + 1,))
+    assert np.count_nonzero(np.tril(L22, -1)) <= Lp[m] - Lp[m - k]
+    x = rhs.copy()
+    check(lib.cuadmm_aat_solve_leading_forward(h, k, P(x)))
+    z2 = sl.solve_triangular(L22, x[m - k:], lower=True, unit_diagonal=True)
+    x[m - k:] = sl.solve_triangular(L22.T, z2 / D2, lower=False, unit_diagonal=True)
+    check(lib.cuadmm_aat_solve_leading_backward(h, k, P(x)))
+    assert np.linalg.norm(x - ref) <= 1e-12 * np.linalg.norm(ref)
+    # the cost model keeps small factors on the host
+    assert lib.cuadmm_aat_tail_plan(h, 32768) == 0
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        check(lib.cuadmm_aat_tail_dense(h, m + 1, P(L22), m + 1, P(D2)))
+    lib.cuadmm_aat_free(h)
+
+
+def test_aat_tail_plan_picks_the_dense_triangle():
+    """PlanarHand_N=1 (BASELINE config 1 data): L has 13.5 M nonzeros, > 90 % of them in the last ~12 000 columns."""
+    from tests.conftest import load_npz_problem
+    p = load_npz_problem("pendulum_N=80")
+    At = sp.csc_matrix((p.At_vals, p.At_row_ids, p.At_col_ptrs), shape=(p.vec_len, p.con_num))
+    A = At.T.tocsc(); A.sort_indices()
+    h = C.c_void_p()
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    check(lib.cuadmm_aat_create(p.con_num, p.vec_len, P(cp), P(ri), P(vx), 1e-15, C.byref(h)))
+    m = p.con_num
+    k = lib.cuadmm_aat_tail_plan(h, 32768)
+    Lp = np.ctypeslib.as_array(lib.cuadmm_aat_factor_colptr(h), shape=(m + 1,))
+    assert 0 < k <= 32768 and k % 256 == 0
+    assert Lp[m] - Lp[m - k] >= 0.4 * Lp[m]                                      # the tail holds a large share of nnz(L)
+    assert lib.cuadmm_aat_tail_plan(h, 128) == 0                                 # cap below the smallest candidate
+    lib.cuadmm_aat_free(h)
