@@ -103,3 +103,33 @@ def config_c4(n_blocks=100000, seed=20240601):
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     blk = blk[rng.permutation(blk.size)]
     return make_synthetic(blk, cons_per_block=3, seed=seed)
+
+
+def config_c3(n=2000, degree=8, seed=20240601):
+    """BASELINE config 3: max-cut relaxation of a random graph, one PSD block of size n.
+
+        min <C, X>  s.t.  X_ii = 1 (i = 1..n),  X >= 0,     C = -(Diag(W 1) - W) / 4
+
+    W: symmetric 0/1 adjacency with about `degree` neighbours per node.  m = n constraints, each a single svec slot.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed + 2))
+    n_edges = n * degree // 2
+    i = rng.integers(0, n, n_edges)
+    j = rng.integers(0, n, n_edges)
+    keep = i != j
+    lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
+    pairs = np.unique(np.stack([lo, hi], 1), axis=0)
+    lo, hi = pairs[:, 0], pairs[:, 1]
+    deg = np.bincount(lo, minlength=n) + np.bincount(hi, minlength=n)
+    L = n * (n + 1) // 2
+    diag_slot = (np.arange(n, dtype=np.int64) * (np.arange(n, dtype=np.int64) + 1)) // 2 + np.arange(n)   # (col i, row i)
+    off_slot = hi.astype(np.int64) * (hi + 1) // 2 + lo                                              # (col hi, row lo)
+    C = np.zeros(L)
+    C[diag_slot] = -deg / 4.0
+    C[off_slot] = SQRT2 * (1.0 / 4.0)            # svec scaling of off-diagonal entries; -(-W_ij)/4
+    cp = np.arange(n + 1, dtype=np.int32)
+    rows = diag_slot.astype(np.int32)
+    vals = np.ones(n)
+    b_idx = np.arange(n, dtype=np.int32)
+    C_idx = np.nonzero(C)[0].astype(np.int32)
+    return SyntheticProblem(L, n, np.array([n], np.int32), cp, rows, vals, b_idx, np.ones(n), C_idx, C[C_idx])
