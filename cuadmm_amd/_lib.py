@@ -81,6 +81,10 @@ PROTOTYPES = {
     "cuadmm_aat_factor_colptr": (C.POINTER(C.c_int64), [C.c_void_p]),
     "cuadmm_aat_solve_permuted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cuadmm_aat_tail_plan": (C.c_int, [C.c_void_p, C.c_int]),
+    "cuadmm_aat_create_split": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
+    "cuadmm_aat_tail_k": (C.c_int, [C.c_void_p]),
+    "cuadmm_aat_tail_schur": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_double))]),
+    "cuadmm_aat_tail_schur_release": (None, [C.c_void_p]),
     "cuadmm_aat_tail_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "cuadmm_aat_solve_leading_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "cuadmm_aat_solve_leading_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -88,6 +92,7 @@ PROTOTYPES = {
     "cuadmm_op_vector_to_matrices": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "cuadmm_op_matrices_to_vector": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "cuadmm_op_gemm_sym": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cuadmm_op_tail_factor_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cuadmm_op_tail_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cuadmm_op_batch_eig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cuadmm_op_max_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -26,6 +26,13 @@ struct cuadmm_aat {
   std::vector<int> Li;
   std::vector<double> Lx;
   std::vector<double> D;
+  // split factorisation (cuadmm_aat_create_split): the last tail_k columns are NOT factored on the host; schur_*
+  // hold the lower triangle (with diagonal) of the Schur complement B22 - L21 D1 L21^T by rows (CSR, tail-local
+  // column indices) for the GPU.  Sparse on purpose: a dense 17 152^2 host matrix costs seconds of page faults.
+  int tail_k = 0;
+  std::vector<int64_t> schur_ptr;
+  std::vector<int> schur_col;
+  std::vector<double> schur_val;
   double analyze_s = 0, factor_s = 0;
 };
 
@@ -132,11 +139,41 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Cost model of the dense-tail split: host 1.2 ns per nonzero of the leading columns (both sweeps, measured),
+// GPU 60 us + k^2 * 8 B at 4 TB/s.  Returns 0 when the split does not pay for its PCIe round trip.
+int plan_tail(const int64_t* Lp, int m, int max_k) {
+  const double host_ns = 1.2, total = host_ns * (double)Lp[m];
+  double best = total;
+  int best_k = 0;
+  for (int k = 256; k <= std::min(m, max_k); k += 256) {
+    const double cost = host_ns * (double)Lp[m - k] + 60e3 + (double)k * k * 8.0 / 4000.0;
+    if (cost < best) { best = cost; best_k = k; }
+  }
+  if (best_k == 0 || best > 0.7 * total || total < 300e3) return 0;
+  return best_k;
+}
+
+int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* Ax, double eps, int split_max_k, cuadmm_aat** out);
+
 }  // namespace
 
 extern "C" {
 
 int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double* Ax, double eps, cuadmm_aat** out) {
+  return aat_create_impl(m, L, Acp, Ari, Ax, eps, 0, out);
+}
+
+// Same, but when the cost model finds a dense tail (k <= max_k) the last k columns are left unfactored and the dense
+// Schur complement is kept for the GPU (cuadmm_aat_tail_k / _tail_schur); cuadmm_aat_solve_permuted is then unavailable.
+int cuadmm_aat_create_split(int m, int L, const int* Acp, const int* Ari, const double* Ax, double eps, int max_k, cuadmm_aat** out) {
+  return aat_create_impl(m, L, Acp, Ari, Ax, eps, max_k, out);   // max_k < 0 forces the tail size -max_k (tests, CUADMM_TAIL_K)
+}
+
+}  // extern "C"
+
+namespace {
+
+int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* Ax, double eps, int split_max_k, cuadmm_aat** out) {
   if (!out || m < 0 || L < 0 || !Acp) { set_error("aat_create: bad arguments"); return CUADMM_ERR_INVALID; }
   *out = nullptr;
   double t0 = now_s();
@@ -235,9 +272,19 @@ int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double
   for (int k = 0; k < m; ++k) f->Lp[k + 1] = f->Lp[k] + Lnz[k];
   f->analyze_s = now_s() - t0;
   t0 = now_s();
+  const int tail_k = split_max_k > 0 ? plan_tail(f->Lp.data(), m, split_max_k) : std::min(m, -split_max_k);
+  const int n1 = m - tail_k;                     // rows / columns >= n1 belong to the unfactored tail
+  f->tail_k = tail_k;
   try {
-    f->Li.resize((size_t)f->Lp[m]);
-    f->Lx.resize((size_t)f->Lp[m]);
+    // the tail columns keep their symbolic counts in Lp (cuadmm_aat_factor_nnz reports the whole factor) but get no
+    // storage: Li / Lx end at Lp[n1]
+    f->Li.resize((size_t)f->Lp[n1]);
+    f->Lx.resize((size_t)f->Lp[n1]);
+    if (tail_k > 0) {
+      f->schur_ptr.assign((size_t)tail_k + 1, 0);
+      f->schur_col.reserve((size_t)(f->Lp[m] - f->Lp[n1]) + (size_t)tail_k);
+      f->schur_val.reserve((size_t)(f->Lp[m] - f->Lp[n1]) + (size_t)tail_k);
+    }
   } catch (const std::bad_alloc&) {
     set_error("aat_create: factor with %lld nonzeros does not fit in host memory", (long long)f->Lp[m]);
     delete f;
@@ -250,7 +297,11 @@ int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double
   std::vector<int> pattern(m);
   std::fill(flag.begin(), flag.end(), -1);
   std::fill(Lnz.begin(), Lnz.end(), 0);
+  double t_lead = 0;
+  const double t_alloc = now_s() - t0;
+  long long upd = 0;
   for (int k = 0; k < m; ++k) {
+    if (k == n1) t_lead = now_s() - t0;
     int top = m;
     flag[k] = k;
     for (int64_t p = Cp[k]; p < Cp[k + 1]; ++p) {
@@ -262,19 +313,35 @@ int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double
     }
     double dk = Y[k];
     Y[k] = 0.0;
+    const int top0 = top;
     for (; top < m; ++top) {
       int i = pattern[top];
+      if (i >= n1) continue;                      // tail column: its Y entry becomes a Schur-complement entry below
       double yi = Y[i];
       Y[i] = 0.0;
       int64_t p2 = f->Lp[i] + Lnz[i];
       const int* li = f->Li.data();
       const double* lx = f->Lx.data();
       for (int64_t p = f->Lp[i]; p < p2; ++p) Y[li[p]] -= lx[p] * yi;
+      upd += p2 - f->Lp[i];
       double lki = yi / f->D[i];
       dk -= lki * yi;
       f->Li[p2] = k;
       f->Lx[p2] = lki;
       Lnz[i]++;
+    }
+    if (k >= n1) {
+      // row k of the Schur complement B22 - L21 D1 L21^T: what the leading columns left in Y (every tail row j < k
+      // they touched is in the reach of row k, so the scan of `pattern` collects all of it)
+      for (int t = top0; t < m; ++t) {
+        int j = pattern[t];
+        if (j >= n1) { f->schur_col.push_back(j - n1); f->schur_val.push_back(Y[j]); Y[j] = 0.0; }
+      }
+      f->schur_col.push_back(k - n1);
+      f->schur_val.push_back(dk);
+      f->schur_ptr[(size_t)(k - n1) + 1] = (int64_t)f->schur_col.size();
+      f->D[k] = 0.0;
+      continue;
     }
     if (dk == 0.0 || !std::isfinite(dk)) {
       set_error("Factorization fails! (zero or non-finite pivot at permuted row %d)", k);
@@ -284,17 +351,34 @@ int cuadmm_aat_create(int m, int L, const int* Acp, const int* Ari, const double
     f->D[k] = dk;
   }
   f->factor_s = now_s() - t0;
-  if (getenv("CUADMM_AAT_TIMING")) fprintf(stderr, "[aat] analyze %.3fs numeric %.3fs nnz(L) %lld\n", f->analyze_s, f->factor_s, (long long)f->Lp[m]);
+  if (getenv("CUADMM_AAT_TIMING")) fprintf(stderr, "[aat] analyze %.3fs numeric %.3fs (alloc %.3fs, leading rows until %.3fs, %lld updates) nnz(L) %lld tail %d\n", f->analyze_s, f->factor_s, t_alloc, t_lead, upd, (long long)f->Lp[m], tail_k);
   *out = f;
   return CUADMM_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 const int* cuadmm_aat_perm(const cuadmm_aat* f) { return f ? f->perm.data() : nullptr; }
 int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f) { return f ? f->Lp[f->m] : 0; }
 const int64_t* cuadmm_aat_factor_colptr(const cuadmm_aat* f) { return f ? f->Lp.data() : nullptr; }
 
+int cuadmm_aat_tail_k(const cuadmm_aat* f) { return f ? f->tail_k : 0; }
+int cuadmm_aat_tail_schur(const cuadmm_aat* f, const int64_t** row_ptr, const int** col, const double** val) {
+  if (!f || !row_ptr || !col || !val) { set_error("aat_tail_schur: null argument"); return CUADMM_ERR_INVALID; }
+  if (f->tail_k == 0 || f->schur_ptr.empty()) { set_error("aat_tail_schur: no Schur complement (factor not split, or released)"); return CUADMM_ERR_INVALID; }
+  *row_ptr = f->schur_ptr.data(); *col = f->schur_col.data(); *val = f->schur_val.data();
+  return CUADMM_OK;
+}
+void cuadmm_aat_tail_schur_release(cuadmm_aat* f) {
+  if (!f) return;
+  std::vector<int64_t>().swap(f->schur_ptr); std::vector<int>().swap(f->schur_col); std::vector<double>().swap(f->schur_val);
+}
+
 int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x) {
   if (!f || !rhs || !x) { set_error("aat_solve: null argument"); return CUADMM_ERR_INVALID; }
+  if (f->tail_k > 0) { set_error("aat_solve: the factor is split (its last %d columns live on the GPU); use the leading sweeps", f->tail_k); return CUADMM_ERR_INVALID; }
   const int m = f->m;
   if (x != rhs) std::memcpy(x, rhs, sizeof(double) * (size_t)m);
   const int64_t* Lp = f->Lp.data();
@@ -325,24 +409,12 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x)
 //   backward : columns j < m-k  (reads x2),                             host
 // ---------------------------------------------------------------------------------------
 // Cost model: host 1.2 ns per nonzero of the leading columns (both sweeps, measured), GPU 60 us + k^2 * 8 B at 4 TB/s.
-int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k) {
-  if (!f) return 0;
-  const int m = f->m;
-  const int64_t* Lp = f->Lp.data();
-  const double host_ns = 1.2, total = host_ns * (double)Lp[m];
-  double best = total;
-  int best_k = 0;
-  for (int k = 256; k <= std::min(m, max_k); k += 256) {
-    const double cost = host_ns * (double)Lp[m - k] + 60e3 + (double)k * k * 8.0 / 4000.0;
-    if (cost < best) { best = cost; best_k = k; }
-  }
-  if (best_k == 0 || best > 0.7 * total || total < 300e3) return 0;   // not worth a PCIe round trip per solve
-  return best_k;
-}
+int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k) { return f ? plan_tail(f->Lp.data(), f->m, max_k) : 0; }
 
 // dense (k x ld, row-major, unit lower triangular, ld >= k) copy of the trailing k x k block of L, and its D
 int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, double* D2) {
   if (!f || !L22 || !D2 || k < 1 || k > f->m || ld < k) { set_error("aat_tail_dense: bad arguments"); return CUADMM_ERR_INVALID; }
+  if (f->tail_k > 0) { set_error("aat_tail_dense: the factor is split, its tail was never factored on the host"); return CUADMM_ERR_INVALID; }
   const int m = f->m, n1 = m - k;
   for (int i = 0; i < k; ++i) {
     std::memset(L22 + (size_t)i * ld, 0, sizeof(double) * (size_t)ld);
@@ -356,7 +428,7 @@ int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, d
 
 // forward sweep over the leading m-k columns, then D scaling of the leading part; x[m-k..] holds z2 on return
 int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
-  if (!f || !x || k < 0 || k > f->m) { set_error("aat_solve_leading_forward: bad arguments"); return CUADMM_ERR_INVALID; }
+  if (!f || !x || k < f->tail_k || k > f->m) { set_error("aat_solve_leading_forward: bad arguments"); return CUADMM_ERR_INVALID; }
   const int n1 = f->m - k;
   const int64_t* Lp = f->Lp.data();
   const int* Li = f->Li.data();
@@ -372,7 +444,7 @@ int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
 
 // backward sweep over the leading m-k columns; x[m-k..] must hold the solved tail x2
 int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
-  if (!f || !x || k < 0 || k > f->m) { set_error("aat_solve_leading_backward: bad arguments"); return CUADMM_ERR_INVALID; }
+  if (!f || !x || k < f->tail_k || k > f->m) { set_error("aat_solve_leading_backward: bad arguments"); return CUADMM_ERR_INVALID; }
   const int n1 = f->m - k;
   const int64_t* Lp = f->Lp.data();
   const int* Li = f->Li.data();

@@ -410,23 +410,33 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       }
   }
 
-  // --- host factor of A A^T + 1e-15 I (solver.cu:91-96, cholesky_cpu.h:62-141)
-  rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
-  if (rc) return rc;
-  // --- dense trailing triangle of L: inverted once on the GPU, two GEMVs per solve (tail_solve.hip)
+  // --- factor of A A^T + 1e-15 I (solver.cu:91-96, cholesky_cpu.h:62-141): ordering, symbolic analysis and the sparse
+  // leading columns on the host; when the cost model finds a dense tail, its Schur complement is factored (dense
+  // LDL^T) and inverted on the GPU and applied as two GEMVs per solve (tail_solve.hip).
+  // CUADMM_TAIL_K: 0 = everything on the host, k > 0 forces the tail size (A/B measurements).
   {
-    int tk = 0;
-    const char* e = getenv("CUADMM_TAIL_K");   // 0 disables, >0 forces the tail size (A/B measurements)
-    if (e) tk = std::min(std::max(0, atoi(e)), m);
-    else tk = cuadmm_aat_tail_plan(s->fac, 32768);
+    int max_k = 32768;
+    if (const char* e = getenv("CUADMM_TAIL_K")) max_k = -std::min(std::max(0, atoi(e)), m);
+    double t0 = wall_s();
+    if (max_k == 0) rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
+    else rc = cuadmm_aat_create_split(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, max_k, &s->fac);
+    if (rc) return rc;
+    double t1 = wall_s();
+    const int tk = cuadmm_aat_tail_k(s->fac);
     if (tk > 0) {
-      std::vector<double> L22((size_t)tk * tk), D2((size_t)tk);
-      rc = cuadmm_aat_tail_dense(s->fac, tk, L22.data(), tk, D2.data());
-      if (!rc) rc = s->tail.build(L22.data(), D2.data(), tk, s->st);
+      const int64_t* srp; const int* sci; const double* sv;
+      rc = cuadmm_aat_tail_schur(s->fac, &srp, &sci, &sv);
+      if (!rc) rc = s->tail.build_from_schur(reinterpret_cast<const long long*>(srp), sci, sv, tk, s->st);
+      cuadmm_aat_tail_schur_release(s->fac);
       if (rc) return rc;
-      if (s->verbose) printf("\n A*A^T solve: last %d of %d columns of L (%.1f%% of nnz(L) = %lld) as dense inverse on the GPU (built in %.2fs)\n", tk, m,
-                             100.0 * (double)(cuadmm_aat_factor_nnz(s->fac) - cuadmm_aat_factor_colptr(s->fac)[m - tk]) / (double)std::max<long long>(1, cuadmm_aat_factor_nnz(s->fac)),
-                             (long long)cuadmm_aat_factor_nnz(s->fac), s->tail.build_s);
+    }
+    if (s->verbose) {
+      const long long lnz = (long long)cuadmm_aat_factor_nnz(s->fac);
+      if (tk > 0)
+        printf("\n A*A^T factor: nnz(L) = %lld; host part %.2fs; last %d of %d columns (%.1f%% of nnz(L)) factored and inverted on the GPU in %.2fs\n",
+               lnz, t1 - t0, tk, m, 100.0 * (double)(lnz - cuadmm_aat_factor_colptr(s->fac)[m - tk]) / (double)std::max<long long>(1, lnz), s->tail.build_s);
+      else
+        printf("\n A*A^T factor: nnz(L) = %lld on the host in %.2fs\n", lnz, t1 - t0);
     }
   }
   s->perm.assign(cuadmm_aat_perm(s->fac), cuadmm_aat_perm(s->fac) + m);
@@ -875,6 +885,14 @@ int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, voi
 int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, double beta, const double* E, double* Cout, void* stream) {
   if (n < 64 || n % 64 != 0 || !A || !B || !Cout) { set_error("gemm_sym: n must be a positive multiple of 64 and pointers non-null"); return CUADMM_ERR_INVALID; }
   return large_gemm_sym(n, A, B, alpha, beta, E, Cout, (hipStream_t)stream);
+}
+
+int cuadmm_op_tail_factor_solve(const int64_t* row_ptr, const int* col, const double* val, int k, double* z_host, int nrhs) {
+  if (!row_ptr || !col || !val || !z_host || k < 1 || nrhs < 0) { set_error("tail_factor_solve: bad arguments"); return CUADMM_ERR_INVALID; }
+  TailSolve t;
+  int rc = t.build_from_schur(reinterpret_cast<const long long*>(row_ptr), col, val, k, nullptr);
+  for (int r = 0; r < nrhs && !rc; ++r) rc = t.solve(z_host + (size_t)r * k, nullptr);
+  return rc;
 }
 
 int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs) {

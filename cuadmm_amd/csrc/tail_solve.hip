@@ -151,6 +151,146 @@ __global__ __launch_bounds__(256) void ts_tri_gemv_kernel(const double* __restri
   if (lane == 0) out[i] = scale ? s * scale[i] : s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Dense LDL^T (no pivoting, as the host factor) of the Schur complement, right-looking, 64-wide block columns:
+//   diag  : S_bb = L_bb D_b L_bb^T                           one workgroup
+//   panel : Y_ib = S_ib L_bb^-T,  L_ib = Y_ib D_b^-1         one workgroup per 64 rows
+//   update: S_ij -= Y_ib L_jb^T  (i >= j > b)                one workgroup per 64 x 64 tile, fp64 MFMA
+// Only the lower triangle is referenced.  Every kernel is deterministic.
+// ------------------------------------------------------------------------------------------
+__global__ void ts_scatter_csr_kernel(const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                                      int k, double* __restrict__ S, long long ld) {
+  const int row = (int)blockIdx.x;
+  if (row >= k) {   // padding rows: identity
+    if (threadIdx.x == 0) S[(size_t)row * ld + row] = 1.0;
+    return;
+  }
+  for (long long p = rp[row] + threadIdx.x; p < rp[row + 1]; p += blockDim.x) S[(size_t)row * ld + ci[p]] = v[p];
+}
+
+__global__ __launch_bounds__(64) void ts_ldlt_diag_kernel(double* __restrict__ S, long long ld, int b0, double* __restrict__ dvec,
+                                                          int* __restrict__ flag) {
+  __shared__ double A[64 * 65];
+  __shared__ double lcol[64];
+  const int r = (int)threadIdx.x;
+  const size_t base = (size_t)b0 * ld + b0;
+  for (int i = 0; i < 64; ++i) A[i * 65 + r] = S[base + (size_t)i * ld + r];
+  for (int j = 0; j < 64; ++j) {
+    __syncthreads();
+    const double d = A[j * 65 + j];
+    double l = 0.0;
+    if (r == j) {
+      dvec[b0 + j] = d;
+      if (d == 0.0 || !(fabs(d) <= 1.7976931348623157e308)) atomicAdd(flag, 1);
+    }
+    if (r > j) { l = A[r * 65 + j] / d; lcol[r] = l; }
+    __syncthreads();
+    if (r > j) {
+      const double ld_ = l * d;
+      for (int c = j + 1; c <= r; ++c) A[r * 65 + c] -= ld_ * lcol[c];
+      A[r * 65 + j] = l;
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) S[base + (size_t)i * ld + r] = A[i * 65 + r];
+}
+
+// rows of block-row (b+1+blockIdx.x): y = x L_bb^-T by forward substitution over the 64 columns, l = y / d
+__global__ __launch_bounds__(64) void ts_ldlt_panel_kernel(double* __restrict__ S, long long ld, int b0, const double* __restrict__ dvec,
+                                                           double* __restrict__ Yp) {
+  __shared__ double Lb[64 * 65];
+  __shared__ double T[64 * 65];
+  const int r = (int)threadIdx.x;
+  const int row0 = b0 + 64 + (int)blockIdx.x * 64;
+  for (int i = 0; i < 64; ++i) {
+    Lb[i * 65 + r] = S[(size_t)(b0 + i) * ld + b0 + r];
+    T[i * 65 + r] = S[(size_t)(row0 + i) * ld + b0 + r];
+  }
+  __syncthreads();
+  double y[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    double s = T[r * 65 + c];
+#pragma unroll
+    for (int j = 0; j < c; ++j) s -= y[j] * Lb[c * 65 + j];
+    y[c] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 64; ++c) { T[r * 65 + c] = y[c]; }
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) {
+    const double yv = T[i * 65 + r];
+    Yp[(size_t)(row0 + i) * 64 + r] = yv;
+    S[(size_t)(row0 + i) * ld + b0 + r] = yv / dvec[b0 + r];
+  }
+}
+
+// trailing update, tile (ti >= tj) of the block rows / columns after b: C -= Y_ti * L_tj^T  (k = 64)
+__global__ __launch_bounds__(256) void ts_ldlt_update_kernel(double* __restrict__ S, long long ld, int b0, const double* __restrict__ Yp) {
+  constexpr int LDS = TS_TM + 16, WT = TS_TM / 2, NTW = WT / 16;
+  __shared__ double As[64 * LDS];   // As[k][row]
+  __shared__ double Bs[64 * LDS];   // Bs[k][col]
+  int ti, tj;
+  {
+    const int e = (int)blockIdx.x;
+    int t = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while (t * (t + 1) / 2 > e) --t;
+    while ((t + 1) * (t + 2) / 2 <= e) ++t;
+    ti = t; tj = e - t * (t + 1) / 2;
+  }
+  const int row0 = b0 + 64 + ti * 64, col0 = b0 + 64 + tj * 64;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1, r16 = lane & 15, kk = lane >> 4;
+  // both operands are 64 x 64 row-major blocks [x][k], staged transposed: thread t: x = t/4, k = (t%4)*16 .. +15
+  {
+    const int x = tid >> 2, kq = (tid & 3) * 16;
+    const double* ya = Yp + (size_t)(row0 + x) * 64 + kq;
+    const double* lb = S + (size_t)(col0 + x) * ld + b0 + kq;
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+      const double2 va = *reinterpret_cast<const double2*>(ya + c);
+      const double2 vb = *reinterpret_cast<const double2*>(lb + c);
+      As[(kq + c) * LDS + x] = va.x; As[(kq + c + 1) * LDS + x] = va.y;
+      Bs[(kq + c) * LDS + x] = vb.x; Bs[(kq + c + 1) * LDS + x] = vb.y;
+    }
+  }
+  __syncthreads();
+  ts_v4f64 acc[NTW][NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = ts_v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 64; ks += 4) {
+    double af[NTW], bf[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      af[t] = As[(ks + kk) * LDS + wy * WT + t * 16 + r16];
+      bf[t] = Bs[(ks + kk) * LDS + wx * WT + t * 16 + r16];
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wy * WT + i * 16 + kk + 4 * r, col = col0 + wx * WT + j * 16 + r16;
+        S[(size_t)row * ld + col] -= acc[i][j][r];
+      }
+}
+
+__global__ void ts_dinv_kernel(const double* __restrict__ d, double* __restrict__ dinv, int K) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < K) dinv[i] = 1.0 / d[i];
+}
+
 static int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, long long sA, const double* B, long long ldb,
                    long long sB, double* C, long long ldc, long long sC, int batch, hipStream_t st) {
   if (batch <= 0 || M <= 0 || N <= 0) return CUADMM_OK;
@@ -167,37 +307,26 @@ void TailSolve::release() {
   k = K = 0;
 }
 
-// L22: k x k dense row-major unit lower triangular (host), D2: k pivots (host)
-int TailSolve::build(const double* L22, const double* D2, int k_, hipStream_t st) {
+int TailSolve::alloc(int k_) {
   release();
   k = k_;
   K = (k + TS_TM - 1) / TS_TM * TS_TM;
-  const long long ld = K;
   const size_t sz = (size_t)K * K;
-  const auto t0 = std::chrono::steady_clock::now();
-  double *dL = nullptr, *dT = nullptr;
-  CUADMM_HIP_TRY(hipMalloc(&dL, sizeof(double) * sz));
-  CUADMM_HIP_TRY(hipMalloc(&dT, sizeof(double) * sz));
   CUADMM_HIP_TRY(hipMalloc(&W, sizeof(double) * sz));
   CUADMM_HIP_TRY(hipMalloc(&Wt, sizeof(double) * sz));
   CUADMM_HIP_TRY(hipMalloc(&dinv, sizeof(double) * (size_t)K));
   CUADMM_HIP_TRY(hipMalloc(&vin, sizeof(double) * (size_t)K));
   CUADMM_HIP_TRY(hipMalloc(&vmid, sizeof(double) * (size_t)K));
   CUADMM_HIP_TRY(hipHostMalloc(&h_vec, sizeof(double) * (size_t)K, hipHostMallocDefault));
-  // upload: rows of L22 (leading dimension k) into the padded matrix (identity in the padding)
-  CUADMM_HIP_TRY(hipMemsetAsync(dL, 0, sizeof(double) * sz, st));
-  CUADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * sz, st));
-  CUADMM_HIP_TRY(hipMemcpy2DAsync(dL, sizeof(double) * (size_t)ld, L22, sizeof(double) * (size_t)k, sizeof(double) * (size_t)k, (size_t)k,
-                                  hipMemcpyHostToDevice, st));
-  {
-    std::vector<double> di((size_t)K, 1.0), ones((size_t)(K - k), 1.0);
-    for (int i = 0; i < k; ++i) di[i] = 1.0 / D2[i];
-    CUADMM_HIP_TRY(hipMemcpyAsync(dinv, di.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
-    if (K > k)   // unit diagonal of the padding
-      CUADMM_HIP_TRY(hipMemcpy2DAsync(dL + (size_t)k * ld + k, sizeof(double) * (size_t)(ld + 1), ones.data(), sizeof(double), sizeof(double),
-                                      (size_t)(K - k), hipMemcpyHostToDevice, st));
-    CUADMM_HIP_TRY(hipStreamSynchronize(st));
-  }
+  return CUADMM_OK;
+}
+
+// W = inv(dL) by recursive doubling (dL: K x K unit lower triangular on the device, strict upper part never read;
+// Wt doubles as the scratch matrix of the products), then Wt = W^T
+int TailSolve::invert(const double* dL, hipStream_t st) {
+  const long long ld = K;
+  double* dT = Wt;
+  CUADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * (size_t)K * K, st));
   hipLaunchKernelGGL(ts_diag_inverse_kernel, dim3(K / 64), dim3(64), 0, st, dL, W, ld);
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = CUADMM_OK;
@@ -217,12 +346,88 @@ int TailSolve::build(const double* L22, const double* D2, int k_, hipStream_t st
       if (!rc) rc = ts_gemm((int)h2, (int)h, (int)h2, -1.0, W + o + h * (ld + 1), ld, 0, dT + o + h * ld, ld, 0, W + o + h * ld, ld, 0, 1, st);
     }
   }
-  if (!rc) {
-    hipLaunchKernelGGL(ts_transpose_kernel, dim3(K / 32, K / 32), dim3(256), 0, st, W, Wt, ld);
-    hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { set_error("tail_solve build: %s", hipGetErrorString(e)); rc = CUADMM_ERR_INVALID; }
+  if (rc) return rc;
+  hipLaunchKernelGGL(ts_transpose_kernel, dim3(K / 32, K / 32), dim3(256), 0, st, W, Wt, ld);
+  CUADMM_HIP_TRY(hipGetLastError());
+  CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  return CUADMM_OK;
+}
+
+// L22: k x k dense row-major unit lower triangular (host), D2: k pivots (host)
+int TailSolve::build(const double* L22, const double* D2, int k_, hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = alloc(k_);
+  if (rc) return rc;
+  const long long ld = K;
+  const size_t sz = (size_t)K * K;
+  double* dL = nullptr;
+  CUADMM_HIP_TRY(hipMalloc(&dL, sizeof(double) * sz));
+  // upload: rows of L22 (leading dimension k) into the padded matrix (identity in the padding)
+  CUADMM_HIP_TRY(hipMemsetAsync(dL, 0, sizeof(double) * sz, st));
+  CUADMM_HIP_TRY(hipMemcpy2DAsync(dL, sizeof(double) * (size_t)ld, L22, sizeof(double) * (size_t)k, sizeof(double) * (size_t)k, (size_t)k,
+                                  hipMemcpyHostToDevice, st));
+  {
+    std::vector<double> di((size_t)K, 1.0);
+    for (int i = 0; i < k; ++i) di[i] = 1.0 / D2[i];
+    CUADMM_HIP_TRY(hipMemcpyAsync(dinv, di.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
+    CUADMM_HIP_TRY(hipStreamSynchronize(st));
   }
-  { hipError_t e = hipFree(dL); (void)e; e = hipFree(dT); (void)e; }
+  rc = invert(dL, st);   // the padding rows of dL are zero: the diagonal is implicit
+  { hipError_t e = hipFree(dL); (void)e; }
+  build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc) release();
+  return rc;
+}
+
+// Schur complement (lower triangle with diagonal, CSR over the k tail rows, host pointers) -> dense LDL^T on the GPU
+// -> W = inv(L22), dinv = 1 / D2
+int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const double* val, int k_, hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = alloc(k_);
+  if (rc) return rc;
+  const long long ld = K;
+  const size_t sz = (size_t)K * K;
+  const long long nnz = row_ptr[k];
+  double *dS = nullptr, *dval = nullptr, *dd = nullptr, *Yp = nullptr;
+  long long* drp = nullptr;
+  int *dci = nullptr, *dflag = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)dS, (void*)dval, (void*)dd, (void*)Yp, (void*)drp, (void*)dci, (void*)dflag}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  };
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMalloc(&dS, sizeof(double) * sz);
+  if (e == hipSuccess) e = hipMalloc(&dval, sizeof(double) * (size_t)std::max<long long>(nnz, 1));
+  if (e == hipSuccess) e = hipMalloc(&dci, sizeof(int) * (size_t)std::max<long long>(nnz, 1));
+  if (e == hipSuccess) e = hipMalloc(&drp, sizeof(long long) * ((size_t)k + 1));
+  if (e == hipSuccess) e = hipMalloc(&dd, sizeof(double) * (size_t)K);
+  if (e == hipSuccess) e = hipMalloc(&Yp, sizeof(double) * (size_t)K * 64);
+  if (e == hipSuccess) e = hipMalloc(&dflag, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(dS, 0, sizeof(double) * sz, st);
+  if (e == hipSuccess) e = hipMemsetAsync(dflag, 0, sizeof(int), st);
+  if (e == hipSuccess) e = hipMemcpyAsync(drp, row_ptr, sizeof(long long) * ((size_t)k + 1), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(dci, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(dval, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return e == hipErrorOutOfMemory ? CUADMM_ERR_INVALID : CUADMM_ERR_NO_DEVICE; }
+  hipLaunchKernelGGL(ts_scatter_csr_kernel, dim3(K), dim3(256), 0, st, drp, dci, dval, k, dS, ld);
+  const int nbk = K / 64;
+  for (int b = 0; b < nbk; ++b) {
+    const int b0 = b * 64, T = nbk - b - 1;
+    hipLaunchKernelGGL(ts_ldlt_diag_kernel, dim3(1), dim3(64), 0, st, dS, ld, b0, dd, dflag);
+    if (T > 0) {
+      hipLaunchKernelGGL(ts_ldlt_panel_kernel, dim3(T), dim3(64), 0, st, dS, ld, b0, dd, Yp);
+      hipLaunchKernelGGL(ts_ldlt_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, st, dS, ld, b0, Yp);
+    }
+  }
+  hipLaunchKernelGGL(ts_dinv_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dd, dinv, K);
+  int hflag = 0;
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  factor_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return CUADMM_ERR_NO_DEVICE; }
+  if (hflag) { set_error("Factorization fails! (%d zero or non-finite pivots in the dense tail of A*A^T)", hflag); cleanup(); release(); return CUADMM_ERR_FACTOR; }
+  rc = invert(dS, st);
+  cleanup();
   build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc) release();
   return rc;

@@ -221,6 +221,17 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs_perm, doubl
  *   solve_leading_forward: forward sweep + D scaling over the leading m-k columns, in place; x[m-k..] then holds z2
  *   solve_leading_backward: backward sweep over the leading columns, in place; x[m-k..] must hold the solved tail */
 int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k);
+/* Split factorisation: like cuadmm_aat_create, but when the cost model finds a dense tail (k <= max_k) the last k
+ * columns are left unfactored; the Schur complement B22 - L21 D1 L21^T (sparse, lower triangle) is kept for the
+ * GPU, which scatters it into a dense matrix, factors and inverts it (tail_solve.hip).
+ * max_k < 0 forces the tail size -max_k.  cuadmm_aat_solve_permuted / _tail_dense are unavailable on a split factor. */
+int cuadmm_aat_create_split(int con_num, int vec_len, const int* A_col_ptrs, const int* A_row_ids,
+                            const double* A_vals, double eps, int max_k, cuadmm_aat** out);
+int cuadmm_aat_tail_k(const cuadmm_aat* f);
+/* lower triangle with diagonal of the Schur complement by rows (CSR over the k tail rows, tail-local column indices,
+ * not sorted within a row); pointers stay valid until _tail_schur_release / _free */
+int cuadmm_aat_tail_schur(const cuadmm_aat* f, const int64_t** row_ptr, const int** col, const double** val);
+void cuadmm_aat_tail_schur_release(cuadmm_aat* f);
 int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, double* D2);
 int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x);
 int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x);
@@ -249,6 +260,9 @@ int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, do
 /* The GPU part of the A*A^T solve on its own (tail_solve.hip): z <- L22^-T D2^-1 L22^-1 z for `nrhs` host vectors
  * of length k (contiguous), L22 dense k x k row-major unit lower triangular and D2 the pivots (host pointers). */
 int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs);
+/* Same with the factorisation on the GPU too: z <- S^-1 z for a symmetric S given by its lower triangle with
+ * diagonal (CSR over k rows, host pointers), dense LDL^T without pivoting (what cuadmm_aat_create_split hands over). */
+int cuadmm_op_tail_factor_solve(const int64_t* row_ptr, const int* col, const double* val, int k, double* z_host, int nrhs);
 /* max_dense_vector_zero (src/kernels/dense_scalar.cu:41-47,93-97) */
 int cuadmm_op_max_zero(double* w, int64_t n, void* stream);
 /* dense_matrix_mul_diag_batch (src/kernels/diagonal_batch.cu:11-62): out = in * diag(w) per matrix */

@@ -189,3 +189,30 @@ def test_tail_solve_op_vs_triangular_solves(k):
     got = z.copy()
     check(lib.cuadmm_op_tail_solve(L.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p), k, got.ctypes.data_as(C.c_void_p), 3))
     assert np.linalg.norm(got - ref) <= 1e-13 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("k", [1, 50, 64, 130, 1000, 2000])
+def test_tail_factor_solve_op_dense_ldlt_on_gpu(k):
+    """Dense LDL^T (no pivoting) + inverse + two GEMVs on the GPU for a Schur complement given as sparse lower triangle
+    (what cuadmm_aat_create_split hands over); indefinite-but-factorable matrices included (LDL^T pivots of both signs)."""
+    rng = np.random.default_rng(k + 7)
+    G = rng.standard_normal((k, k)) / np.sqrt(k)
+    S = G @ G.T + 0.5 * np.eye(k)
+    if k >= 50:                                  # make the trailing half negative definite: pivots change sign
+        J = np.ones(k); J[k // 2:] = -1.0
+        S = (S * J) * J[:, None] * 1.0
+        S[k // 2:, k // 2:] *= -1.0
+    Sl = sp.csr_matrix(np.tril(S))
+    rp, ci, vv = Sl.indptr.astype(np.int64), Sl.indices.astype(np.int32), Sl.data.astype(np.float64)
+    z = rng.standard_normal((2, k))
+    ref = np.linalg.solve(S, z.T).T
+    got = z.copy()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.cuadmm_op_tail_factor_solve(P(rp), P(ci), P(vv), k, P(got), 2))
+    assert np.linalg.norm(got - ref) <= 1e-11 * np.linalg.norm(ref)
+    # a zero pivot is reported like the host factor does ("Factorization fails!")
+    Z = sp.csr_matrix(np.tril(np.zeros((3, 3)) + np.diag([1.0, 0.0, 1.0])))
+    with pytest.raises(cuadmm_amd.CuadmmError) as e:
+        zz = np.ones(3)
+        check(lib.cuadmm_op_tail_factor_solve(P(Z.indptr.astype(np.int64)), P(Z.indices.astype(np.int32)), P(Z.data.astype(np.float64)), 3, P(zz), 1))
+    assert "Factorization fails" in str(e.value)

@@ -248,3 +248,45 @@ def test_aat_tail_plan_picks_the_dense_triangle():
     assert Lp[m] - Lp[m - k] >= 0.4 * Lp[m]                                      # the tail holds a large share of nnz(L)
     assert lib.cuadmm_aat_tail_plan(h, 128) == 0                                 # cap below the smallest candidate
     lib.cuadmm_aat_free(h)
+
+
+@pytest.mark.parametrize("name,frac", [("rose13", 0.3), ("truss5", 0.5), ("hinf12", 1.0), ("ros_2000", 0.1)])
+def test_aat_split_factor_schur_complement(name, frac, problem_dirs):
+    """cuadmm_aat_create_split leaves the last k columns unfactored and hands over the dense Schur complement:
+    it must equal L22 D2 L22^T of the one-piece factor, and the leading columns must be identical."""
+    p = orc.load_problem_txt(problem_dirs[name])
+    m = p.con_num
+    h, A = _aat(p)
+    k = max(1, int(m * frac))
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    hs = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, -k, C.byref(hs)))
+    assert lib.cuadmm_aat_tail_k(hs) == k and lib.cuadmm_aat_tail_k(h) == 0
+    assert lib.cuadmm_aat_factor_nnz(hs) == lib.cuadmm_aat_factor_nnz(h)
+    assert np.array_equal(np.ctypeslib.as_array(lib.cuadmm_aat_perm(hs), shape=(m,)), np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)))
+    rp, ci, vv = C.POINTER(C.c_int64)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    check(lib.cuadmm_aat_tail_schur(hs, C.byref(rp), C.byref(ci), C.byref(vv)))
+    rp = np.ctypeslib.as_array(rp, shape=(k + 1,)).copy()
+    S = sp.csr_matrix((np.ctypeslib.as_array(vv, shape=(rp[-1],)).copy(), np.ctypeslib.as_array(ci, shape=(rp[-1],)).copy(), rp),
+                      shape=(k, k)).toarray()
+    L22 = np.empty((k, k)); D2 = np.empty(k)
+    check(lib.cuadmm_aat_tail_dense(h, k, P(L22), k, P(D2)))
+    ref = np.tril((L22 * D2) @ L22.T)
+    assert np.max(np.abs(np.tril(S) - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+    assert np.all(np.triu(S, 1) == 0.0)
+    # leading sweeps agree bit for bit with the one-piece factor's leading sweeps
+    rhs = np.random.default_rng(2).standard_normal(m)
+    a, b = rhs.copy(), rhs.copy()
+    check(lib.cuadmm_aat_solve_leading_forward(h, k, P(a))); check(lib.cuadmm_aat_solve_leading_forward(hs, k, P(b)))
+    assert np.array_equal(a, b)
+    check(lib.cuadmm_aat_solve_leading_backward(h, k, P(a))); check(lib.cuadmm_aat_solve_leading_backward(hs, k, P(b)))
+    assert np.array_equal(a, b)
+    # a split factor cannot run the one-piece solve
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        check(lib.cuadmm_aat_solve_permuted(hs, P(rhs), P(a)))
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        check(lib.cuadmm_aat_tail_dense(hs, k, P(L22), k, P(D2)))
+    lib.cuadmm_aat_tail_schur_release(hs)
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        check(lib.cuadmm_aat_tail_schur(hs, C.byref(C.POINTER(C.c_int64)()), C.byref(C.POINTER(C.c_int)()), C.byref(C.POINTER(C.c_double)())))
+    lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
