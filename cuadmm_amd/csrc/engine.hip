@@ -469,6 +469,8 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->L = L;
   s->blk_local.assign(blk + s->blk_begin, blk + s->blk_end);
   rc = s->plan.build(s->blk_local.data(), (int)s->blk_local.size());
+  s->plan.overlap = true;
+  s->plan.sign.allow_graph = true;   // same buffers every iteration: replay the sign-path launch sequence from a hipGraph
   if (rc) return rc;
 
   // --- device matrices with the permutation folded in

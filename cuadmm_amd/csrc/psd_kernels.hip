@@ -288,6 +288,11 @@ void PsdPlan::release() {
   if (d_wsoff) hipFree(d_wsoff);
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
   sign.release();
+  if (ev_fork) {
+    hipError_t e = hipEventDestroy(ev_fork); (void)e;
+    for (int i = 0; i < kNumPsdClasses; ++i) { e = hipEventDestroy(ev_done[i]); (void)e; e = hipStreamDestroy(aux[i]); (void)e; }
+    ev_fork = nullptr;
+  }
   for (int c = 0; c < kNumPsdClasses; ++c) { cls_begin[c] = cls_count[c] = 0; cls_maxn[c] = 0; }
 }
 
@@ -360,9 +365,29 @@ static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
 }
 
 // Xproj = Pi_+(Xb) over all blocks of the plan (device pointers, svec layout)
+// Size classes are independent: with `overlap` (engine-owned plans) every class and the sign path run on their own
+// stream between a fork and a join event on `st`, so small classes (a moment relaxation has a handful of blocks per
+// size) overlap instead of queueing behind each other.
 int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
+  static const bool no_overlap = (getenv("CUADMM_PSD_OVERLAP") && atoi(getenv("CUADMM_PSD_OVERLAP")) == 0) || getenv("CUADMM_PSD_DEBUG");
+  int lanes = sign.empty() ? 0 : 1;
+  for (int c = 0; c < kNumPsdClasses; ++c) lanes += cls_count[c] > 0;
+  const bool fork = overlap && !no_overlap && st != nullptr && lanes > 1;
+  if (fork && !ev_fork) {
+    CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < kNumPsdClasses; ++i) {
+      CUADMM_HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+      CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+    }
+  }
+  if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
+  hipStream_t main_st = st;
   for (int c = 0; c < kNumPsdClasses; ++c) {
     if (cls_count[c] == 0) continue;
+    if (fork) {   // the sign path keeps the main stream (it is the longest chain)
+      st = aux[c];
+      CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_fork, 0));
+    }
     PsdArgs a{};
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
@@ -406,8 +431,16 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
       (void)slots; (void)tmin; (void)tmax;
       hipFree(dbg);
     }
+    if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
   }
-  if (!sign.empty()) return sign.project(Xb, Xproj, d_off, d_n, d_fail, st);
+  st = main_st;
+  if (!sign.empty()) {
+    int rc = sign.project(Xb, Xproj, d_off, d_n, d_fail, st);
+    if (rc) return rc;
+  }
+  if (fork)
+    for (int c = 0; c < kNumPsdClasses; ++c)
+      if (cls_count[c] > 0) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_done[c], 0));
   return CUADMM_OK;
 }
 

@@ -17,6 +17,10 @@ struct SignPsd {
   int build(const int* blk, const std::vector<int>& members);
   void release();
   int project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);
+  int project_launch(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);
+  bool allow_graph = false;                  // set by long-lived owners (the engine); one-shot plans launch directly
+  hipGraphExec_t graph_exec = nullptr;       // captured launch sequence of project_launch for (g_in, g_out, ...)
+  const double* g_in = nullptr; double* g_out = nullptr; const long long* g_boff = nullptr; const int* g_bn = nullptr; int* g_fail = nullptr;
   bool empty() const { return groups.empty(); }
   ~SignPsd() { release(); }
 };

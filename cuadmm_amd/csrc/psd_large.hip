@@ -307,6 +307,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
 }
 
 void SignPsd::release() {
+  if (graph_exec) { hipError_t e = hipGraphExecDestroy(graph_exec); (void)e; graph_exec = nullptr; }
   for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   d_ids = nullptr;
@@ -315,7 +316,34 @@ void SignPsd::release() {
 }
 
 // out = svec(P_+(smat(in))) for every member block; boff / bn are the plan's device arrays (all blocks).  Asynchronous.
+// The fixed schedule is ~95 dependent launches per group (1.0 ms for a handful of N = 128 blocks, ~10 us per dependent
+// kernel).  Replaying them from a hipGraph was measured and does NOT help (1.835 vs 1.814 ms per PlanarHand projection):
+// the cost is the device-side drain/flush between dependent kernels, not host launch overhead.  Kept behind
+// CUADMM_PSD_GRAPH=1 for re-measurement on other ROCm versions.
 int SignPsd::project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
+  static const bool use_graph = getenv("CUADMM_PSD_GRAPH") && atoi(getenv("CUADMM_PSD_GRAPH")) == 1 && !getenv("CUADMM_PSD_DEBUG");
+  if (!use_graph || !allow_graph || st == nullptr || groups.empty()) return project_launch(in, out, boff, bn, d_fail, st);
+  if (graph_exec && (g_in != in || g_out != out || g_boff != boff || g_bn != bn || g_fail != d_fail)) {
+    hipError_t e = hipGraphExecDestroy(graph_exec); (void)e;
+    graph_exec = nullptr;
+  }
+  if (!graph_exec) {
+    hipGraph_t graph = nullptr;
+    CUADMM_HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = project_launch(in, out, boff, bn, d_fail, st);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) { hipError_t e2 = hipGraphDestroy(graph); (void)e2; } return rc; }
+    if (e != hipSuccess) { set_error("psd sign path: graph capture failed: %s", hipGetErrorString(e)); return CUADMM_ERR_INVALID; }
+    e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+    { hipError_t e2 = hipGraphDestroy(graph); (void)e2; }
+    if (e != hipSuccess) { graph_exec = nullptr; set_error("psd sign path: graph instantiate failed: %s", hipGetErrorString(e)); return CUADMM_ERR_INVALID; }
+    g_in = in; g_out = out; g_boff = boff; g_bn = bn; g_fail = d_fail;
+  }
+  CUADMM_HIP_TRY(hipGraphLaunch(graph_exec, st));
+  return CUADMM_OK;
+}
+
+int SignPsd::project_launch(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
   static const int debug = getenv("CUADMM_PSD_DEBUG") ? std::max(1, atoi(getenv("CUADMM_PSD_DEBUG"))) : 0;   // 2: per-step updates
   for (const Group& g : groups) {
     const int N = g.N, cnt = g.count;

@@ -25,6 +25,9 @@ struct PsdPlan {
   // CUADMM_PSD_SIGN_MIN=<n> moves the boundary (A/B measurements).
   int sign_min = 65;
   mutable SignPsd sign;
+  bool overlap = false;        // engine-owned plans: classes on their own streams (fork / join on the caller's stream)
+  mutable hipEvent_t ev_fork = nullptr, ev_done[kNumPsdClasses] = {};
+  mutable hipStream_t aux[kNumPsdClasses] = {};
   int cls_begin[kNumPsdClasses] = {0}, cls_count[kNumPsdClasses] = {0}, cls_maxn[kNumPsdClasses] = {0};
 
   int build(const int* blk, int mat_num);
