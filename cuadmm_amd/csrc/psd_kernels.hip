@@ -21,6 +21,7 @@
 #include "psd_plan.h"
 #include "psd_small_reg.h"
 #include "psd_small_pc.h"
+#include "psd_sign_lds.h"
 
 namespace cuadmm {
 
@@ -207,6 +208,30 @@ __global__ __launch_bounds__(NT) void psd_wg_kernel(PsdArgs a) {
 // ---------------------------------------------------------------------------------------
 // planner
 // ---------------------------------------------------------------------------------------
+// 32 < n <= 64 (projection only): matrix-sign iteration resident in LDS, one workgroup per block (psd_sign_lds.h)
+template <int NP>
+__global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(PsdArgs a, int first, int lift_steps, int polish_steps, double lift_mu) {
+  extern __shared__ double sign_smem[];
+  const int m = first + (int)blockIdx.x;
+  const int id = a.ids ? a.ids[m] : m;
+  psd_sign_lds_body<NP>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, lift_steps, polish_steps, lift_mu);
+}
+
+template <int NP>
+static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t st) {
+  if (count <= 0) return CUADMM_OK;
+  const size_t lds = sizeof(double) * 3 * NP * SignLdsCfg<NP>::LD;
+  auto kern = psd_sign_lds_kernel<NP>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(count), dim3(SignLdsCfg<NP>::THREADS), lds, st, a, first, SignPsd::kLiftSteps, SignPsd::kPolishSteps, SignPsd::kLiftMu);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 static size_t wg_lds_bytes(int n, int nt, bool global_m) {
   const int ld = n | 1;
   const int nw = nt / 64;   // a single wavefront runs QL directly on the shared d/e
@@ -241,6 +266,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
   for (int k = 0; k < mat_num; ++k)
     if (blk[k] >= sign_min) sign_members.push_back(k);
   std::vector<int> ids;
+  cls4_big = 0;
   std::vector<long long> wsoff;
   long long ws_total = 0;
   for (int c = 0; c < kNumPsdClasses; ++c) {
@@ -253,6 +279,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
       ids.push_back(k);
       if (c == 6) { wsoff.push_back(ws_total); ws_total += (long long)blk[k] * (blk[k] | 1); }
       if (c >= 4) cls_maxn[c] = std::max(cls_maxn[c], blk[k]);
+      if (c == 4 && blk[k] > 48) ++cls4_big;
     }
     cls_count[c] = (int)ids.size() - cls_begin[c];
   }
@@ -399,7 +426,14 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
       CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));
       a.dbg = dbg;
     }
-    int rc = launch_class<0>(c, a, cls_maxn[c], st);
+    int rc;
+    static const bool no_sign_lds = getenv("CUADMM_PSD_MID") && std::string(getenv("CUADMM_PSD_MID")) == "eig";   // A/B: register eigensolver
+    if (c == 4 && !no_sign_lds) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
+      rc = launch_sign_lds<64>(a, 0, cls4_big, st);
+      if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st);
+    } else {
+      rc = launch_class<0>(c, a, cls_maxn[c], st);
+    }
     if (rc) return rc;
     if (dbg) {
       std::vector<long long> h((size_t)nwg * 8);

@@ -25,6 +25,7 @@ struct PsdPlan {
   // CUADMM_PSD_SIGN_MIN=<n> moves the boundary (A/B measurements).
   int sign_min = 65;
   mutable SignPsd sign;
+  int cls4_big = 0;            // members of class 4 (32 < n <= 64) with n > 48: NP = 64 kernel, the rest NP = 48
   bool overlap = false;        // engine-owned plans: classes on their own streams (fork / join on the caller's stream)
   mutable hipEvent_t ev_fork = nullptr, ev_done[kNumPsdClasses] = {};
   mutable hipStream_t aux[kNumPsdClasses] = {};
