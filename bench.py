@@ -196,6 +196,7 @@ def main():
         alg_bytes = 16.0 * L_local                         # read Xb + write Xproj, 8 B each per svec element
         achieved = alg_bytes / (psd_ms * 1e-3) / 1e9 if psd_ms > 0 else 0.0
         nominal_flops = (32.0 / 3.0) * args.blocks_per_gpu * BLOCK_N ** 3
+        issued_flops = args.blocks_per_gpu * (44 * 56 + 24) * 2048.0     # psd_sign_lds.h: SignWave32, SignPsd schedule
         out = {
             "metric": "ADMM iters/sec, 10k x 32-blk synthetic per GPU (+ PSD-proj TFLOP/s in roofline)",
             "value": world * args.steps / dt,
@@ -208,14 +209,21 @@ def main():
                                    % (args.blocks_per_gpu, BLOCK_N, BLOCK_N, "ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM"),
                        "blocks_total": args.blocks_per_gpu * world, "vec_len": int(prob.vec_len), "con_num": int(prob.con_num),
                        "sharding": "blocks by index" if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
-            "roofline": {"kernel": "psd_small_reg_kernel<32,0> (fused svec->eig->project->svec)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("psd_small_reg_kernel<32, 0>"), "avg_launch_ms": psd_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "latency/VALU-issue bound (implicit-QL recurrence), not HBM bound: DESIGN.md section 4; "
-                                 "traffic = FETCH_SIZE*2 + WRITE_SIZE from the committed rocprofv3 PMC passes (profiles/)",
-                         "psd_proj_nominal_tflops": nominal_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
-                         "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+            # Dominant kernel: psd_sign_wave32_kernel (one wavefront per 32x32 block, matrix-sign iteration on
+            # v_mfma_f64_16x16x4_f64).  It is MFMA bound.  `achieved` uses the ALGORITHMIC flops of SURVEY 8d
+            # (10.67 n^3 per block, what an eigendecomposition-based projection needs); the flops the kernel really
+            # issues on the matrix cores (44 steps x 56 MFMA + 24, 2048 flop each) are reported beside it.
+            "roofline": {"kernel": "psd_sign_wave32_kernel (fused svec -> matrix-sign projection -> svec)", "bound": "mfma",
+                         "achieved": nominal_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (nominal_flops / (psd_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if psd_ms > 0 else 0.0,
+                         "traffic": pmc_traffic("psd_sign_wave32_kernel"), "avg_launch_ms": psd_ms,
+                         "algorithmic_flops_per_launch": nominal_flops,
+                         "mfma_issued_tflops": issued_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
+                         "mfma_pipe_util": (issued_flops / (psd_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if psd_ms > 0 else 0.0,
+                         "hbm_gbs": achieved, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "fp64 matrix-core bound (DESIGN.md section 4); traffic = FETCH_SIZE*2 + WRITE_SIZE from the "
+                                 "committed rocprofv3 PMC passes (profiles/), algorithmic bytes 16 B per svec element",
                          "blocks_per_s": args.blocks_per_gpu / (psd_ms * 1e-3) if psd_ms > 0 else 0.0},
             "final_state": {k: st[k] for k in ("errRp", "errRd", "relgap", "sig")},
         }

@@ -23,6 +23,7 @@ typedef double sl_v4f64 __attribute__((ext_vector_type(4)));
 template <int NP> struct SignLdsCfg;
 // one wavefront per upper sub-tile (NU wavefronts per workgroup): with a single wavefront per SIMD the LDS latency of
 // every k-step is exposed (measured: 25 k cycles per Newton-Schulz step instead of 6 k)
+template <> struct SignLdsCfg<32> { static constexpr int LD = 33, NT = 2, NU = 3, THREADS = 64 * 3; };
 template <> struct SignLdsCfg<48> { static constexpr int LD = 49, NT = 3, NU = 6, THREADS = 64 * 6; };
 template <> struct SignLdsCfg<64> { static constexpr int LD = 65, NT = 4, NU = 10, THREADS = 64 * 10; };
 
@@ -121,6 +122,166 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
     int i, j;
     tri_decode(e, i, j);
     const double v = T[j * LD + i];
+    bad |= !(fabs(v) <= 1.7976931348623157e308);
+    out[e] = (i == j) ? v : v * kSqrt2;
+  }
+  if (bad && fail) atomicAdd(fail, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// n <= 32: one WAVEFRONT per block, no workgroup barrier.  S lives in LDS (32 x 33 doubles per wavefront) only to be
+// re-read in MFMA operand layout; everything else stays in registers:
+//   * the accumulator layout of v_mfma_f64_16x16x4_f64 (lane (kk, c), register r holds element (kk + 4 r, c)) IS the
+//     B-operand layout of k-step r, so Y = S^2 never leaves the registers: its four 16 x 16 sub-tiles feed the second
+//     product directly;
+//   * the 16 operand fragments of S read for Y = S S (8 k-steps x 2 column halves) are the A fragments of S (S Y) too
+//     (S symmetric), so the second product issues no LDS reads;
+//   * T = 1.5 mu S - 0.5 mu^3 S Y is formed on the three upper sub-tiles from the register copy of S in accumulator
+//     layout and written back to LDS mirrored (exact symmetry).
+// Per step: 16 LDS reads, <= 24 LDS writes, 56 MFMAs (32 for Y incl. the redundant lower sub-tile, 24 for S Y).
+// ---------------------------------------------------------------------------------------------------------------
+struct SignWave32 {
+  static constexpr int NP = 32, LD = 33, PER_WAVE = NP * LD;
+};
+
+__device__ __forceinline__ void sw32_unpack(const double* __restrict__ src, int n, double* __restrict__ M, int lane) {
+  constexpr int LD = SignWave32::LD;
+  for (int e = lane; e < 32 * LD; e += 64) M[e] = 0.0;
+  wave_fence();
+  const int len = n * (n + 1) / 2;
+  for (int e = lane; e < len; e += 64) {
+    int i, j;
+    tri_decode(e, i, j);
+    double v = src[e];
+    if (i != j) v *= kSqrt2Inv;
+    M[j * LD + i] = v;
+    M[i * LD + j] = v;
+  }
+  wave_fence();
+}
+
+// all 16 operand fragments of the symmetric matrix in LDS: f[s][x] = M[4 s + kk][16 x + r16]
+__device__ __forceinline__ void sw32_frags(const double* __restrict__ M, int r16, int kk, double (&f)[8][2]) {
+  constexpr int LD = SignWave32::LD;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    f[s][0] = M[(4 * s + kk) * LD + r16];
+    f[s][1] = M[(4 * s + kk) * LD + 16 + r16];
+  }
+}
+
+// accumulator-layout copy of the three upper sub-tiles: d[0] = (0,0), d[1] = (0,1), d[2] = (1,1)
+__device__ __forceinline__ void sw32_dlayout(const double* __restrict__ M, int r16, int kk, sl_v4f64 (&d)[3]) {
+  constexpr int LD = SignWave32::LD;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d[0][r] = M[(kk + 4 * r) * LD + r16];
+    d[1][r] = M[(kk + 4 * r) * LD + 16 + r16];
+    d[2][r] = M[(16 + kk + 4 * r) * LD + 16 + r16];
+  }
+}
+
+// mirrored store of the three upper sub-tiles
+__device__ __forceinline__ void sw32_store(double* __restrict__ M, int r16, int kk, const sl_v4f64 (&d)[3]) {
+  constexpr int LD = SignWave32::LD;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = kk + 4 * r, col = r16;
+    if (col >= row) { M[row * LD + col] = d[0][r]; M[col * LD + row] = d[0][r]; }
+    M[row * LD + 16 + col] = d[1][r];
+    M[(16 + col) * LD + row] = d[1][r];
+    if (col >= row) { M[(16 + row) * LD + 16 + col] = d[2][r]; M[(16 + col) * LD + 16 + row] = d[2][r]; }
+  }
+}
+
+// C(upper sub-tiles) = alpha * A * B + beta * E with A given by its fragments fa (symmetric A) and B by its four
+// sub-tiles in accumulator layout yb[b][c] (row block b, column block c)
+__device__ __forceinline__ void sw32_gemm_regB(const double (&fa)[8][2], const sl_v4f64 (&yb)[2][2], const sl_v4f64 (&e)[3],
+                                               double alpha, double beta, sl_v4f64 (&out)[3]) {
+  sl_v4f64 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ks = 4 * b + s;   // k rows 16 b + 4 s + kk
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][0], yb[b][0][s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][0], yb[b][1][s], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][1], yb[b][1][s], acc[2], 0, 0, 0);
+    }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[t][r] = alpha * acc[t][r] + beta * e[t][r];
+}
+
+__device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
+                                                     double* S, int lift_steps, int polish_steps, double lift_mu) {
+  constexpr int LD = SignWave32::LD;
+  const int lane = lane_id();
+  const int r16 = lane & 15, kk = lane >> 4;
+  sw32_unpack(in, n, S, lane);
+  // ||X||_1 (max column sum; lanes 0..31 own a column each)
+  double cs = 0.0;
+  if (lane < 32)
+    for (int r = 0; r < 32; ++r) cs += fabs(S[r * LD + lane]);
+  double nrm = cs;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double v = __shfl_xor(nrm, o, 64);
+    nrm = (v > nrm || !(v == v)) ? v : nrm;
+  }
+  const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);
+  for (int e = lane; e < 32 * LD; e += 64) S[e] *= scale;
+  wave_fence();
+  sl_v4f64 sd[3];
+  sw32_dlayout(S, r16, kk, sd);
+  double f[8][2];
+  for (int it = 0; it < lift_steps + polish_steps; ++it) {
+    const double mu = it < lift_steps ? lift_mu : 1.0;
+    sw32_frags(S, r16, kk, f);
+    // Y = S S, all four sub-tiles (the lower one is needed as a register operand)
+    sl_v4f64 y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) y[a][c] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      y[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][0], f[s][0], y[0][0], 0, 0, 0);
+      y[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][0], f[s][1], y[0][1], 0, 0, 0);
+      y[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][0], y[1][0], 0, 0, 0);
+      y[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][1], y[1][1], 0, 0, 0);
+    }
+    sl_v4f64 t[3];
+    sw32_gemm_regB(f, y, sd, -0.5 * mu * mu * mu, 1.5 * mu, t);   // T = 1.5 mu S - 0.5 mu^3 S Y
+    wave_fence();                                                 // all fragment reads of S are done
+    sw32_store(S, r16, kk, t);
+    wave_fence();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sd[q] = t[q];
+  }
+  // P = 0.5 (X0 + S X0): A fragments of S from LDS, then LDS is reused for X0, whose sub-tiles are read in accumulator
+  // layout (register B operand).  The lower sub-tile of X0 is read directly too (X0 is exactly symmetric in LDS).
+  sw32_frags(S, r16, kk, f);
+  wave_fence();
+  sw32_unpack(in, n, S, lane);
+  sl_v4f64 x0[3], xb[2][2], p[3];
+  sw32_dlayout(S, r16, kk, x0);
+  xb[0][0] = x0[0]; xb[0][1] = x0[1]; xb[1][1] = x0[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xb[1][0][r] = S[(16 + kk + 4 * r) * LD + r16];
+  sw32_gemm_regB(f, xb, x0, 0.5, 0.5, p);
+  wave_fence();
+  sw32_store(S, r16, kk, p);
+  wave_fence();
+  const int len = n * (n + 1) / 2;
+  bool bad = false;
+  for (int e = lane; e < len; e += 64) {
+    int i, j;
+    tri_decode(e, i, j);
+    const double v = S[j * LD + i];
     bad |= !(fabs(v) <= 1.7976931348623157e308);
     out[e] = (i == j) ? v : v * kSqrt2;
   }
