@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "cuadmm_amd.h"))
-    common = (["-DCUADMM_QL_CHECKS"] if os.environ.get("CUADMM_QL_CHECKS") else []) + ["-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wno-unused-result"]
+    common = (["-DCUADMM_QL_CHECKS"] if os.environ.get("CUADMM_QL_CHECKS") else []) + ["-O3", "-std=c++17", "-fPIC", "-pthread", "-I" + INCLUDE, "-I" + CSRC, "-Wno-unused-result"]
     jobs = []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
@@ -71,7 +71,7 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJDIR, s + ".o") for s in HIP_SOURCES + CPP_SOURCES]
     if force or jobs or not os.path.exists(LIB):
         _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs +
-             ["-ldl", "-Wl,-rpath,/opt/rocm/lib"])
+             ["-ldl", "-pthread", "-Wl,-rpath,/opt/rocm/lib"])
     cli = os.path.join(CSRC, "cli_main.cpp")
     if force or jobs or not _newer(EXE, [cli, LIB]):
         _run(["g++", "-O2", "-std=c++17", "-I" + INCLUDE, cli, "-o", EXE, "-L" + LIBDIR, "-lcuadmm_amd",

@@ -15,7 +15,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "common.h"
 
@@ -29,6 +33,10 @@ struct cuadmm_aat {
   // split factorisation (cuadmm_aat_create_split): the last tail_k columns are NOT factored on the host; schur_*
   // hold the lower triangle (with diagonal) of the Schur complement B22 - L21 D1 L21^T by rows (CSR, tail-local
   // column indices) for the GPU.  Sparse on purpose: a dense 17 152^2 host matrix costs seconds of page faults.
+  // Independent subtrees of the elimination tree, grouped into chunks of columns (ascending within a chunk): the
+  // sweeps of different chunks touch disjoint entries, so cuadmm_aat_solve_permuted runs them on a few host threads
+  // with bit-identical results (used for large block-diagonal systems, e.g. weak-scaled runs with m = 400 000).
+  std::vector<std::vector<int>> chunks;
   int tail_k = 0;
   std::vector<int64_t> schur_ptr;
   std::vector<int> schur_col;
@@ -137,6 +145,69 @@ void min_degree_order(int n, const std::vector<int64_t>& Bp, const std::vector<i
 
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Minimal fork-join pool (mutex + condition variables, generation counter).  run(f) executes f(0..T-1), f(0) on the caller.
+class HostPool {
+ public:
+  explicit HostPool(int threads) : T(std::max(1, threads)) {
+    for (int i = 1; i < T; ++i) workers.emplace_back([this, i] { loop(i); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_start.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  int size() const { return T; }
+  void run(const std::function<void(int)>& f) {
+    if (T == 1) { f(0); return; }
+    { std::lock_guard<std::mutex> lk(mu); job = &f; pending = T - 1; ++gen; }
+    cv_start.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [this] { return pending == 0; });
+    job = nullptr;
+  }
+
+ private:
+  void loop(int id) {
+    unsigned seen = 0;
+    for (;;) {
+      const std::function<void(int)>* j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_start.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+        j = job;
+      }
+      (*j)(id);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_one();
+      }
+    }
+  }
+  const int T;
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void(int)>* job = nullptr;
+  unsigned gen = 0;
+  int pending = 0;
+  bool stop = false;
+};
+
+// CUADMM_HOST_THREADS (default 8, 1 = serial).  Created on first use, lives until process exit.
+HostPool& host_pool() {
+  static HostPool pool([] {
+    const char* e = getenv("CUADMM_HOST_THREADS");
+    int t = e ? atoi(e) : 8;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0) t = std::min(t, hw);
+    return std::max(1, t);
+  }());
+  return pool;
 }
 
 // Cost model of the dense-tail split: host 1.2 ns per nonzero of the leading columns (both sweeps, measured),
@@ -350,6 +421,24 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     }
     f->D[k] = dk;
   }
+  // chunks of independent etree subtrees for the threaded solve (whole factor on the host, large m, many subtrees)
+  if (tail_k == 0 && m >= 200000) {
+    std::vector<int> root(m);
+    for (int j = m - 1; j >= 0; --j) root[j] = parent[j] < 0 ? j : root[parent[j]];   // parent[j] > j
+    std::vector<int64_t> weight(m, 0);                                                 // per root: columns + nonzeros
+    for (int j = 0; j < m; ++j) weight[root[j]] += 1 + (f->Lp[j + 1] - f->Lp[j]);
+    int64_t total = 0, biggest = 0;
+    for (int j = 0; j < m; ++j) if (root[j] == j) { total += weight[j]; biggest = std::max(biggest, weight[j]); }
+    const int T = 16;
+    if (biggest * 4 < total) {                      // no dominating subtree: worth splitting
+      std::vector<int> chunk_of_root(m, -1);
+      int64_t acc = 0;
+      for (int j = 0; j < m; ++j)                   // roots in ascending order of the root column
+        if (root[j] == j) { chunk_of_root[j] = (int)std::min<int64_t>(T - 1, acc * T / total); acc += weight[j]; }
+      f->chunks.assign(T, {});
+      for (int j = 0; j < m; ++j) f->chunks[chunk_of_root[root[j]]].push_back(j);
+    }
+  }
   f->factor_s = now_s() - t0;
   if (getenv("CUADMM_AAT_TIMING")) fprintf(stderr, "[aat] analyze %.3fs numeric %.3fs (alloc %.3fs, leading rows until %.3fs, %lld updates) nnz(L) %lld tail %d\n", f->analyze_s, f->factor_s, t_alloc, t_lead, upd, (long long)f->Lp[m], tail_k);
   *out = f;
@@ -385,6 +474,28 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x)
   const int* Li = f->Li.data();
   const double* Lx = f->Lx.data();
   const double* D = f->D.data();
+  if (!f->chunks.empty() && host_pool().size() > 1) {
+    // every chunk is a union of whole etree subtrees: its three sweeps touch only its own entries of x
+    const int nchunk = (int)f->chunks.size(), T = host_pool().size();
+    host_pool().run([&](int t) {
+      for (int c = t; c < nchunk; c += T) {
+        const std::vector<int>& cols = f->chunks[c];
+        for (int j : cols) {
+          const double xj = x[j];
+          if (xj != 0.0)
+            for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
+        }
+        for (int j : cols) x[j] /= D[j];
+        for (size_t q = cols.size(); q-- > 0;) {
+          const int j = cols[q];
+          double s = x[j];
+          for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
+          x[j] = s;
+        }
+      }
+    });
+    return CUADMM_OK;
+  }
   for (int j = 0; j < m; ++j) {  // L z = b
     double xj = x[j];
     if (xj != 0.0)
@@ -458,5 +569,15 @@ int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
 }
 
 void cuadmm_aat_free(cuadmm_aat* f) { delete f; }
+
+// fn(chunk, ctx) for chunk = 0..nchunks-1 on the host pool (CUADMM_HOST_THREADS); chunks are handed out statically
+// (chunk c runs on thread c mod T), so anything reduced per chunk and combined in chunk order is reproducible.
+void cuadmm_host_parallel_for(int nchunks, void (*fn)(int, void*), void* ctx) {
+  if (nchunks <= 0 || !fn) return;
+  HostPool& pool = host_pool();
+  const int T = pool.size();
+  if (T == 1 || nchunks == 1) { for (int c = 0; c < nchunks; ++c) fn(c, ctx); return; }
+  pool.run([&](int t) { for (int c = t; c < nchunks; c += T) fn(c, ctx); });
+}
 
 }  // extern "C"

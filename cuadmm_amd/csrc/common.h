@@ -49,3 +49,6 @@ void print_blk_census(const std::vector<int>& sizes, const std::vector<int>& num
 void partition_blocks(const int* blk, int mat_num, int world, std::vector<int>& first);
 
 }  // namespace cuadmm
+
+// host thread pool of aat_ldlt.cpp (internal): fn(chunk, ctx) for chunk = 0..nchunks-1
+extern "C" void cuadmm_host_parallel_for(int nchunks, void (*fn)(int, void*), void* ctx);

@@ -78,6 +78,20 @@ struct PinnedBuf {
   ~PinnedBuf() { release(); }
 };
 
+// Host loops over the m constraints: serial below kHostParMin, else kHostChunks fixed index ranges on the host pool
+// (aat_ldlt.cpp).  Sums are formed per range and combined in range order: reproducible for any thread count.
+constexpr int kHostParMin = 200000, kHostChunks = 32;
+template <class F>
+static void host_ranges(int m, F&& body) {   // body(chunk, lo, hi)
+  if (m < kHostParMin) { body(0, 0, m); return; }
+  struct Ctx { F* f; int m; } ctx{&body, m};
+  cuadmm_host_parallel_for(kHostChunks, [](int c, void* p) {
+    Ctx* x = static_cast<Ctx*>(p);
+    const long long lo = (long long)x->m * c / kHostChunks, hi = (long long)x->m * (c + 1) / kHostChunks;
+    (*x->f)(c, (int)lo, (int)hi);
+  }, &ctx);
+}
+
 enum KClass { K_ATY = 0, K_PSD = 1, K_POST = 2, K_SPMV = 3, K_COPY = 4, K_HOST = 5, K_COMM = 6, K_TAIL = 7, K_NUM = CUADMM_NUM_KCLASS };
 
 // direct RCCL binding (symbols resolved at run time so that a process that already loaded an RCCL,
@@ -213,7 +227,9 @@ struct cuadmm_solver {
   int host_solve() {  // y_p = (P(AA^T+eps I)P^T)^-1 rhs_p
     double t0 = wall_s();
     const double isig = 1 / sig;
-    for (int i = 0; i < m; ++i) rhs_p[i] = -ASmC_p[i] + isig * Rp_p[i];   // solver.cu:478-482
+    host_ranges(m, [&](int, int lo, int hi) {
+      for (int i = lo; i < hi; ++i) rhs_p[i] = -ASmC_p[i] + isig * Rp_p[i];   // solver.cu:478-482
+    });
     int rc;
     if (tail.k == 0) {
       rc = cuadmm_aat_solve_permuted(fac, rhs_p.data(), y_p.data());     // solver.cu:494
@@ -691,7 +707,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if ((rc = s->launch_post_mode(1, tau))) return rc;
       if ((rc = s->launch_spmv(false, true))) return rc;
       if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
-      for (int i = 0; i < m; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i];
+      host_ranges(m, [&](int, int lo, int hi) { for (int i = lo; i < hi; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i]; });
       if ((rc = s->host_solve())) return rc;
       if ((rc = s->upload_y())) return rc;
       if ((rc = s->launch_aty(false))) return rc;
@@ -714,7 +730,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       }
       if ((rc = s->launch_spmv(true, true))) return rc;
       if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
-      for (int i = 0; i < m; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i];
+      host_ranges(m, [&](int, int lo, int hi) { for (int i = lo; i < hi; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i]; });
     }
 
     // ---- Step 5 (solver.cu:764-799)
@@ -722,13 +738,19 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       double t0 = wall_s();
       double nr = 0, bty = 0;
       const double* ax = s->h_out.p;
-      for (int i = 0; i < m; ++i) {
-        const double rp = -ax[i] + s->b_p[i];
-        s->Rp_p[i] = rp;
-        const double ro = s->normA_p[i] * rp * s->bscale;
-        nr += ro * ro;
-        bty += s->b_p[i] * s->y_p[i];
-      }
+      double part[2 * kHostChunks] = {0};
+      host_ranges(m, [&](int c, int lo, int hi) {
+        double a = 0, b = 0;
+        for (int i = lo; i < hi; ++i) {
+          const double rp = -ax[i] + s->b_p[i];
+          s->Rp_p[i] = rp;
+          const double ro = s->normA_p[i] * rp * s->bscale;
+          a += ro * ro;
+          b += s->b_p[i] * s->y_p[i];
+        }
+        part[2 * c] = a; part[2 * c + 1] = b;
+      });
+      for (int c = 0; c < kHostChunks; ++c) { nr += part[2 * c]; bty += part[2 * c + 1]; }
       s->errRp = std::sqrt(nr) / s->norm_borg;
       s->pobj = s->h_out.p[(size_t)m + 1] * s->objscale;
       s->errRd = std::sqrt(s->h_out.p[(size_t)m]) * s->Cscale / s->norm_Corg;
