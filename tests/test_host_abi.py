@@ -290,3 +290,42 @@ def test_aat_split_factor_schur_complement(name, frac, problem_dirs):
     with pytest.raises(cuadmm_amd.CuadmmError):
         check(lib.cuadmm_aat_tail_schur(hs, C.byref(C.POINTER(C.c_int64)()), C.byref(C.POINTER(C.c_int)()), C.byref(C.POINTER(C.c_double)())))
     lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
+
+
+def test_aat_threaded_solve_is_bitwise_identical_to_serial(tmp_path):
+    """Large block-diagonal system (weak-scaled C2 structure, m = 200 000): the solve runs independent etree subtrees
+    on the host pool; the result must not depend on the number of threads (bit for bit)."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "solve.py"
+    script.write_text(textwrap.dedent('''
+        import sys, ctypes as C, numpy as np, scipy.sparse as sp
+        sys.path.insert(0, %r)
+        import cuadmm_amd
+        from cuadmm_amd._lib import check
+        lib = cuadmm_amd.load()
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        rng = np.random.default_rng(5)
+        nb, per, L = 40000, 5, 40000 * 30                      # 40 000 independent 5-constraint groups
+        rows = np.repeat(np.arange(nb * per), 6)
+        cols = (np.repeat(np.arange(nb), per * 6) * 30 + rng.integers(0, 30, nb * per * 6))
+        A = sp.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(nb * per, L)); A.sum_duplicates(); A.sort_indices()
+        h = C.c_void_p()
+        check(lib.cuadmm_aat_create(nb * per, L, P(A.indptr.astype(np.int32)), P(A.indices.astype(np.int32)), P(A.data), 1e-15, C.byref(h)))
+        rhs = rng.standard_normal(nb * per); out = np.empty_like(rhs)
+        check(lib.cuadmm_aat_solve_permuted(h, P(rhs), P(out)))
+        perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(nb * per,))
+        y = np.empty_like(out); y[perm] = out
+        B = (A @ A.T).tocsr()
+        r = np.empty_like(rhs); r[perm] = rhs
+        print("RES", np.linalg.norm(B @ y - r) / np.linalg.norm(r))
+        np.save(sys.argv[1], out)
+    ''' % ROOT))
+    outs = []
+    for t in ("1", "6"):
+        f = tmp_path / ("x%s.npy" % t)
+        env = dict(os.environ, CUADMM_HOST_THREADS=t)
+        r = subprocess.run([sys.executable, str(script), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert float(r.stdout.split("RES")[1]) < 1e-8
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1])
