@@ -326,12 +326,8 @@ int PsdPlan::build(const int* blk, int mat_num) {
 }
 
 void PsdPlan::release() {
-  if (d_off) hipFree(d_off);
-  if (d_n) hipFree(d_n);
-  if (d_ids) hipFree(d_ids);
-  if (d_fail) hipFree(d_fail);
-  if (d_ws) hipFree(d_ws);
-  if (d_wsoff) hipFree(d_wsoff);
+  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff})
+    if (p) { hipError_t e = hipFree(p); (void)e; }
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
   sign.release();
   if (ev_fork) {
@@ -487,7 +483,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
                               st / np, pp / np, pc / np, pbr / np, cc / nc, cb / nc);
       }
       (void)slots; (void)tmin; (void)tmax;
-      hipFree(dbg);
+      { hipError_t e = hipFree(dbg); (void)e; }
     }
     if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
   }
@@ -506,7 +502,7 @@ int PsdPlan::fail_count(hipStream_t st) const {
   int h = 0;
   if (!d_fail) return 0;
   if (hipMemcpyAsync(&h, d_fail, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-  hipStreamSynchronize(st);
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
   return h;
 }
 
@@ -531,9 +527,10 @@ int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream
   }
   int rc = launch_class<1>(c, a, n, st);
   if (c == 6) {
-    hipStreamSynchronize(st);
-    hipFree(ws);
-    hipFree(wsoff);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == CUADMM_OK) { set_error("batch_eig: %s", hipGetErrorString(e)); rc = CUADMM_ERR_NO_DEVICE; }
+    e = hipFree(ws); (void)e;
+    e = hipFree(wsoff); (void)e;
   }
   return rc;
 }
