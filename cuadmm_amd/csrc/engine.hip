@@ -160,6 +160,7 @@ struct cuadmm_solver {
 
   // device
   DevBuf<int> At_rp, At_ci, A_rp, A_ci;
+  SpmvLongRows A_long;         // rows of A much longer than the average (trace / all-ones constraints)
   DevBuf<double> At_v, A_v;
   DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
   PinnedBuf<double> h_out, h_y;
@@ -274,7 +275,7 @@ struct cuadmm_solver {
   int launch_spmv(bool doX, bool doS) {
     prof_begin(K_SPMV);
     int rc = launch_spmv_rows(m, A_avg_nnz, A_rp.p, A_ci.p, A_v.p, X.p, S.p, C.p, doX ? out_d.p : nullptr,
-                              doS ? out_d.p + m + 2 : nullptr, st);
+                              doS ? out_d.p + m + 2 : nullptr, st, &A_long);
     prof_end(K_SPMV, 12.0 * (double)A_v.n + 8.0 * m * ((doX ? 1 : 0) + (doS ? 1 : 0)));
     return rc;
   }
@@ -512,6 +513,12 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       arp[pidx + 1] = (int)aci.size();
     }
     s->A_avg_nnz = m > 0 ? (double)aci.size() / m : 1.0;
+    if ((rc = s->A_long.build(m, arp.data()))) return rc;
+    if (s->A_long.nlong > 0) {   // the average that picks the threads-per-row of the main kernel should not count the capped tails
+      long long capped = 0;
+      for (int i = 0; i < m; ++i) capped += std::min(arp[i + 1] - arp[i], s->A_long.cap);
+      s->A_avg_nnz = (double)capped / m;
+    }
     if ((rc = s->A_rp.from(arp)) || (rc = s->A_ci.alloc(std::max<size_t>(aci.size(), 1))) || (rc = s->A_v.alloc(std::max<size_t>(av.size(), 1)))) return rc;
     if ((rc = s->A_ci.upload(aci.data(), aci.size())) || (rc = s->A_v.upload(av.data(), av.size()))) return rc;
     s->A_v.n = av.size();

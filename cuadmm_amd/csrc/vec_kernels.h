@@ -14,9 +14,22 @@ int post_grid(long long L);
 int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, const double* C, double* X, double* S,
                 double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st);
 
+// Rows of A with more than `cap` nonzeros (a trace / all-ones constraint): their tail is summed in segments by extra
+// workgroups and added in segment order (reproducible), so one row cannot serialise the SpMV.
+struct SpmvLongRows {
+  int cap = 256, seg_len = 4096;   // cap is set by build(): max(256, 8 x average row length)
+  int nlong = 0, nseg = 0;
+  int *long_row = nullptr, *long_seg0 = nullptr, *seg_begin = nullptr, *seg_end = nullptr;   // device
+  double* partial = nullptr;                                                                 // device, 2 per segment
+  int build(int rows, const int* rp_host);
+  void release();
+  ~SpmvLongRows() { release(); }
+};
+
 // outX = A*X, outS = A*(S-C) over the rows of A (either output may be null)
 int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, const double* av, const double* X,
-                     const double* S, const double* C, double* outX, double* outS, hipStream_t st);
+                     const double* S, const double* C, double* outX, double* outS, hipStream_t st,
+                     const SpmvLongRows* long_rows = nullptr);
 
 int launch_scale(double* v, long long n, double s, hipStream_t st);
 

@@ -13,6 +13,9 @@
 // deterministic, unlike atomics.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "device_util.h"
 #include "vec_kernels.h"
 
@@ -120,18 +123,24 @@ __global__ __launch_bounds__(kVecThreads) void reduce_pairs_kernel(const double*
 //   outX[row]  = sum a * X[col]            (if outX)
 //   outS[row]  = sum a * (S[col] - C[col]) (if outS)
 // ------------------------------------------------------------------------------------------
+// `cap` > 0: only the first `cap` nonzeros of a row are summed here; the rest of such LONG rows (a trace or all-ones
+// constraint can hold as many nonzeros as the whole svec) is cut into segments summed by spmv_segments_kernel and
+// added in segment order by spmv_finish_kernel -- one row must not serialise the launch (swissroll: one row with
+// 320 000 of the 330 537 nonzeros made this kernel take 4.8 ms).
 template <int T>
 __global__ __launch_bounds__(kVecThreads) void spmv_rows_kernel(int rows, const int* __restrict__ rp,
                                                                 const int* __restrict__ ci, const double* __restrict__ av,
                                                                 const double* __restrict__ X, const double* __restrict__ S,
                                                                 const double* __restrict__ C, double* __restrict__ outX,
-                                                                double* __restrict__ outS) {
+                                                                double* __restrict__ outS, int cap) {
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int sub = (int)(threadIdx.x & (T - 1));
   const long long nsub = (long long)gridDim.x * blockDim.x / T;
   const bool doX = outX != nullptr, doS = outS != nullptr;
   for (long long row = gtid / T; row < rows; row += nsub) {
-    const int p0 = rp[row], p1 = rp[row + 1];
+    const int p0 = rp[row];
+    int p1 = rp[row + 1];
+    if (cap > 0 && p1 - p0 > cap) p1 = p0 + cap;
     double ax = 0.0, as = 0.0;
     for (int p = p0 + sub; p < p1; p += T) {
       const int c = ci[p];
@@ -149,6 +158,40 @@ __global__ __launch_bounds__(kVecThreads) void spmv_rows_kernel(int rows, const 
       if (doS) outS[row] = as;
     }
   }
+}
+
+// one workgroup per segment [seg_begin, seg_end) of a long row: partial[2*seg] (A X), partial[2*seg+1] (A (S - C))
+__global__ __launch_bounds__(kVecThreads) void spmv_segments_kernel(const int* __restrict__ seg_begin, const int* __restrict__ seg_end,
+                                                                    const int* __restrict__ ci, const double* __restrict__ av,
+                                                                    const double* __restrict__ X, const double* __restrict__ S,
+                                                                    const double* __restrict__ C, bool doX, bool doS,
+                                                                    double* __restrict__ partial) {
+  __shared__ double rx[kVecThreads], rs[kVecThreads];
+  const int p0 = seg_begin[blockIdx.x], p1 = seg_end[blockIdx.x];
+  double ax = 0.0, as = 0.0;
+  for (int p = p0 + (int)threadIdx.x; p < p1; p += kVecThreads) {
+    const int c = ci[p];
+    const double a = av[p];
+    if (doX) ax += a * X[c];
+    if (doS) as += a * (S[c] - C[c]);
+  }
+  rx[threadIdx.x] = ax; rs[threadIdx.x] = as;
+  __syncthreads();
+  for (int o = kVecThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { rx[threadIdx.x] += rx[threadIdx.x + o]; rs[threadIdx.x] += rs[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = rx[0]; partial[2 * blockIdx.x + 1] = rs[0]; }
+}
+// out[row] += its segments' partials, in segment order (one thread per long row)
+__global__ void spmv_finish_kernel(int nlong, const int* __restrict__ long_row, const int* __restrict__ long_seg0,
+                                   const double* __restrict__ partial, double* __restrict__ outX, double* __restrict__ outS) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= nlong) return;
+  double ax = 0.0, as = 0.0;
+  for (int sgi = long_seg0[i]; sgi < long_seg0[i + 1]; ++sgi) { ax += partial[2 * sgi]; as += partial[2 * sgi + 1]; }
+  if (outX) outX[long_row[i]] += ax;
+  if (outS) outS[long_row[i]] += as;
 }
 
 int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, const double* av, const double* y,
@@ -181,20 +224,62 @@ int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, c
 }
 
 int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, const double* av, const double* X,
-                     const double* S, const double* C, double* outX, double* outS, hipStream_t st) {
+                     const double* S, const double* C, double* outX, double* outS, hipStream_t st, const SpmvLongRows* lr) {
   if (rows <= 0) return CUADMM_OK;
+  const int cap = (lr && lr->nlong > 0) ? lr->cap : 0;
   int T = 1;
   while (T < 64 && T < avg_nnz) T <<= 1;
   const int grid = grid_for((long long)rows * T, kVecThreads, 256 * 16);
 #define CUADMM_SPMV_CASE(TT) \
-  case TT: hipLaunchKernelGGL(spmv_rows_kernel<TT>, dim3(grid), dim3(kVecThreads), 0, st, rows, rp, ci, av, X, S, C, outX, outS); break;
+  case TT: hipLaunchKernelGGL(spmv_rows_kernel<TT>, dim3(grid), dim3(kVecThreads), 0, st, rows, rp, ci, av, X, S, C, outX, outS, cap); break;
   switch (T) {
     CUADMM_SPMV_CASE(1) CUADMM_SPMV_CASE(2) CUADMM_SPMV_CASE(4) CUADMM_SPMV_CASE(8)
     CUADMM_SPMV_CASE(16) CUADMM_SPMV_CASE(32) CUADMM_SPMV_CASE(64)
   }
 #undef CUADMM_SPMV_CASE
   CUADMM_HIP_TRY(hipGetLastError());
+  if (cap > 0) {
+    hipLaunchKernelGGL(spmv_segments_kernel, dim3(lr->nseg), dim3(kVecThreads), 0, st, lr->seg_begin, lr->seg_end, ci, av, X, S, C,
+                       outX != nullptr, outS != nullptr, lr->partial);
+    hipLaunchKernelGGL(spmv_finish_kernel, dim3((lr->nlong + 63) / 64), dim3(64), 0, st, lr->nlong, lr->long_row, lr->long_seg0, lr->partial,
+                       outX, outS);
+    CUADMM_HIP_TRY(hipGetLastError());
+  }
   return CUADMM_OK;
+}
+
+// rows with more than `cap` nonzeros: segments of `seg_len` nonzeros beyond the first `cap`
+int SpmvLongRows::build(int rows, const int* rp_host) {
+  release();
+  // "long" is relative: 8x the average row, at least 256 nonzeros (a matrix of uniformly long rows has no long rows)
+  cap = (int)std::max<long long>(256, rows > 0 ? 8LL * rp_host[rows] / rows : 0);
+  std::vector<int> lrow, lseg0{0}, sb, se;
+  for (int r = 0; r < rows; ++r) {
+    const int len = rp_host[r + 1] - rp_host[r];
+    if (len <= cap) continue;
+    lrow.push_back(r);
+    for (int p = rp_host[r] + cap; p < rp_host[r + 1]; p += seg_len) { sb.push_back(p); se.push_back(std::min(p + seg_len, rp_host[r + 1])); }
+    lseg0.push_back((int)sb.size());
+  }
+  nlong = (int)lrow.size();
+  nseg = (int)sb.size();
+  if (nlong == 0) return CUADMM_OK;
+  CUADMM_HIP_TRY(hipMalloc(&long_row, sizeof(int) * lrow.size()));
+  CUADMM_HIP_TRY(hipMalloc(&long_seg0, sizeof(int) * lseg0.size()));
+  CUADMM_HIP_TRY(hipMalloc(&seg_begin, sizeof(int) * sb.size()));
+  CUADMM_HIP_TRY(hipMalloc(&seg_end, sizeof(int) * se.size()));
+  CUADMM_HIP_TRY(hipMalloc(&partial, sizeof(double) * 2 * sb.size()));
+  CUADMM_HIP_TRY(hipMemcpy(long_row, lrow.data(), sizeof(int) * lrow.size(), hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMemcpy(long_seg0, lseg0.data(), sizeof(int) * lseg0.size(), hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMemcpy(seg_begin, sb.data(), sizeof(int) * sb.size(), hipMemcpyHostToDevice));
+  CUADMM_HIP_TRY(hipMemcpy(seg_end, se.data(), sizeof(int) * se.size(), hipMemcpyHostToDevice));
+  return CUADMM_OK;
+}
+void SpmvLongRows::release() {
+  for (void* p : {(void*)long_row, (void*)long_seg0, (void*)seg_begin, (void*)seg_end, (void*)partial}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  long_row = long_seg0 = seg_begin = seg_end = nullptr;
+  partial = nullptr;
+  nlong = nseg = 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -58,6 +58,17 @@ LOGS = {
     "rose13/sGS": ("plato/logs/rose13.log", "rose13", dict(switch_admm=11000)),
     "cnhil10/sGS": ("plato/logs/cnhil10.log", "cnhil10", dict(switch_admm=11000)),
     "pendulum_N=80/sGS": ("pendulum/N=80_licols.log", "pendulum_N=80", dict(switch_admm=11000)),
+    # single large blocks (n = 1024 / 861 / 800): the large-block projection path against the reference's own runs
+    "1dc.1024/sGS": ("plato/logs/1dc.1024.log", "1dc.1024", dict(switch_admm=11000)),
+    "bqp-r1-40-1/sGS": ("plato/logs/bqp-r1-40-1.log", "bqp-r1-40-1", dict(switch_admm=11000)),
+    "swissroll/sGS": ("plato/logs/swissroll.log", "swissroll", dict(switch_admm=11000)),
+}
+
+# problems shipped as .mat with At / C / b already in svec form (examples/plato/MATLAB), blk from the TXT directory
+PLATO_MAT = {
+    "1dc.1024": ("plato/MATLAB/1dc.1024.mat", "plato/TXT/1dc.1024"),
+    "bqp-r1-40-1": ("plato/MATLAB/bqp-r1-40-1.mat", "plato/TXT/bqp-r1-40-1"),
+    "swissroll": ("plato/MATLAB/swissroll.mat", "plato/TXT/swissroll"),
 }
 COMMON = dict(sig=1.0, stop_tol=1e-3, sig_update_threshold=0, sig_update_stage_1=50,
               sig_update_stage_2=100, sigscale=1.05)
@@ -173,6 +184,21 @@ def main():
     np.savez_compressed(os.path.join(out_prob, "pendulum_N=80.npz"), blk=blk, con_num=con_num,
                         At_row=At.row.astype(np.int32), At_col=At.col.astype(np.int32), At_val=At.data,
                         C_idx=ci, C_val=cv, b_idx=bi, b_val=bv)
+
+    # --- single-large-block problems from examples/plato/MATLAB (their TXT directories lack At.txt / C.txt)
+    for name, (matrel, txtrel) in PLATO_MAT.items():
+        d = sio.loadmat(os.path.join(EX, matrel))
+        At, Cm = d["At"].tocoo(), d["C"].tocoo()
+        bm = np.asarray(d["b"].todense() if hasattr(d["b"], "todense") else d["b"]).ravel()
+        blk = np.array([n for _, n in orc.read_blk(os.path.join(EX, txtrel, "blk.txt"))], dtype=np.int32)
+        assert At.shape[0] == int(orc.svec_block_offsets(blk)[-1]) and At.shape[1] == bm.size
+        bi_txt, bv_txt = orc.read_sparse_vector(os.path.join(EX, txtrel, "b.txt"))
+        bi = np.nonzero(bm)[0].astype(np.int32)
+        assert np.array_equal(bi, bi_txt) and np.allclose(bm[bi], bv_txt, rtol=0, atol=1e-12)
+        o = np.argsort(Cm.row)
+        np.savez_compressed(os.path.join(out_prob, name + ".npz"), blk=blk, con_num=int(At.shape[1]),
+                            At_row=At.row.astype(np.int32), At_col=At.col.astype(np.int32), At_val=At.data,
+                            C_idx=Cm.row[o].astype(np.int32), C_val=Cm.data[o], b_idx=bi, b_val=bm[bi])
 
     # --- transcribed logs
     logs = {}

@@ -89,3 +89,39 @@ def test_gpu_tail_of_the_aat_solve_matches_host_only_solve(monkeypatch):
     assert runs["gpu_tail"][3]["tail_solve"]["launches"] > 0 and runs["host_only"][3]["tail_solve"]["launches"] == 0
     for a, b in zip(runs["gpu_tail"][:3], runs["host_only"][:3]):
         assert np.linalg.norm(a - b) <= 1e-9 * max(1.0, np.linalg.norm(b))
+
+
+def _check_rows(s, lg, its, rel=6e-3):
+    for row in lg["rows"]:
+        it = int(row[0])
+        if it in its:
+            got = [s.info_arr(n)[it - 1] for n in ("errRp", "errRd", "pobj", "dobj", "relgap")]
+            for g, w in zip(got, [float(x) for x in row[1:6]]):
+                assert abs(g - w) <= rel * abs(w) + 1e-11, (it, got, row)
+
+
+def test_c3_like_1dc1024_converges_at_the_reference_iteration(ref_logs):
+    """examples/plato 1dc.1024 (one block n = 1024, m = 24 064, dense C): the large-block projection (matrix sign on
+    the matrix cores) inside the full sGS-ADMM run.  Every printed row of examples/plato/logs/1dc.1024.log and the
+    iteration at which the reference converged (353) must be reproduced."""
+    lg = ref_logs["1dc.1024/sGS"]
+    p = load_npz_problem("1dc.1024")
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.init_problem(problem_to_amd(p))
+    s.solve(20000, 1e-3, 0, 50, 100, 11000, 1.05)
+    assert s.info_iter_num == int(lg["rows"][-1][0]) == 353
+    _check_rows(s, lg, (50, 100, 150, 300, 353))
+    assert abs(s.state()["pobj"] - float(lg["final"]["pobj"])) <= 1e-6 * abs(float(lg["final"]["pobj"]))
+    assert abs(s.state()["dobj"] - float(lg["final"]["dobj"])) <= 1e-6 * abs(float(lg["final"]["dobj"]))
+
+
+@pytest.mark.parametrize("name", ["swissroll", "bqp-r1-40-1"])
+def test_large_single_block_examples_first_log_rows(name, ref_logs):
+    """swissroll (n = 800, one constraint row with 320 000 nonzeros: the long-row SpMV path) and bqp-r1-40-1
+    (n = 861, m = 269 001): rows at it 50 and 100 of the reference's logs."""
+    lg = ref_logs[name + "/sGS"]
+    p = load_npz_problem(name)
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.init_problem(problem_to_amd(p))
+    s.solve(100, 1e-3, 0, 50, 100, 11000, 1.05)
+    _check_rows(s, lg, (50, 100))
