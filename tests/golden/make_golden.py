@@ -200,6 +200,18 @@ def main():
                             At_row=At.row.astype(np.int32), At_col=At.col.astype(np.int32), At_val=At.data,
                             C_idx=Cm.row[o].astype(np.int32), C_val=Cm.data[o], b_idx=bi, b_val=bm[bi])
 
+    # --- source-format inputs of the converters (cuadmm_amd/convert.py): the expected outputs are the shipped TXT
+    # directories (problems/hinf12, truss5, PushT_N=10_MOMENT above; biggs below)
+    fmt = os.path.join(HERE, "formats")
+    os.makedirs(fmt, exist_ok=True)
+    shutil.copyfile(os.path.join(EX, "dimacs/data/MATLAB/hinf12.mat"), os.path.join(fmt, "hinf12_sedumi.mat"))
+    shutil.copyfile(os.path.join(EX, "dimacs/data/MATLAB/truss5.mat"), os.path.join(fmt, "truss5_sedumi.mat"))
+    shutil.copyfile(os.path.join(EX, "SPOT/data/MOSEK/PushT_N=10_MOMENT.mat"), os.path.join(fmt, "PushT_N=10_MOMENT_mosek.mat"))
+    shutil.copyfile(os.path.join(EX, "plato/MATLAB/rose13.mat"), os.path.join(fmt, "rose13_svec.mat"))
+    gz_copy(os.path.join(EX, "plato/MATLAB/biggs.dat-s"), os.path.join(fmt, "biggs.dat-s.gz"))
+    for fn in ("blk.txt", "con_num.txt", "At.txt", "b.txt", "C.txt"):
+        gz_copy(os.path.join(EX, "plato/TXT/biggs", fn), os.path.join(out_prob, "biggs", fn + ".gz"))
+
     # --- transcribed logs
     logs = {}
     for key, (rel, prob, mode) in LOGS.items():
