@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--mode", choices=["admm", "sgs"], default="admm")
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=12)       # ~12 s of host work on 30 threads
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

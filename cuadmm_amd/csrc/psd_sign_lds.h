@@ -194,10 +194,12 @@ __device__ __forceinline__ void sw32_store(double* __restrict__ M, int r16, int 
   }
 }
 
-// C(upper sub-tiles) = alpha * A * B + beta * E with A given by its fragments fa (symmetric A) and B by its four
-// sub-tiles in accumulator layout yb[b][c] (row block b, column block c)
-__device__ __forceinline__ void sw32_gemm_regB(const double (&fa)[8][2], const sl_v4f64 (&yb)[2][2], const sl_v4f64 (&e)[3],
-                                               double alpha, double beta, sl_v4f64 (&out)[3]) {
+// C(upper sub-tiles) = alpha * A * B + beta * E with A given by its fragments fa (symmetric A), B by its four sub-tiles
+// in accumulator layout yb[b][c] (row block b, column block c) and E read from LDS in accumulator layout at the very
+// end (short live range: the kernel sits at the 128-VGPR boundary)
+__device__ __forceinline__ void sw32_gemm_regB(const double (&fa)[8][2], const sl_v4f64 (&yb)[2][2], const double* __restrict__ E,
+                                               int r16, int kk, double alpha, double beta, sl_v4f64 (&out)[3]) {
+  constexpr int LD = SignWave32::LD;
   sl_v4f64 acc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
@@ -211,9 +213,11 @@ __device__ __forceinline__ void sw32_gemm_regB(const double (&fa)[8][2], const s
       acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][1], yb[b][1][s], acc[2], 0, 0, 0);
     }
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[t][r] = alpha * acc[t][r] + beta * e[t][r];
+  for (int r = 0; r < 4; ++r) {
+    out[0][r] = alpha * acc[0][r] + beta * E[(kk + 4 * r) * LD + r16];
+    out[1][r] = alpha * acc[1][r] + beta * E[(kk + 4 * r) * LD + 16 + r16];
+    out[2][r] = alpha * acc[2][r] + beta * E[(16 + kk + 4 * r) * LD + 16 + r16];
+  }
 }
 
 __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
@@ -235,8 +239,6 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);
   for (int e = lane; e < 32 * LD; e += 64) S[e] *= scale;
   wave_fence();
-  sl_v4f64 sd[3];
-  sw32_dlayout(S, r16, kk, sd);
   double f[8][2];
   for (int it = 0; it < lift_steps + polish_steps; ++it) {
     const double mu = it < lift_steps ? lift_mu : 1.0;
@@ -254,13 +256,13 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
       y[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][0], y[1][0], 0, 0, 0);
       y[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][1], y[1][1], 0, 0, 0);
     }
+    // T = 1.5 mu S - 0.5 mu^3 S Y; the S term is re-read from LDS in accumulator layout (12 reads) rather than kept
+    // in 24 VGPRs across the loop: that is what keeps the kernel at 128 VGPRs (4 wavefronts per SIMD) without spills
     sl_v4f64 t[3];
-    sw32_gemm_regB(f, y, sd, -0.5 * mu * mu * mu, 1.5 * mu, t);   // T = 1.5 mu S - 0.5 mu^3 S Y
-    wave_fence();                                                 // all fragment reads of S are done
+    sw32_gemm_regB(f, y, S, r16, kk, -0.5 * mu * mu * mu, 1.5 * mu, t);
+    wave_fence();                                                 // all reads of S are done
     sw32_store(S, r16, kk, t);
     wave_fence();
-#pragma unroll
-    for (int q = 0; q < 3; ++q) sd[q] = t[q];
   }
   // P = 0.5 (X0 + S X0): A fragments of S from LDS, then LDS is reused for X0, whose sub-tiles are read in accumulator
   // layout (register B operand).  The lower sub-tile of X0 is read directly too (X0 is exactly symmetric in LDS).
@@ -272,7 +274,7 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   xb[0][0] = x0[0]; xb[0][1] = x0[1]; xb[1][1] = x0[2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) xb[1][0][r] = S[(16 + kk + 4 * r) * LD + r16];
-  sw32_gemm_regB(f, xb, x0, 0.5, 0.5, p);
+  sw32_gemm_regB(f, xb, S, r16, kk, 0.5, 0.5, p);
   wave_fence();
   sw32_store(S, r16, kk, p);
   wave_fence();
