@@ -233,3 +233,23 @@ def test_project_sign_path_flags_non_finite_input():
     x[17] = np.nan
     with pytest.raises(cuadmm_amd.CuadmmError):
         psd_project_gpu(x, blk)
+
+
+@pytest.mark.parametrize("n,count", [(45, 3000), (64, 1500), (33, 2000), (28, 4000)])
+def test_project_mid_sizes_in_bulk_properties(n, count):
+    """BASELINE config 4 sizes in bulk (several workgroups / wavefronts per CU at once): Moreau decomposition,
+    idempotence, complementarity, and a spot check against the oracle."""
+    blk = np.full(count, n, dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = _rand_svec(blk, 31 + n)
+    p1 = psd_project_gpu(x, blk)
+    pm = psd_project_gpu(-x, blk)
+    p2 = psd_project_gpu(p1, blk)
+    scale = np.max(np.abs(x)) * n
+    assert np.max(np.abs(p2 - p1)) <= 1e-12 * scale
+    assert np.max(np.abs((p1 - pm) - x)) <= 1e-12 * scale
+    assert abs(np.dot(p1, pm)) <= 1e-10 * np.dot(x, x)
+    for k in np.random.default_rng(1).choice(count, 24, replace=False):
+        sl = slice(int(bidx.off[k]), int(bidx.off[k + 1]))
+        ref = orc.psd_project_svec(orc.BlockIndex([n]), x[sl])
+        assert np.max(np.abs(p1[sl] - ref)) <= 1e-12 * scale
