@@ -466,6 +466,7 @@ void cuadmm_aat_tail_schur_release(cuadmm_aat* f) {
 }
 
 int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x) {
+  if (f && f->m == 0) return CUADMM_OK;   // a rank without constraints (owned-constraints sharding)
   if (!f || !rhs || !x) { set_error("aat_solve: null argument"); return CUADMM_ERR_INVALID; }
   if (f->tail_k > 0) { set_error("aat_solve: the factor is split (its last %d columns live on the GPU); use the leading sweeps", f->tail_k); return CUADMM_ERR_INVALID; }
   const int m = f->m;

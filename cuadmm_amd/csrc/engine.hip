@@ -141,6 +141,18 @@ struct cuadmm_solver {
   std::vector<int> blk_local;
 
   // host state (constraint space, permuted order unless noted)
+  // "Owned constraints" mode of a sharded run: when every constraint touches the blocks of ONE rank only (block-diagonal
+  // problems: the synthetic weak-scaling configurations), each rank keeps just its own constraints -- its own small
+  // factor, its own PCIe traffic -- and the ranks exchange four scalars per iteration instead of all-reducing A*X and
+  // replicating the whole solve.  world / rank are then 1 / 0 for the sharding logic, comm_world / comm_rank hold the
+  // communicator, m_full / cons_local / sv_off / blk_off map back to the caller's numbering.
+  bool local_mode = false;
+  int comm_world = 1, comm_rank = 0, m_full = 0, blk_off = 0;
+  long long sv_off = 0;
+  std::vector<int> cons_local;
+  double ov_nb = 0, ov_nc = 0, ov_nb2 = 0;
+  DevBuf<double> scal_d, yfull_d;
+  std::vector<double> y_full;
   cuadmm_aat* fac = nullptr;
   TailSolve tail;              // dense trailing triangle of L on the GPU (tail.k == 0: whole solve on the host)
   std::vector<int> perm, perm_inv;
@@ -210,6 +222,10 @@ struct cuadmm_solver {
 
   int do_allreduce(double* buf, size_t count) {
     if (world <= 1 && !force_comm) return CUADMM_OK;
+    return comm_allreduce(buf, count);
+  }
+  // all-reduce over the communicator (the sharding world, or comm_world in owned-constraints mode)
+  int comm_allreduce(double* buf, size_t count) {
     prof_begin(K_COMM);
     int rc = 0;
     if (allreduce) {
@@ -217,11 +233,22 @@ struct cuadmm_solver {
     } else if (rccl_comm) {
       rc = g_rccl.AllReduce(buf, buf, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, rccl_comm, st);
     } else {
-      set_error("world=%d but no all-reduce hook installed (cuadmm_set_allreduce / cuadmm_use_rccl)", world);
+      set_error("world=%d but no all-reduce hook installed (cuadmm_set_allreduce / cuadmm_use_rccl)", local_mode ? comm_world : world);
       return CUADMM_ERR_COMM;
     }
     prof_end(K_COMM, (double)count * 8);
     if (rc) { set_error("all-reduce hook failed with code %d", rc); return CUADMM_ERR_COMM; }
+    return CUADMM_OK;
+  }
+
+  // owned-constraints mode: v[0..n) <- sum over ranks (host values through a small device buffer; blocks)
+  int allreduce_scalars(double* v, int n) {
+    if (!local_mode || comm_world <= 1) return CUADMM_OK;
+    CUADMM_HIP_TRY(hipMemcpyAsync(scal_d.p, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    int rc = comm_allreduce(scal_d.p, (size_t)n);
+    if (rc) return rc;
+    CUADMM_HIP_TRY(hipMemcpyAsync(v, scal_d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    CUADMM_HIP_TRY(hipStreamSynchronize(st));
     return CUADMM_OK;
   }
 
@@ -390,6 +417,72 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   for (int p = 0; p < At_nnz; ++p)
     if (At_ri[p] < 0 || At_ri[p] >= vec_len) { set_error("init: At row index %d out of range at %d", At_ri[p], p); return CUADMM_ERR_INVALID; }
 
+  if (s->world > 1 && !s->local_mode && !getenv("CUADMM_NO_LOCAL_CONSTRAINTS")) {
+    // does every constraint live inside one rank's block range?
+    std::vector<int> first;
+    partition_blocks(blk, mat_num, s->world, first);
+    std::vector<long long> svb((size_t)s->world + 1, 0);
+    {
+      long long off = 0;
+      int r = 0;
+      for (int k = 0; k <= mat_num; ++k) {
+        while (r <= s->world && first[r] == k) svb[r++] = off;
+        if (k < mat_num) off += (long long)blk[k] * (blk[k] + 1) / 2;
+      }
+    }
+    std::vector<int> owner(con_num, 0);
+    bool all_owned = true;
+    for (int j = 0; j < con_num && all_owned; ++j) {
+      if (At_cp[j] == At_cp[j + 1]) continue;                      // empty constraint: rank 0
+      const int r = (int)(std::upper_bound(svb.begin(), svb.end(), (long long)At_ri[At_cp[j]]) - svb.begin()) - 1;
+      for (int p = At_cp[j]; p < At_cp[j + 1]; ++p)
+        if (At_ri[p] < svb[r] || At_ri[p] >= svb[r + 1]) { all_owned = false; break; }
+      owner[j] = r;
+    }
+    if (all_owned) {
+      const int me = s->rank;
+      // global norms (solver.cu:169-191) from the full inputs every rank holds
+      double nb = 0, nc = 0, nb2 = 0;
+      for (int i = 0; i < b_nnz; ++i) {
+        if (b_idx[i] < 0 || b_idx[i] >= con_num) { set_error("init: b index %d out of range", b_idx[i]); return CUADMM_ERR_INVALID; }
+        nb += b_vals[i] * b_vals[i];
+        double cn = 0;
+        for (int p = At_cp[b_idx[i]]; p < At_cp[b_idx[i] + 1]; ++p) cn += At_vx[p] * At_vx[p];
+        const double v = b_vals[i] / std::max(1.0, std::sqrt(cn));
+        nb2 += v * v;
+      }
+      for (int i = 0; i < C_nnz; ++i) nc += C_vals[i] * C_vals[i];
+      std::vector<int> cons, g2l(con_num, -1);
+      for (int j = 0; j < con_num; ++j) if (owner[j] == me) { g2l[j] = (int)cons.size(); cons.push_back(j); }
+      const long long lo = svb[me], hi = svb[me + 1];
+      std::vector<int> lcp(cons.size() + 1, 0), lri, lbi, lCi;
+      std::vector<double> lvx, lbv, lCv, ly0;
+      for (size_t q = 0; q < cons.size(); ++q) {
+        for (int p = At_cp[cons[q]]; p < At_cp[cons[q] + 1]; ++p) { lri.push_back((int)(At_ri[p] - lo)); lvx.push_back(At_vx[p]); }
+        lcp[q + 1] = (int)lri.size();
+      }
+      for (int i = 0; i < b_nnz; ++i) if (g2l[b_idx[i]] >= 0) { lbi.push_back(g2l[b_idx[i]]); lbv.push_back(b_vals[i]); }
+      for (int i = 0; i < C_nnz; ++i) {
+        if (C_idx[i] < 0 || C_idx[i] >= vec_len) { set_error("init: C index %d out of range", C_idx[i]); return CUADMM_ERR_INVALID; }
+        if (C_idx[i] >= lo && C_idx[i] < hi) { lCi.push_back((int)(C_idx[i] - lo)); lCv.push_back(C_vals[i]); }
+      }
+      if (y0) { ly0.resize(cons.size()); for (size_t q = 0; q < cons.size(); ++q) ly0[q] = y0[cons[q]]; }
+      s->local_mode = true;
+      s->comm_world = s->world; s->comm_rank = s->rank;
+      s->m_full = con_num; s->cons_local = cons; s->sv_off = lo; s->blk_off = first[me];
+      s->ov_nb = nb; s->ov_nc = nc; s->ov_nb2 = nb2;
+      s->world = 1; s->rank = 0;
+      if (s->comm_rank != 0) s->verbose = 0;      // one console table per job
+      int one = 0;
+      return cuadmm_init(s, eig_stream_num_per_gpu, cpu_eig_thread_num, (int)(hi - lo), (int)cons.size(), lcp.data(),
+                         lri.empty() ? &one : lri.data(), lvx.empty() ? nullptr : lvx.data(), (int)lri.size(),
+                         lbi.empty() ? nullptr : lbi.data(), lbv.empty() ? nullptr : lbv.data(), (int)lbi.size(),
+                         lCi.empty() ? nullptr : lCi.data(), lCv.empty() ? nullptr : lCv.data(), (int)lCi.size(),
+                         blk + first[me], first[me + 1] - first[me], X0 ? X0 + lo : nullptr, y0 ? ly0.data() : nullptr,
+                         S0 ? S0 + lo : nullptr, sig);
+    }
+  }
+
   int rc = check_device(s->device);
   if (rc) return rc;
   s->t_init0 = wall_s();                                  // the reference's timer starts in init (solver.cu:41-44)
@@ -528,6 +621,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   double nb = 0, nc = 0;
   for (int i = 0; i < b_nnz; ++i) nb += b_vals[i] * b_vals[i];
   for (int i = 0; i < C_nnz; ++i) nc += C_vals[i] * C_vals[i];
+  if (s->local_mode) { nb = s->ov_nb; nc = s->ov_nc; }      // norms over ALL constraints / the whole C
   s->norm_borg = 1 + std::sqrt(nb);
   s->norm_Corg = 1 + std::sqrt(nc);
   std::vector<double> bfull(m, 0.0);
@@ -538,6 +632,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     bfull[b_idx[i]] = v;
     nb2 += v * v;
   }
+  if (s->local_mode) nb2 = s->ov_nb2;
   s->bscale = 1 + std::sqrt(nb2);
   s->Cscale = 1 + std::sqrt(nc);
   s->objscale = s->bscale * s->Cscale;
@@ -566,7 +661,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   }
   if ((rc = s->Rd1.alloc(L)) || (rc = s->Xb.alloc(L)) || (rc = s->Xproj.alloc(L)) || (rc = s->y_d.alloc(std::max(m, 1))) ||
       (rc = s->out_d.alloc(2 * (size_t)m + 2)) || (rc = s->partials.alloc(2 * (size_t)post_grid(L) + 2)) ||
-      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))))
+      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8)))
     return rc;
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
 
@@ -586,6 +681,11 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       double ro = s->normA_p[i] * s->Rp_p[i] * s->bscale;
       nr += ro * ro;
       bty += s->b_p[i] * s->y_p[i];
+    }
+    {
+      double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
+      if ((rc = s->allreduce_scalars(v, 4))) return rc;
+      nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
     }
     s->errRp = std::sqrt(nr) / s->norm_borg;
     s->errRd = std::sqrt(s->h_out.p[(size_t)m]) * s->Cscale / s->norm_Corg;
@@ -758,6 +858,11 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         part[2 * c] = a; part[2 * c + 1] = b;
       });
       for (int c = 0; c < kHostChunks; ++c) { nr += part[2 * c]; bty += part[2 * c + 1]; }
+      {
+        double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
+        if ((rc = s->allreduce_scalars(v, 4))) return rc;
+        nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
+      }
       s->errRp = std::sqrt(nr) / s->norm_borg;
       s->pobj = s->h_out.p[(size_t)m + 1] * s->objscale;
       s->errRd = std::sqrt(s->h_out.p[(size_t)m]) * s->Cscale / s->norm_Corg;
@@ -785,6 +890,17 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   if ((rc = launch_scale(s->S.p, L, s->Cscale, s->st))) return rc;
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
   for (int i = 0; i < m; ++i) s->y_p[i] = s->y_p[i] / s->normA_p[i] * s->Cscale;
+  if (s->local_mode) {   // y is replicated for the caller: gather the owned pieces once per solve
+    s->y_full.assign((size_t)s->m_full, 0.0);
+    for (int i = 0; i < m; ++i) s->y_full[s->cons_local[s->perm[i]]] = s->y_p[i];
+    if (s->comm_world > 1 && s->m_full > 0) {
+      if (!s->yfull_d.p && (rc = s->yfull_d.alloc((size_t)s->m_full))) return rc;
+      CUADMM_HIP_TRY(hipMemcpyAsync(s->yfull_d.p, s->y_full.data(), sizeof(double) * (size_t)s->m_full, hipMemcpyHostToDevice, s->st));
+      if ((rc = s->comm_allreduce(s->yfull_d.p, (size_t)s->m_full))) return rc;
+      CUADMM_HIP_TRY(hipMemcpyAsync(s->y_full.data(), s->yfull_d.p, sizeof(double) * (size_t)s->m_full, hipMemcpyDeviceToHost, s->st));
+      CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+    }
+  }
   s->eig_fail_total = s->plan.fail_count(s->st);
   if (s->eig_fail_total > 0) {
     set_error("solve: %d block projections hit the QL sweep cap", s->eig_fail_total);
@@ -846,6 +962,11 @@ int cuadmm_get_X(cuadmm_solver* s, double* out) { return get_vec(s, s->X, out); 
 int cuadmm_get_S(cuadmm_solver* s, double* out) { return get_vec(s, s->S, out); }
 int cuadmm_get_y(cuadmm_solver* s, double* out) {
   if (!s || !s->initialised || !out) { set_error("get_y: bad arguments"); return CUADMM_ERR_INVALID; }
+  if (s->local_mode) {
+    if ((int)s->y_full.size() == s->m_full) std::copy(s->y_full.begin(), s->y_full.end(), out);   // gathered at the end of solve
+    else { std::fill(out, out + s->m_full, 0.0); for (int i = 0; i < s->m; ++i) out[s->cons_local[s->perm[i]]] = s->y_p[i]; }
+    return CUADMM_OK;
+  }
   for (int i = 0; i < s->m; ++i) out[s->perm[i]] = s->y_p[i];          // y[perm[i]] = y_perm[i], solver.cu:500
   return CUADMM_OK;
 }
@@ -854,9 +975,9 @@ int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const dou
   if (!s || !s->initialised) { set_error("set_XyS: not initialised"); return CUADMM_ERR_INVALID; }
   int rc = check_device(s->device);
   if (rc) return rc;
-  if (X && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->X.p, X + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
-  if (S && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->S.p, S + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
-  if (y) for (int i = 0; i < s->m; ++i) s->y_p[i] = y[s->perm[i]];
+  if (X && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->X.p, X + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
+  if (S && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->S.p, S + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
+  if (y) for (int i = 0; i < s->m; ++i) s->y_p[i] = s->local_mode ? y[s->cons_local[s->perm[i]]] : y[s->perm[i]];
   if (sig > 0) s->sig = sig;
   return CUADMM_OK;
 }
@@ -871,10 +992,10 @@ int cuadmm_get_device_ptrs(cuadmm_solver* s, double** X, double** y, double** S)
 
 int cuadmm_get_shard(const cuadmm_solver* s, int64_t* b, int64_t* e, int* kb, int* ke) {
   if (!s || !s->initialised) { set_error("get_shard: not initialised"); return CUADMM_ERR_INVALID; }
-  if (b) *b = s->sv_begin;
-  if (e) *e = s->sv_end;
-  if (kb) *kb = s->blk_begin;
-  if (ke) *ke = s->blk_end;
+  if (b) *b = s->sv_off + s->sv_begin;
+  if (e) *e = s->sv_off + s->sv_end;
+  if (kb) *kb = s->blk_off + s->blk_begin;
+  if (ke) *ke = s->blk_off + s->blk_end;
   return CUADMM_OK;
 }
 

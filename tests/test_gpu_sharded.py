@@ -42,8 +42,17 @@ class HostAllReduce:
         return fn
 
 
+@pytest.mark.parametrize("mode", ["owned_constraints", "replicated_solve"])
 @pytest.mark.parametrize("sw,iters", [(0, 25), (10 ** 9, 12), (8, 20)])
-def test_two_shards_match_single_engine(sw, iters):
+def test_two_shards_match_single_engine(sw, iters, mode, monkeypatch):
+    """Every constraint of the synthetic problem touches one block, hence one rank: by default each rank then keeps only
+    its own constraints and the ranks exchange four scalars per iteration ("owned constraints"); with
+    CUADMM_NO_LOCAL_CONSTRAINTS=1 the general path runs (A*X all-reduced, solve replicated).  Both must agree with the
+    single engine."""
+    if mode == "replicated_solve":
+        monkeypatch.setenv("CUADMM_NO_LOCAL_CONSTRAINTS", "1")
+    else:
+        monkeypatch.delenv("CUADMM_NO_LOCAL_CONSTRAINTS", raising=False)
     blk = [32] * 40 + [7] * 30 + [15] * 21 + [40, 3, 3, 28]
     rng = np.random.default_rng(2)
     blk = list(np.array(blk)[rng.permutation(len(blk))])
@@ -81,6 +90,40 @@ def test_two_shards_match_single_engine(sw, iters):
     assert np.max(np.abs(X - ref.X)) <= 1e-9 * (1 + np.max(np.abs(ref.X)))
     assert np.max(np.abs(S - ref.S)) <= 1e-9 * (1 + np.max(np.abs(ref.S)))
     assert np.max(np.abs(solvers[0].y - ref.y)) <= 1e-8 * (1 + np.max(np.abs(ref.y)))
+
+
+@pytest.mark.parametrize("name", ["truss5", "hinf12"])
+def test_coupled_constraints_fall_back_to_the_replicated_solve(name, problem_dirs):
+    """truss5 (34 blocks, every constraint couples several of them): no constraint is owned by one rank, the general
+    path (A*X all-reduced, solve replicated) is taken.  hinf12 (blocks 6, 6, 12): the contiguous split balanced by n^3
+    leaves rank 1 without blocks -- and, all constraints being owned by rank 0, without constraints."""
+    from oracle import cuadmm_oracle as orc
+    q = orc.load_problem_txt(problem_dirs[name])
+    p = cuadmm_amd.Problem(q.vec_len, q.con_num, q.blk, q.At_col_ptrs, q.At_row_ids, q.At_vals, q.b_idx, q.b_vals, q.C_idx, q.C_vals)
+    ref = cuadmm_amd.SDPSolver(verbose=False)
+    ref.init_problem(p)
+    ref.solve(30, 0.0, 0, 50, 100, 11000, 1.05)
+    world = 2
+    ar = HostAllReduce(world)
+    solvers = [cuadmm_amd.SDPSolver(verbose=False, rank=r, world=world, profile=1) for r in range(world)]
+    errs = []
+
+    def run(r):
+        try:
+            solvers[r].set_allreduce(ar.hook(r))
+            solvers[r].init_problem(p)
+            solvers[r].solve(30, 0.0, 0, 50, 100, 11000, 1.05)
+        except Exception as e:          # pragma: no cover
+            errs.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+        a, b0 = ref.info_arr(nm), solvers[0].info_arr(nm)
+        assert np.max(np.abs(a - b0) / (1e-12 + np.abs(a))) <= 1e-8, nm
+    assert np.max(np.abs(solvers[1].y - ref.y)) <= 1e-8 * (1 + np.max(np.abs(ref.y)))
 
 
 def test_world_without_hook_is_an_error():
