@@ -208,7 +208,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d PSD blocks of %dx%d per GPU, m=5/blk, nnz=8/constraint, dense C, %s"
                                    % (args.blocks_per_gpu, BLOCK_N, BLOCK_N, "ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM"),
                        "blocks_total": args.blocks_per_gpu * world, "vec_len": int(prob.vec_len), "con_num": int(prob.con_num),
-                       "sharding": "blocks by index" if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
+                       "sharding": ("blocks by index; every C2 constraint touches one block, so each rank keeps its own constraints and "
+                                    "the ranks all-reduce 4 scalars per iteration (DESIGN.md section 5)") if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
             # Dominant kernel: psd_sign_wave32_kernel (one wavefront per 32x32 block, matrix-sign iteration on
             # v_mfma_f64_16x16x4_f64).  It is MFMA bound.  `achieved` uses the ALGORITHMIC flops of SURVEY 8d
             # (10.67 n^3 per block, what an eigendecomposition-based projection needs); the flops the kernel really
