@@ -196,7 +196,7 @@ def main():
         alg_bytes = 16.0 * L_local                         # read Xb + write Xproj, 8 B each per svec element
         achieved = alg_bytes / (psd_ms * 1e-3) / 1e9 if psd_ms > 0 else 0.0
         nominal_flops = (32.0 / 3.0) * args.blocks_per_gpu * BLOCK_N ** 3
-        issued_flops = args.blocks_per_gpu * (44 * 56 + 24) * 2048.0     # psd_sign_lds.h: SignWave32, SignPsd schedule
+        issued_flops = args.blocks_per_gpu * (44 * 48 + 24) * 2048.0     # psd_sign_lds.h: SignWave32, SignPsd schedule
         out = {
             "metric": "ADMM iters/sec, 10k x 32-blk synthetic per GPU (+ PSD-proj TFLOP/s in roofline)",
             "value": world * args.steps / dt,
@@ -213,7 +213,7 @@ def main():
             # Dominant kernel: psd_sign_wave32_kernel (one wavefront per 32x32 block, matrix-sign iteration on
             # v_mfma_f64_16x16x4_f64).  It is MFMA bound.  `achieved` uses the ALGORITHMIC flops of SURVEY 8d
             # (10.67 n^3 per block, what an eigendecomposition-based projection needs); the flops the kernel really
-            # issues on the matrix cores (44 steps x 56 MFMA + 24, 2048 flop each) are reported beside it.
+            # issues on the matrix cores (44 steps x 48 MFMA + 24, 2048 flop each) are reported beside it.
             "roofline": {"kernel": "psd_sign_wave32_kernel (fused svec -> matrix-sign projection -> svec)", "bound": "mfma",
                          "achieved": nominal_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -138,10 +138,12 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
 //     (S symmetric), so the second product issues no LDS reads;
 //   * T = 1.5 mu S - 0.5 mu^3 S Y is formed on the three upper sub-tiles from the register copy of S in accumulator
 //     layout and written back to LDS mirrored (exact symmetry).
-// Per step: 16 LDS reads, <= 24 LDS writes, 56 MFMAs (32 for Y incl. the redundant lower sub-tile, 24 for S Y).
+// Per step: 16 + 12 + 4 LDS reads, <= 24 + 4 LDS writes, 48 MFMAs (24 for the upper sub-tiles of Y, 24 for S Y; the
+// lower sub-tile of Y is transposed through LDS).
 // ---------------------------------------------------------------------------------------------------------------
 struct SignWave32 {
-  static constexpr int NP = 32, LD = 33, PER_WAVE = NP * LD;
+  static constexpr int NP = 32, LD = 33, SCR_LD = 17;
+  static constexpr int PER_WAVE = NP * LD + 16 * SCR_LD;   // S + a 16 x 16 transposition tile
 };
 
 __device__ __forceinline__ void sw32_unpack(const double* __restrict__ src, int n, double* __restrict__ M, int lane) {
@@ -225,6 +227,7 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   constexpr int LD = SignWave32::LD;
   const int lane = lane_id();
   const int r16 = lane & 15, kk = lane >> 4;
+  double* scr = S + 32 * LD;
   sw32_unpack(in, n, S, lane);
   // ||X||_1 (max column sum; lanes 0..31 own a column each)
   double cs = 0.0;
@@ -243,19 +246,23 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   for (int it = 0; it < lift_steps + polish_steps; ++it) {
     const double mu = it < lift_steps ? lift_mu : 1.0;
     sw32_frags(S, r16, kk, f);
-    // Y = S S, all four sub-tiles (the lower one is needed as a register operand)
+    // Y = S S: the three upper sub-tiles on the matrix cores (24 MFMAs); the lower one, needed as a register operand
+    // of S Y, is the transpose of Y(0,1): 4 LDS writes + 4 reads through a 16 x 17 tile instead of 8 more MFMAs (the
+    // MFMA pipe is what bounds this kernel)
     sl_v4f64 y[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) y[a][c] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
+    y[0][0] = y[0][1] = y[1][1] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       y[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][0], f[s][0], y[0][0], 0, 0, 0);
       y[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][0], f[s][1], y[0][1], 0, 0, 0);
-      y[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][0], y[1][0], 0, 0, 0);
       y[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][1], y[1][1], 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[r16 * SignWave32::SCR_LD + kk + 4 * r] = y[0][1][r];   // element (kk+4r, r16) -> scr[r16][kk+4r]
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[1][0][r] = scr[(kk + 4 * r) * SignWave32::SCR_LD + r16];
+    wave_fence();
     // T = 1.5 mu S - 0.5 mu^3 S Y; the S term is re-read from LDS in accumulator layout (12 reads) rather than kept
     // in 24 VGPRs across the loop: that is what keeps the kernel at 128 VGPRs (4 wavefronts per SIMD) without spills
     sl_v4f64 t[3];
