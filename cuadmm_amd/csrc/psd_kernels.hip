@@ -218,7 +218,7 @@ __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(P
 }
 
 // n <= 32 (projection only): one wavefront per block, 4 per workgroup (psd_sign_lds.h, SignWave32)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void psd_sign_wave32_kernel(PsdArgs a, int first, int count, int lift_steps, int polish_steps, double lift_mu) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void psd_sign_wave32_kernel(PsdArgs a, int first, int count, int lift_steps, int polish_steps, double lift_mu) {
   __shared__ double sw_smem[4 * SignWave32::PER_WAVE];
   const int w = (int)threadIdx.x >> 6;
   const int m = (int)blockIdx.x * 4 + w;

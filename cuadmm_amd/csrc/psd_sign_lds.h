@@ -23,7 +23,6 @@ typedef double sl_v4f64 __attribute__((ext_vector_type(4)));
 template <int NP> struct SignLdsCfg;
 // one wavefront per upper sub-tile (NU wavefronts per workgroup): with a single wavefront per SIMD the LDS latency of
 // every k-step is exposed (measured: 25 k cycles per Newton-Schulz step instead of 6 k)
-template <> struct SignLdsCfg<32> { static constexpr int LD = 33, NT = 2, NU = 3, THREADS = 64 * 3; };
 template <> struct SignLdsCfg<48> { static constexpr int LD = 49, NT = 3, NU = 6, THREADS = 64 * 6; };
 template <> struct SignLdsCfg<64> { static constexpr int LD = 65, NT = 4, NU = 10, THREADS = 64 * 10; };
 
