@@ -157,7 +157,8 @@ struct cuadmm_solver {
   TailSolve tail;              // dense trailing triangle of L on the GPU (tail.k == 0: whole solve on the host)
   std::vector<int> perm, perm_inv;
   std::vector<double> normA;      // original order
-  std::vector<double> normA_p, b_p, y_p, Rp_p, ASmC_p, rhs_p, y_best_p;
+  std::vector<double> normA_p, b_p, y_p, Rp_p, y_best_p;
+  bool y_registered = false;   // y_p.data() page-locked with hipHostRegister (its storage is never reallocated)
   double norm_borg = 1, norm_Corg = 1, bscale = 1, Cscale = 1, objscale = 1;
   double sig = 1, errRp = 0, errRd = 0, maxfeas = 0, pobj = 0, dobj = 0, relgap = 0, feasratio = 0;
   int prim_win = 0, dual_win = 0;
@@ -185,6 +186,7 @@ struct cuadmm_solver {
   double prof_count[K_NUM] = {0}, prof_ms[K_NUM] = {0}, prof_bytes[K_NUM] = {0};
 
   ~cuadmm_solver() {
+    if (y_registered) { hipError_t e = hipHostUnregister(y_p.data()); (void)e; }
     if (fac) cuadmm_aat_free(fac);
     for (int k = 0; k < K_NUM; ++k)
       for (int j = 0; j < 2; ++j) {
@@ -255,14 +257,16 @@ struct cuadmm_solver {
   int host_solve() {  // y_p = (P(AA^T+eps I)P^T)^-1 rhs_p
     double t0 = wall_s();
     const double isig = 1 / sig;
+    // the right-hand side is formed in y_p from the pinned result buffer (A(S-C) lives at h_out[m+2..) since the last
+    // fetch) and solved in place: no copies of m-vectors on the critical path between two GPU phases
+    const double* asmc = h_out.p + (size_t)m + 2;
     host_ranges(m, [&](int, int lo, int hi) {
-      for (int i = lo; i < hi; ++i) rhs_p[i] = -ASmC_p[i] + isig * Rp_p[i];   // solver.cu:478-482
+      for (int i = lo; i < hi; ++i) y_p[i] = -asmc[i] + isig * Rp_p[i];   // solver.cu:478-482
     });
     int rc;
     if (tail.k == 0) {
-      rc = cuadmm_aat_solve_permuted(fac, rhs_p.data(), y_p.data());     // solver.cu:494
+      rc = cuadmm_aat_solve_permuted(fac, y_p.data(), y_p.data());     // solver.cu:494
     } else {   // sparse leading columns here, dense trailing triangle on the GPU
-      y_p = rhs_p;
       rc = cuadmm_aat_solve_leading_forward(fac, tail.k, y_p.data());
       double t1 = wall_s();
       if (!rc) rc = tail.solve(y_p.data() + (m - tail.k), st);
@@ -277,8 +281,11 @@ struct cuadmm_solver {
 
   int upload_y() {
     prof_begin(K_COPY);
-    std::memcpy(h_y.p, y_p.data(), sizeof(double) * (size_t)m);
-    CUADMM_HIP_TRY(hipMemcpyAsync(y_d.p, h_y.p, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, st));
+    // y_p is registered (page-locked) at init: the copy engine reads it directly; it is not written again before the
+    // next fetch_out has synchronised the stream
+    const double* src = y_p.data();
+    if (!y_registered) { std::memcpy(h_y.p, y_p.data(), sizeof(double) * (size_t)m); src = h_y.p; }
+    CUADMM_HIP_TRY(hipMemcpyAsync(y_d.p, src, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, st));
     prof_end(K_COPY, (double)m * 8);
     return CUADMM_OK;
   }
@@ -638,7 +645,9 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->objscale = s->bscale * s->Cscale;
   const double ibs = 1 / s->bscale, ics = 1 / s->Cscale;   // *_div_scalar multiply by 1/s (dense_scalar.cu:77-81)
   s->normA_p.resize(m); s->b_p.resize(m); s->y_p.assign(m, 0.0); s->Rp_p.assign(m, 0.0);
-  s->ASmC_p.assign(m, 0.0); s->rhs_p.assign(m, 0.0); s->y_best_p.assign(m, 0.0);
+  s->y_best_p.assign(m, 0.0);
+  if (m > 0 && hipHostRegister(s->y_p.data(), sizeof(double) * (size_t)m, hipHostRegisterDefault) == hipSuccess) s->y_registered = true;
+  else { hipError_t e = hipGetLastError(); (void)e; }   // not fatal: upload_y then stages through the pinned buffer
   for (int pidx = 0; pidx < m; ++pidx) {
     const int j = s->perm[pidx];
     s->normA_p[pidx] = s->normA[j];
@@ -677,7 +686,6 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     double nr = 0, bty = 0;
     for (int i = 0; i < m; ++i) {
       s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i];
-      s->ASmC_p[i] = s->h_out.p[m + 2 + i];
       double ro = s->normA_p[i] * s->Rp_p[i] * s->bscale;
       nr += ro * ro;
       bty += s->b_p[i] * s->y_p[i];
@@ -728,7 +736,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     if ((rc = launch_scale(s->S.p, L, 1 / s->Cscale, s->st))) return rc;
     if ((rc = s->launch_spmv(true, true))) return rc;
     if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
-    for (int i = 0; i < m; ++i) { s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i]; s->ASmC_p[i] = s->h_out.p[m + 2 + i]; }
+    for (int i = 0; i < m; ++i) s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i];
   }
 
   if (verbose) {
@@ -767,7 +775,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         CUADMM_HIP_TRY(hipMemcpyAsync(s->X.p, s->X_best.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         CUADMM_HIP_TRY(hipMemcpyAsync(s->S.p, s->S_best.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
-        s->y_p = s->y_best_p;
+        std::copy(s->y_best_p.begin(), s->y_best_p.end(), s->y_p.begin());   // in place: y_p's storage is page-locked
         if (verbose) printf("best max KKT residual after switch  = %2.1e \n", s->best_KKT);
       }
       break;
@@ -814,7 +822,6 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if ((rc = s->launch_post_mode(1, tau))) return rc;
       if ((rc = s->launch_spmv(false, true))) return rc;
       if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
-      host_ranges(m, [&](int, int lo, int hi) { for (int i = lo; i < hi; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i]; });
       if ((rc = s->host_solve())) return rc;
       if ((rc = s->upload_y())) return rc;
       if ((rc = s->launch_aty(false))) return rc;
@@ -837,7 +844,6 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       }
       if ((rc = s->launch_spmv(true, true))) return rc;
       if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
-      host_ranges(m, [&](int, int lo, int hi) { for (int i = lo; i < hi; ++i) s->ASmC_p[i] = s->h_out.p[m + 2 + i]; });
     }
 
     // ---- Step 5 (solver.cu:764-799)
