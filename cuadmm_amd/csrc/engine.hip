@@ -173,6 +173,7 @@ struct cuadmm_solver {
 
   // device
   DevBuf<int> At_rp, At_ci, A_rp, A_ci;
+  AtyLongRows At_long;         // svec rows of At with more than 128 entries
   SpmvLongRows A_long;         // rows of A much longer than the average (trace / all-ones constraints)
   DevBuf<double> At_v, A_v;
   DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
@@ -302,7 +303,7 @@ struct cuadmm_solver {
 
   int launch_aty(bool write_xb) {
     prof_begin(K_ATY);
-    int rc = launch_aty_xb(write_xb, L, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st);
+    int rc = launch_aty_xb(write_xb, L, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st, &At_long);
     prof_end(K_ATY, (write_xb ? 32.0 : 16.0) * (double)L + 4.0 * (double)L);
     return rc;
   }
@@ -599,6 +600,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     lci.resize(cnt); lv.resize(cnt);
     for (long long i = 0; i <= L; ++i) lrp[i] = rp[s->sv_begin + i] - base;
     for (int q = 0; q < cnt; ++q) { lci[q] = s->perm_inv[rci[base + q]]; lv[q] = rv[base + q]; }
+    if ((rc = s->At_long.build(L, lrp.data()))) return rc;
     if ((rc = s->At_rp.from(lrp)) || (rc = s->At_ci.from(lci)) || (rc = s->At_v.from(lv))) return rc;
     // A rows in permuted order, local columns
     std::vector<int> arp((size_t)m + 1, 0), aci;

@@ -4,9 +4,20 @@
 
 namespace cuadmm {
 
+// svec rows of At with more than `cap` entries (slots shared by thousands of constraints): one workgroup each
+struct AtyLongRows {
+  int cap = 128;
+  int nlong = 0;
+  int* rows = nullptr;   // device
+  int build(long long L, const int* rp_host);
+  void release();
+  ~AtyLongRows() { release(); }
+};
+
 // Rd1 = At*y - C ; optionally Xb = X + sig*Rd1.   At in CSR over the L svec rows.
 int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, const double* av, const double* y,
-                  const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st);
+                  const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st,
+                  const AtyLongRows* long_rows = nullptr);
 
 // mode 0: S, Rd, X update, sums | mode 1: S only | mode 2: Rd, X update, sums.
 // sums_out[0] = sum Rd^2, sums_out[1] = sum C.*X (device pointer); partials: 2*post_grid(L) doubles.

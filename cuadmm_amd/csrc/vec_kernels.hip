@@ -56,17 +56,45 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
 // ------------------------------------------------------------------------------------------
 // Rd1 = At*y - C ; Xb = X + sig*Rd1          (one thread per svec row; rows are mostly 0..few nnz)
 // ------------------------------------------------------------------------------------------
+// Rows with more than `skip_above` entries (> 0) are left to aty_xb_long_kernel: a moment relaxation has svec slots --
+// the (1,1) entry of the moment matrix -- that appear in thousands of constraints (PushT_N=10: one row with 2720 of
+// the 46 388 nonzeros made this kernel take 0.39 ms of a 0.89 ms iteration).
 template <bool WRITE_XB>
 __global__ __launch_bounds__(kVecThreads) void aty_xb_kernel(long long L, const int* __restrict__ rp,
                                                              const int* __restrict__ ci, const double* __restrict__ av,
                                                              const double* __restrict__ y, const double* __restrict__ C,
                                                              const double* __restrict__ X, double sig,
-                                                             double* __restrict__ Rd1, double* __restrict__ Xb) {
+                                                             double* __restrict__ Rd1, double* __restrict__ Xb, int skip_above) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
     const int p0 = rp[i], p1 = rp[i + 1];
+    if (skip_above > 0 && p1 - p0 > skip_above) continue;
     double t = 0.0;
     for (int p = p0; p < p1; ++p) t += av[p] * y[ci[p]];
     const double r = t - C[i];
+    Rd1[i] = r;
+    if (WRITE_XB) Xb[i] = X[i] + r * sig;
+  }
+}
+
+// one workgroup per long row (two-stage sum in a fixed order: reproducible)
+template <bool WRITE_XB>
+__global__ __launch_bounds__(kVecThreads) void aty_xb_long_kernel(const int* __restrict__ long_rows, const int* __restrict__ rp,
+                                                                  const int* __restrict__ ci, const double* __restrict__ av,
+                                                                  const double* __restrict__ y, const double* __restrict__ C,
+                                                                  const double* __restrict__ X, double sig,
+                                                                  double* __restrict__ Rd1, double* __restrict__ Xb) {
+  __shared__ double red[kVecThreads];
+  const int i = long_rows[blockIdx.x];
+  double t = 0.0;
+  for (int p = rp[i] + (int)threadIdx.x; p < rp[i + 1]; p += kVecThreads) t += av[p] * y[ci[p]];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = kVecThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double r = red[0] - C[i];
     Rd1[i] = r;
     if (WRITE_XB) Xb[i] = X[i] + r * sig;
   }
@@ -195,14 +223,38 @@ __global__ void spmv_finish_kernel(int nlong, const int* __restrict__ long_row, 
 }
 
 int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, const double* av, const double* y,
-                  const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st) {
+                  const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st, const AtyLongRows* lr) {
   const int grid = grid_for(L, kVecThreads, 256 * 16);
+  const int skip = (lr && lr->nlong > 0) ? lr->cap : 0;
   if (write_xb)
-    hipLaunchKernelGGL(aty_xb_kernel<true>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb);
+    hipLaunchKernelGGL(aty_xb_kernel<true>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb, skip);
   else
-    hipLaunchKernelGGL(aty_xb_kernel<false>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb);
+    hipLaunchKernelGGL(aty_xb_kernel<false>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb, skip);
+  if (skip > 0) {
+    if (write_xb)
+      hipLaunchKernelGGL(aty_xb_long_kernel<true>, dim3(lr->nlong), dim3(kVecThreads), 0, st, lr->rows, rp, ci, av, y, C, X, sig, Rd1, Xb);
+    else
+      hipLaunchKernelGGL(aty_xb_long_kernel<false>, dim3(lr->nlong), dim3(kVecThreads), 0, st, lr->rows, rp, ci, av, y, C, X, sig, Rd1, Xb);
+  }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
+}
+
+int AtyLongRows::build(long long L, const int* rp_host) {
+  release();
+  std::vector<int> lr;
+  for (long long i = 0; i < L; ++i)
+    if (rp_host[i + 1] - rp_host[i] > cap) lr.push_back((int)i);
+  nlong = (int)lr.size();
+  if (nlong == 0) return CUADMM_OK;
+  CUADMM_HIP_TRY(hipMalloc(&rows, sizeof(int) * lr.size()));
+  CUADMM_HIP_TRY(hipMemcpy(rows, lr.data(), sizeof(int) * lr.size(), hipMemcpyHostToDevice));
+  return CUADMM_OK;
+}
+void AtyLongRows::release() {
+  if (rows) { hipError_t e = hipFree(rows); (void)e; }
+  rows = nullptr;
+  nlong = 0;
 }
 
 int post_grid(long long L) { return grid_for(L, kVecThreads * 4, 256 * 8); }
