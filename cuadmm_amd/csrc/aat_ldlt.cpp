@@ -486,10 +486,9 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x)
           if (xj != 0.0)
             for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
         }
-        for (int j : cols) x[j] /= D[j];
-        for (size_t q = cols.size(); q-- > 0;) {
+        for (size_t q = cols.size(); q-- > 0;) {   // D^-1 folded into the backward sweep (same arithmetic per entry)
           const int j = cols[q];
-          double s = x[j];
+          double s = x[j] / D[j];
           for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
           x[j] = s;
         }
@@ -502,9 +501,8 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x)
     if (xj != 0.0)
       for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
   }
-  for (int j = 0; j < m; ++j) x[j] /= D[j];
-  for (int j = m - 1; j >= 0; --j) {  // L^T x = z
-    double s = x[j];
+  for (int j = m - 1; j >= 0; --j) {  // D^-1, then L^T x = z (one pass: x[j] / D[j] is what the separate scaling pass produced)
+    double s = x[j] / D[j];
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
     x[j] = s;
   }
@@ -538,7 +536,7 @@ int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, d
   return CUADMM_OK;
 }
 
-// forward sweep over the leading m-k columns, then D scaling of the leading part; x[m-k..] holds z2 on return
+// forward sweep over the leading m-k columns; x[m-k..] holds z2 on return (D1^-1 is applied by the backward sweep)
 int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
   if (!f || !x || k < f->tail_k || k > f->m) { set_error("aat_solve_leading_forward: bad arguments"); return CUADMM_ERR_INVALID; }
   const int n1 = f->m - k;
@@ -550,19 +548,19 @@ int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
     if (xj != 0.0)
       for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
   }
-  for (int j = 0; j < n1; ++j) x[j] /= f->D[j];
-  return CUADMM_OK;
+  return CUADMM_OK;   // the D1^-1 scaling of the leading part is folded into the backward sweep
 }
 
-// backward sweep over the leading m-k columns; x[m-k..] must hold the solved tail x2
+// D1^-1 and the backward sweep over the leading m-k columns; x[m-k..] must hold the solved tail x2
 int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
   if (!f || !x || k < f->tail_k || k > f->m) { set_error("aat_solve_leading_backward: bad arguments"); return CUADMM_ERR_INVALID; }
   const int n1 = f->m - k;
   const int64_t* Lp = f->Lp.data();
   const int* Li = f->Li.data();
   const double* Lx = f->Lx.data();
+  const double* D = f->D.data();
   for (int j = n1 - 1; j >= 0; --j) {
-    double s = x[j];
+    double s = x[j] / D[j];
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
     x[j] = s;
   }

@@ -218,8 +218,8 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs_perm, doubl
  * and runs it as two GEMVs per solve, the host keeps the sparse leading columns.
  *   tail_plan            : k chosen by the cost model (0 = keep everything on the host), k <= max_k
  *   tail_dense           : trailing k x k block of L as dense row-major unit-lower matrix (leading dimension ld) and D
- *   solve_leading_forward: forward sweep + D scaling over the leading m-k columns, in place; x[m-k..] then holds z2
- *   solve_leading_backward: backward sweep over the leading columns, in place; x[m-k..] must hold the solved tail */
+ *   solve_leading_forward: forward sweep over the leading m-k columns, in place; x[m-k..] then holds z2
+ *   solve_leading_backward: D1^-1 and backward sweep over the leading columns, in place; x[m-k..] must hold the solved tail */
 int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k);
 /* Split factorisation: like cuadmm_aat_create, but when the cost model finds a dense tail (k <= max_k) the last k
  * columns are left unfactored; the Schur complement B22 - L21 D1 L21^T (sparse, lower triangle) is kept for the
