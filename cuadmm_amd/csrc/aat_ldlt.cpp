@@ -37,6 +37,7 @@ struct cuadmm_aat {
   // sweeps of different chunks touch disjoint entries, so cuadmm_aat_solve_permuted runs them on a few host threads
   // with bit-identical results (used for large block-diagonal systems, e.g. weak-scaled runs with m = 400 000).
   std::vector<std::vector<int>> chunks;
+  std::vector<int> nzcols;   // columns j < m - tail_k with at least one sub-diagonal entry, ascending (block-diagonal A A^T: few)
   int tail_k = 0;
   std::vector<int64_t> schur_ptr;
   std::vector<int> schur_col;
@@ -421,6 +422,7 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     }
     f->D[k] = dk;
   }
+  for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->nzcols.push_back(j);
   // chunks of independent etree subtrees for the threaded solve (whole factor on the host, large m, many subtrees)
   if (tail_k == 0 && m >= 200000) {
     std::vector<int> root(m);
@@ -496,13 +498,20 @@ int cuadmm_aat_solve_permuted(const cuadmm_aat* f, const double* rhs, double* x)
     });
     return CUADMM_OK;
   }
-  for (int j = 0; j < m; ++j) {  // L z = b
-    double xj = x[j];
+  // only columns with sub-diagonal entries take part in the sweeps; D^-1 is one streaming pass in between (per entry
+  // the arithmetic is that of the textbook three-pass solve: updates, division, subtractions)
+  const int* nz = f->nzcols.data();
+  const size_t nnzc = f->nzcols.size();
+  for (size_t q = 0; q < nnzc; ++q) {  // L z = b
+    const int j = nz[q];
+    const double xj = x[j];
     if (xj != 0.0)
       for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
   }
-  for (int j = m - 1; j >= 0; --j) {  // D^-1, then L^T x = z (one pass: x[j] / D[j] is what the separate scaling pass produced)
-    double s = x[j] / D[j];
+  for (int j = 0; j < m; ++j) x[j] /= D[j];
+  for (size_t q = nnzc; q-- > 0;) {  // L^T x = z
+    const int j = nz[q];
+    double s = x[j];
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
     x[j] = s;
   }
@@ -538,29 +547,47 @@ int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, d
 
 // forward sweep over the leading m-k columns; x[m-k..] holds z2 on return (D1^-1 is applied by the backward sweep)
 int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
-  if (!f || !x || k < f->tail_k || k > f->m) { set_error("aat_solve_leading_forward: bad arguments"); return CUADMM_ERR_INVALID; }
+  if (!f || !x || k < 0 || k > f->m || (f->tail_k > 0 && k != f->tail_k)) { set_error("aat_solve_leading_forward: bad arguments (a split factor takes its own tail size)"); return CUADMM_ERR_INVALID; }
   const int n1 = f->m - k;
   const int64_t* Lp = f->Lp.data();
   const int* Li = f->Li.data();
   const double* Lx = f->Lx.data();
-  for (int j = 0; j < n1; ++j) {
+  if (k != f->tail_k && f->tail_k == 0) {   // split requested on a one-piece factor (tests): walk all leading columns
+    for (int j = 0; j < n1; ++j) {
+      const double xj = x[j];
+      if (xj != 0.0)
+        for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
+    }
+    return CUADMM_OK;
+  }
+  for (int j : f->nzcols) {
     const double xj = x[j];
     if (xj != 0.0)
       for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
   }
-  return CUADMM_OK;   // the D1^-1 scaling of the leading part is folded into the backward sweep
+  return CUADMM_OK;   // the D1^-1 scaling of the leading part is applied by the backward sweep
 }
 
 // D1^-1 and the backward sweep over the leading m-k columns; x[m-k..] must hold the solved tail x2
 int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
-  if (!f || !x || k < f->tail_k || k > f->m) { set_error("aat_solve_leading_backward: bad arguments"); return CUADMM_ERR_INVALID; }
+  if (!f || !x || k < 0 || k > f->m || (f->tail_k > 0 && k != f->tail_k)) { set_error("aat_solve_leading_backward: bad arguments (a split factor takes its own tail size)"); return CUADMM_ERR_INVALID; }
   const int n1 = f->m - k;
   const int64_t* Lp = f->Lp.data();
   const int* Li = f->Li.data();
   const double* Lx = f->Lx.data();
   const double* D = f->D.data();
-  for (int j = n1 - 1; j >= 0; --j) {
-    double s = x[j] / D[j];
+  for (int j = 0; j < n1; ++j) x[j] /= D[j];
+  if (k != f->tail_k && f->tail_k == 0) {
+    for (int j = n1 - 1; j >= 0; --j) {
+      double s = x[j];
+      for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
+      x[j] = s;
+    }
+    return CUADMM_OK;
+  }
+  for (size_t q = f->nzcols.size(); q-- > 0;) {
+    const int j = f->nzcols[q];
+    double s = x[j];
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
     x[j] = s;
   }
