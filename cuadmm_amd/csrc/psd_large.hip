@@ -49,11 +49,12 @@ constexpr int LG_TM = 64;   // measured on MI355X: 64x64 tiles (4 workgroups per
 
 // C = alpha * A*B + beta * E over a batch (blockIdx.y = matrix, stride N*N).  A (and, when MIRROR, the product) symmetric.
 // MIRROR: blockIdx.x enumerates the tiles (by <= bx) of the upper triangle; C[row][col] and C[col][row] are both written.
-template <bool MIRROR>
+// TM = 64: 4 MFMA tiles per wavefront (16 flop per byte of operand traffic); TM = 32: one MFMA tile per wavefront, four
+// times as many workgroups -- for matrices whose 64 x 64 tiles would leave most of the 256 CUs idle (N ~ 1000: 136 tiles).
+template <bool MIRROR, int TM>
 __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
                                                           double alpha, double beta, const double* __restrict__ Eb,
                                                           double* __restrict__ Cb, int sb) {
-  constexpr int TM = LG_TM;
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
@@ -99,16 +100,27 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = lg_v4f64{0.0, 0.0, 0.0, 0.0};
 
-  // staging: tile[k][0..TM-1] = M[k0 + k][c0 .. c0+TM-1]; thread t loads row k = t/16, 4 doubles at column (t%16)*4
-  const int lk = tid >> 4, lc = (tid & 15) * 4;
+  // staging: tile[k][0..TM-1] = M[k0 + k][c0 .. c0+TM-1]; thread t loads row k = t/16, TM/16 doubles at column (t%16)*TM/16
+  constexpr int PT = TM / 16;       // doubles per thread per operand per k-tile (4 or 2)
+  const int lk = tid >> 4, lc = (tid & 15) * PT;
   // register prefetch two k-tiles ahead (an L2 miss costs several k-tiles of MFMA work); scalars, not arrays (scratch)
-  double2 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+  double2 pa0, pa1 = {0, 0}, pb0, pb1 = {0, 0}, qa0, qa1 = {0, 0}, qb0, qb1 = {0, 0};
   const double2* ap = reinterpret_cast<const double2*>(A + (size_t)lk * N + row0 + lc);   // A symmetric: A[row][k] = A[k][row]
   const double2* bp = reinterpret_cast<const double2*>(B + (size_t)lk * N + col0 + lc);
   const size_t kstep = (size_t)LG_BK * N / 2;
-  pa0 = ap[0]; pa1 = ap[1]; pb0 = bp[0]; pb1 = bp[1];
+#define LG_LOAD(a0, a1, b0, b1)                                  \
+  do {                                                           \
+    a0 = ap[0]; b0 = bp[0];                                      \
+    if constexpr (PT == 4) { a1 = ap[1]; b1 = bp[1]; }           \
+  } while (0)
+#define LG_STORE(a0, a1, b0, b1)                                 \
+  do {                                                           \
+    sa[0] = a0; sb2[0] = b0;                                     \
+    if constexpr (PT == 4) { sa[1] = a1; sb2[1] = b1; }          \
+  } while (0)
+  LG_LOAD(pa0, pa1, pb0, pb1);
   ap += kstep; bp += kstep;
-  qa0 = ap[0]; qa1 = ap[1]; qb0 = bp[0]; qb1 = bp[1];     // N / LG_BK is a multiple of 4
+  LG_LOAD(qa0, qa1, qb0, qb1);                            // N / LG_BK is a multiple of 4
   double2* sa = reinterpret_cast<double2*>(As + lk * LDS + lc);
   double2* sb2 = reinterpret_cast<double2*>(Bs + lk * LDS + lc);
 #define LG_COMPUTE()                                                                                              \
@@ -124,17 +136,19 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
   }
   for (int k0 = 0; k0 < N; k0 += 2 * LG_BK) {
     __syncthreads();
-    sa[0] = pa0; sa[1] = pa1; sb2[0] = pb0; sb2[1] = pb1;
+    LG_STORE(pa0, pa1, pb0, pb1);
     __syncthreads();
-    if (k0 + 2 * LG_BK < N) { ap += kstep; bp += kstep; pa0 = ap[0]; pa1 = ap[1]; pb0 = bp[0]; pb1 = bp[1]; }
+    if (k0 + 2 * LG_BK < N) { ap += kstep; bp += kstep; LG_LOAD(pa0, pa1, pb0, pb1); }
     LG_COMPUTE();
     __syncthreads();
-    sa[0] = qa0; sa[1] = qa1; sb2[0] = qb0; sb2[1] = qb1;
+    LG_STORE(qa0, qa1, qb0, qb1);
     __syncthreads();
-    if (k0 + 3 * LG_BK < N) { ap += kstep; bp += kstep; qa0 = ap[0]; qa1 = ap[1]; qb0 = bp[0]; qb1 = bp[1]; }
+    if (k0 + 3 * LG_BK < N) { ap += kstep; bp += kstep; LG_LOAD(qa0, qa1, qb0, qb1); }
     LG_COMPUTE();
   }
 #undef LG_COMPUTE
+#undef LG_LOAD
+#undef LG_STORE
   // epilogue: D[row = (l>>4) + 4*reg][col = l&15] per 16x16 tile.  The mirrored copy goes through LDS so that it is
   // stored row-wise too (a direct transposed store puts the 16 lanes of a fragment 8N bytes apart: one L2 channel).
   if (MIRROR) __syncthreads();   // everyone is done with As / Bs: Ct overlays them
@@ -154,9 +168,9 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
       }
   if (MIRROR) {
     __syncthreads();
-    const int q = tid & 63;                           // original row   -> column of the mirrored tile
+    const int q = tid % TM;                           // original row   -> column of the mirrored tile
 #pragma unroll 4
-    for (int p = tid >> 6; p < TM; p += 4)            // original column -> row of the mirrored tile
+    for (int p = tid / TM; p < TM; p += 256 / TM)     // original column -> row of the mirrored tile
       if (by != bx || q < p) C[(size_t)(col0 + p) * N + row0 + q] = Ct[p * (TM + 1) + q];
   }
 }
@@ -249,14 +263,21 @@ static int lg_pad(int n) { return (n + LG_TM - 1) / LG_TM * LG_TM; }
 
 static int lg_gemm(bool mirror, int N, int count, const double* A, const double* B, double alpha, double beta, const double* E,
                    double* C, hipStream_t st) {
-  const int nb = N / LG_TM;
+  // 32 x 32 tiles when the 64 x 64 tiling would leave the chip under-filled (CUADMM_LG_TILE=32|64 forces one)
+  static const int tile_force = getenv("CUADMM_LG_TILE") ? atoi(getenv("CUADMM_LG_TILE")) : 0;
+  const int nb64 = N / 64;
+  const long long tiles64 = (long long)(mirror ? nb64 * (nb64 + 1) / 2 : nb64 * nb64) * count;
+  const bool small_tiles = tile_force ? tile_force == 32 : (mirror && N >= 256 && tiles64 < 1300);   // measured: better up to N ~ 3000
+  const int nb = small_tiles ? N / 32 : nb64;
   if (mirror && count == 1 && nb >= 16) {
     const int sb = (nb + 7) / 8;                               // 8x8-tile super-blocks per direction
-    hipLaunchKernelGGL(lg_gemm_sym_kernel<true>, dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
   } else if (mirror) {
-    hipLaunchKernelGGL(lg_gemm_sym_kernel<true>, dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
   } else {
-    hipLaunchKernelGGL(lg_gemm_sym_kernel<false>, dim3(nb * nb, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    hipLaunchKernelGGL((lg_gemm_sym_kernel<false, 64>), dim3(nb * nb, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
   }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
