@@ -51,17 +51,17 @@ constexpr int LG_TM = 64;   // measured on MI355X: 64x64 tiles (4 workgroups per
 // MIRROR: blockIdx.x enumerates the tiles (by <= bx) of the upper triangle; C[row][col] and C[col][row] are both written.
 // TM = 64: 4 MFMA tiles per wavefront (16 flop per byte of operand traffic); TM = 32: one MFMA tile per wavefront, four
 // times as many workgroups -- for matrices whose 64 x 64 tiles would leave most of the 256 CUs idle (N ~ 1000: 136 tiles).
-template <bool MIRROR, int TM>
+template <bool MIRROR, int TM, int BK>
 __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
                                                           double alpha, double beta, const double* __restrict__ Eb,
                                                           double* __restrict__ Cb, int sb) {
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
-  constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * LG_BK * LDS ? TM * (TM + 1) : 2 * LG_BK * LDS) : 2 * LG_BK * LDS;
+  constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * BK * LDS ? TM * (TM + 1) : 2 * BK * LDS) : 2 * BK * LDS;
   __shared__ double smem[SMEM];
   double* As = smem;
-  double* Bs = smem + LG_BK * LDS;
+  double* Bs = smem + BK * LDS;
   double* Ct = smem;                // TM x (TM+1) transposed output tile (MIRROR), after the k loop
   const size_t mat = (size_t)blockIdx.y * (size_t)N * (size_t)N;
   const double* A = Ab + mat;
@@ -100,14 +100,15 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = lg_v4f64{0.0, 0.0, 0.0, 0.0};
 
-  // staging: tile[k][0..TM-1] = M[k0 + k][c0 .. c0+TM-1]; thread t loads row k = t/16, TM/16 doubles at column (t%16)*TM/16
-  constexpr int PT = TM / 16;       // doubles per thread per operand per k-tile (4 or 2)
-  const int lk = tid >> 4, lc = (tid & 15) * PT;
+  // staging: tile[k][0..TM-1] = M[k0 + k][c0 .. c0+TM-1]; BK k-rows, 256/BK threads per row
+  constexpr int TPR = 256 / BK;     // threads per k-row of the staged tile
+  constexpr int PT = TM / TPR;      // doubles per thread per operand per k-tile (4 or 2)
+  const int lk = tid / TPR, lc = (tid % TPR) * PT;
   // register prefetch two k-tiles ahead (an L2 miss costs several k-tiles of MFMA work); scalars, not arrays (scratch)
   double2 pa0, pa1 = {0, 0}, pb0, pb1 = {0, 0}, qa0, qa1 = {0, 0}, qb0, qb1 = {0, 0};
   const double2* ap = reinterpret_cast<const double2*>(A + (size_t)lk * N + row0 + lc);   // A symmetric: A[row][k] = A[k][row]
   const double2* bp = reinterpret_cast<const double2*>(B + (size_t)lk * N + col0 + lc);
-  const size_t kstep = (size_t)LG_BK * N / 2;
+  const size_t kstep = (size_t)BK * N / 2;
 #define LG_LOAD(a0, a1, b0, b1)                                  \
   do {                                                           \
     a0 = ap[0]; b0 = bp[0];                                      \
@@ -120,11 +121,11 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
   } while (0)
   LG_LOAD(pa0, pa1, pb0, pb1);
   ap += kstep; bp += kstep;
-  LG_LOAD(qa0, qa1, qb0, qb1);                            // N / LG_BK is a multiple of 4
+  LG_LOAD(qa0, qa1, qb0, qb1);                            // N / BK is even (N is a multiple of 64)
   double2* sa = reinterpret_cast<double2*>(As + lk * LDS + lc);
   double2* sb2 = reinterpret_cast<double2*>(Bs + lk * LDS + lc);
 #define LG_COMPUTE()                                                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < LG_BK; ks += 4) {                                                       \
+  _Pragma("unroll") for (int ks = 0; ks < BK; ks += 4) {                                                       \
     double af[NTW], bf[NTW];                                                                                      \
     _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                             \
       af[t] = As[(ks + kk) * LDS + wy * WT + t * 16 + r16];                                                       \
@@ -134,16 +135,16 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
       _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                             \
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                       \
   }
-  for (int k0 = 0; k0 < N; k0 += 2 * LG_BK) {
+  for (int k0 = 0; k0 < N; k0 += 2 * BK) {
     __syncthreads();
     LG_STORE(pa0, pa1, pb0, pb1);
     __syncthreads();
-    if (k0 + 2 * LG_BK < N) { ap += kstep; bp += kstep; LG_LOAD(pa0, pa1, pb0, pb1); }
+    if (k0 + 2 * BK < N) { ap += kstep; bp += kstep; LG_LOAD(pa0, pa1, pb0, pb1); }
     LG_COMPUTE();
     __syncthreads();
     LG_STORE(qa0, qa1, qb0, qb1);
     __syncthreads();
-    if (k0 + 3 * LG_BK < N) { ap += kstep; bp += kstep; LG_LOAD(qa0, qa1, qb0, qb1); }
+    if (k0 + 3 * BK < N) { ap += kstep; bp += kstep; LG_LOAD(qa0, qa1, qb0, qb1); }
     LG_COMPUTE();
   }
 #undef LG_COMPUTE
@@ -271,13 +272,13 @@ static int lg_gemm(bool mirror, int N, int count, const double* A, const double*
   const int nb = small_tiles ? N / 32 : nb64;
   if (mirror && count == 1 && nb >= 16) {
     const int sb = (nb + 7) / 8;                               // 8x8-tile super-blocks per direction
-    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
-    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
   } else if (mirror) {
-    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
-    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
   } else {
-    hipLaunchKernelGGL((lg_gemm_sym_kernel<false, 64>), dim3(nb * nb, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    hipLaunchKernelGGL((lg_gemm_sym_kernel<false, 64, 16>), dim3(nb * nb, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
   }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
