@@ -125,3 +125,23 @@ def test_large_single_block_examples_first_log_rows(name, ref_logs):
     s.init_problem(problem_to_amd(p))
     s.solve(100, 1e-3, 0, 50, 100, 11000, 1.05)
     _check_rows(s, lg, (50, 100))
+
+
+def test_c4_full_size_against_the_oracle():
+    """BASELINE config 4 at its full size -- 100 000 blocks of sizes {3,6,10,15,28,45}, m = 300 000, L = 27.4 M: five sGS
+    and five ADMM iterations against the oracle (every projection kernel class in bulk, long svec / constraint vectors)."""
+    _compare(config_c4(100000), 5, 10 ** 9)
+    _compare(config_c4(100000), 5, 0)
+
+
+def test_c2_full_size_against_the_oracle():
+    """BASELINE config 2 at its full size (10 000 blocks of 32 x 32, the bench workload): ten ADMM iterations."""
+    from cuadmm_amd.synthetic import config_c2
+    _compare(config_c2(10000), 10, 0)
+
+
+def test_c3_full_size_against_the_oracle():
+    """BASELINE config 3 at its full size (max-cut relaxation, one block n = 2000, m = 2000): five sGS iterations; the
+    projection is 89 mirrored fp64-MFMA GEMMs of size 2048 per iteration."""
+    from cuadmm_amd.synthetic import config_c3
+    _compare(config_c3(2000), 5, 10 ** 9)
