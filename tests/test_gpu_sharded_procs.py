@@ -1,0 +1,27 @@
+"""Two PROCESSES (torch.distributed.run, gloo rendezvous on 127.0.0.1) share GPU 0 and run one sharded solve each way:
+owned constraints (block-diagonal problem) and the replicated solve (one constraint couples all blocks).  This is the
+process / rendezvous structure of `bench.py --gpus N`; only the transport differs (host-staged gloo instead of RCCL)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("kind,port", [("owned", 29641), ("coupled", 29642)])
+def test_two_processes_one_gpu(kind, port, tmp_path):
+    out = tmp_path / "res.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "_sharded_worker.py"), str(out), kind],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = np.load(out)
+    assert np.max(np.abs(d["pobj"] - d["pobj_ref"]) / (1e-12 + np.abs(d["pobj_ref"]))) <= 1e-9
+    assert np.max(np.abs(d["errRp"] - d["errRp_ref"]) / (1e-12 + np.abs(d["errRp_ref"]))) <= 1e-8
+    assert np.max(np.abs(d["X"] - d["Xref"])) <= 1e-9 * (1 + np.max(np.abs(d["Xref"])))
+    assert np.max(np.abs(d["y"] - d["yref"])) <= 1e-8 * (1 + np.max(np.abs(d["yref"])))
