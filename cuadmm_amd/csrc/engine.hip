@@ -177,6 +177,11 @@ struct cuadmm_solver {
   SpmvLongRows A_long;         // rows of A much longer than the average (trace / all-ones constraints)
   DevBuf<double> At_v, A_v;
   DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
+  // Where the kernels write [A*X | sums | A*(S-C)]: the device buffer out_d when it has to be all-reduced, otherwise the
+  // pinned host buffer h_out itself through its device mapping -- the results cross PCIe as the kernels produce them and
+  // fetch_out is a stream synchronisation without a copy.
+  double* out_w = nullptr;
+  bool out_mapped = false;
   PinnedBuf<double> h_out, h_y;
   double A_avg_nnz = 1;
   PsdPlan plan;
@@ -293,9 +298,11 @@ struct cuadmm_solver {
 
   // D2H of out_d[first, first+count) after the optional all-reduce; blocks until it has landed
   int fetch_out(size_t first, size_t count) {
-    int rc = do_allreduce(out_d.p + first, count);
-    if (rc) return rc;
-    CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    if (!out_mapped) {
+      int rc = do_allreduce(out_d.p + first, count);
+      if (rc) return rc;
+      CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    }
     CUADMM_HIP_TRY(hipStreamSynchronize(st));
     prof_collect();
     return CUADMM_OK;
@@ -309,8 +316,8 @@ struct cuadmm_solver {
   }
   int launch_spmv(bool doX, bool doS) {
     prof_begin(K_SPMV);
-    int rc = launch_spmv_rows(m, A_avg_nnz, A_rp.p, A_ci.p, A_v.p, X.p, S.p, C.p, doX ? out_d.p : nullptr,
-                              doS ? out_d.p + m + 2 : nullptr, st, &A_long);
+    int rc = launch_spmv_rows(m, A_avg_nnz, A_rp.p, A_ci.p, A_v.p, X.p, S.p, C.p, doX ? out_w : nullptr,
+                              doS ? out_w + m + 2 : nullptr, st, &A_long);
     prof_end(K_SPMV, 12.0 * (double)A_v.n + 8.0 * m * ((doX ? 1 : 0) + (doS ? 1 : 0)));
     return rc;
   }
@@ -322,7 +329,7 @@ struct cuadmm_solver {
   }
   int launch_post_mode(int mode, double tau) {
     prof_begin(K_POST);
-    int rc = launch_post(mode, L, Xproj.p, Rd1.p, C.p, X.p, S.p, 1 / sig, tau * sig, partials.p, out_d.p + (size_t)m, st);
+    int rc = launch_post(mode, L, Xproj.p, Rd1.p, C.p, X.p, S.p, 1 / sig, tau * sig, partials.p, out_w + (size_t)m, st);
     prof_end(K_POST, (mode == 0 ? 48.0 : (mode == 1 ? 32.0 : 40.0)) * (double)L);
     return rc;
   }
@@ -675,12 +682,19 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8)))
     return rc;
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
+  std::memset(s->h_out.p, 0, sizeof(double) * (2 * (size_t)m + 2));
+  s->out_w = s->out_d.p;
+  if (s->world <= 1 && !s->force_comm && !getenv("CUADMM_NO_MAPPED_OUT")) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, s->h_out.p, 0) == hipSuccess && dp) { s->out_w = static_cast<double*>(dp); s->out_mapped = true; }
+    else { hipError_t e = hipGetLastError(); (void)e; }
+  }
 
   // --- initial residuals (solver.cu:195-228)
   if ((rc = s->upload_y())) return rc;
   if ((rc = s->launch_aty(false))) return rc;                               // Rd1 = At*y - C
   if ((rc = launch_post(2, L, s->Xproj.p, s->Rd1.p, s->C.p, s->X.p, s->S.p, 1.0, 0.0, s->partials.p,
-                        s->out_d.p + (size_t)m, s->st)))                    // Rd = Rd1 + S, sums (X untouched)
+                        s->out_w + (size_t)m, s->st)))                      // Rd = Rd1 + S, sums (X untouched)
     return rc;
   if ((rc = s->launch_spmv(true, true))) return rc;
   if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
