@@ -10,6 +10,7 @@
 #include <set>
 
 #include "common.h"
+#include "sign_sched.h"
 
 namespace cuadmm {
 
@@ -189,6 +190,12 @@ int cuadmm_partition_blocks(const int* blk, int mat_num, int world, int* first_b
   partition_blocks(blk, mat_num, world, f);
   for (int r = 0; r <= world; ++r) first_block_out[r] = f[r];
   return CUADMM_OK;
+}
+
+// host model of the adaptive matrix-sign schedule (sign_sched.h): the kernels run the same state machine per block
+int cuadmm_sign_sched_simulate(double* s, int n, int lagged, double* max_err_out) {
+  if (!s || n < 0) { set_error("sign_sched_simulate: bad arguments"); return CUADMM_ERR_INVALID; }
+  return sign_sched_simulate(s, n, lagged != 0, max_err_out);
 }
 
 }  // extern "C"

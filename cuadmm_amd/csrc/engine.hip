@@ -801,14 +801,15 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     if ((rc = s->upload_y())) return rc;
     if ((rc = s->launch_aty(true))) return rc;
     if ((rc = s->launch_project())) return rc;
-    if (getenv("CUADMM_DEBUG_EIG")) {   // developer aid: dump the projection input when a block hits the QL cap
+    static const char* const debug_eig_dir = getenv("CUADMM_DEBUG_EIG");   // read once, not per iteration
+    if (debug_eig_dir) {   // developer aid: dump the projection input when a block hits the QL cap
       int f = s->plan.fail_count(s->st);
       if (f != s->eig_fail_total) {
         fprintf(stderr, "[cuadmm debug] iter %d: QL cap hits %d -> %d\n", iter, s->eig_fail_total, f);
         std::vector<double> h((size_t)L);
         if (hipMemcpy(h.data(), s->Xb.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost) == hipSuccess) {
           char fn[256];
-          snprintf(fn, sizeof fn, "%s/xb_fail_iter%d.bin", getenv("CUADMM_DEBUG_EIG"), iter);
+          snprintf(fn, sizeof fn, "%s/xb_fail_iter%d.bin", debug_eig_dir, iter);
           if (FILE* fp = fopen(fn, "wb")) { fwrite(h.data(), sizeof(double), (size_t)L, fp); fclose(fp); }
         }
         s->eig_fail_total = f;
@@ -1078,10 +1079,19 @@ int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, d
 }
 
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream) {
+  return cuadmm_op_psd_project_steps(Xb, Xproj, blk_host, mat_num, nullptr, stream);
+}
+
+int cuadmm_op_psd_project_steps(const double* Xb, double* Xproj, const int* blk_host, int mat_num, int* steps_dev, void* stream) {
   if (!blk_host || mat_num < 0) { set_error("psd_project: bad arguments"); return CUADMM_ERR_INVALID; }
   PsdPlan plan;
   int rc = plan.build(blk_host, mat_num);
   if (rc) return rc;
+  if (steps_dev) {
+    CUADMM_HIP_TRY(hipMemsetAsync(steps_dev, 0, sizeof(int) * (size_t)mat_num, (hipStream_t)stream));
+    plan.d_steps = steps_dev;
+    plan.sign.d_steps = steps_dev;
+  }
   rc = plan.project(Xb, Xproj, (hipStream_t)stream);
   if (rc) return rc;
   int fails = plan.fail_count((hipStream_t)stream);   // synchronises the stream

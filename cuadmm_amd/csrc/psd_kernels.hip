@@ -1,9 +1,13 @@
 // PSD-cone projection kernels (gfx950) and their host-side planner/launcher.
 //
-// One launch per size class:
-//   n <= 4 / 8 / 16 / 32 : psd_small_kernel<LPB>: a block per LPB-lane group, 64/LPB blocks per
-//                          wavefront, everything in LDS (one wavefront per workgroup)
-//   33 <= n <= ~136      : psd_wg_kernel<NT,false>: one workgroup per block, matrix in LDS
+// Projection (MODE 0), one launch per size class:
+//   n <= 16              : psd_small_reg_kernel<4|8|16>: register-resident eigensolver, 16..4 blocks per wavefront
+//   17 <= n <= 32        : psd_sign_wave32_kernel: matrix-sign iteration on the fp64 matrix cores, one wavefront per block
+//   33 <= n <= 64        : psd_sign_lds_kernel<48|64>: same iteration resident in LDS, one workgroup per block
+//   larger               : psd_large.hip (batched GEMM launches)
+// The sign kernels stop per block (sign_sched.h).  Explicit eigendecomposition (MODE 1, cuadmm_op_batch_eig):
+//   n <= 64              : psd_small_reg_kernel<NMAX>
+//   65 <= n <= ~136      : psd_wg_kernel<NT,false>: one workgroup per block, matrix in LDS
 //   larger               : psd_wg_kernel<NT,true>: one workgroup per block, matrix in an HBM workspace
 // MODE 0: svec in -> projected svec out (the fused replacement of solver.cu:534-647)
 // MODE 1: dense column-major symmetric in -> eigenvectors (column-major) + ascending eigenvalues
@@ -20,7 +24,6 @@
 #include "psd_device.h"
 #include "psd_plan.h"
 #include "psd_small_reg.h"
-#include "psd_small_pc.h"
 #include "psd_sign_lds.h"
 
 namespace cuadmm {
@@ -38,71 +41,8 @@ struct PsdArgs {
   double* workspace;       // GLOBAL variant
   const long long* ws_off; // GLOBAL variant: workspace offset per member
   long long* dbg;          // developer aid: per-workgroup phase timestamps (CUADMM_PSD_DEBUG)
+  int* steps;              // developer aid: Newton-Schulz steps taken per block (sign kernels; may be null)
 };
-
-template <int LPB, int MODE>
-__global__ __launch_bounds__(64) void psd_small_kernel(PsdArgs a) {
-  constexpr int BPW = 64 / LPB;
-  constexpr int LD = LPB + 1;
-  constexpr int PER = LPB * LD + 5 * LPB;
-  __shared__ double smem[BPW * PER];
-  using Gp = SubGroup<LPB>;
-  const int lane = lane_id();
-  const int slot0 = (int)blockIdx.x * BPW;
-
-  // cooperative, coalesced load of the wavefront's blocks into LDS
-  for (int gg = 0; gg < BPW; ++gg) {
-    const int slot = slot0 + gg;
-    if (slot >= a.count) break;
-    const int bi = a.ids ? a.ids[slot] : slot;
-    double* Mg = smem + gg * PER;
-    if (MODE == 0) {
-      const int n = a.bn[bi];
-      const double* src = a.in + a.boff[bi];
-      const int len = n * (n + 1) / 2;
-      for (int e = lane; e < len; e += 64) {
-        int i, j;
-        tri_decode(e, i, j);
-        double v = src[e];
-        if (i != j) v *= kSqrt2Inv;
-        Mg[j * LD + i] = v;
-        Mg[i * LD + j] = v;
-      }
-    } else {
-      const int n = a.n_uniform;
-      const double* src = a.in + (long long)bi * n * n;
-      for (int idx = lane; idx < n * n; idx += 64) {
-        const int c = idx / n, r = idx - c * n;
-        if (r >= c) {  // lower triangle is the input (uplo = LOWER, cusolver.h:36,117)
-          const double v = src[idx];
-          Mg[r * LD + c] = v;
-          Mg[c * LD + r] = v;
-        }
-      }
-    }
-  }
-  wave_fence();
-
-  const int g = lane / LPB;
-  const int slot = slot0 + g;
-  if (slot >= a.count) return;
-  const int bi = a.ids ? a.ids[slot] : slot;
-  const int n = (MODE == 0) ? a.bn[bi] : a.n_uniform;
-  double* M = smem + g * PER;
-  double* d = M + LPB * LD;
-  double* e = d + LPB;
-  double* tau = e + LPB;
-  double* vv = tau + LPB;
-  double* ww = vv + LPB;
-  const int fail = sym_eig_inplace<Gp>(M, LD, n, d, e, tau, vv, ww, d, e, nullptr);
-  if (MODE == 0) {
-    reconstruct_to_svec<Gp>(M, LD, n, d, vv, a.out + a.boff[bi]);
-    if (fail && Gp::rank() == 0 && a.info) atomicAdd(a.info, 1);
-  } else {
-    write_sorted_eig<Gp>(M, LD, n, d, a.out + (long long)bi * n * n, a.Wout + (long long)bi * n);
-    if (Gp::rank() == 0 && a.info) a.info[bi] = fail;
-  }
-}
 
 // register-resident variant (psd_small_reg.h): the production path for n <= 32
 template <int NMAX, int MODE>
@@ -119,28 +59,6 @@ __global__ __launch_bounds__(64) void psd_small_reg_kernel(PsdArgs a) {
       if (dbg && lane_id() == 0) dbg[6] = (long long)__builtin_readcyclecounter() - t0;
     }
     psd_small_reg_store<NMAX, RegLayout<NMAX>>(a, smem, slot0, dbg);
-  }
-}
-
-// producer/consumer variant (psd_small_pc.h): WAVES wavefronts per workgroup, the last one also produces
-// the QL rotations of all the workgroup's blocks
-template <int NMAX, int WAVES, int MODE>
-__global__ __launch_bounds__(64 * WAVES, 2) void psd_small_pc_kernel(PsdArgs a) {
-  __shared__ double smem[WAVES * (64 / NMAX) * PcLayout<NMAX>::kPer];
-  __shared__ int flags[2];
-  psd_small_pc_body<NMAX, WAVES, MODE>(a, smem, flags);
-  if (MODE == 0) {
-    wave_fence();
-    const int wave = (int)(threadIdx.x >> 6);
-    const int slot0 = ((int)blockIdx.x * WAVES + wave) * (64 / NMAX);
-    double* wsm = smem + wave * (64 / NMAX) * PcLayout<NMAX>::kPer;
-    long long* dbg = a.dbg ? a.dbg + ((long long)blockIdx.x * WAVES + wave) * 8 : nullptr;
-    if constexpr (NMAX >= 16) {
-      const long long t0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
-      psd_small_reg_rebuild_mfma<NMAX, PcLayout<NMAX>>(a, wsm, slot0);
-      if (dbg && lane_id() == 0) dbg[6] = (long long)__builtin_readcyclecounter() - t0;
-    }
-    psd_small_reg_store<NMAX, PcLayout<NMAX>>(a, wsm, slot0, dbg);
   }
 }
 
@@ -210,28 +128,32 @@ __global__ __launch_bounds__(NT) void psd_wg_kernel(PsdArgs a) {
 // ---------------------------------------------------------------------------------------
 // 32 < n <= 64 (projection only): matrix-sign iteration resident in LDS, one workgroup per block (psd_sign_lds.h)
 template <int NP>
-__global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(PsdArgs a, int first, int lift_steps, int polish_steps, double lift_mu) {
+__global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(PsdArgs a, int first) {
   extern __shared__ double sign_smem[];
   const int m = first + (int)blockIdx.x;
   const int id = a.ids ? a.ids[m] : m;
-  psd_sign_lds_body<NP>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, lift_steps, polish_steps, lift_mu);
+  psd_sign_lds_body<NP>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, a.steps ? a.steps + id : nullptr);
 }
 
-// n <= 32 (projection only): one wavefront per block, 4 per workgroup (psd_sign_lds.h, SignWave32)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void psd_sign_wave32_kernel(PsdArgs a, int first, int count, int lift_steps, int polish_steps, double lift_mu) {
-  __shared__ double sw_smem[4 * SignWave32::PER_WAVE];
+// n <= 32 (projection only): one wavefront per block (psd_sign_lds.h, SignWave32); WPG wavefronts per workgroup.
+// Blocks stop at different steps, so small workgroups (a workgroup's LDS and wave slots are released when its last
+// wavefront ends) keep the SIMDs fed.
+template <int WPG>
+__global__ __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(3, 4))) void psd_sign_wave32_kernel(PsdArgs a, int first, int count) {
+  __shared__ double sw_smem[WPG * SignWave32::PER_WAVE];
   const int w = (int)threadIdx.x >> 6;
-  const int m = (int)blockIdx.x * 4 + w;
+  const int m = (int)blockIdx.x * WPG + w;
   if (m >= count) return;
   const int id = a.ids ? a.ids[first + m] : first + m;
-  psd_sign_wave32_body(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sw_smem + w * SignWave32::PER_WAVE, lift_steps, polish_steps,
-                       lift_mu);
+  psd_sign_wave32_body(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sw_smem + w * SignWave32::PER_WAVE, a.steps ? a.steps + id : nullptr);
 }
 
 static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_t st) {
   if (count <= 0) return CUADMM_OK;
-  hipLaunchKernelGGL(psd_sign_wave32_kernel, dim3((count + 3) / 4), dim3(256), 0, st, a, first, count, SignPsd::kLiftSteps, SignPsd::kPolishSteps,
-                     SignPsd::kLiftMu);
+  static const int wpg = getenv("CUADMM_PSD_W32_WPG") ? atoi(getenv("CUADMM_PSD_W32_WPG")) : 1;
+  if (wpg == 4) hipLaunchKernelGGL(psd_sign_wave32_kernel<4>, dim3((count + 3) / 4), dim3(256), 0, st, a, first, count);
+  else if (wpg == 2) hipLaunchKernelGGL(psd_sign_wave32_kernel<2>, dim3((count + 1) / 2), dim3(128), 0, st, a, first, count);
+  else hipLaunchKernelGGL(psd_sign_wave32_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
@@ -246,7 +168,7 @@ static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t s
     CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(count), dim3(SignLdsCfg<NP>::THREADS), lds, st, a, first, SignPsd::kLiftSteps, SignPsd::kPolishSteps, SignPsd::kLiftMu);
+  hipLaunchKernelGGL(kern, dim3(count), dim3(SignLdsCfg<NP>::THREADS), lds, st, a, first);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
@@ -350,49 +272,16 @@ static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
   return CUADMM_OK;
 }
 
-// CUADMM_PSD_SMALL=lds selects the LDS-resident small-block kernel (kept for A/B measurements)
-// CUADMM_PSD_SMALL = lds | reg | pc selects the small-block kernel (default reg; the others are kept for A/B runs)
-static int small_kernel_kind() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CUADMM_PSD_SMALL");
-    v = !e ? 1 : (std::string(e) == "lds" ? 0 : (std::string(e) == "pc" ? 2 : 1));
-  }
-  return v;
-}
-static bool use_reg_kernel() { return small_kernel_kind() >= 1; }
-
+// eigensolver kernels per size class (MODE 0: projection of the n <= 16 classes; MODE 1: explicit eigendecomposition)
 template <int MODE>
 static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
   if (a.count <= 0) return CUADMM_OK;
-  if (c == 3 && small_kernel_kind() == 2) {
-    constexpr int W = 4, NB = W * 2;
-    hipLaunchKernelGGL((psd_small_pc_kernel<32, W, MODE>), dim3((a.count + NB - 1) / NB), dim3(64 * W), 0, st, a);
-    CUADMM_HIP_TRY(hipGetLastError());
-    return CUADMM_OK;
-  }
-  if (c <= 3 && use_reg_kernel()) {
-    switch (c) {
-      case 0: hipLaunchKernelGGL((psd_small_reg_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
-      case 1: hipLaunchKernelGGL((psd_small_reg_kernel<8, MODE>), dim3((a.count + 7) / 8), dim3(64), 0, st, a); break;
-      case 2: hipLaunchKernelGGL((psd_small_reg_kernel<16, MODE>), dim3((a.count + 3) / 4), dim3(64), 0, st, a); break;
-      default: hipLaunchKernelGGL((psd_small_reg_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
-    }
-    CUADMM_HIP_TRY(hipGetLastError());
-    return CUADMM_OK;
-  }
   switch (c) {
-    case 0: hipLaunchKernelGGL((psd_small_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((psd_small_kernel<8, MODE>), dim3((a.count + 7) / 8), dim3(64), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((psd_small_kernel<16, MODE>), dim3((a.count + 3) / 4), dim3(64), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((psd_small_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
-    case 4:
-      if (use_reg_kernel() && !getenv("CUADMM_PSD_NO_REG64")) {
-        hipLaunchKernelGGL((psd_small_reg_kernel<64, MODE>), dim3(a.count), dim3(64), 0, st, a);
-        CUADMM_HIP_TRY(hipGetLastError());
-        return CUADMM_OK;
-      }
-      return launch_wg<64, MODE, false>(a, maxn, st);
+    case 0: hipLaunchKernelGGL((psd_small_reg_kernel<4, MODE>), dim3((a.count + 15) / 16), dim3(64), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((psd_small_reg_kernel<8, MODE>), dim3((a.count + 7) / 8), dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((psd_small_reg_kernel<16, MODE>), dim3((a.count + 3) / 4), dim3(64), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((psd_small_reg_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((psd_small_reg_kernel<64, MODE>), dim3(a.count), dim3(64), 0, st, a); break;
     case 5:
       if (maxn <= 64) return launch_wg<64, MODE, false>(a, maxn, st);
       if (maxn <= 128) return launch_wg<128, MODE, false>(a, maxn, st);
@@ -411,7 +300,8 @@ static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
 // stream between a fork and a join event on `st`, so small classes (a moment relaxation has a handful of blocks per
 // size) overlap instead of queueing behind each other.
 int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
-  static const bool no_overlap = (getenv("CUADMM_PSD_OVERLAP") && atoi(getenv("CUADMM_PSD_OVERLAP")) == 0) || getenv("CUADMM_PSD_DEBUG");
+  static const bool psd_debug = getenv("CUADMM_PSD_DEBUG") != nullptr;     // environment read once, not per projection
+  static const bool no_overlap = (getenv("CUADMM_PSD_OVERLAP") && atoi(getenv("CUADMM_PSD_OVERLAP")) == 0) || psd_debug;
   int lanes = sign.empty() ? 0 : 1;
   for (int c = 0; c < kNumPsdClasses; ++c) lanes += cls_count[c] > 0;
   const bool fork = overlap && !no_overlap && st != nullptr && lanes > 1;
@@ -436,10 +326,10 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     PsdArgs a{};
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
-    a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff;
+    a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff; a.steps = d_steps;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
-    if (c == 3 && getenv("CUADMM_PSD_DEBUG")) {
+    if (c == 3 && psd_debug) {
       CUADMM_HIP_TRY(hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)nwg));
       CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));
       a.dbg = dbg;
@@ -469,19 +359,6 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
       // MFMA utilisation of the rebuild: 2 blocks x 3 upper tiles x 8 k-steps x 64 cycles per v_mfma_f64_16x16x4
       fprintf(stderr, "[psd debug] %d waves: cycles/wave load %.0f tridiag %.0f ql %.0f handoff %.0f tail %.0f | mfma rebuild %.0f cycles/wave -> MFMA busy %.1f%%\n",
               nwg, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, its / nwg, 100.0 * (2 * 3 * 8 * 64.0) / (its / nwg));
-      if (small_kernel_kind() == 2) {   // producer/consumer split of the QL phase: wave 3 of each workgroup produces
-        double pp = 0, pc = 0, pbr = 0, cp = 0, cc = 0, cb = 0, st = 0; int np = 0, nc = 0;
-        for (int w = 0; w < nwg; ++w) {
-          const long long v = h[w * 8 + 7];
-          const double a1 = (double)(v >> 40), a2 = (double)((v >> 20) & 0xFFFFF), a3 = (double)(v & 0xFFFFF) * 16;
-          if (w % 4 == 3) { pp += a1; pc += a2; pbr += a3; ++np; st += (double)h[w * 8 + 6]; } else { cp += a1; cc += a2; cb += a3; ++nc; }
-        }
-        double sc = 0, lp = 0, sl = 0, stp = 0;
-        for (int w = 3; w < nwg; w += 4) { sc += -(double)h[w * 8 + 1]; lp += -(double)h[w * 8 + 2]; sl += -(double)h[w * 8 + 3]; stp += -(double)h[w * 8 + 4]; }
-        if (np) fprintf(stderr, "[psd debug] producer lane0 per wg: steps %.1f scan %.0f loop %.0f cycles, slots(block0) %.0f -> %.0f cycles/slot-iteration\n", stp / np, sc / np, lp / np, sl / np, lp / (sl > 0 ? sl : 1));
-        if (np && nc) fprintf(stderr, "[psd debug] QL steps/wg %.1f | producer wave: produce %.0f consume %.0f barrier %.0f | consumer waves: consume %.0f barrier %.0f cycles\n",
-                              st / np, pp / np, pc / np, pbr / np, cc / nc, cb / nc);
-      }
       (void)slots; (void)tmin; (void)tmax;
       { hipError_t e = hipFree(dbg); (void)e; }
     }

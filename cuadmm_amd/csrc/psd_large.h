@@ -13,6 +13,7 @@ struct SignPsd {
   struct Group { int N = 0, begin = 0, count = 0; };
   std::vector<Group> groups;                 // same padded size N, bounded workspace
   int* d_ids = nullptr;                      // block ids, group after group
+  int* d_steps = nullptr;                    // not owned; when set: Newton-Schulz steps taken per block
   double *X0 = nullptr, *S = nullptr, *Y = nullptr, *T = nullptr, *colsum = nullptr, *scale = nullptr;
   int build(const int* blk, const std::vector<int>& members);
   void release();

@@ -18,6 +18,7 @@ struct PsdPlan {
   int* d_n = nullptr;          // block sizes
   int* d_ids = nullptr;        // block ids grouped by class
   int* d_fail = nullptr;       // number of blocks whose QL iteration hit its cap (cumulative)
+  int* d_steps = nullptr;      // not owned; when set, the sign kernels record their Newton-Schulz step count per block
   double* d_ws = nullptr;      // HBM workspace of the large-block path
   long long* d_wsoff = nullptr;
   // blocks with n >= sign_min (default 65: everything beyond the register kernels) take the GEMM-only matrix-sign

@@ -15,10 +15,35 @@
 #include <hip/hip_runtime.h>
 
 #include "psd_device.h"
+#include "sign_sched.h"
 
 namespace cuadmm {
 
 typedef double sl_v4f64 __attribute__((ext_vector_type(4)));
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-wide sums for the schedule statistics (sign_sched.h): xor-butterfly inside each row of 16 lanes on the DPP
+// crossbar (quad_perm, row_half_mirror, row_mirror -- no LDS traffic, fixed association order, so every lane of a row
+// holds bit-identical sums), then the four row sums through v_readlane.  The result is wave-uniform (SGPR operands),
+// so the schedule's branches are scalar.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double sw_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sw_readlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += sw_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += sw_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += sw_dpp<0x141>(v);   // row_half_mirror
+  v += sw_dpp<0x140>(v);   // row_mirror
+  return (sw_readlane(v, 0) + sw_readlane(v, 16)) + (sw_readlane(v, 32) + sw_readlane(v, 48));
+}
 
 template <int NP> struct SignLdsCfg;
 // one wavefront per upper sub-tile (NU wavefronts per workgroup): with a single wavefront per SIMD the LDS latency of
@@ -35,27 +60,39 @@ __device__ __forceinline__ void sl_upper_tile(int q, int& i, int& j) {
   j = i + rem;
 }
 
-// C = alpha * A * B + beta * E on the upper sub-tiles, mirrored.  A symmetric (read as A[k][row]).  All in LDS.
-// Wavefront w owns the w-th upper sub-tile (ti, tj).
+// acc = A * B on the wavefront's upper sub-tile (ti, tj).  A symmetric (read as A[k][row]).  Operands in LDS.
 template <int NP>
-__device__ __forceinline__ void sl_gemm(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ E,
-                                        double alpha, double beta, double* __restrict__ C, int ti, int tj, int lane) {
-  using Cfg = SignLdsCfg<NP>;
-  constexpr int LD = Cfg::LD;
+__device__ __forceinline__ sl_v4f64 sl_mma(const double* __restrict__ A, const double* __restrict__ B, int ti, int tj, int lane) {
+  constexpr int LD = SignLdsCfg<NP>::LD;
   const int r16 = lane & 15, kk = lane >> 4;
   const double* arow = A + kk * LD + ti * 16 + r16;
   const double* brow = B + kk * LD + tj * 16 + r16;
   sl_v4f64 acc = sl_v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k0 = 0; k0 < NP; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k0 * LD], brow[k0 * LD], acc, 0, 0, 0);
+  return acc;
+}
+// the sub-tile (ti, tj) of a matrix in LDS, in accumulator layout
+template <int NP>
+__device__ __forceinline__ sl_v4f64 sl_tile(const double* __restrict__ E, int ti, int tj, int lane) {
+  constexpr int LD = SignLdsCfg<NP>::LD;
+  const int r16 = lane & 15, kk = lane >> 4;
+  sl_v4f64 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = E[(ti * 16 + kk + 4 * r) * LD + tj * 16 + r16];
+  return v;
+}
+// mirrored store of the sub-tile (ti, tj); on a diagonal sub-tile the upper triangle decides
+template <int NP>
+__device__ __forceinline__ void sl_store(double* __restrict__ C, const sl_v4f64& v, int ti, int tj, int lane) {
+  constexpr int LD = SignLdsCfg<NP>::LD;
+  const int r16 = lane & 15, kk = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = ti * 16 + kk + 4 * r, col = tj * 16 + r16;
-    if (ti == tj && col < row) continue;      // diagonal sub-tile: the upper triangle decides
-    double v = alpha * acc[r];
-    if (E) v += beta * E[row * LD + col];
-    C[row * LD + col] = v;
-    C[col * LD + row] = v;
+    if (ti == tj && col < row) continue;
+    C[row * LD + col] = v[r];
+    C[col * LD + row] = v[r];
   }
 }
 
@@ -76,19 +113,24 @@ __device__ __forceinline__ void sl_unpack(const double* __restrict__ src, int n,
   __syncthreads();
 }
 
-// kLift / kPolish / kMu: the schedule of psd_large.hip (SignPsd)
+// Per-block adaptive schedule (sign_sched.h): every wavefront reduces the statistics of its own sub-tile (off-diagonal
+// sub-tiles count twice), the workgroup sums the NU partials in a fixed order after the barrier that the products need
+// anyway (+1 barrier per step between S Y and the combine), and every thread runs the same (uniform) state machine.
 template <int NP>
 __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
-                                                  double* smem, int lift_steps, int polish_steps, double lift_mu) {
+                                                  double* smem, int* steps_out) {
   using Cfg = SignLdsCfg<NP>;
   constexpr int LD = Cfg::LD;
   double* S = smem;
   double* Y = S + NP * LD;
   double* T = Y + NP * LD;
   __shared__ double red[64];
+  __shared__ double stat[3 * 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kk = lane >> 4;
   int ti, tj;
   sl_upper_tile<Cfg::NT>(wave, ti, tj);
+  const double wgt = ti == tj ? 1.0 : 2.0;
   sl_unpack<NP>(in, n, S, tid);
   // ||X||_1 = max column sum (symmetric: row sums), S <- X / ||X||_1
   if (tid < 64) {
@@ -103,17 +145,51 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);
   for (int e = tid; e < NP * LD; e += Cfg::THREADS) S[e] *= scale;
   __syncthreads();
-  for (int it = 0; it < lift_steps + polish_steps; ++it) {
-    const double mu = it < lift_steps ? lift_mu : 1.0;
-    sl_gemm<NP>(S, S, nullptr, 1.0, 0.0, Y, ti, tj, lane);                          // Y = S*S
+  SignSched sched;
+  bool last = false;
+  while (!last) {
+    const sl_v4f64 y = sl_mma<NP>(S, S, ti, tj, lane);                               // Y = S*S
+    sl_store<NP>(Y, y, ti, tj, lane);
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ti == tj && kk + 4 * r == r16) pa += y[r];
+      pb += y[r] * y[r];
+    }
+    pa = wave_sum(pa);
+    pb = wave_sum(pb) * wgt;
     __syncthreads();
-    sl_gemm<NP>(S, Y, S, -0.5 * mu * mu * mu, 1.5 * mu, T, ti, tj, lane);           // T = 1.5 mu S - 0.5 mu^3 S*Y
+    const sl_v4f64 z = sl_mma<NP>(S, Y, ti, tj, lane);                               // S*Y
+    const sl_v4f64 e = sl_tile<NP>(S, ti, tj, lane);
+    double pg = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const double d = e[r] - z[r]; pg += d * d; }
+    pg = wave_sum(pg) * wgt;
+    if (lane == 0) { stat[wave] = pa; stat[16 + wave] = pb; stat[32 + wave] = pg; }
     __syncthreads();
-    double* t = S; S = T; T = t;
+    double ta = 0.0, tb = 0.0, tg = 0.0;
+#pragma unroll
+    for (int w = 0; w < Cfg::NU; ++w) { ta += stat[w]; tb += stat[16 + w]; tg += stat[32 + w]; }
+    const double mu = sched.decide<false>(n, ta, tb, tg, last);
+    const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
+    sl_v4f64 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = alpha * z[r] + beta * e[r];                   // T = 1.5 mu S - 0.5 mu^3 S*Y
+    sl_store<NP>(T, t, ti, tj, lane);
+    __syncthreads();
+    double* sw = S; S = T; T = sw;
   }
+  if (steps_out && tid == 0) *steps_out = sched.steps;
   // P = 0.5 * (X0 + X0 * S): X0 is unpacked again (three matrices fit in LDS, four do not at NP = 64)
   sl_unpack<NP>(in, n, Y, tid);
-  sl_gemm<NP>(Y, S, Y, 0.5, 0.5, T, ti, tj, lane);
+  {
+    const sl_v4f64 z = sl_mma<NP>(Y, S, ti, tj, lane);
+    const sl_v4f64 e = sl_tile<NP>(Y, ti, tj, lane);
+    sl_v4f64 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = 0.5 * z[r] + 0.5 * e[r];
+    sl_store<NP>(T, t, ti, tj, lane);
+  }
   __syncthreads();
   const int len = n * (n + 1) / 2;
   bool bad = false;
@@ -195,13 +271,9 @@ __device__ __forceinline__ void sw32_store(double* __restrict__ M, int r16, int 
   }
 }
 
-// C(upper sub-tiles) = alpha * A * B + beta * E with A given by its fragments fa (symmetric A), B by its four sub-tiles
-// in accumulator layout yb[b][c] (row block b, column block c) and E read from LDS in accumulator layout at the very
-// end (short live range: the kernel sits at the 128-VGPR boundary)
-__device__ __forceinline__ void sw32_gemm_regB(const double (&fa)[8][2], const sl_v4f64 (&yb)[2][2], const double* __restrict__ E,
-                                               int r16, int kk, double alpha, double beta, sl_v4f64 (&out)[3]) {
-  constexpr int LD = SignWave32::LD;
-  sl_v4f64 acc[3];
+// acc(upper sub-tiles) = A * B with A given by its fragments fa (symmetric A) and B by its four sub-tiles in accumulator
+// layout yb[b][c] (row block b, column block c)
+__device__ __forceinline__ void sw32_mma_regB(const double (&fa)[8][2], const sl_v4f64 (&yb)[2][2], sl_v4f64 (&acc)[3]) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -213,16 +285,13 @@ __device__ __forceinline__ void sw32_gemm_regB(const double (&fa)[8][2], const s
       acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][0], yb[b][1][s], acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][1], yb[b][1][s], acc[2], 0, 0, 0);
     }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    out[0][r] = alpha * acc[0][r] + beta * E[(kk + 4 * r) * LD + r16];
-    out[1][r] = alpha * acc[1][r] + beta * E[(kk + 4 * r) * LD + 16 + r16];
-    out[2][r] = alpha * acc[2][r] + beta * E[(16 + kk + 4 * r) * LD + 16 + r16];
-  }
 }
 
+// Per-block adaptive schedule (sign_sched.h): the statistics come from registers the step already holds -- tr Y and
+// ||Y||_F^2 from the accumulators of Y = S S, ||S - S Y||_F^2 from the accumulators of S Y and the copy of S that the
+// combine step reads anyway -- three wave reductions per step next to 48 MFMAs.
 __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
-                                                     double* S, int lift_steps, int polish_steps, double lift_mu) {
+                                                     double* S, int* steps_out) {
   constexpr int LD = SignWave32::LD;
   const int lane = lane_id();
   const int r16 = lane & 15, kk = lane >> 4;
@@ -242,8 +311,9 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   for (int e = lane; e < 32 * LD; e += 64) S[e] *= scale;
   wave_fence();
   double f[8][2];
-  for (int it = 0; it < lift_steps + polish_steps; ++it) {
-    const double mu = it < lift_steps ? lift_mu : 1.0;
+  SignSched sched;
+  bool last = false;
+  while (!last) {
     sw32_frags(S, r16, kk, f);
     // Y = S S: the three upper sub-tiles on the matrix cores (24 MFMAs); the lower one, needed as a register operand
     // of S Y, is the transpose of Y(0,1): 4 LDS writes + 4 reads through a 16 x 17 tile instead of 8 more MFMAs (the
@@ -258,18 +328,42 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) scr[r16 * SignWave32::SCR_LD + kk + 4 * r] = y[0][1][r];   // element (kk+4r, r16) -> scr[r16][kk+4r]
+    // tr Y and ||Y||_F^2 (the off-diagonal sub-tile counts twice)
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (kk + 4 * r == r16) pa += y[0][0][r] + y[1][1][r];
+      pb += y[0][0][r] * y[0][0][r] + y[1][1][r] * y[1][1][r] + 2.0 * (y[0][1][r] * y[0][1][r]);
+    }
     wave_fence();
 #pragma unroll
     for (int r = 0; r < 4; ++r) y[1][0][r] = scr[(kk + 4 * r) * SignWave32::SCR_LD + r16];
     wave_fence();
-    // T = 1.5 mu S - 0.5 mu^3 S Y; the S term is re-read from LDS in accumulator layout (12 reads) rather than kept
-    // in 24 VGPRs across the loop: that is what keeps the kernel at 128 VGPRs (4 wavefronts per SIMD) without spills
+    // S Y on the three upper sub-tiles (24 MFMAs, no LDS traffic), then S in accumulator layout (12 LDS reads, short
+    // live range: that is what keeps the kernel at 128 VGPRs, 4 wavefronts per SIMD, without spills)
+    sl_v4f64 z[3], e[3];
+    sw32_mma_regB(f, y, z);
+    const double ta = wave_sum(pa), tb = wave_sum(pb);
+    sw32_dlayout(S, r16, kk, e);
+    double pg = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double d0 = e[0][r] - z[0][r], d1 = e[1][r] - z[1][r], d2 = e[2][r] - z[2][r];
+      pg += d0 * d0 + d2 * d2 + 2.0 * (d1 * d1);
+    }
+    const double tg = wave_sum(pg);
+    const double mu = sched.decide<false>(n, ta, tb, tg, last);
+    const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
     sl_v4f64 t[3];
-    sw32_gemm_regB(f, y, S, r16, kk, -0.5 * mu * mu * mu, 1.5 * mu, t);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[q][r] = alpha * z[q][r] + beta * e[q][r];
     wave_fence();                                                 // all reads of S are done
     sw32_store(S, r16, kk, t);
     wave_fence();
   }
+  if (steps_out && lane == 0) *steps_out = sched.steps;
   // P = 0.5 (X0 + S X0): A fragments of S from LDS, then LDS is reused for X0, whose sub-tiles are read in accumulator
   // layout (register B operand).  The lower sub-tile of X0 is read directly too (X0 is exactly symmetric in LDS).
   sw32_frags(S, r16, kk, f);
@@ -280,18 +374,22 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   xb[0][0] = x0[0]; xb[0][1] = x0[1]; xb[1][1] = x0[2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) xb[1][0][r] = S[(16 + kk + 4 * r) * LD + r16];
-  sw32_gemm_regB(f, xb, S, r16, kk, 0.5, 0.5, p);
+  sw32_mma_regB(f, xb, p);
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[q][r] = 0.5 * p[q][r] + 0.5 * x0[q][r];
   wave_fence();
   sw32_store(S, r16, kk, p);
   wave_fence();
   const int len = n * (n + 1) / 2;
   bool bad = false;
-  for (int e = lane; e < len; e += 64) {
+  for (int e2 = lane; e2 < len; e2 += 64) {
     int i, j;
-    tri_decode(e, i, j);
+    tri_decode(e2, i, j);
     const double v = S[j * LD + i];
     bad |= !(fabs(v) <= 1.7976931348623157e308);
-    out[e] = (i == j) ? v : v * kSqrt2;
+    out[e2] = (i == j) ? v : v * kSqrt2;
   }
   if (bad && fail) atomicAdd(fail, 1);
 }

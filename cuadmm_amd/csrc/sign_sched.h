@@ -1,0 +1,195 @@
+// Per-block adaptive schedule of the matrix-sign (Newton-Schulz) PSD projection.
+//
+// Round 1 ran a fixed worst-case schedule for every block: 36 "lift" steps S <- p(mu S), mu = 1.53, followed by 8 plain
+// steps (mu = 1), p(x) = 1.5 x - 0.5 x^3, which resolves every eigenvalue with |lambda| >= 1e-13 ||X||_1.  Typical ADMM
+// iterates need a quarter of that.  This header is the state machine every sign kernel (one wavefront per block, one
+// workgroup per block, batched-GEMM path) runs PER BLOCK, on quantities it already has in registers:
+//
+//     Y = S^2 :  a = tr Y,  b = ||Y||_F^2          =>  d2 = ||I - Y||_F^2 = n - 2a + b
+//     S Y     :  g2 = ||S - S Y||_F^2 = sum_i s_i^2 (1 - s_i^2)^2
+//
+// (s_i: eigenvalues of the current iterate; every iterate is a polynomial in X, so these sums are exact functions of the
+// spectrum.)  With "basin" eigenvalues (close to 1: u_i = 1 - s_i^2 small) and "unresolved" ones (v_i = s_i^2 small):
+//
+//     d2 - k            =  sum u^2 - 2 sum v + sum v^2           (k = number of unresolved = rint(d2))
+//     g2 - (d2 - k)     = -sum u^3 + 3 sum v - ...               => sum v ~ (g2 - (d2 - k)) / 3, polluted at 3rd order only
+//
+// Phases.  LIFT (mu = 1.53): unresolved eigenvalues grow by 2.295 per step, basin eigenvalues bounce inside [0.5, 1].
+// PROBE: two optimally scaled steps for the interval [0.5, 1] (mu = 1.309, 1.0845: basin error 0.5 -> 0.158 -> 0.011),
+// then plain steps; after j probe steps the basin error is E_j, so d2 / g2 reveal what is left:
+//     d2 < 0.5                      -> nothing unresolved (rigorous: every s_i^2 > 0.29): plain steps until g <= 2.3e-7,
+//                                      one more update, done (error after the update <= 0.375 g^2 = 2e-14);
+//     unresolved <= tol * G         -> what is left is below the resolution tol = 1e-13 relative to ||X||_1 (G = product of
+//                                      the slopes 1.5 mu so far = growth of a tiny eigenvalue): finish the basin and stop;
+//     unresolved visible (s_hat)    -> burst of lift steps that carries s_hat to the basin (no probing in between);
+//     below the probe's noise floor -> one more plain step (every probe step squares the floor).
+// The first step uses mu = 1.53 / t with t = min(1, ||Y||_F^(1/2)) >= spectral radius: a free tighter normalisation than
+// ||X||_1.  Any mu in [1, 1.53] keeps [0.5, 1] invariant, so the heuristics only cost steps, never accuracy: the exit
+// tests are the rigorous part, and kCap bounds the work (the result is then what the fixed schedule would have given).
+//
+// LAGGED variant (batched-GEMM path, psd_large.hip): there g2 of iterate k is only complete after the launch that
+// applies mu_k, so decisions at step k use (a_k, b_k) and g2 of iterate k-1 (plain phase: g_k <= 0.75 g_{k-1}^2).
+//
+// Compiles for host and device: tests/test_sign_schedule.py drives it on the CPU through cuadmm_sign_sched_simulate.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define CUADMM_SCHED_HD __host__ __device__ __forceinline__
+#else
+#define CUADMM_SCHED_HD inline
+#endif
+
+namespace cuadmm {
+
+struct SignSched {
+  static constexpr double kMu = 1.53;          // p(1.53) = 0.5
+  static constexpr double kSlope = 1.5 * 1.53; // growth of a tiny eigenvalue per lift step
+  static constexpr double kMuP1 = 1.309;       // sqrt(3 / (1 + l + l^2)), l = 0.5
+  static constexpr double kMuP2 = 1.0845;      // same for l = p(1.309 * 0.5) = 0.8417
+  static constexpr double kTol = 1e-13;        // resolution relative to ||X||_1 (the fixed schedule's)
+  static constexpr double kGExit = 2.3e-7;     // g at which one more plain update leaves an error <= 2e-14
+  static constexpr int kLift0 = 3;
+  static constexpr int kCap = 64;
+
+  double G = 1.0, gprev = -1.0, muprev = 1.0;
+  int k = 0, j = 0, fin = 0, steps = 0;
+  bool plain = false, plain_prev = false;
+
+  // basin error after j probe steps starting from [0.5, 1]
+  static CUADMM_SCHED_HD double probe_err(int j) {
+    return j <= 2 ? 0.011 : (j == 3 ? 1.8e-4 : (j == 4 ? 5e-8 : 4e-15));
+  }
+
+  // lifts that carry an eigenvalue of size sh to (just below) the basin, bounded by the resolution limit
+  CUADMM_SCHED_HD int burst_len(double sh) const {
+    int c = 0;
+    double x = sh > 1e-300 ? sh : 1e-300, g = G;
+    while (x * kSlope <= 0.45 && g * kTol < 0.5 && c < kCap) { x *= kSlope; g *= kSlope; ++c; }
+    return c > 1 ? c : 1;
+  }
+
+  // One decision per Newton-Schulz step.  n: true block size; a, b from Y = S^2 of the CURRENT iterate; g2: ||S - SY||_F^2
+  // of the current iterate (LAG = false) or of the previous one (LAG = true; ignored at the first step).
+  // Returns mu of this step; `last` = this update is the final one.
+  template <bool LAG>
+  CUADMM_SCHED_HD double decide(int n, double a, double b, double g2, bool& last) {
+    const double d2 = (double)n - 2.0 * a + b;
+    double g = sqrt(g2 > 0.0 ? g2 : 0.0);
+    if (LAG) g = gprev;                 // iterate k-1
+    double mu = 1.0;
+    last = false;
+    const bool was_plain = plain;
+    if (steps == 0) {
+      if (!(b > 0.0)) { last = true; }  // zero (or non-finite) block: one harmless update
+      else {
+        double t = sqrt(sqrt(b));
+        t = t < 1.0 ? t : 1.0;
+        mu = kMu / t;
+        k = kLift0 - 1;
+        j = 0;
+      }
+    } else if (fin > 0) {
+      --fin;
+      last = fin == 0;
+      if (!LAG && g <= kGExit) last = true;
+    } else if (plain) {
+      if (LAG) last = plain_prev && gprev >= 0.0 && 0.75 * gprev * gprev <= kGExit;
+      else last = g <= kGExit;
+    } else if (k > 0) {
+      mu = kMu; --k; j = 0;
+    } else if (j == 0) {
+      mu = kMuP1; j = 1;
+    } else if (j == 1) {
+      mu = kMuP2; j = 2;
+    } else if (d2 < 0.5) {
+      plain = true;
+      if (!LAG) last = g <= kGExit;
+    } else {
+      // Unresolved eigenvalues exist.  Rigorous facts (no assumption on the spectrum): every eigenvalue satisfies
+      // s (1 - s^2) <= g, i.e. it is either <= gb = g (1 + 1.5 g^2) or within gb / 2 of 1 (for g <= 0.3).
+      double gb = -1.0, eb = 0.0;          // bounds for the CURRENT iterate: unresolved <= gb, basin error <= eb
+      if (!LAG) {
+        if (g <= 0.3) { gb = g * (1.0 + 1.5 * g * g); eb = 0.5 * gb; }
+      } else if (j >= 3 && gprev >= 0.0 && gprev <= 0.3) {   // previous step was plain (mu = 1)
+        const double gq = gprev * (1.0 + 1.5 * gprev * gprev);
+        gb = 1.5 * gq;
+        eb = 0.375 * gq * gq;
+      }
+      const bool at_limit = G * kTol >= 0.5;             // whatever is still unresolved is below the resolution
+      if (at_limit || (gb >= 0.0 && gb <= kTol * G)) {
+        // finish the basin and stop: plain steps until the error bound is <= 1.15e-7, then the last update
+        int c;
+        if (gb >= 0.0) {
+          c = 1;
+          double e = eb;
+          while (e > 1.15e-7 && c < 8) { e = 1.5 * e * e; ++c; }
+        } else {
+          c = (5 - j > 0 ? 5 - j : 0) + 2;               // g carries no bound: basin error table + stragglers
+        }
+        fin = c - 1;
+        last = fin == 0;
+      } else {
+        // Heuristics from here on (they only cost steps): what is left, and how far below the basin is it?
+        const double kk = rint(d2), frac = d2 - kk;
+        const double e = probe_err(j), u = 2.0 * e;
+        double v, noise;
+        if (LAG) { v = -frac * 0.5; noise = (double)n * (0.5 * u * u + 1e-15); }
+        else { v = (g2 - frac) * (1.0 / 3.0); noise = (double)n * (u * u * u * (1.0 / 3.0) + 1e-15); }
+        v = v > 0.0 ? v : 0.0;
+        const bool exact = j >= 5 && gb >= 0.0;
+        if (frac > 0.05 || frac < -0.05 || j >= 6) {     // mid-range eigenvalues (s > 0.16) present: keep lifting
+          k = 2; mu = kMu; --k; j = 0;
+        } else if (exact || v > 2.0 * noise) {
+          k = burst_len(exact ? gb : sqrt(v + 2.0 * noise));
+          mu = kMu; --k; j = 0;
+        } else {
+          ++j;                                           // below the probe's noise floor: one more plain step
+        }
+      }
+    }
+    plain_prev = was_plain;
+    muprev = mu;
+    if (!LAG) gprev = g;
+    G *= 1.5 * mu;
+    ++steps;
+    if (steps >= kCap) last = true;
+    return mu;
+  }
+};
+
+// Scalar model of the iteration on a spectrum (the iteration acts on eigenvalues independently): used by the CPU tests
+// and by tools/sign_schedule_sim.py.  s[i] = |lambda_i| / ||X||_1 on entry, the sign estimates on exit.
+inline int sign_sched_simulate(double* s, int n, bool lag, double* err_out) {
+  SignSched st;
+  double orig_max_err = 0.0;
+  double* s0 = new double[n > 0 ? n : 1];
+  for (int i = 0; i < n; ++i) s0[i] = s[i];
+  bool last = false;
+  double g2_prev = 0.0;
+  while (!last) {
+    double a = 0, b = 0, g2 = 0;
+    for (int i = 0; i < n; ++i) {
+      const double y = s[i] * s[i], r = s[i] * (1.0 - y);
+      a += y; b += y * y; g2 += r * r;
+    }
+    double mu;
+    if (lag) {
+      st.gprev = st.steps == 0 ? -1.0 : sqrt(g2_prev);
+      mu = st.decide<true>(n, a, b, 0.0, last);
+    } else {
+      mu = st.decide<false>(n, a, b, g2, last);
+    }
+    g2_prev = g2;
+    for (int i = 0; i < n; ++i) s[i] = 1.5 * mu * s[i] - 0.5 * mu * mu * mu * s[i] * s[i] * s[i];
+  }
+  for (int i = 0; i < n; ++i) {
+    const double e = s0[i] * fabs(1.0 - s[i]) * 0.5;
+    orig_max_err = e > orig_max_err ? e : orig_max_err;
+  }
+  delete[] s0;
+  if (err_out) *err_out = orig_max_err;
+  return st.steps;
+}
+
+}  // namespace cuadmm

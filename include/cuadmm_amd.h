@@ -273,6 +273,13 @@ int cuadmm_op_mul_trans_batch(double* P, const double* T, const double* V, int n
  * blk[mat_num] sizes in blk.txt order; Xproj may alias Xb.  eig_fail (device int, may be
  * NULL) is incremented per block whose QL iteration hit its cap. */
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream);
+/* Same, also returning how many Newton-Schulz steps the adaptive matrix-sign schedule took per block (device int array of
+ * mat_num entries, 0 for blocks served by the eigensolver kernels); developer/diagnostic entry. */
+int cuadmm_op_psd_project_steps(const double* Xb, double* Xproj, const int* blk_host, int mat_num, int* steps_dev, void* stream);
+/* Host model of the per-block adaptive schedule of the matrix-sign projection (csrc/sign_sched.h), no device needed:
+ * s[n] = |eigenvalue| / ||X||_1 on entry, the sign estimates on exit; returns the number of steps the kernels would
+ * take on that spectrum and, in *max_err_out, max_i s_i(0) |1 - s_i| / 2 (projection error relative to ||X||_1). */
+int cuadmm_sign_sched_simulate(double* s, int n, int lagged, double* max_err_out);
 /* perform_permutation (src/kernels/permutation.cu:12-33): v1[perm[i]] = v2[i] */
 int cuadmm_op_permute(double* v1, const double* v2, const int* perm, int n, void* stream);
 /* get_normA (src/kernels/sparse_matrix_norm.cu:11-44): per CSC column norm=max(1,||col||), col/=norm */

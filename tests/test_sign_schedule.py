@@ -1,0 +1,101 @@
+"""CPU tests of the per-block adaptive matrix-sign schedule (cuadmm_amd/csrc/sign_sched.h).
+
+The Newton-Schulz iteration acts on the eigenvalues of a block independently, so the state machine the kernels run can
+be exercised on spectra alone through the host model exported by the C ABI (no device).  What is pinned here:
+termination inside the cap, the resolution contract (every eigenvalue with |lambda| >= 1e-13 ||X||_1 ends with its sign
+resolved to <= 1e-13 relative error of the projection; smaller ones contribute at most their own size), and that typical
+ADMM spectra take a quarter of the fixed 44-step schedule of round 1.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cuadmm_amd
+
+
+def _run(spec, lagged=False):
+    lib = cuadmm_amd.load()
+    s = np.ascontiguousarray(np.abs(spec), dtype=np.float64).copy()
+    err = C.c_double(0.0)
+    steps = lib.cuadmm_sign_sched_simulate(s.ctypes.data_as(C.c_void_p), int(s.size), int(lagged), C.byref(err))
+    return steps, err.value, s
+
+
+def _spectra(rng):
+    out = {}
+    n = 32
+    w = rng.standard_normal(n)
+    out["generic"] = w / (2.5 * np.abs(w).max())
+    g = np.logspace(0, -10, n) * np.where(np.arange(n) % 2, 1, -1)
+    out["graded"] = g / 1.3
+    r = w.copy(); r[:20] = 0.0
+    out["rank_deficient_exact"] = r / (2.0 * np.abs(r).max())
+    r2 = w.copy(); r2[:20] = 1e-17 * rng.standard_normal(20)
+    out["rank_deficient_roundoff"] = r2 / (2.0 * np.abs(r2).max())
+    t = w.copy(); t[0] = 1e-13; t[1] = -1e-13; t[2] = 3e-12
+    out["pm1e-13"] = t / (1.5 * np.abs(t).max())
+    out["identity"] = np.ones(n) / 1.0
+    out["zero"] = np.zeros(n)
+    out["single"] = np.array([0.7])
+    m = np.concatenate([[0.8, 0.3], 10.0 ** rng.uniform(-16, -11, 8)])   # moment-matrix like (PlanarHand blocks)
+    out["moment_like"] = m
+    out["clustered_small"] = np.concatenate([[1.0], np.full(31, 1e-6)]) / 1.2
+    return out
+
+
+@pytest.mark.parametrize("lagged", [False, True])
+def test_schedule_terminates_and_meets_the_resolution_contract(lagged):
+    rng = np.random.default_rng(7)
+    for name, spec in _spectra(rng).items():
+        steps, err, s = _run(spec, lagged)
+        assert 1 <= steps <= 64, (name, steps)
+        # projection error relative to ||X||_1: resolved eigenvalues to roundoff, unresolved ones <= their own size
+        assert err <= 2.5e-13, (name, steps, err)
+        big = np.abs(spec) >= 1e-11
+        assert np.all(np.abs(1.0 - s[big]) <= 1e-12), (name, steps, s[big])
+
+
+def test_typical_spectra_take_a_fraction_of_the_fixed_schedule():
+    rng = np.random.default_rng(11)
+    tot = 0
+    for _ in range(300):
+        w = rng.standard_normal(32)
+        w /= np.abs(w).sum() * 0.35 + np.abs(w).max()      # 1-norm style over-estimate of the spectral radius
+        steps, err, _ = _run(w)
+        assert err <= 1e-13
+        tot += steps
+    assert tot / 300 <= 16.0          # fixed schedule of round 1: 44
+
+
+def test_exactly_rank_deficient_blocks_stop_early():
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal(32)
+    w[:24] = 0.0
+    steps, err, _ = _run(w / (3 * np.abs(w).max()))
+    assert steps <= 14 and err <= 1e-13
+
+
+def test_random_spectra_fuzz():
+    rng = np.random.default_rng(5)
+    worst = 0
+    for trial in range(2000):
+        n = int(rng.integers(1, 65))
+        kind = trial % 4
+        if kind == 0:
+            w = rng.standard_normal(n)
+        elif kind == 1:
+            w = 10.0 ** rng.uniform(-18, 0, n) * rng.choice([-1, 1], n)
+        elif kind == 2:
+            w = rng.standard_normal(n); w[rng.random(n) < 0.5] = 0.0
+        else:
+            w = np.concatenate([rng.uniform(0.2, 1, n // 2 + 1), 10.0 ** rng.uniform(-15, -3, n)])[:n]
+        scale = np.abs(w).max() * rng.uniform(1.0, 6.0)
+        if scale == 0:
+            scale = 1.0
+        for lag in (False, True):
+            steps, err, _ = _run(w / scale, lag)
+            assert steps <= 64
+            assert err <= 2.5e-13, (trial, lag, steps, err)
+            worst = max(worst, steps)
+    assert worst <= 64
