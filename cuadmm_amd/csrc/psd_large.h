@@ -7,14 +7,17 @@
 namespace cuadmm {
 
 struct SignPsd {
-  static constexpr int kLiftSteps = 36;      // scaled Newton-Schulz steps (mu = kLiftMu): resolves |lambda| >= 1e-13 ||X||_1
-  static constexpr int kPolishSteps = 8;     // plain steps: quadratic convergence from [0.5, 1]
-  static constexpr double kLiftMu = 1.53;    // p(mu) = 0.5: converged eigenvalues never drop below 0.5
-  struct Group { int N = 0, begin = 0, count = 0; };
+  struct Group { int N = 0, begin = 0, count = 0, pred = 0; };   // pred: steps the previous projection needed
   std::vector<Group> groups;                 // same padded size N, bounded workspace
   int* d_ids = nullptr;                      // block ids, group after group
   int* d_steps = nullptr;                    // not owned; when set: Newton-Schulz steps taken per block
   double *X0 = nullptr, *S = nullptr, *Y = nullptr, *T = nullptr, *colsum = nullptr, *scale = nullptr;
+  void* d_state = nullptr;                   // 2 x SignDevState per member of the largest group (adaptive schedule, sign_sched.h)
+  void* d_done = nullptr;                    // SignDone per member
+  double* d_part = nullptr;                  // per-tile partial sums of the schedule statistics (p1 | p2)
+  size_t part_half = 0;
+  int* d_group = nullptr;                    // [members not finished, largest step count] of the group in flight
+  int* h_group = nullptr;                    // pinned host copy (polled between chunks of steps)
   int build(const int* blk, const std::vector<int>& members);
   void release();
   int project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);

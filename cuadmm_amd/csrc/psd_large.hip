@@ -11,12 +11,18 @@
 // v_mfma_f64_16x16x4_f64: that is what CDNA4 is good at, while the sequential rotation chains of a tridiagonal
 // eigensolver (5 million dependent rotations at n = 2000) are what it is bad at.
 //
-// Schedule (fixed, no host synchronisation, so the whole projection is asynchronous on the stream):
-//   * kLiftSteps = 36 steps with mu = 1.53: eigenvalues in (0, 1] stay in (0, 1] and never fall below p(1.53) = 0.5
-//     once they are there (the gap between the + and - invariant subspaces stays wide: stable), while small ones
-//     grow by 1.5 mu = 2.3 per step instead of 1.5, so |lambda| >= 1e-13 ||X||_1 is resolved after 36 steps;
-//   * kPolishSteps = 8 plain steps (mu = 1): quadratic convergence from [0.5, 1] to 1 within roundoff.
-//   An eigenvalue still below resolution contributes an error <= |lambda| <= 1e-13 ||X||_1 to the projection.
+// Schedule: per block, adaptive, decided ON THE DEVICE (sign_sched.h, lagged variant) -- still no host synchronisation, the
+// projection stays stream-ordered.  The products leave tr Y, ||Y||_F^2 and ||S - S Y||_F^2 as per-tile partial sums in
+// fixed slots (plain stores: no atomics, no fences inside a launch); the NEXT launch sums the slots in slot order -- every
+// workgroup of the S Y product redundantly when there are few tiles, a one-workgroup kernel between the two products when
+// there are many -- and runs the state machine, so the sums and with them every decision are bit-reproducible.  The state
+// is double-buffered by step parity (readers and the one writer of a launch never touch the same copy).  The launches of a
+// finished block return at once.
+//   * lift steps (mu = 1.53): eigenvalues in (0, 1] stay in (0, 1] and never fall below p(1.53) = 0.5 once they are
+//     there (the gap between the + and - invariant subspaces stays wide: stable), small ones grow by 2.295 per step;
+//   * probe / plain steps: quadratic convergence from [0.5, 1] to 1 within roundoff; the statistics tell whether
+//     anything is left unresolved and how far below the basin it is.
+//   An eigenvalue below the resolution 1e-13 ||X||_1 contributes an error <= |lambda| to the projection.
 //
 // Every iterate is a polynomial in X, hence symmetric, and all products are of commuting symmetric matrices.  The
 // GEMM kernel uses that twice: the left operand is read transposed (row tile of A = rows k of A, coalesced, no LDS
@@ -34,12 +40,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "common.h"
 #include "device_util.h"
 #include "psd_device.h"
 #include "psd_large.h"
+#include "sign_sched.h"
+#include "wave_reduce.h"
 
 namespace cuadmm {
 
@@ -51,15 +60,100 @@ constexpr int LG_TM = 64;   // measured on MI355X: 64x64 tiles (4 workgroups per
 // MIRROR: blockIdx.x enumerates the tiles (by <= bx) of the upper triangle; C[row][col] and C[col][row] are both written.
 // TM = 64: 4 MFMA tiles per wavefront (16 flop per byte of operand traffic); TM = 32: one MFMA tile per wavefront, four
 // times as many workgroups -- for matrices whose 64 x 64 tiles would leave most of the 256 CUs idle (N ~ 1000: 136 tiles).
-template <bool MIRROR, int TM, int BK>
+// Per-member device state of the adaptive schedule, double-buffered by step parity: step k reads version k at
+// st[(k & 1) * count + member] and its single writer stores version k + 1 into the other copy.
+struct SignDevState {
+  SignSched sched;
+  double mu;                // of the step that produced this version
+  int n;                    // true block size
+};
+// written once per projection (by the writer of the last step): a launch of step j skips the member iff done_at <= j, which
+// reads the same whether a concurrent workgroup of step done_at - 1 sees the old or the new value
+struct SignDone { int done_at; int steps; };
+struct SignArgs {
+  SignDevState* st;         // 2 * count
+  SignDone* done;           // count
+  double* p1;               // [member][tile][2]: tr Y, ||Y||_F^2 of the current step
+  double* p2;               // [parity][member][tile]: ||S - S Y||_F^2 of the step with that parity
+  int* group;               // group[0]: members not finished, group[1]: largest step count (polled by the host)
+  int count, step;
+};
+
+// Sums the statistics' slots in a fixed order (all 256 threads), runs the schedule's decision for step sa.step on thread 0
+// and returns mu to every thread; `writer` stores version step + 1 of the state (exactly one workgroup per member does).
+__device__ __forceinline__ double lg_reduce_decide(const SignArgs& sa, int member, int ntiles, bool writer, double* red) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int par = sa.step & 1;
+  const double* p1 = sa.p1 + (size_t)member * 2 * (size_t)ntiles;
+  const double* p2 = sa.p2 + ((size_t)(par ^ 1) * sa.count + member) * (size_t)ntiles;
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+  for (int t = tid; t < ntiles; t += 256) {
+    q0 += p1[2 * t];
+    q1 += p1[2 * t + 1];
+    if (sa.step > 0) q2 += p2[t];
+  }
+  q0 = wave_sum(q0);
+  q1 = wave_sum(q1);
+  q2 = wave_sum(q2);
+  __syncthreads();
+  if (lane == 0) { red[wave] = q0; red[4 + wave] = q1; red[8 + wave] = q2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double a = (red[0] + red[1]) + (red[2] + red[3]);
+    const double b = (red[4] + red[5]) + (red[6] + red[7]);
+    const double g2 = (red[8] + red[9]) + (red[10] + red[11]);
+    SignDevState v = sa.st[(size_t)par * sa.count + member];
+    v.sched.gprev = sa.step == 0 ? -1.0 : sqrt(g2 > 0.0 ? g2 : 0.0);
+    bool last;
+    v.mu = v.sched.decide<true>(v.n, a, b, 0.0, last);
+    red[12] = v.mu;
+    if (writer) {
+      sa.st[(size_t)(par ^ 1) * sa.count + member] = v;
+      if (last) {
+        sa.done[member].steps = v.sched.steps;
+        sa.done[member].done_at = sa.step + 1;
+        atomicMax(sa.group + 1, v.sched.steps);
+        atomicSub(sa.group, 1);
+      }
+    }
+  }
+  __syncthreads();
+  return red[12];
+}
+
+// one workgroup per member: the decision of step sa.step as a launch of its own (between Y = S S and S Y) for matrices with
+// so many tiles that summing the slots in every workgroup of the S Y product would cost more than a launch
+__global__ __launch_bounds__(256) void lg_decide_kernel(SignArgs sa, int ntiles) {
+  __shared__ double red[16];
+  const int member = (int)blockIdx.x;
+  if (sa.done[member].done_at <= sa.step) return;
+  (void)lg_reduce_decide(sa, member, ntiles, true, red);
+}
+
+// ROLE 0: plain product.  Roles of the sign iteration (MIRROR only; member = blockIdx.y):
+// ROLE 1: C = A*A (Y = S S), leaves the slots tr Y, ||Y||_F^2;
+// ROLE 2: C = 1.5 mu E - 0.5 mu^3 A*B (T from S, Y), mu decided here by every workgroup (lg_reduce_decide), leaves the
+//         slots ||S - S Y||_F^2;   ROLE 4: the same with mu read from the state (lg_decide_kernel ran in between);
+// ROLE 3: the final product: B = the buffer that holds the last iterate (Bb after an even number of steps, B2b after
+//         an odd one).
+template <bool MIRROR, int TM, int BK, int ROLE>
 __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
                                                           double alpha, double beta, const double* __restrict__ Eb,
-                                                          double* __restrict__ Cb, int sb) {
+                                                          double* __restrict__ Cb, int sb, SignArgs sg, const double* __restrict__ B2b) {
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
   constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * BK * LDS ? TM * (TM + 1) : 2 * BK * LDS) : 2 * BK * LDS;
   __shared__ double smem[SMEM];
+  __shared__ double red[16];
+  const int member = (int)blockIdx.y;
+  if (ROLE == 1 || ROLE == 2 || ROLE == 4) {
+    if (sg.done[member].done_at <= sg.step) return;   // uniform over the workgroup: before any barrier
+  }
+  if (ROLE == 3) {
+    const int steps = sg.done[member].done_at <= sg.step ? sg.done[member].steps : sg.step;   // sg.step = steps enqueued
+    if (steps & 1) Bb = B2b;
+  }
   double* As = smem;
   double* Bs = smem + BK * LDS;
   double* Ct = smem;                // TM x (TM+1) transposed output tile (MIRROR), after the k loop
@@ -93,6 +187,17 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
   const int wy = wave >> 1, wx = wave & 1;
   const int row0 = by * TM, col0 = bx * TM;
   const int r16 = lane & 15, kk = lane >> 4;
+  const int nbt = N / TM, ntiles = nbt * (nbt + 1) / 2;
+  if (ROLE == 2) {
+    const double mu = lg_reduce_decide(sg, member, ntiles, bx == 0 && by == 0, red);
+    alpha = -0.5 * mu * mu * mu;
+    beta = 1.5 * mu;
+  }
+  if (ROLE == 4) {
+    const double mu = sg.st[(size_t)((sg.step & 1) ^ 1) * sg.count + member].mu;
+    alpha = -0.5 * mu * mu * mu;
+    beta = 1.5 * mu;
+  }
 
   lg_v4f64 acc[NTW][NTW];
 #pragma unroll
@@ -153,6 +258,7 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
   // epilogue: D[row = (l>>4) + 4*reg][col = l&15] per 16x16 tile.  The mirrored copy goes through LDS so that it is
   // stored row-wise too (a direct transposed store puts the 16 lanes of a fragment 8N bytes apart: one L2 channel).
   if (MIRROR) __syncthreads();   // everyone is done with As / Bs: Ct overlays them
+  double p0 = 0.0, p1 = 0.0;     // ROLE 1: tr Y, ||Y||_F^2; ROLE 2 / 4: ||S - S Y||_F^2 (this tile's share)
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
@@ -163,7 +269,15 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
         const int row = row0 + lrow, col = col0 + lcol;
         const size_t idx = (size_t)row * N + col;
         double c = alpha * acc[i][j][r];
-        if (E) c += beta * E[idx];
+        if (E) {
+          const double ev = E[idx];
+          c += beta * ev;
+          if (ROLE == 2 || ROLE == 4) { const double d = ev - acc[i][j][r]; p0 += d * d; }
+        }
+        if (ROLE == 1) {
+          p1 += acc[i][j][r] * acc[i][j][r];
+          if (row == col) p0 += acc[i][j][r];
+        }
         if (!MIRROR || col >= row) C[idx] = c;        // diagonal tiles: the upper triangle decides
         if (MIRROR) Ct[lcol * (TM + 1) + lrow] = c;
       }
@@ -173,6 +287,27 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
 #pragma unroll 4
     for (int p = tid / TM; p < TM; p += 256 / TM)     // original column -> row of the mirrored tile
       if (by != bx || q < p) C[(size_t)(col0 + p) * N + row0 + q] = Ct[p * (TM + 1) + q];
+  }
+  if (ROLE == 1 || ROLE == 2 || ROLE == 4) {
+    // this tile's partial sums -> its fixed slot (read by the next launch)
+    const double w = (by == bx) ? 1.0 : 2.0;                 // an off-diagonal tile stands for its mirror image too
+    p0 = wave_sum(p0);
+    p1 = wave_sum(p1);
+    __syncthreads();
+    if (lane == 0) { red[wave] = p0; red[4 + wave] = p1; }
+    __syncthreads();
+    if (tid == 0) {
+      const int slot = bx * (bx + 1) / 2 + by;
+      const double s0 = (red[0] + red[1]) + (red[2] + red[3]);
+      const double s1 = (red[4] + red[5]) + (red[6] + red[7]);
+      if (ROLE == 1) {
+        double* p = sg.p1 + ((size_t)member * ntiles + slot) * 2;
+        p[0] = s0;
+        p[1] = s1 * w;
+      } else {
+        sg.p2[((size_t)(sg.step & 1) * sg.count + member) * (size_t)ntiles + slot] = s0 * w;
+      }
+    }
   }
 }
 
@@ -211,21 +346,25 @@ __global__ void lg_pack_kernel(const double* __restrict__ src, const int* __rest
   }
   if (bad && fail) atomicAdd(fail, 1);   // non-finite input: same counter as the QL sweep cap of the eigensolver kernels
 }
-// column sums of |X| (X symmetric: = row sums), then scale[m] = 1 / max_c colsum (0 for a zero block)
+// column sums of |X| (X symmetric: = row sums) in LG_CS_ROWS row chunks (blockIdx.z), then scale[m] = 1 / max_c colsum
+// (0 for a zero block).  One thread per column over ALL rows takes 0.49 ms at N = 2048 (8 workgroups on 256 CUs).
+constexpr int LG_CS_ROWS = 32;
 __global__ __launch_bounds__(256) void lg_colsum_kernel(const double* __restrict__ Mb, int N, double* __restrict__ colsum) {
   const double* M = Mb + (size_t)blockIdx.y * N * N;
   const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int rows = (N + LG_CS_ROWS - 1) / LG_CS_ROWS, r0 = (int)blockIdx.z * rows, r1 = r0 + rows < N ? r0 + rows : N;
   if (col < N) {
     double s = 0.0;
-    for (int r = 0; r < N; ++r) s += fabs(M[(size_t)r * N + col]);
-    colsum[(size_t)blockIdx.y * N + col] = s;
+    for (int r = r0; r < r1; ++r) s += fabs(M[(size_t)r * N + col]);
+    colsum[((size_t)blockIdx.y * LG_CS_ROWS + blockIdx.z) * N + col] = s;
   }
 }
 __global__ __launch_bounds__(256) void lg_scale_kernel(const double* __restrict__ colsum, int N, double* __restrict__ scale) {
   __shared__ double red[256];
   double m = 0.0;
   for (int c = (int)threadIdx.x; c < N; c += 256) {
-    const double v = colsum[(size_t)blockIdx.x * N + c];
+    double v = 0.0;
+    for (int z = 0; z < LG_CS_ROWS; ++z) v += colsum[((size_t)blockIdx.x * LG_CS_ROWS + z) * N + c];   // fixed order
     m = (v > m || !(v == v)) ? v : m;   // NaN propagates (flagged by the pack kernel)
   }
   red[threadIdx.x] = m;
@@ -262,30 +401,55 @@ __global__ __launch_bounds__(256) void lg_diff_kernel(const double* __restrict__
 
 static int lg_pad(int n) { return (n + LG_TM - 1) / LG_TM * LG_TM; }
 
-static int lg_gemm(bool mirror, int N, int count, const double* A, const double* B, double alpha, double beta, const double* E,
-                   double* C, hipStream_t st) {
+static bool lg_small_tiles(bool mirror, int N, int count) {
   // 32 x 32 tiles when the 64 x 64 tiling would leave the chip under-filled (CUADMM_LG_TILE=32|64 forces one)
   static const int tile_force = getenv("CUADMM_LG_TILE") ? atoi(getenv("CUADMM_LG_TILE")) : 0;
   const int nb64 = N / 64;
   const long long tiles64 = (long long)(mirror ? nb64 * (nb64 + 1) / 2 : nb64 * nb64) * count;
-  const bool small_tiles = tile_force ? tile_force == 32 : (mirror && N >= 256 && tiles64 < 1300);   // measured: better up to N ~ 3000
-  const int nb = small_tiles ? N / 32 : nb64;
-  if (mirror && count == 1 && nb >= 16) {
+  return tile_force ? tile_force == 32 : (mirror && N >= 256 && tiles64 < 1300);   // measured: better up to N ~ 3000
+}
+
+template <int ROLE>
+static int lg_gemm_mirror(int N, int count, const double* A, const double* B, double alpha, double beta, const double* E, double* C,
+                          hipStream_t st, const SignArgs& sa, const double* B2) {
+  const bool small_tiles = lg_small_tiles(true, N, count);
+  const int nb = small_tiles ? N / 32 : N / 64;
+  if (count == 1 && nb >= 16) {
     const int sb = (nb + 7) / 8;                               // 8x8-tile super-blocks per direction
-    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
-    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb);
-  } else if (mirror) {
-    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
-    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32, ROLE>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb, sa, B2);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16, ROLE>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb, sa, B2);
   } else {
-    hipLaunchKernelGGL((lg_gemm_sym_kernel<false, 64, 16>), dim3(nb * nb, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0);
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32, ROLE>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0, sa, B2);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16, ROLE>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0, sa, B2);
   }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
 
 int large_gemm_sym(int N, const double* A, const double* B, double alpha, double beta, const double* E, double* C, hipStream_t st) {
-  return lg_gemm(false, N, 1, A, B, alpha, beta, E, C, st);
+  hipLaunchKernelGGL((lg_gemm_sym_kernel<false, 64, 16, 0>), dim3((N / 64) * (N / 64), 1), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0,
+                     SignArgs{}, (const double*)nullptr);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// one thread per member: fresh schedule state (version 0)
+__global__ void lg_state_init_kernel(SignArgs sa, const int* __restrict__ ids, const int* __restrict__ bn) {
+  const int m = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (m == 0) { sa.group[0] = sa.count; sa.group[1] = 0; }
+  if (m >= sa.count) return;
+  SignDevState s;
+  s.sched = SignSched();
+  s.mu = 1.0;
+  s.n = bn[ids[m]];
+  sa.st[m] = s;
+  sa.done[m].done_at = 0x7fffffff;
+  sa.done[m].steps = 0;
+}
+__global__ void lg_steps_out_kernel(SignArgs sa, const int* __restrict__ ids, int* __restrict__ steps) {
+  const int m = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (m >= sa.count) return;
+  steps[ids[m]] = sa.done[m].done_at <= sa.step ? sa.done[m].steps : sa.step;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,7 +476,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
       g.count = (int)std::min<size_t>((size_t)chunk, kv.second.size() - b);
       for (int i = 0; i < g.count; ++i) ids.push_back(kv.second[b + i]);
       max_elems = std::max(max_elems, (size_t)g.count * N * N);
-      max_cols = std::max(max_cols, (size_t)g.count * N);
+      max_cols = std::max(max_cols, (size_t)g.count * N * LG_CS_ROWS);
       max_count = std::max(max_count, g.count);
       groups.push_back(g);
     }
@@ -325,14 +489,24 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   CUADMM_HIP_TRY(hipMalloc(&T, sizeof(double) * max_elems));
   CUADMM_HIP_TRY(hipMalloc(&colsum, sizeof(double) * max_cols));
   CUADMM_HIP_TRY(hipMalloc(&scale, sizeof(double) * (size_t)max_count));
+  CUADMM_HIP_TRY(hipMalloc(&d_state, sizeof(SignDevState) * 2 * (size_t)max_count));
+  CUADMM_HIP_TRY(hipMalloc(&d_done, sizeof(SignDone) * (size_t)max_count));
+  CUADMM_HIP_TRY(hipMalloc(&d_group, sizeof(int) * 2));
+  CUADMM_HIP_TRY(hipHostMalloc(&h_group, sizeof(int) * 2, hipHostMallocDefault));
+  size_t max_part = 0;
+  for (const Group& g : groups) max_part = std::max(max_part, (size_t)g.count * 2 * (size_t)(g.N / 32) * (size_t)(g.N / 32 + 1) / 2);
+  CUADMM_HIP_TRY(hipMalloc(&d_part, sizeof(double) * 2 * max_part));   // p1 | p2 (two parities)
+  part_half = max_part;
   return CUADMM_OK;
 }
 
 void SignPsd::release() {
   if (graph_exec) { hipError_t e = hipGraphExecDestroy(graph_exec); (void)e; graph_exec = nullptr; }
-  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale})
+  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done})
     if (p) { hipError_t e = hipFree(p); (void)e; }
-  d_ids = nullptr;
+  if (d_group) { hipError_t e = hipFree(d_group); (void)e; d_group = nullptr; }
+  if (h_group) { hipError_t e = hipHostFree(h_group); (void)e; h_group = nullptr; }
+  d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr;
   X0 = S = Y = T = colsum = scale = nullptr;
   groups.clear();
 }
@@ -366,8 +540,14 @@ int SignPsd::project(const double* in, double* out, const long long* boff, const
 }
 
 int SignPsd::project_launch(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
-  static const int debug = getenv("CUADMM_PSD_DEBUG") ? std::max(1, atoi(getenv("CUADMM_PSD_DEBUG"))) : 0;   // 2: per-step updates
-  for (const Group& g : groups) {
+  static const int debug = getenv("CUADMM_PSD_DEBUG") ? std::max(1, atoi(getenv("CUADMM_PSD_DEBUG"))) : 0;
+  static const int max_steps = getenv("CUADMM_PSD_SIGN_MAXSTEPS") ? std::max(1, atoi(getenv("CUADMM_PSD_SIGN_MAXSTEPS"))) : SignSched::kCap;
+  static const int decide_force = !getenv("CUADMM_LG_DECIDE") ? 0 : (std::string(getenv("CUADMM_LG_DECIDE")) == "kernel" ? 2 : 1);
+  static const bool sync_ok = !(getenv("CUADMM_PSD_SIGN_SYNC") && atoi(getenv("CUADMM_PSD_SIGN_SYNC")) == 0);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st) { hipError_t e = hipStreamIsCapturing(st, &cap); (void)e; }
+  const bool poll = sync_ok && cap == hipStreamCaptureStatusNone;
+  for (Group& g : groups) {
     const int N = g.N, cnt = g.count;
     const size_t per = (size_t)N * N;
     const int* ids = d_ids + g.begin;
@@ -375,41 +555,70 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     const auto t0 = std::chrono::steady_clock::now();
     CUADMM_HIP_TRY(hipMemsetAsync(X0, 0, sizeof(double) * per * (size_t)cnt, st));
     hipLaunchKernelGGL(lg_unpack_kernel, dim3(gx, cnt), dim3(256), 0, st, in, ids, boff, bn, N, X0);
-    hipLaunchKernelGGL(lg_colsum_kernel, dim3((N + 255) / 256, cnt), dim3(256), 0, st, X0, N, colsum);
+    hipLaunchKernelGGL(lg_colsum_kernel, dim3((N + 255) / 256, cnt, LG_CS_ROWS), dim3(256), 0, st, X0, N, colsum);
     hipLaunchKernelGGL(lg_scale_kernel, dim3(cnt), dim3(256), 0, st, colsum, N, scale);
     hipLaunchKernelGGL(lg_scaled_copy_kernel, dim3(gx, cnt), dim3(256), 0, st, X0, S, per, scale);
     CUADMM_HIP_TRY(hipGetLastError());
+    SignArgs sa{};
+    sa.st = static_cast<SignDevState*>(d_state);
+    sa.done = static_cast<SignDone*>(d_done);
+    sa.p1 = d_part;
+    sa.p2 = d_part + part_half;
+    sa.group = d_group;
+    sa.count = cnt;
+    sa.step = 0;
+    hipLaunchKernelGGL(lg_state_init_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, bn);
     double* s = S;
     double* t = T;
     int rc;
-    for (int it = 0; it < kLiftSteps + kPolishSteps; ++it) {
-      const double mu = it < kLiftSteps ? kLiftMu : 1.0;
-      // Y = S*S ; T = 1.5 mu S - 0.5 mu^3 S*Y
-      if ((rc = lg_gemm(true, N, cnt, s, s, 1.0, 0.0, nullptr, Y, st))) return rc;
-      if ((rc = lg_gemm(true, N, cnt, s, Y, -0.5 * mu * mu * mu, 1.5 * mu, s, t, st))) return rc;
-      if (debug >= 2 && it >= kLiftSteps) {
-        hipLaunchKernelGGL(lg_diff_kernel, dim3(cnt), dim3(256), 0, st, s, t, per, colsum);
-        std::vector<double> h((size_t)cnt);
-        CUADMM_HIP_TRY(hipMemcpyAsync(h.data(), colsum, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, st));
-        CUADMM_HIP_TRY(hipStreamSynchronize(st));
-        double mx = 0;
-        for (double v : h) mx = std::max(mx, std::sqrt(v));
-        fprintf(stderr, "[psd debug]   N=%d step %d  max ||S_new - S||_F = %.3e\n", N, it + 1, mx);
+    // The decision of a step sums the tiles' slots: inside every workgroup of the S Y product when they are few, as a launch
+    // of its own when that would cost more than a launch (CUADMM_LG_DECIDE=inline|kernel forces one).
+    const int nbt = lg_small_tiles(true, N, cnt) ? N / 32 : N / 64, ntiles = nbt * (nbt + 1) / 2;
+    const bool decide_kernel = decide_force ? decide_force == 2 : ntiles > 300;
+    // Steps are enqueued in chunks; between chunks the host polls "members not finished" (8 bytes, one stream
+    // synchronisation of ~20 us) instead of enqueueing the worst case kCap: a launch for a finished group costs ~5 us,
+    // i.e. 0.5 ms per projection when the blocks stop after 16 of 64 steps.  The first chunk is the previous projection's
+    // step count + 2 (ADMM iterates change slowly), so there is normally exactly one poll.  Inside a graph capture (or
+    // with CUADMM_PSD_SIGN_SYNC=0) the whole cap is enqueued and nothing synchronises.
+    int enq = 0;
+    int chunk = poll ? std::min(max_steps, g.pred > 0 ? g.pred + 2 : 24) : max_steps;
+    while (enq < max_steps) {
+      for (int it = 0; it < chunk && enq < max_steps; ++it, ++enq) {
+        // Y = S*S ; [decision] ; T = 1.5 mu S - 0.5 mu^3 S*Y ; finished members return at once
+        sa.step = enq;
+        if ((rc = lg_gemm_mirror<1>(N, cnt, s, s, 1.0, 0.0, nullptr, Y, st, sa, nullptr))) return rc;
+        if (decide_kernel) {
+          hipLaunchKernelGGL(lg_decide_kernel, dim3(cnt), dim3(256), 0, st, sa, ntiles);
+          if ((rc = lg_gemm_mirror<4>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr))) return rc;
+        } else {
+          if ((rc = lg_gemm_mirror<2>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr))) return rc;
+        }
+        std::swap(s, t);
       }
-      std::swap(s, t);
+      if (!poll) break;
+      CUADMM_HIP_TRY(hipMemcpyAsync(h_group, d_group, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      if (h_group[0] <= 0) { g.pred = h_group[1]; break; }
+      chunk = 6;
     }
-    // P = 0.5 * (X0 + X0 * S)
-    if ((rc = lg_gemm(true, N, cnt, X0, s, 0.5, 0.5, X0, Y, st))) return rc;
+    // P = 0.5 * (X0 + X0 * S_final); S_final is in S after an even number of steps, in T after an odd one
+    sa.step = enq;
+    if ((rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T))) return rc;
     hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
+    if (d_steps) hipLaunchKernelGGL(lg_steps_out_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, d_steps);
     CUADMM_HIP_TRY(hipGetLastError());
     if (debug) {
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      const int steps = kLiftSteps + kPolishSteps;
+      std::vector<SignDone> hs((size_t)cnt);
+      CUADMM_HIP_TRY(hipMemcpy(hs.data(), sa.done, sizeof(SignDone) * (size_t)cnt, hipMemcpyDeviceToHost));
+      double steps = 0;
+      int smax = 0;
+      for (const SignDone& x : hs) { steps += x.steps; smax = std::max(smax, x.steps); }
       const int nb = N / LG_TM;
-      const double flops = (2.0 * steps + 1.0) * 2.0 * (double)N * LG_TM * LG_TM * (nb * (nb + 1) / 2) * cnt;
-      fprintf(stderr, "[psd debug] sign path: %d blocks padded to N=%d: %d steps, %.2f ms, %.1f TFLOP/s fp64 MFMA (upper-triangle tiles)\n",
-              cnt, N, steps, ms, flops / ms * 1e-9);
+      const double flops = (2.0 * steps + cnt) * 2.0 * (double)N * LG_TM * LG_TM * (nb * (nb + 1) / 2);
+      fprintf(stderr, "[psd debug] sign path: %d blocks padded to N=%d: steps mean %.1f max %d (%d enqueued, decision %s), %.2f ms, %.1f TFLOP/s fp64 MFMA (upper-triangle tiles)\n",
+              cnt, N, steps / cnt, smax, enq, decide_kernel ? "kernel" : "inline", ms, flops / ms * 1e-9);
     }
   }
   return CUADMM_OK;
