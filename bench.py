@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""Benchmark of the SDP-ADMM iteration hot path on MI355X (contract: see the task brief / DESIGN.md).
+"""Benchmark of the SDP-ADMM iteration hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 200 --warmup 20                       # the headline line (BASELINE configs[1])
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config c3            # max-cut, one block n = 2000 (BASELINE configs[2])
+    python bench.py --config c4            # 100 000 mixed moment-SOS blocks (BASELINE configs[3]; --scaling strong at N > 1)
+    ... --sharding allreduce               # force the general sharded path: RCCL all-reduce of [A X | sums | A(S-C)] (2m+2
+                                           # doubles) before every replicated host y-solve, instead of owned constraints
 
-Workload (BASELINE.json configs[1]): synthetic strictly-feasible SDP with 10 000 PSD blocks of 32x32 PER GPU
-(5 constraints/block, 8 nnz each, dense C; cuadmm_amd.synthetic.config_c2), fp64, ADMM-only iterations
-(switch_admm=0), stop_tol=0 so exactly K iterations run.  A "step" is one ADMM iteration over one
-10 000-block shard: at N GPUs the job is ONE SDP with N*10 000 blocks sharded by block index (weak scaling),
-with an RCCL all-reduce of the A*svec(X) partials before each host y-solve; value = N * iterations / time.
-Prints one JSON line on rank 0.
+Workload c2 (default): synthetic strictly-feasible SDP with 10 000 PSD blocks of 32x32 PER GPU (5 constraints/block, 8 nnz
+each, dense C; cuadmm_amd.synthetic.config_c2), fp64, ADMM-only iterations (switch_admm=0), stop_tol=0 so exactly K
+iterations run.  A "step" is one ADMM iteration over one 10 000-block shard: at N GPUs the job is ONE SDP with N*10 000
+blocks sharded by block index (weak scaling); value = N * iterations / time.  The C2 problem is block-diagonal (every
+constraint touches one block), so by default each rank keeps its own constraints and the ranks exchange only the four
+scalars of the stopping test, folded into one small all-reduce per iteration; `--sharding allreduce`
+measures the general path the north star names (A*svec(X) all-reduce + replicated solve) on the same problem.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -30,51 +36,56 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak (256 CU x 128 FLOP/clk x 2.4 GHz)
 
 
-def cpu_baseline(prob, n_iters, threads):
-    """The oracle (numpy restatement of solver.cu) with the reference's eig_cpu layout: per-block LAPACK
-    dsyevd on `threads` host threads over contiguous block ranges (duo_solver.cu:344-371,598-606)."""
-    from concurrent.futures import ThreadPoolExecutor
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:                                   # pragma: no cover
-        threadpool_limits = None
+def cpu_baseline(prob, threads, budget_s=20.0):
+    """The reference's eig_cpu path beside the GPU number (baseline only, never the target): per-block LAPACK dsyevd on
+    `threads` host threads with the reference's static contiguous split (oracle/cpu_eig_baseline.c restating
+    include/cuadmm/eig_cpu.h:31-51 and src/duo_solver.cu:344-371,598-606), BLAS threads = 1.  Two numbers on a bounded
+    sample: projection-only blocks/s, and whole ADMM iterations/s of the numpy oracle with that projection."""
+    from oracle import cpu_baseline as cb
     from oracle import cuadmm_oracle as orc
 
-    n = BLOCK_N
-    ii, jj = np.tril_indices(n)
-    scale_in = np.where(ii == jj, 1.0, orc.SQRT2INV)
-    scale_out = np.where(ii == jj, 1.0, orc.SQRT2)
-    seg = n * (n + 1) // 2
-    pool = ThreadPoolExecutor(max_workers=threads)
+    blk = np.asarray(prob.blk, np.int32)
+    rng = np.random.default_rng(0)
+    xb = rng.standard_normal(int(prob.vec_len))
+    # warm-up + choice of engine on a slice of the blocks (LAPACK from scipy's OpenBLAS vs the scalar tridiagonal-QL port)
+    nslice = max(1, min(blk.size, 2000 if blk.max() <= 64 else 1))
+    Ls = int(np.sum(blk[:nslice].astype(np.int64) * (blk[:nslice] + 1) // 2))
+    best = None
+    for eng in ("lapack", "ql"):
+        if eng == "ql" and blk.max() > 512:
+            continue                                       # the scalar port is far off LAPACK's blocked code at n ~ 2000
+        cb.psd_project(xb[:Ls], blk[:nslice], threads, engine=eng)
+        _, secs = cb.psd_project(xb[:Ls], blk[:nslice], threads, engine=eng)
+        if best is None or secs < best[1]:
+            best = (eng, secs)
+    eng = best[0]
+    per_block = best[1] / nslice
+    n_proj = blk.size if per_block * blk.size <= budget_s / 4 else max(1, int(budget_s / 4 / per_block))
+    Lp = int(np.sum(blk[:n_proj].astype(np.int64) * (blk[:n_proj] + 1) // 2))
+    _, secs = cb.psd_project(xb[:Lp], blk[:n_proj], threads, engine=eng)
+    blocks_per_s = n_proj / secs
+    proj_s_full = blk.size / blocks_per_s
 
-    def chunk(x2d):
-        M = np.zeros((x2d.shape[0], n, n))
-        v = x2d * scale_in[None, :]
-        M[:, jj, ii] = v
-        M[:, ii, jj] = v
-        w, V = np.linalg.eigh(M)                         # LAPACK dsyevd, the reference's eig_cpu.h:31-51
-        P = (V * np.maximum(w, 0.0)[:, None, :]) @ np.swapaxes(V, 1, 2)
-        return P[:, jj, ii] * scale_out[None, :]
+    def eig_fn(_bidx, x):
+        return cb.psd_project(x, blk, threads, engine=eng)[0]
 
-    def eig_fn(_bidx, xb):
-        x2d = xb.reshape(-1, seg)
-        bounds = np.linspace(0, x2d.shape[0], threads + 1).astype(int)
-        parts = list(pool.map(lambda k: chunk(x2d[bounds[k]:bounds[k + 1]]), range(threads)))
-        return np.concatenate(parts).reshape(-1)
-
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    try:
-        s = orc.OracleSolver(eig_fn=eig_fn).init(prob.vec_len, prob.con_num, prob.At_col_ptrs, prob.At_row_ids,
-                                                 prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals, prob.blk)
-        s.solve(1, 0.0, 0, 50, 100, 0, 1.05)             # warm-up iteration
-        t0 = time.perf_counter()
-        s.solve(n_iters, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
-        dt = time.perf_counter() - t0
-    finally:
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
-        pool.shutdown()
-    return n_iters / dt, dt
+    s = orc.OracleSolver(eig_fn=eig_fn).init(prob.vec_len, prob.con_num, prob.At_col_ptrs, prob.At_row_ids,
+                                             prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals, prob.blk)
+    t0 = time.perf_counter()
+    s.solve(1, 0.0, 0, 50, 100, 0, 1.05)                   # first iteration (also measures the per-iteration cost)
+    t_it = time.perf_counter() - t0
+    n_iters = int(max(1, min(20, (budget_s * 0.7) / max(t_it, 1e-3))))
+    t0 = time.perf_counter()
+    s.solve(n_iters, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
+    dt = time.perf_counter() - t0
+    return {"value": n_iters / dt, "unit": "iters/s", "cores": threads, "kind": "port",
+            "nproc": os.cpu_count(),
+            "projection_blocks_per_s": blocks_per_s, "projection_ms": proj_s_full * 1e3,
+            "engine": "LAPACK dsyevd (scipy OpenBLAS, BLAS threads = 1) + DGEMM" if eng == "lapack" else
+                      "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native)",
+            "sample": "%d ADMM iterations of the same problem on the numpy oracle with the per-block projection in C on %d "
+                      "host threads (static contiguous split as duo_solver.cu:344-371), %.1f s; projection-only: %d blocks in %.2f s"
+                      % (n_iters, threads, dt, n_proj, secs)}
 
 
 def pmc_traffic(kernel_substr):
@@ -95,17 +106,52 @@ def pmc_traffic(kernel_substr):
     return best
 
 
+def issued_mfma_flops(blk, steps):
+    """fp64 flops the projection kernels issue on the matrix cores for the measured per-block step counts
+    (v_mfma_f64_16x16x4_f64 = 2048 flop): n <= 32: 48 MFMA per step + 24 (psd_sign_lds.h, SignWave32); n <= 48 / 64:
+    6 / 10 upper sub-tiles x NP/4 MFMA per product (psd_sign_lds.h); larger: upper-triangle tiles of the batched GEMMs
+    (psd_large.hip).  Blocks served by the register eigensolver (n <= 16) issue 0 here (their rebuild is a few MFMAs)."""
+    blk = np.asarray(blk, np.int64)
+    steps = np.asarray(steps, np.float64)
+    fl = np.zeros(blk.size)
+    m = (blk > 16) & (blk <= 32)
+    fl[m] = (steps[m] * 48 + 24) * 2048.0
+    m = (blk > 32) & (blk <= 48)
+    fl[m] = (steps[m] * 2 + 1) * 6 * 12 * 2048.0
+    m = (blk > 48) & (blk <= 64)
+    fl[m] = (steps[m] * 2 + 1) * 10 * 16 * 2048.0
+    m = blk > 64
+    if m.any():
+        N = (blk[m] + 63) // 64 * 64
+        tm = np.where((N >= 256) & (N <= 3000), 32, 64)      # lg_small_tiles (single large matrix / small groups)
+        nb = N // tm
+        fl[m] = (steps[m] * 2 + 1) * 2.0 * N * tm * tm * (nb * (nb + 1) // 2)
+    return float(fl.sum())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks-per-gpu", type=int, default=BLOCKS_PER_GPU)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--blocks-per-gpu", type=int, default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
+    ap.add_argument("--sharding", choices=["owned", "allreduce"], default="owned")
     ap.add_argument("--mode", choices=["admm", "sgs"], default="admm")
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=12)       # ~12 s of host work on 30 threads
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"c2": 200, "c3": 50, "c4": 100}[args.config]
+    if args.warmup is None:
+        args.warmup = {"c2": 20, "c3": 5, "c4": 10}[args.config]
+    if args.scaling is None:
+        args.scaling = "weak" if args.config == "c2" else "strong"
+    if args.blocks_per_gpu is None:
+        args.blocks_per_gpu = {"c2": BLOCKS_PER_GPU, "c3": 1, "c4": 100000}[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,9 +160,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
+    if args.sharding == "allreduce":
+        os.environ["CUADMM_NO_LOCAL_CONSTRAINTS"] = "1"     # engine.hip: keep every constraint on every rank
 
     # CUADMM_BENCH_FORCE_DIST=1 exercises the torch.distributed/RCCL hook with a single rank (transport check)
     force_dist = os.environ.get("CUADMM_BENCH_FORCE_DIST") == "1"
+    replicas = args.config == "c3"                          # one block: nothing to shard -- N independent replicas
     dist = None
     torch = None
     if world > 1 or force_dist:
@@ -130,17 +179,32 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import cuadmm_amd
-    from cuadmm_amd.synthetic import config_c2
+    from cuadmm_amd import synthetic
 
     lib = cuadmm_amd.load()
     if lib.cuadmm_device_count() < 1:
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
-    prob = config_c2(args.blocks_per_gpu * world, BLOCK_N)
-    solver = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=rank, world=world, profile=2, force_comm=force_dist)
+    n_units = args.blocks_per_gpu * (world if args.scaling == "weak" else 1)
+    if args.config == "c2":
+        prob = synthetic.config_c2(n_units, BLOCK_N)
+        workload = "BASELINE configs[1]: %d PSD blocks of %dx%d %s, m=5/blk, nnz=8/constraint, dense C" % (
+            args.blocks_per_gpu, BLOCK_N, BLOCK_N, "per GPU" if args.scaling == "weak" else "in total")
+    elif args.config == "c4":
+        prob = synthetic.config_c4(n_units)
+        workload = "BASELINE configs[3]: %d moment-SOS blocks of sizes {3,6,10,15,28,45} %s, m=3/blk" % (
+            args.blocks_per_gpu, "per GPU" if args.scaling == "weak" else "in total")
+    else:
+        prob = synthetic.config_c3(2000)
+        workload = "BASELINE configs[2]: max-cut relaxation, one PSD block n=2000 (N independent replicas at N GPUs)"
+    workload += ", " + ("ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM")
+    eng_world, eng_rank = (1, 0) if replicas else (world, rank)
+    use_comm = (world > 1 and not replicas) or force_dist
+    solver = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, profile=2,
+                                  force_comm=force_dist, psd_steps=True)
 
     keep = []
-    if world > 1 or force_dist:
+    if use_comm:
         if args.comm == "rccl":
             uid = ctypes.create_string_buffer(128)
             if rank == 0:
@@ -164,8 +228,10 @@ def main():
             solver.set_allreduce(allreduce)
             keep.append(allreduce)
 
+    t_init = time.perf_counter()
     solver.init_problem(cuadmm_amd.Problem(prob.vec_len, prob.con_num, prob.blk, prob.At_col_ptrs, prob.At_row_ids,
                                            prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals))
+    t_init = time.perf_counter() - t_init
     switch = 0 if args.mode == "admm" else 10 ** 9
 
     def sync():
@@ -188,52 +254,79 @@ def main():
     assert solver.info_iter_num == args.steps
     prof = solver.profile()
     st = solver.state()
+    steps_blk = solver.psd_steps()
+    _, _, kb, ke = solver.shard()
+    blk_local = np.asarray(prob.blk)[kb:ke]
+
+    # per-class breakdown (hipEvent pairs around every kernel class + host timers), outside the timed region
+    breakdown = None
+    if not args.no_breakdown:
+        cuadmm_amd._lib.check(lib.cuadmm_set_option(solver._h, b"profile", 1.0))
+        solver.reset_profile()
+        nb = max(5, min(50, args.steps))
+        solver.solve(nb, 0.0, 0, 50, 100, switch, 1.05, if_first=False)
+        sync()
+        breakdown = {k: v["ms"] / nb for k, v in solver.profile().items() if v["launches"]}
 
     if rank == 0:
-        L_local = args.blocks_per_gpu * BLOCK_N * (BLOCK_N + 1) // 2
         psd = prof["psd_project"]
         psd_ms = psd["ms"] / max(psd["launches"], 1)
+        L_local = int(np.sum(blk_local.astype(np.int64) * (blk_local + 1) // 2))
         alg_bytes = 16.0 * L_local                         # read Xb + write Xproj, 8 B each per svec element
-        achieved = alg_bytes / (psd_ms * 1e-3) / 1e9 if psd_ms > 0 else 0.0
-        nominal_flops = (32.0 / 3.0) * args.blocks_per_gpu * BLOCK_N ** 3
-        issued_flops = args.blocks_per_gpu * (44 * 48 + 24) * 2048.0     # psd_sign_lds.h: SignWave32, SignPsd schedule
+        nominal_flops = (32.0 / 3.0) * float(np.sum(blk_local.astype(np.float64) ** 3))
+        issued_flops = issued_mfma_flops(blk_local, steps_blk)
+        sign_blocks = blk_local > 16
+        kernel = {"c2": "psd_sign_wave32_kernel (fused svec -> adaptive matrix-sign projection -> svec, one wavefront per block)",
+                  "c3": "lg_gemm_sym_kernel (adaptive matrix-sign projection of the n=2000 block as batched upper-triangle fp64-MFMA GEMMs)",
+                  "c4": "psd_project phase: psd_sign_lds_kernel<48> (n=45) | psd_sign_wave32_kernel (n=28) | psd_small_reg_kernel (n<=15), concurrent streams"}[args.config]
+        kname = {"c2": "psd_sign_wave32_kernel", "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_lds_kernel"}[args.config]
+        per_s = psd_ms * 1e-3
+        shard_iters = (world if (args.scaling == "weak" or replicas) else 1) * args.steps
         out = {
-            "metric": "ADMM iters/sec, 10k x 32-blk synthetic per GPU (+ PSD-proj TFLOP/s in roofline)",
-            "value": world * args.steps / dt,
-            "unit": "iters/s (one iteration over a 10k-block shard; N shards advance together)",
+            "metric": {"c2": "ADMM iters/sec, 10k x 32-blk synthetic per GPU (+ PSD-proj TFLOP/s in roofline)",
+                       "c3": "ADMM iters/sec, max-cut n=2000 single block (+ PSD-proj TFLOP/s in roofline)",
+                       "c4": "ADMM iters/sec, 100k mixed moment-SOS blocks (+ PSD-proj TFLOP/s in roofline)"}[args.config],
+            "value": shard_iters / dt,
+            "unit": "iters/s (one iteration over a shard; N shards advance together)" if args.scaling == "weak" or replicas
+                    else "iters/s of the whole job",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (args.scaling == "weak" or replicas) else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d PSD blocks of %dx%d per GPU, m=5/blk, nnz=8/constraint, dense C, %s"
-                                   % (args.blocks_per_gpu, BLOCK_N, BLOCK_N, "ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM"),
-                       "blocks_total": args.blocks_per_gpu * world, "vec_len": int(prob.vec_len), "con_num": int(prob.con_num),
-                       "sharding": ("blocks by index; every C2 constraint touches one block, so each rank keeps its own constraints and "
-                                    "the ranks all-reduce 4 scalars per iteration (DESIGN.md section 5)") if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
-            # Dominant kernel: psd_sign_wave32_kernel (one wavefront per 32x32 block, matrix-sign iteration on
-            # v_mfma_f64_16x16x4_f64).  It is MFMA bound.  `achieved` uses the ALGORITHMIC flops of SURVEY 8d
-            # (10.67 n^3 per block, what an eigendecomposition-based projection needs); the flops the kernel really
-            # issues on the matrix cores (44 steps x 48 MFMA + 24, 2048 flop each) are reported beside it.
-            "roofline": {"kernel": "psd_sign_wave32_kernel (fused svec -> matrix-sign projection -> svec)", "bound": "mfma",
-                         "achieved": nominal_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
+            "config": {"workload": workload,
+                       "blocks_total": int(np.asarray(prob.blk).size) * (world if replicas else 1), "vec_len": int(prob.vec_len), "con_num": int(prob.con_num),
+                       "sharding": "single GPU" if world == 1 and not force_dist else (
+                           "replicas only (one block does not shard)" if replicas else (
+                               "blocks by index; all-reduce of [A X | sums | A(S-C)] (2m+2 doubles) before every replicated host y-solve"
+                               if args.sharding == "allreduce" else
+                               "blocks by index; constraints owned by the rank whose blocks they touch when the problem is block-diagonal "
+                               "(one all-reduce of 4 scalars per iteration), else the 2m+2 all-reduce (DESIGN.md section 5)")),
+                       "comm": args.comm if use_comm else None, "init_s": t_init},
+            # `achieved` uses the ALGORITHMIC flops of SURVEY 8d (10.67 n^3 per block, what an eigendecomposition-based
+            # projection needs) over the measured launch time of the projection; the flops the kernels really issue on the
+            # matrix cores for the measured per-block Newton-Schulz step counts are reported beside it.
+            "roofline": {"kernel": kernel, "bound": "mfma",
+                         "achieved": nominal_flops / per_s / 1e12 if per_s > 0 else 0.0,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (nominal_flops / (psd_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if psd_ms > 0 else 0.0,
-                         "traffic": pmc_traffic("psd_sign_wave32_kernel"), "avg_launch_ms": psd_ms,
+                         "frac": (nominal_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
+                         "traffic": pmc_traffic(kname), "avg_launch_ms": psd_ms,
                          "algorithmic_flops_per_launch": nominal_flops,
-                         "mfma_issued_tflops": issued_flops / (psd_ms * 1e-3) / 1e12 if psd_ms > 0 else 0.0,
-                         "mfma_pipe_util": (issued_flops / (psd_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if psd_ms > 0 else 0.0,
-                         "hbm_gbs": achieved, "algorithmic_bytes_per_launch": alg_bytes,
+                         "mfma_issued_tflops": issued_flops / per_s / 1e12 if per_s > 0 else 0.0,
+                         "mfma_pipe_util": (issued_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
+                         "newton_schulz_steps": {"mean": float(steps_blk[sign_blocks].mean()) if sign_blocks.any() else 0.0,
+                                                 "max": int(steps_blk.max()) if steps_blk.size else 0,
+                                                 "note": "per-block adaptive schedule (csrc/sign_sched.h); round 1 ran a fixed 44"},
+                         "hbm_gbs": alg_bytes / per_s / 1e9 if per_s > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64 matrix-core bound (DESIGN.md section 4); traffic = FETCH_SIZE*2 + WRITE_SIZE from the "
                                  "committed rocprofv3 PMC passes (profiles/), algorithmic bytes 16 B per svec element",
-                         "blocks_per_s": args.blocks_per_gpu / (psd_ms * 1e-3) if psd_ms > 0 else 0.0},
+                         "blocks_per_s": blk_local.size / per_s if per_s > 0 else 0.0},
             "final_state": {k: st[k] for k in ("errRp", "errRd", "relgap", "sig")},
         }
+        if breakdown is not None:
+            out["breakdown_ms_per_iter"] = breakdown      # psd_project / aty_xb / post_proj / spmv_A / copies / comm / host / tail_solve
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(30, os.cpu_count() or 1)          # the reference's cpu_eig_thread_num default (main.cu:11)
-            v, secs = cpu_baseline(prob, args.cpu_iters, threads)
-            out["cpu_baseline"] = {"value": v, "unit": "iters/s", "cores": threads, "kind": "port",
-                                   "sample": "%d ADMM iterations of the same 10k x 32 problem on the numpy oracle, "
-                                             "per-block LAPACK dsyevd on %d threads (%.1f s)" % (args.cpu_iters, threads, secs)}
+            threads = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(prob, threads, args.cpu_budget_s)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

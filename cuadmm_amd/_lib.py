@@ -57,6 +57,7 @@ PROTOTYPES = {
     "cuadmm_set_XyS": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "cuadmm_get_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "cuadmm_get_shard": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_int_p, c_int_p]),
+    "cuadmm_get_psd_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "cuadmm_sign_sched_simulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
     "cuadmm_op_psd_project_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cuadmm_get_info_iter_num": (C.c_int, [C.c_void_p]),
@@ -123,7 +124,17 @@ def load(rebuild=False):
     if _lib is not None and not rebuild:
         return _lib
     if rebuild or not os.path.exists(LIB_PATH):
-        _build.build(force=rebuild)
+        # several ranks of one job may get here together (torch.distributed.run on a fresh checkout): one builds under an
+        # exclusive file lock, the others wait and then find the library
+        import fcntl
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        with open(LIB_PATH + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if rebuild or not os.path.exists(LIB_PATH):
+                    _build.build(force=rebuild)
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it

@@ -149,6 +149,10 @@ double now_s() {
 }
 
 // Minimal fork-join pool (mutex + condition variables, generation counter).  run(f) executes f(0..T-1), f(0) on the caller.
+// The pool is a process-wide singleton and run() is a single-occupancy fork-join (job / pending / gen belong to the one
+// call in flight), so concurrent callers (two engines driven from two host threads, tests/test_gpu_sharded.py) are
+// serialised by `run_mu`: the caller that finds the pool busy runs its chunks inline instead of waiting -- the chunks'
+// results do not depend on which thread runs them.
 class HostPool {
  public:
   explicit HostPool(int threads) : T(std::max(1, threads)) {
@@ -162,6 +166,11 @@ class HostPool {
   int size() const { return T; }
   void run(const std::function<void(int)>& f) {
     if (T == 1) { f(0); return; }
+    std::unique_lock<std::mutex> occupancy(run_mu, std::try_to_lock);
+    if (!occupancy.owns_lock()) {
+      for (int i = 0; i < T; ++i) f(i);
+      return;
+    }
     { std::lock_guard<std::mutex> lk(mu); job = &f; pending = T - 1; ++gen; }
     cv_start.notify_all();
     f(0);
@@ -191,7 +200,7 @@ class HostPool {
   }
   const int T;
   std::vector<std::thread> workers;
-  std::mutex mu;
+  std::mutex mu, run_mu;
   std::condition_variable cv_start, cv_done;
   const std::function<void(int)>* job = nullptr;
   unsigned gen = 0;

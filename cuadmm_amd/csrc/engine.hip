@@ -123,7 +123,7 @@ RcclApi g_rccl;
 
 struct cuadmm_solver {
   // options
-  int device = 0, verbose = 1, rank = 0, world = 1, profile = 0, force_comm = 0;
+  int device = 0, verbose = 1, rank = 0, world = 1, profile = 0, force_comm = 0, psd_steps = 0;
   cuadmm_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   void* rccl_comm = nullptr;
@@ -148,6 +148,7 @@ struct cuadmm_solver {
   // communicator, m_full / cons_local / sv_off / blk_off map back to the caller's numbering.
   bool local_mode = false;
   int comm_world = 1, comm_rank = 0, m_full = 0, blk_off = 0;
+  int L_caller = 0, nblk_caller = 0;   // the caller's vec_len / mat_num (cuadmm_get_dims reports the caller's numbering)
   long long sv_off = 0;
   std::vector<int> cons_local;
   double ov_nb = 0, ov_nc = 0, ov_nb2 = 0;
@@ -177,6 +178,7 @@ struct cuadmm_solver {
   SpmvLongRows A_long;         // rows of A much longer than the average (trace / all-ones constraints)
   DevBuf<double> At_v, A_v;
   DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
+  DevBuf<int> steps_d;
   // Where the kernels write [A*X | sums | A*(S-C)]: the device buffer out_d when it has to be all-reduced, otherwise the
   // pinned host buffer h_out itself through its device mapping -- the results cross PCIe as the kernels produce them and
   // fetch_out is a stream synchronisation without a copy.
@@ -200,6 +202,7 @@ struct cuadmm_solver {
         if (ev1[k][j]) { hipError_t e = hipEventDestroy(ev1[k][j]); (void)e; }
       }
     if (st) { hipError_t e = hipStreamDestroy(st); (void)e; }
+    if (rccl_comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(rccl_comm); rccl_comm = nullptr; }
   }
 
   bool prof_on(int k) const { return profile == 1 || (profile == 2 && k == K_PSD); }
@@ -375,6 +378,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "world") s->world = (int)value;
   else if (k == "profile") s->profile = (int)value;
   else if (k == "force_comm") s->force_comm = (int)value;   // call the collective hook even when world == 1 (testing)
+  else if (k == "psd_steps") s->psd_steps = (int)value;       // record the sign kernels' step count per block (cuadmm_get_psd_steps)
   else if (k == "graph") {}
   else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
   return CUADMM_OK;
@@ -485,6 +489,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       s->local_mode = true;
       s->comm_world = s->world; s->comm_rank = s->rank;
       s->m_full = con_num; s->cons_local = cons; s->sv_off = lo; s->blk_off = first[me];
+      s->L_caller = vec_len; s->nblk_caller = mat_num;
       s->ov_nb = nb; s->ov_nc = nc; s->ov_nb2 = nb2;
       s->world = 1; s->rank = 0;
       if (s->comm_rank != 0) s->verbose = 0;      // one console table per job
@@ -547,14 +552,43 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     else rc = cuadmm_aat_create_split(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, max_k, &s->fac);
     if (rc) return rc;
     double t1 = wall_s();
-    const int tk = cuadmm_aat_tail_k(s->fac);
+    int tk = cuadmm_aat_tail_k(s->fac);
     if (tk > 0) {
       const int64_t* srp; const int* sci; const double* sv;
       rc = cuadmm_aat_tail_schur(s->fac, &srp, &sci, &sv);
       if (!rc) rc = s->tail.build_from_schur(reinterpret_cast<const long long*>(srp), sci, sv, tk, s->st);
+      // The tail is applied as an explicit inverse built without pivoting (tail_solve.hip); with (nearly) dependent
+      // constraints the pivots approach the regularisation 1e-15 and inv(L22) loses accuracy silently.  Probe it: x ->
+      // S x on the host (S = the Schur complement the tail factors, lower triangle with diagonal), solve on the GPU,
+      // compare.  On failure fall back to the host-only factor (CHOLMOD-style substitution, no explicit inverse).
+      bool tail_ok = rc == CUADMM_OK;
+      if (rc == CUADMM_OK) {
+        std::vector<double> x((size_t)tk), z((size_t)tk, 0.0);
+        unsigned long long seed = 0x9e3779b97f4a7c15ull;
+        for (int i = 0; i < tk; ++i) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; x[i] = 0.5 + (double)(seed >> 11) * (1.0 / 9007199254740992.0); }
+        for (int i = 0; i < tk; ++i)
+          for (int64_t q = srp[i]; q < srp[i + 1]; ++q) {
+            const int j = sci[q];
+            z[i] += sv[q] * x[j];
+            if (j != i) z[j] += sv[q] * x[i];
+          }
+        rc = s->tail.solve(z.data(), s->st);
+        double err = 0;
+        for (int i = 0; i < tk; ++i) err = std::max(err, std::fabs(z[i] - x[i]));
+        tail_ok = rc == CUADMM_OK && err <= 1e-6;          // x in [0.5, 1.5]: absolute = relative
+        if (!tail_ok && rc == CUADMM_OK && s->verbose)
+          printf("\n A*A^T factor: the GPU tail of size %d fails its probe solve (error %.1e): falling back to the host-only factor\n", tk, err);
+      }
       cuadmm_aat_tail_schur_release(s->fac);
-      if (rc) return rc;
+      if (rc && rc != CUADMM_ERR_FACTOR) return rc;
+      if (!tail_ok) {
+        s->tail.release();
+        cuadmm_aat_free(s->fac);
+        s->fac = nullptr;
+        if ((rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac))) return rc;
+      }
     }
+    tk = s->tail.k;
     if (s->verbose) {
       const long long lnz = (long long)cuadmm_aat_factor_nnz(s->fac);
       if (tk > 0)
@@ -595,6 +629,12 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->blk_local.assign(blk + s->blk_begin, blk + s->blk_end);
   rc = s->plan.build(s->blk_local.data(), (int)s->blk_local.size());
   s->plan.overlap = true;
+  if (!rc && s->psd_steps && !s->blk_local.empty()) {
+    if ((rc = s->steps_d.alloc(s->blk_local.size()))) return rc;
+    CUADMM_HIP_TRY(hipMemset(s->steps_d.p, 0, sizeof(int) * s->blk_local.size()));
+    s->plan.d_steps = s->steps_d.p;
+    s->plan.sign.d_steps = s->steps_d.p;
+  }
   s->plan.sign.allow_graph = true;   // same buffers every iteration: replay the sign-path launch sequence from a hipGraph
   if (rc) return rc;
 
@@ -641,9 +681,13 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->norm_borg = 1 + std::sqrt(nb);
   s->norm_Corg = 1 + std::sqrt(nc);
   std::vector<double> bfull(m, 0.0);
+  std::vector<char> seen_b((size_t)m, 0);
   double nb2 = 0;
   for (int i = 0; i < b_nnz; ++i) {
     if (b_idx[i] < 0 || b_idx[i] >= m) { set_error("init: b index %d out of range", b_idx[i]); return CUADMM_ERR_INVALID; }
+    // a sparse vector with a repeated index has no defined value (the norms would count both entries, the vector one)
+    if (seen_b[b_idx[i]]) { set_error("init: b index %d appears twice", b_idx[i]); return CUADMM_ERR_INVALID; }
+    seen_b[b_idx[i]] = 1;
     double v = b_vals[i] / s->normA[b_idx[i]];             // sparse_dense.cu:11-20
     bfull[b_idx[i]] = v;
     nb2 += v * v;
@@ -665,9 +709,14 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   }
   {
     std::vector<double> Cl((size_t)L, 0.0);
+    std::vector<char> seen_C((size_t)L, 0);
     for (int i = 0; i < C_nnz; ++i) {
       if (C_idx[i] < 0 || C_idx[i] >= vec_len) { set_error("init: C index %d out of range", C_idx[i]); return CUADMM_ERR_INVALID; }
-      if (C_idx[i] >= s->sv_begin && C_idx[i] < s->sv_end) Cl[C_idx[i] - s->sv_begin] = C_vals[i] * ics;
+      if (C_idx[i] >= s->sv_begin && C_idx[i] < s->sv_end) {
+        if (seen_C[C_idx[i] - s->sv_begin]) { set_error("init: C index %d appears twice", C_idx[i]); return CUADMM_ERR_INVALID; }
+        seen_C[C_idx[i] - s->sv_begin] = 1;
+        Cl[C_idx[i] - s->sv_begin] = C_vals[i] * ics;
+      }
     }
     if ((rc = s->C.from(Cl))) return rc;
     std::vector<double> tmp((size_t)L, 0.0);
@@ -966,9 +1015,11 @@ int cuadmm_duo_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_up
 
 int cuadmm_get_dims(const cuadmm_solver* s, int* vec_len, int* con_num, int* mat_num) {
   if (!s) { set_error("get_dims: null"); return CUADMM_ERR_INVALID; }
-  if (vec_len) *vec_len = s->L_full;
-  if (con_num) *con_num = s->m;
-  if (mat_num) *mat_num = s->nblk_full;
+  // the caller's numbering in every sharding mode: cuadmm_get_y writes con_num doubles, cuadmm_set_XyS / cuadmm_get_shard
+  // index the global svec
+  if (vec_len) *vec_len = s->local_mode ? s->L_caller : s->L_full;
+  if (con_num) *con_num = s->local_mode ? s->m_full : s->m;
+  if (mat_num) *mat_num = s->local_mode ? s->nblk_caller : s->nblk_full;
   return CUADMM_OK;
 }
 
@@ -1043,6 +1094,14 @@ int cuadmm_get_profile(const cuadmm_solver* s, double out[3 * CUADMM_NUM_KCLASS]
   if (!s || !out) { set_error("get_profile: null"); return CUADMM_ERR_INVALID; }
   for (int k = 0; k < K_NUM; ++k) { out[3 * k] = s->prof_count[k]; out[3 * k + 1] = s->prof_ms[k]; out[3 * k + 2] = s->prof_bytes[k]; }
   return CUADMM_OK;
+}
+int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap) {
+  if (!s || !out) { set_error("get_psd_steps: null"); return CUADMM_ERR_INVALID; }
+  if (!s->steps_d.p) { set_error("get_psd_steps: set option psd_steps=1 before init"); return CUADMM_ERR_INVALID; }
+  const int n = (int)std::min<size_t>(s->steps_d.n, (size_t)std::max(cap, 0));
+  CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+  CUADMM_HIP_TRY(hipMemcpy(out, s->steps_d.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  return n;
 }
 int cuadmm_reset_profile(cuadmm_solver* s) {
   if (!s) { set_error("reset_profile: null"); return CUADMM_ERR_INVALID; }

@@ -74,12 +74,12 @@ class Problem:
 class SDPSolver:
     """Mirror of class SDPSolver (include/cuadmm/solver.h:30-248)."""
 
-    def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False, force_comm=False):
+    def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False, force_comm=False, psd_steps=False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.cuadmm_create(C.byref(self._h)))
         for k, v in (("device", device), ("verbose", int(bool(verbose))), ("rank", rank), ("world", world),
-                     ("profile", int(profile)), ("force_comm", int(bool(force_comm)))):
+                     ("profile", int(profile)), ("force_comm", int(bool(force_comm))), ("psd_steps", int(bool(psd_steps)))):
             check(self._lib.cuadmm_set_option(self._h, k.encode(), float(v)))
         self._cb = None
         self.vec_len = self.con_num = 0
@@ -222,6 +222,14 @@ class SDPSolver:
         check(self._lib.cuadmm_get_profile(self._h, _p(o)))
         names = ["aty_xb", "psd_project", "post_proj", "spmv_A", "copies", "host", "allreduce", "tail_solve"]
         return {n: dict(launches=o[3 * i], ms=o[3 * i + 1], bytes_per_launch=o[3 * i + 2]) for i, n in enumerate(names)}
+
+    def psd_steps(self):
+        """Newton-Schulz steps of the last projection per local block (needs psd_steps=True at construction)."""
+        b, e, kb, ke = self.shard()
+        out = np.zeros(max(ke - kb, 1), np.int32)
+        n = self._lib.cuadmm_get_psd_steps(self._h, _p(out), out.size)
+        check(min(n, 0))
+        return out[:n]
 
     def reset_profile(self):
         check(self._lib.cuadmm_reset_profile(self._h))

@@ -52,6 +52,8 @@ void cuadmm_destroy(cuadmm_solver* s);
  *   "profile"       1 = time every kernel class with HIP events on the engine stream;
  *                   2 = time only the dominant kernel (psd_project)
  *   "force_comm"    1 = call the collective hook even when world == 1 (transport tests on one GPU)
+ *   "psd_steps"     1 = record how many Newton-Schulz steps the adaptive matrix-sign projection took per block
+ *                   (cuadmm_get_psd_steps); set before cuadmm_init
  *   "graph"         reserved
  */
 int cuadmm_set_option(cuadmm_solver* s, const char* key, double value);
@@ -148,6 +150,9 @@ int cuadmm_get_state(const cuadmm_solver* s, double out12[12]);
 #define CUADMM_NUM_KCLASS 8
 int cuadmm_get_profile(const cuadmm_solver* s, double out[3 * CUADMM_NUM_KCLASS]);
 int cuadmm_reset_profile(cuadmm_solver* s);
+/* Steps of the last projection per block of this rank's shard (0 for blocks served by the eigensolver kernels); needs
+ * option "psd_steps".  Returns the number of entries written (<= cap) or a negative error code. */
+int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
 
 /* ------------------------------------------------------------------------------------ */
 /* TXT problem loader: Problem::from_txt (reference src/problem.cu:11-83, src/utils/io.cu). */

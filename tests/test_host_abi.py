@@ -329,3 +329,39 @@ def test_aat_threaded_solve_is_bitwise_identical_to_serial(tmp_path):
         assert float(r.stdout.split("RES")[1]) < 1e-8
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_host_pool_survives_two_concurrent_solvers():
+    """Two factors with m >= 200 000 solved from two host threads at once (two engines in one process): the chunked solve
+    of both reaches the process-wide host thread pool concurrently.  Round 1 deadlocked here (single-occupancy fork-join
+    without an outer lock); run in a child process so that a regression is a timeout, not a hung test session."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, threading, numpy as np, scipy.sparse as sp
+        import cuadmm_amd
+        lib = cuadmm_amd.load()
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        m, L = 200000, 400000
+        rng = np.random.default_rng(0)
+        rows = np.repeat(np.arange(m), 2); cols = rng.integers(0, L, 2 * m)
+        A = sp.csc_matrix((rng.standard_normal(2 * m), (rows, cols)), shape=(m, L)); A.sum_duplicates(); A.sort_indices()
+        cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        hs = []
+        for _ in range(2):
+            h = C.c_void_p()
+            assert lib.cuadmm_aat_create(m, L, P(cp), P(ri), P(vx), 1e-15, C.byref(h)) == 0
+            hs.append(h)
+        rhs = rng.standard_normal(m); ref = np.empty(m)
+        assert lib.cuadmm_aat_solve_permuted(hs[0], P(rhs), P(ref)) == 0
+        outs = [np.empty(m), np.empty(m)]
+        def work(i):
+            for _ in range(30):
+                assert lib.cuadmm_aat_solve_permuted(hs[i], P(rhs), P(outs[i])) == 0
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert np.array_equal(outs[0], ref) and np.array_equal(outs[1], ref)
+        print("OK")
+    """)
+    env = dict(os.environ, CUADMM_HOST_THREADS="6", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
