@@ -48,17 +48,21 @@ def cpu_baseline(prob, threads, budget_s=20.0):
     rng = np.random.default_rng(0)
     xb = rng.standard_normal(int(prob.vec_len))
     # warm-up + choice of engine on a slice of the blocks (LAPACK from scipy's OpenBLAS vs the scalar tridiagonal-QL port)
-    nslice = max(1, min(blk.size, 2000 if blk.max() <= 64 else 1))
+    nslice = max(1, min(blk.size, 8 * threads if blk.max() <= 64 else 1))
     Ls = int(np.sum(blk[:nslice].astype(np.int64) * (blk[:nslice] + 1) // 2))
     best = None
+    # LAPACK leg: the reference's own thread count (cpu_eig_thread_num = 30, main.cu:11) -- the bundled OpenBLAS is built for
+    # at most 64 caller threads and aborts beyond ("too many memory regions"); the scalar port runs on every core
+    tcount = {"lapack": min(threads, 30), "ql": threads}
     for eng in ("lapack", "ql"):
         if eng == "ql" and blk.max() > 512:
             continue                                       # the scalar port is far off LAPACK's blocked code at n ~ 2000
-        cb.psd_project(xb[:Ls], blk[:nslice], threads, engine=eng)
-        _, secs = cb.psd_project(xb[:Ls], blk[:nslice], threads, engine=eng)
+        cb.psd_project(xb[:Ls], blk[:nslice], tcount[eng], engine=eng)
+        _, secs = cb.psd_project(xb[:Ls], blk[:nslice], tcount[eng], engine=eng)
         if best is None or secs < best[1]:
             best = (eng, secs)
     eng = best[0]
+    threads = tcount[eng]
     per_block = best[1] / nslice
     n_proj = blk.size if per_block * blk.size <= budget_s / 4 else max(1, int(budget_s / 4 / per_block))
     Lp = int(np.sum(blk[:n_proj].astype(np.int64) * (blk[:n_proj] + 1) // 2))

@@ -152,7 +152,12 @@ struct cuadmm_solver {
   long long sv_off = 0;
   std::vector<int> cons_local;
   double ov_nb = 0, ov_nc = 0, ov_nb2 = 0;
-  DevBuf<double> scal_d, yfull_d;
+  DevBuf<double> scal_d, yfull_d, b_d, normA_d;
+  PinnedBuf<double> h_scal;
+  // owned-constraints mode over > 1 ranks: the four scalars of the stopping test are formed on the device (rp_stats_kernel),
+  // all-reduced on the stream and copied down with the result vector: one stream synchronisation per iteration, no
+  // H2D -> collective -> D2H -> sync round trip of their own
+  bool dev_scalars = false;
   std::vector<double> y_full;
   cuadmm_aat* fac = nullptr;
   TailSolve tail;              // dense trailing triangle of L on the GPU (tail.k == 0: whole solve on the host)
@@ -304,6 +309,11 @@ struct cuadmm_solver {
     if (!out_mapped) {
       int rc = do_allreduce(out_d.p + first, count);
       if (rc) return rc;
+      if (dev_scalars && first == 0) {     // [||Rp||^2, b.y, sum Rd^2, <C,X>] of this rank -> sum over ranks, on the stream
+        if ((rc = launch_rp_stats(m, out_d.p, b_d.p, normA_d.p, y_d.p, bscale, out_d.p + (size_t)m, scal_d.p, st))) return rc;
+        if ((rc = comm_allreduce(scal_d.p, 4))) return rc;
+        CUADMM_HIP_TRY(hipMemcpyAsync(h_scal.p, scal_d.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+      }
       CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
     }
     CUADMM_HIP_TRY(hipStreamSynchronize(st));
@@ -733,7 +743,12 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
   std::memset(s->h_out.p, 0, sizeof(double) * (2 * (size_t)m + 2));
   s->out_w = s->out_d.p;
-  if (s->world <= 1 && !s->force_comm && !getenv("CUADMM_NO_MAPPED_OUT")) {
+  s->dev_scalars = s->local_mode && s->comm_world > 1 && !getenv("CUADMM_HOST_SCALARS");
+  if (s->dev_scalars) {
+    if ((rc = s->b_d.alloc(std::max(m, 1))) || (rc = s->normA_d.alloc(std::max(m, 1))) || (rc = s->h_scal.alloc(4))) return rc;
+    if ((rc = s->b_d.upload(s->b_p.data(), (size_t)m)) || (rc = s->normA_d.upload(s->normA_p.data(), (size_t)m))) return rc;
+  }
+  if (s->world <= 1 && !s->force_comm && !s->dev_scalars && !getenv("CUADMM_NO_MAPPED_OUT")) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, s->h_out.p, 0) == hipSuccess && dp) { s->out_w = static_cast<double*>(dp); s->out_mapped = true; }
     else { hipError_t e = hipGetLastError(); (void)e; }
@@ -757,7 +772,8 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     }
     {
       double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
-      if ((rc = s->allreduce_scalars(v, 4))) return rc;
+      if (s->dev_scalars) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // summed over ranks on the device
+      else if ((rc = s->allreduce_scalars(v, 4))) return rc;
       nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
     }
     s->errRp = std::sqrt(nr) / s->norm_borg;
@@ -932,7 +948,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       for (int c = 0; c < kHostChunks; ++c) { nr += part[2 * c]; bty += part[2 * c + 1]; }
       {
         double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
-        if ((rc = s->allreduce_scalars(v, 4))) return rc;
+        if (s->dev_scalars) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // summed over ranks on the device
+        else if ((rc = s->allreduce_scalars(v, 4))) return rc;
         nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
       }
       s->errRp = std::sqrt(nr) / s->norm_borg;

@@ -43,5 +43,8 @@ int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, con
                      const SpmvLongRows* long_rows = nullptr);
 
 int launch_scale(double* v, long long n, double s, hipStream_t st);
+// owned-constraints sharding: [||Rp org||^2, b.y, sums[0], sums[1]] from A*X on the device (one workgroup, deterministic)
+int launch_rp_stats(int m, const double* ax, const double* b, const double* normA, const double* y, double bscale,
+                    const double* sums, double* out4, hipStream_t st);
 
 }  // namespace cuadmm

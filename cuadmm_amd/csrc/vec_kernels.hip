@@ -146,6 +146,31 @@ __global__ __launch_bounds__(kVecThreads) void reduce_pairs_kernel(const double*
   if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
 }
 
+// Owned-constraints sharding: the two constraint-space sums of the stopping test, formed on the device from A*X so that
+// all four scalars of an iteration travel in ONE small all-reduce enqueued on the stream (no host round trip):
+//   out4[0] = sum_i (normA_i (b_i - (A X)_i) bscale)^2   (|| Rp org ||^2, solver.cu:768-772)
+//   out4[1] = sum_i b_i y_i                               (solver.cu:781)
+//   out4[2..3] = sums[0..1] (sum Rd^2, <C, X>: copied next to them)
+// One workgroup, fixed summation order: bit-reproducible.
+__global__ __launch_bounds__(kVecThreads) void rp_stats_kernel(int m, const double* __restrict__ ax, const double* __restrict__ b,
+                                                               const double* __restrict__ normA, const double* __restrict__ y,
+                                                               double bscale, const double* __restrict__ sums, double* __restrict__ out4) {
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    const double ro = normA[i] * (b[i] - ax[i]) * bscale;
+    a += ro * ro;
+    c += b[i] * y[i];
+  }
+  block_sum2<kVecThreads>(a, c);
+  if (threadIdx.x == 0) { out4[0] = a; out4[1] = c; out4[2] = sums[0]; out4[3] = sums[1]; }
+}
+int launch_rp_stats(int m, const double* ax, const double* b, const double* normA, const double* y, double bscale,
+                    const double* sums, double* out4, hipStream_t st) {
+  hipLaunchKernelGGL(rp_stats_kernel, dim3(1), dim3(kVecThreads), 0, st, m, ax, b, normA, y, bscale, sums, out4);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // rows of A (constraints, already in the solver's permuted order): T lanes per row.
 //   outX[row]  = sum a * X[col]            (if outX)

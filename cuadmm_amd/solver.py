@@ -152,6 +152,12 @@ class SDPSolver:
         return self
 
     # -- results (public members of the reference class) -----------------------------------------
+    def dims(self):
+        """(vec_len, con_num, mat_num) in the caller's numbering (cuadmm_get_dims)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.cuadmm_get_dims(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def shard(self):
         b, e, kb, ke = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
         check(self._lib.cuadmm_get_shard(self._h, C.byref(b), C.byref(e), C.byref(kb), C.byref(ke)))

@@ -51,6 +51,8 @@ def load():
 def psd_project(xb, blk, threads=1, eig_only=False, engine="lapack"):
     """-> (projected svec, seconds of the threaded region); engine: "lapack" (dsyevd + DGEMM) | "ql" (scalar twin)"""
     lib = load()
+    if engine != "ql":
+        threads = min(int(threads), 48)     # scipy's OpenBLAS is built for <= 64 caller threads and aborts beyond
     xb = np.ascontiguousarray(xb, dtype=np.float64)
     blk = np.ascontiguousarray(blk, dtype=np.int32)
     out = np.zeros_like(xb)

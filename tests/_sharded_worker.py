@@ -54,7 +54,8 @@ if rank == 0:
     ref = cuadmm_amd.SDPSolver(device=0, verbose=False)
     ref.init_problem(prob)
     ref.solve(15, 0.0, 0, 50, 100, 8, 1.05)
-    np.savez(sys.argv[1], X=X, y=s.y, pobj=s.info_arr("pobj"), errRp=s.info_arr("errRp"),
-             Xref=ref.X, yref=ref.y, pobj_ref=ref.info_arr("pobj"), errRp_ref=ref.info_arr("errRp"))
+    np.savez(sys.argv[1], X=X, y=s.y, pobj=s.info_arr("pobj"), errRp=s.info_arr("errRp"), dobj=s.info_arr("dobj"), errRd=s.info_arr("errRd"),
+             Xref=ref.X, yref=ref.y, pobj_ref=ref.info_arr("pobj"), errRp_ref=ref.info_arr("errRp"), dobj_ref=ref.info_arr("dobj"),
+             errRd_ref=ref.info_arr("errRd"), dims=np.array(s.dims()))
 dist.barrier()
 dist.destroy_process_group()

@@ -23,5 +23,10 @@ def test_two_processes_one_gpu(kind, port, tmp_path):
     d = np.load(out)
     assert np.max(np.abs(d["pobj"] - d["pobj_ref"]) / (1e-12 + np.abs(d["pobj_ref"]))) <= 1e-9
     assert np.max(np.abs(d["errRp"] - d["errRp_ref"]) / (1e-12 + np.abs(d["errRp_ref"]))) <= 1e-8
+    # the four scalars of the stopping test: summed over ranks on the device in owned-constraints mode (rp_stats_kernel)
+    assert np.max(np.abs(d["dobj"] - d["dobj_ref"]) / (1e-12 + np.abs(d["dobj_ref"]))) <= 1e-9
+    assert np.max(np.abs(d["errRd"] - d["errRd_ref"]) / (1e-12 + np.abs(d["errRd_ref"]))) <= 1e-8
+    # cuadmm_get_dims reports the caller's numbering in every sharding mode (the y buffer is sized from it)
+    assert tuple(d["dims"]) == (d["X"].size, d["y"].size, 49)
     assert np.max(np.abs(d["X"] - d["Xref"])) <= 1e-9 * (1 + np.max(np.abs(d["Xref"])))
     assert np.max(np.abs(d["y"] - d["yref"])) <= 1e-8 * (1 + np.max(np.abs(d["yref"])))
