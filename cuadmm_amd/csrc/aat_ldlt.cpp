@@ -11,6 +11,7 @@
 // Contract kept from the reference: the solve works on the PERMUTED system and applies no
 // permutation itself (cholesky_cpu.h:146-155; solver.cu:487,500 permute around it).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -148,7 +149,11 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Minimal fork-join pool (mutex + condition variables, generation counter).  run(f) executes f(0..T-1), f(0) on the caller.
+// Minimal fork-join pool.  run(f) executes f(0..T-1), f(0) on the caller.
+// Hand-off is spin-then-sleep: a worker polls the generation counter for kSpinUs after its last job before it blocks on the
+// condition variable, and the caller polls the completion counter.  Inside an ADMM solve the host phases come every few
+// hundred microseconds, so the workers stay hot and a fork-join costs ~1 us instead of the ~50 us of a condition-variable
+// wake-up (which made threads a loss below m = 200 000 in round 1); an idle pool sleeps.
 // The pool is a process-wide singleton and run() is a single-occupancy fork-join (job / pending / gen belong to the one
 // call in flight), so concurrent callers (two engines driven from two host threads, tests/test_gpu_sharded.py) are
 // serialised by `run_mu`: the caller that finds the pool busy runs its chunks inline instead of waiting -- the chunks'
@@ -159,7 +164,7 @@ class HostPool {
     for (int i = 1; i < T; ++i) workers.emplace_back([this, i] { loop(i); });
   }
   ~HostPool() {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    { std::lock_guard<std::mutex> lk(mu); stop.store(true); }
     cv_start.notify_all();
     for (auto& t : workers) t.join();
   }
@@ -171,41 +176,62 @@ class HostPool {
       for (int i = 0; i < T; ++i) f(i);
       return;
     }
-    { std::lock_guard<std::mutex> lk(mu); job = &f; pending = T - 1; ++gen; }
-    cv_start.notify_all();
+    job = &f;
+    pending.store(T - 1, std::memory_order_relaxed);
+    gen.fetch_add(1, std::memory_order_release);
+    if (sleepers.load(std::memory_order_acquire) > 0) {
+      std::lock_guard<std::mutex> lk(mu);      // pairs with the predicate check of a worker about to block
+      cv_start.notify_all();
+    }
     f(0);
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [this] { return pending == 0; });
+    for (int spins = 0; pending.load(std::memory_order_acquire) != 0; ++spins) {
+      if (spins < 20000) cpu_relax();
+      else std::this_thread::yield();
+    }
     job = nullptr;
   }
 
  private:
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
+  static constexpr double kSpinUs = 2000.0;
   void loop(int id) {
     unsigned seen = 0;
     for (;;) {
-      const std::function<void(int)>* j;
-      {
+      // poll, then block
+      const auto t0 = std::chrono::steady_clock::now();
+      bool got = false;
+      for (int it = 0;; ++it) {
+        if (gen.load(std::memory_order_acquire) != seen) { got = true; break; }
+        if (stop.load(std::memory_order_relaxed)) return;
+        cpu_relax();
+        if ((it & 255) == 255 &&
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kSpinUs) break;
+      }
+      if (!got) {
         std::unique_lock<std::mutex> lk(mu);
-        cv_start.wait(lk, [&] { return stop || gen != seen; });
-        if (stop) return;
-        seen = gen;
-        j = job;
+        sleepers.fetch_add(1, std::memory_order_acq_rel);
+        cv_start.wait(lk, [&] { return stop.load() || gen.load(std::memory_order_acquire) != seen; });
+        sleepers.fetch_sub(1, std::memory_order_acq_rel);
+        if (stop.load()) return;
       }
+      seen = gen.load(std::memory_order_acquire);
+      const std::function<void(int)>* j = job;
       (*j)(id);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (--pending == 0) cv_done.notify_one();
-      }
+      pending.fetch_sub(1, std::memory_order_release);
     }
   }
   const int T;
   std::vector<std::thread> workers;
   std::mutex mu, run_mu;
-  std::condition_variable cv_start, cv_done;
+  std::condition_variable cv_start;
   const std::function<void(int)>* job = nullptr;
-  unsigned gen = 0;
-  int pending = 0;
-  bool stop = false;
+  std::atomic<unsigned> gen{0};
+  std::atomic<int> pending{0}, sleepers{0};
+  std::atomic<bool> stop{false};
 };
 
 // CUADMM_HOST_THREADS (default 8, 1 = serial).  Created on first use, lives until process exit.
@@ -433,7 +459,7 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
   }
   for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->nzcols.push_back(j);
   // chunks of independent etree subtrees for the threaded solve (whole factor on the host, large m, many subtrees)
-  if (tail_k == 0 && m >= 200000) {
+  if (tail_k == 0 && m >= 20000) {
     std::vector<int> root(m);
     for (int j = m - 1; j >= 0; --j) root[j] = parent[j] < 0 ? j : root[parent[j]];   // parent[j] > j
     std::vector<int64_t> weight(m, 0);                                                 // per root: columns + nonzeros

@@ -80,7 +80,7 @@ struct PinnedBuf {
 
 // Host loops over the m constraints: serial below kHostParMin, else kHostChunks fixed index ranges on the host pool
 // (aat_ldlt.cpp).  Sums are formed per range and combined in range order: reproducible for any thread count.
-constexpr int kHostParMin = 200000, kHostChunks = 32;
+constexpr int kHostParMin = 20000, kHostChunks = 32;
 template <class F>
 static void host_ranges(int m, F&& body) {   // body(chunk, lo, hi)
   if (m < kHostParMin) { body(0, 0, m); return; }

@@ -138,22 +138,36 @@ __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(P
 // n <= 32 (projection only): one wavefront per block (psd_sign_lds.h, SignWave32); WPG wavefronts per workgroup.
 // Blocks stop at different steps, so small workgroups (a workgroup's LDS and wave slots are released when its last
 // wavefront ends) keep the SIMDs fed.
-template <int WPG>
-__global__ __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(3, 4))) void psd_sign_wave32_kernel(PsdArgs a, int first, int count) {
-  __shared__ double sw_smem[WPG * SignWave32::PER_WAVE];
-  const int w = (int)threadIdx.x >> 6;
-  const int m = (int)blockIdx.x * WPG + w;
-  if (m >= count) return;
-  const int id = a.ids ? a.ids[first + m] : first + m;
-  psd_sign_wave32_body(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sw_smem + w * SignWave32::PER_WAVE, a.steps ? a.steps + id : nullptr);
-}
+#define CUADMM_SW32_KERNEL(NAME, OCC, DBG)                                                                                           \
+  template <int WPG>                                                                                                                \
+  __global__ __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(OCC, 4))) void NAME(PsdArgs a, int first, int count) { \
+    __shared__ double sw_smem[WPG * SignWave32::PER_WAVE];                                                                          \
+    const int w = (int)threadIdx.x >> 6;                                                                                            \
+    const int m = (int)blockIdx.x * WPG + w;                                                                                        \
+    if (m >= count) return;                                                                                                         \
+    const int id = a.ids ? a.ids[first + m] : first + m;                                                                            \
+    psd_sign_wave32_body<DBG>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sw_smem + w * SignWave32::PER_WAVE,          \
+                              a.steps ? a.steps + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr);                       \
+  }
+// two register budgets of the same kernel: 4 wavefronts per SIMD (<= 128 VGPRs, a few spills outside the iteration) and 3
+// (<= 168, no spills); CUADMM_PSD_W32_OCC=3|4 selects, the default is the measured winner
+CUADMM_SW32_KERNEL(psd_sign_wave32_kernel, 4, false)
+CUADMM_SW32_KERNEL(psd_sign_wave32_occ3_kernel, 3, false)
+CUADMM_SW32_KERNEL(psd_sign_wave32_dbg_kernel, 3, true)     // CUADMM_PSD_DEBUG: per-phase cycle stamps inside the step
+#undef CUADMM_SW32_KERNEL
 
 static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_t st) {
   if (count <= 0) return CUADMM_OK;
   static const int wpg = getenv("CUADMM_PSD_W32_WPG") ? atoi(getenv("CUADMM_PSD_W32_WPG")) : 1;
-  if (wpg == 4) hipLaunchKernelGGL(psd_sign_wave32_kernel<4>, dim3((count + 3) / 4), dim3(256), 0, st, a, first, count);
-  else if (wpg == 2) hipLaunchKernelGGL(psd_sign_wave32_kernel<2>, dim3((count + 1) / 2), dim3(128), 0, st, a, first, count);
-  else hipLaunchKernelGGL(psd_sign_wave32_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
+  static const int occ = getenv("CUADMM_PSD_W32_OCC") ? atoi(getenv("CUADMM_PSD_W32_OCC")) : 3;
+  if (a.dbg) {
+    hipLaunchKernelGGL(psd_sign_wave32_dbg_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
+  } else if (occ == 3) {
+    if (wpg == 4) hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<4>, dim3((count + 3) / 4), dim3(256), 0, st, a, first, count);
+    else hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
+  } else {
+    hipLaunchKernelGGL(psd_sign_wave32_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
+  }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
@@ -329,6 +343,25 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff; a.steps = d_steps;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
+    if (c == 3 && psd_debug && sign32) {   // phase cycles of the one-wavefront-per-block sign kernel
+      std::vector<long long> h((size_t)cls_count[c] * 10);
+      long long* d = nullptr;
+      CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
+      a.dbg = d;
+      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st);
+      if (rc2) return rc2;
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      double ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 10; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
+      const double nw = cls_count[c], ns = std::max(ph[3], 1.0);
+      fprintf(stderr, "[psd debug] sign wave32: %d blocks: ticks/block prologue %.0f iteration %.0f (%.1f steps, %.0f per step) epilogue %.0f | per step: "
+                      "frags %.0f  Y=SS %.0f  transpose+stats %.0f  SY %.0f  reduce+decide %.0f  combine+store %.0f\n",
+              cls_count[c], ph[0] / nw, ph[1] / nw, ph[3] / nw, ph[1] / ns, ph[2] / nw, ph[4] / ns, ph[5] / ns, ph[6] / ns, ph[7] / ns, ph[8] / ns, ph[9] / ns);
+      { hipError_t e = hipFree(d); (void)e; }
+      if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
+      continue;
+    }
     if (c == 3 && psd_debug) {
       CUADMM_HIP_TRY(hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)nwg));
       CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));

@@ -215,6 +215,51 @@ __device__ __forceinline__ void sw32_unpack(const double* __restrict__ src, int 
   wave_fence();
 }
 
+// svec <-> LDS tile by COLUMNS: column c of the upper triangle is the contiguous svec range [c (c + 1) / 2, + c + 1), and
+// column c + 1 follows it immediately, so the two half-waves take columns 2 q and 2 q + 1 (lane & 31 = row): 16 coalesced,
+// independent loads per lane, no index decoding (tri_decode costs a float sqrt and two correction loops per element; the
+// prologue and epilogue were 37 % of a block's lifetime once the adaptive schedule cut the iteration to 12 steps).
+template <int NQ>
+__device__ __forceinline__ void sw32_load_cols(const double* __restrict__ src, int n, int lane, int q0, double (&v)[NQ]) {
+  const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = 2 * (q0 + q) + h;
+    v[q] = (r <= c && c < n) ? src[c * (c + 1) / 2 + r] : 0.0;
+  }
+}
+// M (32 x 32, stride LD) = scale * smat(v), both triangles; the padding rows / columns (>= n) receive zeros
+template <int NQ>
+__device__ __forceinline__ void sw32_tile_from_cols(double* __restrict__ M, int lane, int q0, const double (&v)[NQ], double scale) {
+  constexpr int LD = SignWave32::LD;
+  const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = 2 * (q0 + q) + h;
+    if (r <= c) {
+      const double x = v[q] * (r == c ? scale : scale * kSqrt2Inv);
+      M[r * LD + c] = x;
+      M[c * LD + r] = x;
+    }
+  }
+}
+// svec(out) = upper triangle of M by columns (sqrt2 off the diagonal); returns whether a non-finite value was seen
+__device__ __forceinline__ bool sw32_store_cols(const double* __restrict__ M, double* __restrict__ out, int n, int lane) {
+  constexpr int LD = SignWave32::LD;
+  const int h = lane >> 5, r = lane & 31;
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = 2 * q + h;
+    if (r <= c && c < n) {
+      const double x = M[r * LD + c];
+      bad |= !(fabs(x) <= 1.7976931348623157e308);
+      out[c * (c + 1) / 2 + r] = (r == c) ? x : x * kSqrt2;
+    }
+  }
+  return bad;
+}
+
 // all 16 operand fragments of the symmetric matrix in LDS: f[s][x] = M[4 s + kk][16 x + r16]
 __device__ __forceinline__ void sw32_frags(const double* __restrict__ M, int r16, int kk, double (&f)[8][2]) {
   constexpr int LD = SignWave32::LD;
@@ -268,31 +313,39 @@ __device__ __forceinline__ void sw32_mma_regB(const double (&fa)[8][2], const sl
 // Per-block adaptive schedule (sign_sched.h): the statistics come from registers the step already holds -- tr Y and
 // ||Y||_F^2 from the accumulators of Y = S S, ||S - S Y||_F^2 from the accumulators of S Y and the copy of S that the
 // combine step reads anyway -- three wave reductions per step next to 48 MFMAs.
+template <bool DBG>
 __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
-                                                     double* S, int* steps_out) {
+                                                     double* S, int* steps_out, long long* dbg) {
+#define SW32_STAMP(k) do { if (DBG) { const long long now_ = (long long)__builtin_readcyclecounter(); ph[k] += now_ - tprev; tprev = now_; } } while (0)
+  long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
   constexpr int LD = SignWave32::LD;
   const int lane = lane_id();
+  const long long c0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   const int r16 = lane & 15, kk = lane >> 4;
   double* scr = S + 32 * LD;
-  sw32_unpack(in, n, S, lane);
-  // ||X||_1 (max column sum; lanes 0..31 own a column each)
-  double cs = 0.0;
-  if (lane < 32)
-    for (int r = 0; r < 32; ++r) cs += fabs(S[r * LD + lane]);
-  double nrm = cs;
+  // S_0 = X / ||X||_F.  The Frobenius norm is the 2-norm of the svec itself (the sqrt2 on the off-diagonals counts
+  // them twice), so it comes from the loaded values with one wave reduction -- no pass over the tile in LDS; like the
+  // 1-norm it bounds the spectral radius, and the first step re-normalises by ||Y||_F^(1/2) anyway (sign_sched.h).
+  {
+    double v[16];
+    sw32_load_cols<16>(in, n, lane, 0, v);
+    double ss = 0.0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double v = __shfl_xor(nrm, o, 64);
-    nrm = (v > nrm || !(v == v)) ? v : nrm;
+    for (int q = 0; q < 16; ++q) ss += v[q] * v[q];
+    const double nrm = sqrt(wave_sum(ss));
+    const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);   // NaN propagates (flagged at the store)
+    sw32_tile_from_cols<16>(S, lane, 0, v, scale);
   }
-  const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);
-  for (int e = lane; e < 32 * LD; e += 64) S[e] *= scale;
   wave_fence();
   double f[8][2];
   SignSched sched;
   bool last = false;
+  const long long c1 = dbg ? (long long)__builtin_readcyclecounter() : 0;
+  tprev = c1;
   while (!last) {
     sw32_frags(S, r16, kk, f);
+    if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    SW32_STAMP(0);
     // Y = S S: the three upper sub-tiles on the matrix cores (24 MFMAs); the lower one, needed as a register operand
     // of S Y, is the transpose of Y(0,1): 4 LDS writes + 4 reads through a 16 x 17 tile instead of 8 more MFMAs (the
     // MFMA pipe is what bounds this kernel)
@@ -304,6 +357,8 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
       y[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][0], f[s][1], y[0][1], 0, 0, 0);
       y[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][1], f[s][1], y[1][1], 0, 0, 0);
     }
+    if (DBG) { asm volatile("s_nop 0" :: "v"(y[0][0][0]), "v"(y[0][1][0]), "v"(y[1][1][0]) : "memory"); }
+    SW32_STAMP(1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) scr[r16 * SignWave32::SCR_LD + kk + 4 * r] = y[0][1][r];   // element (kk+4r, r16) -> scr[r16][kk+4r]
     // tr Y and ||Y||_F^2 (the off-diagonal sub-tile counts twice)
@@ -320,7 +375,10 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
     // S Y on the three upper sub-tiles (24 MFMAs, no LDS traffic), then S in accumulator layout (12 LDS reads, short
     // live range: that is what keeps the kernel at 128 VGPRs, 4 wavefronts per SIMD, without spills)
     sl_v4f64 z[3], e[3];
+    SW32_STAMP(2);
     sw32_mma_regB(f, y, z);
+    if (DBG) { asm volatile("s_nop 0" :: "v"(z[0][0]), "v"(z[1][0]), "v"(z[2][0]) : "memory"); }
+    SW32_STAMP(3);
     const double ta = wave_sum(pa), tb = wave_sum(pb);
     sw32_dlayout(S, r16, kk, e);
     double pg = 0.0;
@@ -331,6 +389,8 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
     }
     const double tg = wave_sum(pg);
     const double mu = sched.decide<false>(n, ta, tb, tg, last);
+    if (DBG) { asm volatile("s_nop 0" :: "v"(mu) : "memory"); }
+    SW32_STAMP(4);
     const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
     sl_v4f64 t[3];
 #pragma unroll
@@ -340,13 +400,23 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
     wave_fence();                                                 // all reads of S are done
     sw32_store(S, r16, kk, t);
     wave_fence();
+    if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    SW32_STAMP(5);
   }
+#undef SW32_STAMP
   if (steps_out && lane == 0) *steps_out = sched.steps;
+  const long long c2 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   // P = 0.5 (X0 + S X0): A fragments of S from LDS, then LDS is reused for X0, whose sub-tiles are read in accumulator
   // layout (register B operand).  The lower sub-tile of X0 is read directly too (X0 is exactly symmetric in LDS).
   sw32_frags(S, r16, kk, f);
   wave_fence();
-  sw32_unpack(in, n, S, lane);
+#pragma unroll 1
+  for (int q0 = 0; q0 < 16; q0 += 4) {   // X0 again (L2-hot), four columns per lane at a time: the fragments f are live
+    double v[4];
+    sw32_load_cols<4>(in, n, lane, q0, v);
+    sw32_tile_from_cols<4>(S, lane, q0, v, 1.0);
+  }
+  wave_fence();
   sl_v4f64 x0[3], xb[2][2], p[3];
   sw32_dlayout(S, r16, kk, x0);
   xb[0][0] = x0[0]; xb[0][1] = x0[1]; xb[1][1] = x0[2];
@@ -360,16 +430,13 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   wave_fence();
   sw32_store(S, r16, kk, p);
   wave_fence();
-  const int len = n * (n + 1) / 2;
-  bool bad = false;
-  for (int e2 = lane; e2 < len; e2 += 64) {
-    int i, j;
-    tri_decode(e2, i, j);
-    const double v = S[j * LD + i];
-    bad |= !(fabs(v) <= 1.7976931348623157e308);
-    out[e2] = (i == j) ? v : v * kSqrt2;
-  }
+  const bool bad = sw32_store_cols(S, out, n, lane);
   if (bad && fail) atomicAdd(fail, 1);
+  if (dbg && lane == 0) {   // developer aid (CUADMM_PSD_DEBUG): cycles of prologue / iteration / epilogue, steps
+    const long long c3 = (long long)__builtin_readcyclecounter();
+    dbg[0] = c1 - c0; dbg[1] = c2 - c1; dbg[2] = c3 - c2; dbg[3] = sched.steps;
+    if (DBG) for (int q = 0; q < 6; ++q) dbg[4 + q] = ph[q];
+  }
 }
 
 }  // namespace cuadmm
