@@ -57,8 +57,20 @@ PROTOTYPES = {
     "cuadmm_set_XyS": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "cuadmm_get_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "cuadmm_get_shard": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_int_p, c_int_p]),
+    "cuadmm_mex_call": (C.c_int, [C.c_int, C.c_int, C.c_double,
+                                   C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cuadmm_mex_result_dims": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_double)]),
+    "cuadmm_mex_result_XyS": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cuadmm_mex_result_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cuadmm_mex_result_free": (None, [C.c_void_p]),
     "cuadmm_get_psd_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "cuadmm_sign_sched_simulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    "cuadmm_op_psd_project_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cuadmm_op_psd_project_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cuadmm_get_info_iter_num": (C.c_int, [C.c_void_p]),
     "cuadmm_get_info_array": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),

@@ -89,12 +89,13 @@ void MatrixSizes::print() const {
 // Contiguous block ranges per rank, balanced by the projection cost sum n^3.
 void partition_blocks(const int* blk, int mat_num, int world, std::vector<int>& first) {
   first.assign((size_t)world + 1, 0);
+  auto cost = [](int b) { return b > 0 ? (double)b * b * b : (double)(-(long long)b); };   // 'u' blocks: a copy
   double total = 0;
-  for (int i = 0; i < mat_num; ++i) total += (double)blk[i] * blk[i] * blk[i];
+  for (int i = 0; i < mat_num; ++i) total += cost(blk[i]);
   double acc = 0;
   int r = 1;
   for (int i = 0; i < mat_num && r < world; ++i) {
-    acc += (double)blk[i] * blk[i] * blk[i];
+    acc += cost(blk[i]);
     // close rank r-1 once it holds its share; keep at least the blocks needed by later ranks possible
     while (r < world && acc >= total * r / world) first[r++] = i + 1;
   }

@@ -24,6 +24,10 @@ struct ProblemData {
   std::vector<char> blk_types;
 };
 
+// svec slots of a block: n (n + 1) / 2 for a PSD block of size n; an UNCONSTRAINED block of n variables (blk.txt type
+// 'u', README.md:55-64 of the reference: "WIP") is carried as the negative size -n through every blk array and owns n slots
+inline long long blk_svec_len(int b) { return b >= 0 ? (long long)b * (b + 1) / 2 : -(long long)b; }
+
 // io.cpp
 int read_blk_file(const std::string& fn, std::vector<char>& types, std::vector<int>& sizes);
 int read_triplets(const std::string& fn, std::vector<int>& r, std::vector<int>& c, std::vector<double>& v, bool allow_missing);

@@ -124,6 +124,10 @@ RcclApi g_rccl;
 struct cuadmm_solver {
   // options
   int device = 0, verbose = 1, rank = 0, world = 1, profile = 0, force_comm = 0, psd_steps = 0;
+  // rank-limited projection (dormant in the reference: duo_solver.cu:428-438,843-850): keep only the eig_rank
+  // largest eigenvalues of every PSD block from iteration eig_rank_begin_iter on, or once maxfeas < eig_rank_maxfeas
+  int eig_rank = 0, eig_rank_begin_iter = 0;
+  double eig_rank_maxfeas = 0.0;
   cuadmm_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   void* rccl_comm = nullptr;
@@ -388,6 +392,9 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "world") s->world = (int)value;
   else if (k == "profile") s->profile = (int)value;
   else if (k == "force_comm") s->force_comm = (int)value;   // call the collective hook even when world == 1 (testing)
+  else if (k == "eig_rank") s->eig_rank = (int)value;
+  else if (k == "eig_rank_begin_iter") s->eig_rank_begin_iter = (int)value;
+  else if (k == "eig_rank_maxfeas") s->eig_rank_maxfeas = value;
   else if (k == "psd_steps") s->psd_steps = (int)value;       // record the sign kernels' step count per block (cuadmm_get_psd_steps)
   else if (k == "graph") {}
   else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
@@ -438,8 +445,8 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   if (s->world < 1 || s->rank < 0 || s->rank >= s->world) { set_error("init: bad rank/world %d/%d", s->rank, s->world); return CUADMM_ERR_INVALID; }
   long long Lchk = 0;
   for (int k = 0; k < mat_num; ++k) {
-    if (blk[k] < 1) { set_error("init: block %d has size %d", k, blk[k]); return CUADMM_ERR_INVALID; }
-    Lchk += (long long)blk[k] * (blk[k] + 1) / 2;
+    if (blk[k] == 0) { set_error("init: block %d has size 0", k); return CUADMM_ERR_INVALID; }
+    Lchk += blk_svec_len(blk[k]);                       // negative size = unconstrained block of -blk[k] variables
   }
   if (Lchk != vec_len) { set_error("init: vec_len %d does not match blk (sum n(n+1)/2 = %lld)", vec_len, Lchk); return CUADMM_ERR_INVALID; }
   if (At_cp[0] != 0 || At_cp[con_num] != At_nnz) { set_error("init: At column pointers inconsistent with At_nnz"); return CUADMM_ERR_INVALID; }
@@ -456,7 +463,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       int r = 0;
       for (int k = 0; k <= mat_num; ++k) {
         while (r <= s->world && first[r] == k) svb[r++] = off;
-        if (k < mat_num) off += (long long)blk[k] * (blk[k] + 1) / 2;
+        if (k < mat_num) off += blk_svec_len(blk[k]);
       }
     }
     std::vector<int> owner(con_num, 0);
@@ -615,7 +622,9 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   // --- census (analyze_blk.cu:63-99, matrix_sizes.cu:75-113)
   if (s->verbose) {
     std::vector<int> sizes, nums;
-    analyze_blk(blk, mat_num, sizes, nums);
+    std::vector<int> psd_blk;
+    for (int k = 0; k < mat_num; ++k) if (blk[k] > 0) psd_blk.push_back(blk[k]);
+    analyze_blk(psd_blk.data(), (int)psd_blk.size(), sizes, nums);
     print_blk_census(sizes, nums);
     MatrixSizes ms;
     ms.init(sizes, nums);
@@ -630,13 +639,14 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->sv_begin = 0;
   for (int k = 0; k < mat_num; ++k) {
     if (k == s->blk_begin) s->sv_begin = off;
-    off += (long long)blk[k] * (blk[k] + 1) / 2;
+    off += blk_svec_len(blk[k]);
     if (k + 1 == s->blk_end) s->sv_end = off;
   }
   if (s->blk_begin == s->blk_end) { s->sv_begin = s->sv_end = (s->blk_begin == mat_num ? off : s->sv_begin); }
   const long long L = s->sv_end - s->sv_begin;
   s->L = L;
   s->blk_local.assign(blk + s->blk_begin, blk + s->blk_end);
+  s->plan.eig_rank = s->eig_rank > 0 ? s->eig_rank : 0;
   rc = s->plan.build(s->blk_local.data(), (int)s->blk_local.size());
   s->plan.overlap = true;
   if (!rc && s->psd_steps && !s->blk_local.empty()) {
@@ -865,6 +875,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     // ---- Step 2 (solver.cu:514-656)
     if ((rc = s->upload_y())) return rc;
     if ((rc = s->launch_aty(true))) return rc;
+    s->plan.rank_active = s->eig_rank > 0 && (iter >= s->eig_rank_begin_iter || s->maxfeas < s->eig_rank_maxfeas);   // duo_solver.cu:844
     if ((rc = s->launch_project())) return rc;
     static const char* const debug_eig_dir = getenv("CUADMM_DEBUG_EIG");   // read once, not per iteration
     if (debug_eig_dir) {   // developer aid: dump the projection input when a block hits the QL cap
@@ -1003,8 +1014,15 @@ int cuadmm_duo_init(cuadmm_solver* s, int if_gpu_eig_mom, int device_num_request
                     int cpu_eig_thread_num, int vec_len, int con_num, const int* At_cp, const int* At_ri, const double* At_vx,
                     int At_nnz, const int* b_idx, const double* b_vals, int b_nnz, const int* C_idx, const double* C_vals,
                     int C_nnz, const int* blk, int mat_num, const double* X0, const double* y0, const double* S0, double sig) {
-  (void)if_gpu_eig_mom; (void)device_num_requested;
+  (void)if_gpu_eig_mom;     // false = the reference's host-LAPACK moment-matrix path: this engine has no CPU projection
   if (!s || !blk || mat_num <= 0) { set_error("duo_init: invalid argument"); return CUADMM_ERR_INVALID; }
+  // duo_solver.cu:487-577 spreads the moment matrices over device_num_requested GPUs from ONE process; here a GPU is a
+  // rank (options "rank" / "world", one process per GPU), so the request must agree with the sharding in force
+  if (device_num_requested > 1 && device_num_requested != s->world) {
+    set_error("duo_init: device_num_requested = %d but this engine runs one process per GPU: launch %d ranks and set the options rank / world",
+              device_num_requested, device_num_requested);
+    return CUADMM_ERR_INVALID;
+  }
   std::vector<int> sizes, nums;
   analyze_blk(blk, mat_num, sizes, nums);
   if (sizes.size() != 2) {   // analyze_blk_duo, src/utils/analyze_blk.cu:39-43
@@ -1159,8 +1177,13 @@ int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, 
 }
 
 int cuadmm_op_psd_project_steps(const double* Xb, double* Xproj, const int* blk_host, int mat_num, int* steps_dev, void* stream) {
-  if (!blk_host || mat_num < 0) { set_error("psd_project: bad arguments"); return CUADMM_ERR_INVALID; }
+  return cuadmm_op_psd_project_ex(Xb, Xproj, blk_host, mat_num, 0, steps_dev, stream);
+}
+
+int cuadmm_op_psd_project_ex(const double* Xb, double* Xproj, const int* blk_host, int mat_num, int eig_rank, int* steps_dev, void* stream) {
+  if (!blk_host || mat_num < 0 || eig_rank < 0) { set_error("psd_project: bad arguments"); return CUADMM_ERR_INVALID; }
   PsdPlan plan;
+  plan.eig_rank = eig_rank;
   int rc = plan.build(blk_host, mat_num);
   if (rc) return rc;
   if (steps_dev) {

@@ -146,11 +146,14 @@ int load_problem_txt(const std::string& prefix, ProblemData& p, bool verbose) {
   p.mat_num = (int)p.blk.size();
   long long L = 0;
   for (int i = 0; i < p.mat_num; ++i) {
-    if (p.blk_types[i] != 's') {  // problem.cu:28-36
+    if (p.blk_types[i] == 'u') {  // unconstrained block of n variables (README.md:55-64): carried as -n
+      if (p.blk[i] < 1) { set_error("ERROR: block %d 'u %d' in blk.txt", i, p.blk[i]); return CUADMM_ERR_IO; }
+      p.blk[i] = -p.blk[i];
+    } else if (p.blk_types[i] != 's') {  // problem.cu:28-36
       set_error("ERROR: unknown block type '%c' in blk.txt", p.blk_types[i]);
       return CUADMM_ERR_IO;
     }
-    L += (long long)p.blk[i] * (p.blk[i] + 1) / 2;
+    L += blk_svec_len(p.blk[i]);
   }
   if (L > 2147483647LL) { set_error("vector length %lld exceeds int32 (reference API uses int)", L); return CUADMM_ERR_INVALID; }
   p.vec_len = (int)L;

@@ -343,10 +343,19 @@ CUADMM_HD __forceinline__ int sym_eig_inplace(double* __restrict__ M, const int 
 // that svec stores is computed.
 template <class Gp>
 CUADMM_HD __forceinline__ void reconstruct_to_svec(const double* __restrict__ M, const int ld, const int n, const double* dq, double* vv,
-                                    double* __restrict__ out) {
+                                    double* __restrict__ out, const int eig_rank = 0) {
   constexpr int GS = Gp::kSize;
   const int rank = Gp::rank();
-  for (int k = rank; k < n; k += GS) { double lam = dq[k]; vv[k] = lam > 0.0 ? lam : 0.0; }   // dense_scalar.cu:41-47
+  for (int k = rank; k < n; k += GS) {   // dense_scalar.cu:41-47; with a rank limit :51-57 + get_eig_rank_mask.cu:13-37
+    const double lam = dq[k];
+    double lp = lam > 0.0 ? lam : 0.0;
+    if (eig_rank > 0) {                  // keep only the eig_rank largest eigenvalues (ties: higher index first)
+      int above = 0;
+      for (int j = 0; j < n; ++j) { const double lj = dq[j]; above += (lj > lam) || (lj == lam && j > k); }
+      if (above >= eig_rank) lp = 0.0;
+    }
+    vv[k] = lp;
+  }
   Gp::sync();
   for (int b = rank; b < n; b += GS) {
     const double* rb = M + b * ld;

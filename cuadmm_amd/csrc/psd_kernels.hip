@@ -42,6 +42,7 @@ struct PsdArgs {
   const long long* ws_off; // GLOBAL variant: workspace offset per member
   long long* dbg;          // developer aid: per-workgroup phase timestamps (CUADMM_PSD_DEBUG)
   int* steps;              // developer aid: Newton-Schulz steps taken per block (sign kernels; may be null)
+  int eig_rank;            // > 0: rank-limited projection, only the eig_rank largest eigenvalues survive (eigensolver kernels)
 };
 
 // register-resident variant (psd_small_reg.h): the production path for n <= 32
@@ -115,12 +116,20 @@ __global__ __launch_bounds__(NT) void psd_wg_kernel(PsdArgs a) {
   __syncthreads();
   const int fail = sym_eig_inplace<Gp>(M, ld, n, dsh, esh, tau, vv, ww, dq, eq, scratch);
   if (MODE == 0) {
-    reconstruct_to_svec<Gp>(M, ld, n, dq, vv, a.out + a.boff[bi]);
+    reconstruct_to_svec<Gp>(M, ld, n, dq, vv, a.out + a.boff[bi], a.eig_rank);
     if (fail && tid == 0 && a.info) atomicAdd(a.info, 1);
   } else {
     write_sorted_eig<Gp>(M, ld, n, dq, a.out + (long long)bi * n * n, a.Wout + (long long)bi * n);
     if (tid == 0 && a.info) a.info[bi] = fail;
   }
+}
+
+// unconstrained ('u') blocks: the projection onto R^n is the identity -- one workgroup per block copies its svec range
+__global__ __launch_bounds__(256) void copy_ranges_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                          const long long* __restrict__ off, const long long* __restrict__ len) {
+  const double* s = in + off[blockIdx.x];
+  double* d = out + off[blockIdx.x];
+  for (long long i = threadIdx.x; i < len[blockIdx.x]; i += 256) d[i] = s[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -210,13 +219,22 @@ int PsdPlan::build(const int* blk, int mat_num) {
   release();
   nblk = mat_num;
   std::vector<long long> off((size_t)mat_num + 1, 0);
+  std::vector<long long> free_off, free_len;   // unconstrained blocks (negative size): identity "projection"
   for (int k = 0; k < mat_num; ++k) {
-    if (blk[k] < 1) { set_error("block %d has size %d", k, blk[k]); return CUADMM_ERR_INVALID; }
+    if (blk[k] == 0) { set_error("block %d has size 0", k); return CUADMM_ERR_INVALID; }
     if (blk[k] > kMaxBlockSize) { set_error("block %d has size %d > %d (largest supported this build)", k, blk[k], kMaxBlockSize); return CUADMM_ERR_INVALID; }
-    off[k + 1] = off[k] + (long long)blk[k] * (blk[k] + 1) / 2;
+    if (eig_rank > 0 && blk[k] > kMaxEigSize && !getenv("CUADMM_EIG_ALLOW_SLOW")) {
+      set_error("rank-limited projection: block %d has size %d > %d (explicit eigendecomposition of large blocks is too slow; CUADMM_EIG_ALLOW_SLOW=1 overrides)",
+                k, blk[k], kMaxEigSize);
+      return CUADMM_ERR_INVALID;
+    }
+    off[k + 1] = off[k] + blk_svec_len(blk[k]);
+    if (blk[k] < 0) { free_off.push_back(off[k]); free_len.push_back(-(long long)blk[k]); }
   }
   vec_len = off[mat_num];
   if (const char* e = getenv("CUADMM_PSD_SIGN_MIN")) sign_min = std::max(65, atoi(e));
+  // a rank mask needs eigenvalues: with eig_rank set every block goes through the eigensolver kernels
+  if (eig_rank > 0) sign_min = 0x7fffffff;
   std::vector<int> sign_members;
   for (int k = 0; k < mat_num; ++k)
     if (blk[k] >= sign_min) sign_members.push_back(k);
@@ -228,7 +246,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     cls_begin[c] = (int)ids.size();
     std::vector<int> members;
     for (int k = 0; k < mat_num; ++k)
-      if (psd_class_of(blk[k]) == c && blk[k] < sign_min) members.push_back(k);
+      if (blk[k] > 0 && psd_class_of(blk[k]) == c && blk[k] < sign_min) members.push_back(k);
     std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return blk[x] > blk[y]; });
     for (int k : members) {
       ids.push_back(k);
@@ -237,6 +255,13 @@ int PsdPlan::build(const int* blk, int mat_num) {
       if (c == 4 && blk[k] > 48) ++cls4_big;
     }
     cls_count[c] = (int)ids.size() - cls_begin[c];
+  }
+  n_free = (int)free_off.size();
+  if (n_free > 0) {
+    CUADMM_HIP_TRY(hipMalloc(&d_free_off, sizeof(long long) * free_off.size()));
+    CUADMM_HIP_TRY(hipMalloc(&d_free_len, sizeof(long long) * free_len.size()));
+    CUADMM_HIP_TRY(hipMemcpy(d_free_off, free_off.data(), sizeof(long long) * free_off.size(), hipMemcpyHostToDevice));
+    CUADMM_HIP_TRY(hipMemcpy(d_free_len, free_len.data(), sizeof(long long) * free_len.size(), hipMemcpyHostToDevice));
   }
   CUADMM_HIP_TRY(hipMalloc(&d_off, sizeof(long long) * ((size_t)mat_num + 1)));
   CUADMM_HIP_TRY(hipMalloc(&d_n, sizeof(int) * (size_t)std::max(mat_num, 1)));
@@ -257,14 +282,15 @@ int PsdPlan::build(const int* blk, int mat_num) {
   }
   // nominal flops 10.67 n^3 per block, GEMM-shaped part 2 n^3
   sum_n3 = 0;
-  for (int k = 0; k < mat_num; ++k) sum_n3 += (double)blk[k] * blk[k] * blk[k];
+  for (int k = 0; k < mat_num; ++k) if (blk[k] > 0) sum_n3 += (double)blk[k] * blk[k] * blk[k];
   return CUADMM_OK;
 }
 
 void PsdPlan::release() {
-  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff})
+  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
+  d_free_off = d_free_len = nullptr; n_free = 0;
   sign.release();
   if (ev_fork) {
     hipError_t e = hipEventDestroy(ev_fork); (void)e;
@@ -341,9 +367,10 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
     a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff; a.steps = d_steps;
+    a.eig_rank = (eig_rank > 0 && rank_active) ? eig_rank : 0;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
-    if (c == 3 && psd_debug && sign32) {   // phase cycles of the one-wavefront-per-block sign kernel
+    if (c == 3 && psd_debug && sign32 && eig_rank == 0) {   // phase cycles of the one-wavefront-per-block sign kernel
       std::vector<long long> h((size_t)cls_count[c] * 10);
       long long* d = nullptr;
       CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
@@ -369,10 +396,10 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     }
     int rc;
     static const bool no_sign_lds = getenv("CUADMM_PSD_MID") && std::string(getenv("CUADMM_PSD_MID")) == "eig";   // A/B: register eigensolver
-    if (c == 4 && !no_sign_lds) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
+    if (c == 4 && !no_sign_lds && eig_rank == 0) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
       rc = launch_sign_lds<64>(a, 0, cls4_big, st);
       if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st);
-    } else if (c == 3 && sign32) {
+    } else if (c == 3 && sign32 && eig_rank == 0) {
       rc = launch_sign_wave32(a, 0, cls_count[c], st);
     } else {
       rc = launch_class<0>(c, a, cls_maxn[c], st);
@@ -398,6 +425,10 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
   }
   st = main_st;
+  if (n_free > 0 && Xb != Xproj) {   // unconstrained blocks: Xproj = Xb on their svec ranges
+    hipLaunchKernelGGL(copy_ranges_kernel, dim3(n_free), dim3(256), 0, st, Xb, Xproj, d_free_off, d_free_len);
+    CUADMM_HIP_TRY(hipGetLastError());
+  }
   if (!sign.empty()) {
     int rc = sign.project(Xb, Xproj, d_off, d_n, d_fail, st);
     if (rc) return rc;
@@ -420,6 +451,11 @@ int PsdPlan::fail_count(hipStream_t st) const {
 int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream_t st) {
   if (n < 1 || count < 0) { set_error("batch_eig: bad n/count"); return CUADMM_ERR_INVALID; }
   if (n > kMaxBlockSize) { set_error("batch_eig: n=%d > %d", n, kMaxBlockSize); return CUADMM_ERR_INVALID; }
+  if (n > kMaxEigSize && !getenv("CUADMM_EIG_ALLOW_SLOW")) {
+    set_error("batch_eig: n=%d > %d: the explicit eigendecomposition of one large block runs on a single workgroup (76 s at n = 2000); "
+              "set CUADMM_EIG_ALLOW_SLOW=1 to run it anyway", n, kMaxEigSize);
+    return CUADMM_ERR_INVALID;
+  }
   if (count == 0) return CUADMM_OK;
   const int c = psd_class_of(n);
   PsdArgs a{};

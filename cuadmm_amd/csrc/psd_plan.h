@@ -25,6 +25,13 @@ struct PsdPlan {
   // path (psd_large.hip); the workgroup eigensolver kernels (classes 5, 6) then only serve cuadmm_op_batch_eig.
   // CUADMM_PSD_SIGN_MIN=<n> moves the boundary (A/B measurements).
   int sign_min = 65;
+  // f4: unconstrained blocks (negative size in blk) are copied through; eig_rank > 0 (set before build)
+  // keeps only the eig_rank largest eigenvalues of every PSD block while rank_active (reference: dense_scalar.cu:51-57,
+  // get_eig_rank_mask.cu:13-37) and routes every block through the eigensolver kernels
+  int eig_rank = 0;
+  bool rank_active = true;
+  int n_free = 0;
+  long long *d_free_off = nullptr, *d_free_len = nullptr;
   mutable SignPsd sign;
   int cls4_big = 0;            // members of class 4 (32 < n <= 64) with n > 48: NP = 64 kernel, the rest NP = 48
   bool overlap = false;        // engine-owned plans: classes on their own streams (fork / join on the caller's stream)

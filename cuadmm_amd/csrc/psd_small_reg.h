@@ -229,18 +229,29 @@ __device__ __forceinline__ void psd_small_reg_body(const Args& a, double* smem) 
   CUADMM_STAMP(3);
   // ---- output ------------------------------------------------------------------------------------------
   if (MODE == 0) {
+    // lambda+ = max(d,0) (dense_scalar.cu:41-47); with a rank limit only the a.eig_rank LARGEST eigenvalues keep their
+    // positive part: max(W,0) * mask with mask = 1 on the last eig_rank entries of the ascending spectrum
+    // (dense_scalar.cu:51-57, get_eig_rank_mask.cu:13-37).  D is unsorted here, so "among the eig_rank largest" is
+    // decided by counting the eigenvalues above (ties: higher index first).
+    {
+      const double lam = rank < n ? D[rank] : 0.0;
+      double lp = lam > 0.0 ? lam : 0.0;
+      if (a.eig_rank > 0 && rank < n) {
+        int above = 0;
+        for (int j = 0; j < n; ++j) { const double lj = D[j]; above += (lj > lam) || (lj == lam && j > rank); }
+        if (above >= a.eig_rank) lp = 0.0;
+      }
+      vv[rank] = lp;
+    }
+    wave_fence();
     if constexpr (NMAX >= 16) {
-      // hand Z (unscaled) and max(d,0) to the matrix-core rebuild that follows (psd_small_reg_rebuild_mfma)
+      // hand Z (unscaled) and lambda+ (in vv) to the matrix-core rebuild that follows (psd_small_reg_rebuild_mfma)
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) T[rank * LD + k] = q[k];
-      { const double lam = rank < n ? D[rank] : 0.0; vv[rank] = lam > 0.0 ? lam : 0.0; }   // dense_scalar.cu:41-47
     } else {
-      // T = Z * diag(max(d,0))   (dense_scalar.cu:41-47, diagonal_batch.cu:11-23)
+      // T = Z * diag(lambda+)   (diagonal_batch.cu:11-23)
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        const double lam = (k < n) ? D[k] : 0.0;
-        T[rank * LD + k] = q[k] * (lam > 0.0 ? lam : 0.0);
-      }
+      for (int k = 0; k < NMAX; ++k) T[rank * LD + k] = q[k] * vv[k];
       wave_fence();
       // P = T * Z^T, upper triangle, row a at a time; row a of T is dead once it has been used
       for (int aa = 0; aa < n; ++aa) {

@@ -64,7 +64,8 @@ class Problem:
         """COO triplets of At (svec_row, constraint_col, value) -> sorted CSC (COO_to_CSC, io.cu:187-243)."""
         lib = _lib.load()
         blk = _i32(blk)
-        vec_len = int(np.sum(blk.astype(np.int64) * (blk.astype(np.int64) + 1) // 2))
+        b64 = blk.astype(np.int64)
+        vec_len = int(np.sum(np.where(b64 >= 0, b64 * (b64 + 1) // 2, -b64)))     # negative size: unconstrained block
         rows, cols, vals = _i32(At_row).copy(), _i32(At_col).copy(), _f64(At_val).copy()
         cp = np.zeros(con_num + 1, np.int32)
         check(lib.cuadmm_coo_to_csc(_p(cp), _p(cols), _p(rows), _p(vals), int(vals.size), int(con_num)))
@@ -74,12 +75,14 @@ class Problem:
 class SDPSolver:
     """Mirror of class SDPSolver (include/cuadmm/solver.h:30-248)."""
 
-    def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False, force_comm=False, psd_steps=False):
+    def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False, force_comm=False, psd_steps=False,
+                 eig_rank=0, eig_rank_begin_iter=0, eig_rank_maxfeas=0.0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.cuadmm_create(C.byref(self._h)))
         for k, v in (("device", device), ("verbose", int(bool(verbose))), ("rank", rank), ("world", world),
-                     ("profile", int(profile)), ("force_comm", int(bool(force_comm))), ("psd_steps", int(bool(psd_steps)))):
+                     ("profile", int(profile)), ("force_comm", int(bool(force_comm))), ("psd_steps", int(bool(psd_steps))),
+                     ("eig_rank", int(eig_rank)), ("eig_rank_begin_iter", int(eig_rank_begin_iter)), ("eig_rank_maxfeas", float(eig_rank_maxfeas))):
             check(self._lib.cuadmm_set_option(self._h, k.encode(), float(v)))
         self._cb = None
         self.vec_len = self.con_num = 0

@@ -52,6 +52,10 @@ void cuadmm_destroy(cuadmm_solver* s);
  *   "profile"       1 = time every kernel class with HIP events on the engine stream;
  *                   2 = time only the dominant kernel (psd_project)
  *   "force_comm"    1 = call the collective hook even when world == 1 (transport tests on one GPU)
+ *   "eig_rank"      r > 0: rank-limited projection (only the r largest eigenvalues of every PSD block survive; reference
+ *                   dense_scalar.cu:51-57 + get_eig_rank_mask.cu, dormant there); active from iteration
+ *                   "eig_rank_begin_iter" (default 0) on, or once maxfeas < "eig_rank_maxfeas" (default 0 = never);
+ *                   set before cuadmm_init (every block then takes the eigensolver kernels)
  *   "psd_steps"     1 = record how many Newton-Schulz steps the adaptive matrix-sign projection took per block
  *                   (cuadmm_get_psd_steps); set before cuadmm_init
  *   "graph"         reserved
@@ -69,6 +73,9 @@ int cuadmm_set_allreduce(cuadmm_solver* s, cuadmm_allreduce_fn fn, void* user);
 int cuadmm_rccl_unique_id(char out128[128]);
 int cuadmm_use_rccl(cuadmm_solver* s, const char unique_id128[128], int rank, int world);
 
+/* Block types: blk_vals[k] > 0 is a PSD block of that size ('s n' in blk.txt); blk_vals[k] < 0 is an UNCONSTRAINED block of
+ * -blk_vals[k] variables ('u n', reference README.md:55-64, "WIP" there: its loader rejects it, problem.cu:28-36), which owns
+ * that many svec slots and is left untouched by the cone projection.  cuadmm_problem_from_txt maps 'u n' lines to -n. */
 /* SDPSolver::init  (reference include/cuadmm/solver.h:208-223, src/solver.cu:27-342).
  * Same argument list and meaning.  At is the CSC of A^T (vec_len x con_num): column j =
  * constraint j, row ids = svec indices.  X/y/S may be NULL (cold start, zeros).  Caller keeps
@@ -243,6 +250,31 @@ int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x);
 void cuadmm_aat_free(cuadmm_aat* f);
 
 /* ------------------------------------------------------------------------------------ */
+/* MATLAB front end (reference MATLAB/cuadmm_MATLAB.cu): the marshalled call behind            */
+/*   [X, y, S, info] = cuadmm_MATLAB(eig_stream_num_per_gpu, max_iter, stop_tol, At, b, C, blk, X0, y0, S0, sig, ...)  */
+/* Arguments are what mexFunction extracts from its mxArrays (cuadmm_MATLAB.cu:197-293): At as a sparse    */
+/* vec_len x con_num matrix (size_t jc[At_cols+1], ir[nnz], pr[nnz]); b, C as sparse column vectors       */
+/* (jc[2], ir, pr); blk as doubles; X0, y0, S0 dense; `optional5` = {sig_update_threshold, stage_1,        */
+/* stage_2, switch_admm, sigscale} or NULL, read only under the reference's own conditions `nlhs >= 12..16`  */
+/* (:297-333; nlhs <= 4, so the effective values are always 500, 50, 100, 11000 and sigscale 1.0).            */
+/* The shim that calls this from a mexFunction: MATLAB/cuadmm_MATLAB_amd.cpp.                                  */
+/* ------------------------------------------------------------------------------------ */
+typedef struct cuadmm_mex_result cuadmm_mex_result;
+int cuadmm_mex_call(int eig_stream_num_per_gpu, int max_iter, double stop_tol,
+                    size_t At_rows, size_t At_cols, const size_t* At_jc, const size_t* At_ir, const double* At_pr,
+                    size_t b_rows, const size_t* b_jc, const size_t* b_ir, const double* b_pr,
+                    size_t C_rows, const size_t* C_jc, const size_t* C_ir, const double* C_pr,
+                    size_t blk_len, const double* blk_pr,
+                    size_t X0_len, const double* X0, size_t y0_len, const double* y0, size_t S0_len, const double* S0,
+                    double sig, int nlhs, const double* optional5, cuadmm_mex_result** out);
+/* what the MEX packs into its outputs (cuadmm_MATLAB.cu:366-424): X, y, S (unscaled) and the 10 x 2 `info` cell:
+ * iter_num, the eight per-iteration arrays (which = CUADMM_INFO_*, iter_num doubles each) and total_time */
+int cuadmm_mex_result_dims(const cuadmm_mex_result* r, int* vec_len, int* con_num, int* iter_num, double* total_time);
+int cuadmm_mex_result_XyS(const cuadmm_mex_result* r, double* X, double* y, double* S);
+int cuadmm_mex_result_info(const cuadmm_mex_result* r, int which, double* out);
+void cuadmm_mex_result_free(cuadmm_mex_result* r);
+
+/* ------------------------------------------------------------------------------------ */
 /* Op-level device entry points (pointers are DEVICE pointers; `stream` is a hipStream_t   */
 /* or NULL).  Each mirrors one reference kernel/wrapper so parity can be tested per op.    */
 /* ------------------------------------------------------------------------------------ */
@@ -278,6 +310,10 @@ int cuadmm_op_mul_trans_batch(double* P, const double* T, const double* V, int n
  * blk[mat_num] sizes in blk.txt order; Xproj may alias Xb.  eig_fail (device int, may be
  * NULL) is incremented per block whose QL iteration hit its cap. */
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream);
+/* General form: blk[k] < 0 is an UNCONSTRAINED block of -blk[k] variables (blk.txt type 'u', reference README.md:55-64),
+ * copied through; eig_rank > 0 keeps only the eig_rank largest eigenvalues of every PSD block: V diag(max(W,0) * mask) V^T with
+ * the mask of get_eig_rank_mask.cu:13-37 (dense_scalar.cu:51-57) -- computed through the eigensolver kernels. */
+int cuadmm_op_psd_project_ex(const double* Xb, double* Xproj, const int* blk_host, int mat_num, int eig_rank, int* steps_dev, void* stream);
 /* Same, also returning how many Newton-Schulz steps the adaptive matrix-sign schedule took per block (device int array of
  * mat_num entries, 0 for blocks served by the eigensolver kernels); developer/diagnostic entry. */
 int cuadmm_op_psd_project_steps(const double* Xb, double* Xproj, const int* blk_host, int mat_num, int* steps_dev, void* stream);

@@ -288,11 +288,18 @@ def matrices_to_vector(large_mat, small_mat, map_B, map_M1, map_M2):
     return out
 
 
+def blk_svec_len(blk):
+    """svec slots per block: n(n+1)/2 for a PSD block 's n'; an unconstrained block 'u n' (README.md:55-64, WIP in the
+    reference, whose loader still rejects it, problem.cu:28-36) is carried as the NEGATIVE size -n and owns n slots."""
+    blk = np.asarray(blk, dtype=np.int64)
+    return np.where(blk >= 0, blk * (blk + 1) // 2, -blk)
+
+
 def svec_block_offsets(blk):
     """svec offsets of each block in blk.txt order (get_maps.cu:116-117 walk)."""
     blk = np.asarray(blk, dtype=np.int64)
     off = np.zeros(blk.size + 1, dtype=np.int64)
-    np.cumsum(blk * (blk + 1) // 2, out=off[1:])
+    np.cumsum(blk_svec_len(blk), out=off[1:])
     return off
 
 
@@ -303,7 +310,9 @@ class BlockIndex:
         self.blk = np.asarray(blk, dtype=np.int64)
         self.off = svec_block_offsets(self.blk)
         self.groups = []
-        for n in sorted(set(int(x) for x in self.blk)):
+        # unconstrained blocks (negative size): their svec ranges pass through the projection unchanged
+        self.free = [(int(self.off[k]), int(self.off[k + 1])) for k in np.nonzero(self.blk < 0)[0]]
+        for n in sorted(set(int(x) for x in self.blk if x > 0)):
             ids = np.nonzero(self.blk == n)[0]
             ii, jj = np.tril_indices(n)       # svec slot t <-> (col ii[t], row jj[t]), jj<=ii
             gather = self.off[ids][:, None] + np.arange(n * (n + 1) // 2)[None, :]
@@ -324,18 +333,22 @@ class BlockIndex:
 
     def pack(self, mats):
         """dense -> svec with sqrt2 off-diagonals, reading the upper element (vec_mat_conversion.cu:51)."""
-        x = np.empty(int(self.off[-1]))
+        x = np.zeros(int(self.off[-1]))
         for (n, ids, ii, jj, gather), M in zip(self.groups, mats):
             scale = np.where(ii == jj, 1.0, SQRT2)
             x[gather] = M[:, jj, ii] * scale[None, :]
         return x
 
 
-def psd_project_svec(bidx: BlockIndex, xb: np.ndarray, return_eigs=False):
+def psd_project_svec(bidx: BlockIndex, xb: np.ndarray, return_eigs=False, eig_rank=0):
     """Steps solver.cu:534-647: unpack, eig, max(W,0), V diag(W) V^T, pack.
 
     The eigendecomposition is LAPACK dsyevd (numpy.linalg.eigh), i.e. the reference's
     eig_cpu routine (eig_cpu.h:31-51); the GPU reference uses cuSOLVER (cusolver.h:86,164).
+    eig_rank > 0: the rank-limited projection the reference prepares but leaves switched off
+    (duo_solver.cu:428-438,843-850): W = max(W,0) * mask (dense_scalar.cu:51-57) with mask = 1 on the LAST eig_rank
+    entries of the ascending eigenvalues of every block (get_eig_rank_mask.cu:13-37), i.e. only the eig_rank largest
+    eigenvalues survive.  Unconstrained blocks (negative size) are copied through.
     """
     mats = bidx.unpack(xb)
     proj = []
@@ -343,10 +356,14 @@ def psd_project_svec(bidx: BlockIndex, xb: np.ndarray, return_eigs=False):
     for M in mats:
         w, V = np.linalg.eigh(M)
         wp = np.maximum(w, 0.0)                                  # dense_scalar.cu:41-47
+        if eig_rank > 0 and eig_rank < wp.shape[1]:
+            wp[:, : wp.shape[1] - eig_rank] = 0.0                # get_eig_rank_mask.cu:30-35 (ascending: last r kept)
         tmp = V * wp[:, None, :]                                 # diagonal_batch.cu:11-23
         proj.append(tmp @ np.swapaxes(V, 1, 2))                  # cublas.h:18-35 (N,T)
         eigs.append(w)
     x = bidx.pack(proj)
+    for lo, hi in bidx.free:
+        x[lo:hi] = xb[lo:hi]
     return (x, eigs) if return_eigs else x
 
 
@@ -372,8 +389,11 @@ class SolveInfo:
 class OracleSolver:
     """Restatement of SDPSolver (include/cuadmm/solver.h:30-248, src/solver.cu)."""
 
-    def __init__(self, eig_fn=None):
+    def __init__(self, eig_fn=None, eig_rank=0, eig_rank_begin_iter=0, eig_rank_maxfeas=0.0):
         self.eig_fn = eig_fn
+        # rank-limited projection, dormant in the reference (duo_solver.cu:428 eig_rank = 5; :843-850 the switch
+        # `iter >= begin_low_rank_proj || maxfeas < 1e-3` is commented out): 0 = off
+        self.eig_rank, self.eig_rank_begin_iter, self.eig_rank_maxfeas = int(eig_rank), int(eig_rank_begin_iter), float(eig_rank_maxfeas)
 
     # -- SDPSolver::init, src/solver.cu:27-342 -----------------------------------------
     def init(self, vec_len, con_num, At_col_ptrs, At_row_ids, At_vals,
@@ -457,10 +477,13 @@ class OracleSolver:
         # P^T (L D L^T)^-1 P applied to rhs == (A A^T + eps I)^-1 rhs.
         return self._solve(rhs)
 
-    def project(self, xb):
+    def project(self, xb, it=0):
         if self.eig_fn is not None:
             return self.eig_fn(self.bidx, xb)
-        return psd_project_svec(self.bidx, xb)
+        rank = 0
+        if self.eig_rank > 0 and (it >= self.eig_rank_begin_iter or self.maxfeas < self.eig_rank_maxfeas):   # duo_solver.cu:844
+            rank = self.eig_rank
+        return psd_project_svec(self.bidx, xb, eig_rank=rank)
 
     # -- SDPSolver::solve, src/solver.cu:355-823 ------------------------------------------
     def solve(self, max_iter, stop_tol, sig_update_threshold=500, sig_update_stage_1=50,
@@ -510,7 +533,7 @@ class OracleSolver:
                 if it > switch_admm and X_best is not None:
                     self.X, self.y, self.S = X_best.copy(), y_best.copy(), S_best.copy()
                 break
-            Xproj = self.project(Xb)                                          # solver.cu:534-647
+            Xproj = self.project(Xb, it)                                      # solver.cu:534-647
             Xdiff = 1.0 * Xproj + (-1.0) * self.X                             # :652
             self.S = (1 / self.sig) * Xdiff + (-1.0) * Rd1                    # :656
             if stage_hook is not None:

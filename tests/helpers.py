@@ -39,12 +39,12 @@ class Dev:
             pass
 
 
-def psd_project_gpu(x, blk):
+def psd_project_gpu(x, blk, eig_rank=0):
     lib = cuadmm_amd.load()
     blk = np.ascontiguousarray(blk, dtype=np.int32)
     din = Dev(np.ascontiguousarray(x, dtype=np.float64))
     dout = Dev(shape=(x.size,), dtype=np.float64)
-    check(lib.cuadmm_op_psd_project(din.ptr, dout.ptr, blk.ctypes.data_as(C.c_void_p), int(blk.size), None))
+    check(lib.cuadmm_op_psd_project_ex(din.ptr, dout.ptr, blk.ctypes.data_as(C.c_void_p), int(blk.size), int(eig_rank), None, None))
     return dout.get()
 
 

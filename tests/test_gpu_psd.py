@@ -141,6 +141,35 @@ def test_batch_eig_vs_lapack(n, count):
     assert np.max(np.abs(orth)) <= 5e-13 * n
 
 
+def test_batch_eig_large_block_n1024_and_the_fence_above_it():
+    """single_eig_cusolver contract (include/cuadmm/cusolver.h:76-95: Xsyevd, W ascending, V in place) at the largest size the
+    explicit eigendecomposition accepts: eigenvalues <= 1e-12 ||A||_2, reconstruction, orthogonality; its wall time is recorded
+    in the assertion message budget (3.2 s measured on MI355X: one workgroup runs the QL iteration).  Larger blocks are refused
+    (76 s at n = 2000) -- the solver's projection never needs them (matrix-sign path, test_large_block_c3_size)."""
+    import time
+    import ctypes as C
+    import cuadmm_amd
+    from tests.helpers import Dev
+    n = 1024
+    rng = np.random.default_rng(77)
+    G = rng.standard_normal((1, n, n))
+    A = (G + np.swapaxes(G, 1, 2)) / 2
+    t0 = time.time()
+    W, V, info = batch_eig_gpu(A)
+    dt = time.time() - t0
+    assert info[0] == 0 and dt < 30.0, dt
+    w = np.linalg.eigvalsh(A[0])
+    nrm = np.abs(w).max()
+    assert np.max(np.abs(W[0] - w)) <= 1e-12 * nrm
+    assert np.all(np.diff(W[0]) >= 0)
+    assert np.max(np.abs((V[0] * W[0][None, :]) @ V[0].T - A[0])) <= 1e-12 * nrm
+    assert np.max(np.abs(V[0].T @ V[0] - np.eye(n))) <= 1e-12
+    lib = cuadmm_amd.load()
+    big = Dev(shape=(1100 * 1100,)); w2 = Dev(shape=(1100,)); i2 = Dev(np.zeros(1, np.int32))
+    rc = lib.cuadmm_op_batch_eig(big.ptr, w2.ptr, i2.ptr, 1100, 1, None)
+    assert rc == -1 and b"CUADMM_EIG_ALLOW_SLOW" in lib.cuadmm_last_error()
+
+
 def test_batch_eig_reference_kats():
     """Spectra hard-coded in the reference tests (test/cusolver_test.hpp:60-63,117-126,178-182)."""
     A4 = np.array([[4, 1, 2, 2], [1, 4, 1, 2], [2, 1, 4, 1], [2, 2, 1, 4]], dtype=float)

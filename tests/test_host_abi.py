@@ -122,12 +122,12 @@ def test_problem_from_txt_errors(tmp_path):
         cuadmm_amd.Problem.from_txt(str(tmp_path) + "/")
     assert e.value.code == -3
     d = tmp_path / "p"; d.mkdir()
-    (d / "blk.txt").write_text("u 3\n"); (d / "con_num.txt").write_text("1\n")
+    (d / "blk.txt").write_text("q 3\n"); (d / "con_num.txt").write_text("1\n")      # 'u n' is accepted since round 2 (test_f4_free_and_rank.py)
     for f in ("At.txt", "b.txt", "C.txt"):
         (d / f).write_text("")
     with pytest.raises(cuadmm_amd.CuadmmError) as e:
         cuadmm_amd.Problem.from_txt(str(d) + "/")
-    assert "unknown block type 'u'" in str(e.value)                               # problem.cu:33-35
+    assert "unknown block type 'q'" in str(e.value)                               # problem.cu:33-35
 
 
 def _aat(p):
