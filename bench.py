@@ -83,13 +83,26 @@ def cpu_baseline(prob, threads, budget_s=20.0):
     s.solve(n_iters, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
     dt = time.perf_counter() - t0
     return {"value": n_iters / dt, "unit": "iters/s", "cores": threads, "kind": "port",
-            "nproc": os.cpu_count(),
+            "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
             "projection_blocks_per_s": blocks_per_s, "projection_ms": proj_s_full * 1e3,
             "engine": "LAPACK dsyevd (scipy OpenBLAS, BLAS threads = 1) + DGEMM" if eng == "lapack" else
                       "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native)",
             "sample": "%d ADMM iterations of the same problem on the numpy oracle with the per-block projection in C on %d "
                       "host threads (static contiguous split as duo_solver.cu:344-371), %.1f s; projection-only: %d blocks in %.2f s"
                       % (n_iters, threads, dt, n_proj, secs)}
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows nproc = 256 under
+    a 16-CPU quota; 256 busy threads there are 16 CPUs' worth of work)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def pmc_traffic(kernel_substr):
@@ -329,7 +342,7 @@ def main():
         if breakdown is not None:
             out["breakdown_ms_per_iter"] = breakdown      # psd_project / aty_xb / post_proj / spmv_A / copies / comm / host / tail_solve
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            threads = usable_cpus()
             out["cpu_baseline"] = cpu_baseline(prob, threads, args.cpu_budget_s)
         print(json.dumps(out), flush=True)
     if dist is not None:

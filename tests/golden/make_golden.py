@@ -62,6 +62,10 @@ LOGS = {
     "1dc.1024/sGS": ("plato/logs/1dc.1024.log", "1dc.1024", dict(switch_admm=11000)),
     "bqp-r1-40-1/sGS": ("plato/logs/bqp-r1-40-1.log", "bqp-r1-40-1", dict(switch_admm=11000)),
     "swissroll/sGS": ("plato/logs/swissroll.log", "swissroll", dict(switch_admm=11000)),
+    # inputs that exist only as MOSEK / svec .mat files (round 2: long-run parity on problems never run before)
+    "PushT_N=30_MOMENT/sGS": ("benchmarks/PushT_N=30_MOMENT/sGS-cuADMM.log", "PushT_N=30_MOMENT", dict(switch_admm=11000)),
+    "chs_5000/cuADMM": ("benchmarks/chs_5000/cuADMM.log", "chs_5000", dict(switch_admm=0)),
+    "chs_5000/sGS": ("benchmarks/chs_5000/sGS-cuADMM.log", "chs_5000", dict(switch_admm=11000)),
 }
 
 # problems shipped as .mat with At / C / b already in svec form (examples/plato/MATLAB), blk from the TXT directory
@@ -69,6 +73,7 @@ PLATO_MAT = {
     "1dc.1024": ("plato/MATLAB/1dc.1024.mat", "plato/TXT/1dc.1024"),
     "bqp-r1-40-1": ("plato/MATLAB/bqp-r1-40-1.mat", "plato/TXT/bqp-r1-40-1"),
     "swissroll": ("plato/MATLAB/swissroll.mat", "plato/TXT/swissroll"),
+    "chs_5000": ("plato/MATLAB/chs_5000.mat", "plato/TXT/chs5000"),
 }
 COMMON = dict(sig=1.0, stop_tol=1e-3, sig_update_threshold=0, sig_update_stage_1=50,
               sig_update_stage_2=100, sigscale=1.05)
@@ -162,6 +167,18 @@ def main():
     assert ph["At_val"].size == 156635         # benchmarks/PlanarHand_N=1_MOMENT/cuADMM.log:5
     np.savez_compressed(os.path.join(out_prob, "PlanarHand_N=1_MOMENT.npz"), **ph)
 
+    # --- PushT_N=30 (the A*A^T factorisation stress test: 369 s before iteration 0 in the reference's log), same transform
+    p30 = mosek_to_problem(os.path.join(EX, "SPOT/data/MOSEK/PushT_N=30_MOMENT.mat"))
+    txt = os.path.join(EX, "SPOT/data/TXT/PushT_N=30_MOMENT/")
+    assert [n for _, n in orc.read_blk(txt + "blk.txt")] == p30["blk"].tolist()
+    ci, cv = orc.read_sparse_vector(txt + "C.txt")
+    o = np.argsort(p30["C_idx"])
+    assert np.array_equal(p30["C_idx"][o], ci) and np.allclose(p30["C_val"][o], cv, rtol=0, atol=1e-15)
+    bi, bv = orc.read_sparse_vector(txt + "b.txt")
+    assert np.array_equal(p30["b_idx"], bi) and np.allclose(p30["b_val"], bv, rtol=0, atol=1e-15)
+    p30["C_idx"], p30["C_val"], p30["b_idx"], p30["b_val"] = ci, cv, bi, bv
+    np.savez_compressed(os.path.join(out_prob, "PushT_N=30_MOMENT.npz"), **p30)
+
     # the same transform reproduces the shipped PushT_N=10 At.txt (validation of the transform)
     pt = mosek_to_problem(os.path.join(EX, "SPOT/data/MOSEK/PushT_N=10_MOMENT.mat"))
     r, c, v = orc.read_coo(os.path.join(EX, "SPOT/data/TXT/PushT_N=10_MOMENT/At.txt"))
@@ -188,9 +205,23 @@ def main():
     # --- single-large-block problems from examples/plato/MATLAB (their TXT directories lack At.txt / C.txt)
     for name, (matrel, txtrel) in PLATO_MAT.items():
         d = sio.loadmat(os.path.join(EX, matrel))
+        blk = np.array([n for _, n in orc.read_blk(os.path.join(EX, txtrel, "blk.txt"))], dtype=np.int32)
+        if "At" not in d:      # SeDuMi (A, b, c, K): through the converter (cuadmm_amd/convert.py = examples/sedumi_to_txt.m)
+            from cuadmm_amd import convert
+            import scipy.sparse as sp
+            q = convert.problem_from_sedumi_mat(os.path.join(EX, matrel))
+            assert list(q.blk_vals) == blk.tolist()
+            At = sp.csc_matrix((q.At_csc_vals, q.At_csc_row_ids, q.At_csc_col_ptrs), shape=(q.vec_len, q.con_num)).tocoo()
+            bi_txt, bv_txt = orc.read_sparse_vector(os.path.join(EX, txtrel, "b.txt"))
+            ci_txt, cv_txt = orc.read_sparse_vector(os.path.join(EX, txtrel, "C.txt"))
+            assert np.array_equal(q.b_indices, bi_txt) and np.allclose(q.b_vals, bv_txt, rtol=0, atol=1e-12)
+            assert np.array_equal(q.C_indices, ci_txt) and np.allclose(q.C_vals, cv_txt, rtol=0, atol=1e-12)
+            np.savez_compressed(os.path.join(out_prob, name + ".npz"), blk=blk, con_num=int(q.con_num),
+                                At_row=At.row.astype(np.int32), At_col=At.col.astype(np.int32), At_val=At.data,
+                                C_idx=ci_txt, C_val=cv_txt, b_idx=bi_txt, b_val=bv_txt)
+            continue
         At, Cm = d["At"].tocoo(), d["C"].tocoo()
         bm = np.asarray(d["b"].todense() if hasattr(d["b"], "todense") else d["b"]).ravel()
-        blk = np.array([n for _, n in orc.read_blk(os.path.join(EX, txtrel, "blk.txt"))], dtype=np.int32)
         assert At.shape[0] == int(orc.svec_block_offsets(blk)[-1]) and At.shape[1] == bm.size
         bi_txt, bv_txt = orc.read_sparse_vector(os.path.join(EX, txtrel, "b.txt"))
         bi = np.nonzero(bm)[0].astype(np.int32)

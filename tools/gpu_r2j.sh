@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python tools/run_all_real.py 2>&1 | cut -c1-400
+timeout 2400 python -X faulthandler -m pytest tests/test_gpu_longrun.py -q -s > gpurun_out/r2i_pytest.log 2>&1
+echo "pytest rc $?"
+grep "longrun\|passed\|failed\|Error\|assert" gpurun_out/r2i_pytest.log | cut -c1-400 | head -60
