@@ -79,5 +79,19 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_host_sanitized():
+    """ASan + UBSan build of the HOST sources only (loader, block bookkeeping, A*A^T ordering / factor / solve, schedule
+    model) -> cuadmm_amd/lib/libcuadmm_host_asan.so.  CPU only (the GPU pool refuses sanitizers); driven by
+    tests/test_host_sanitizers.py through tests/_asan_host_driver.py under LD_PRELOAD=libasan."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libcuadmm_host_asan.so")
+    srcs = [os.path.join(CSRC, s) for s in ("io.cpp", "blocks.cpp", "aat_ldlt.cpp", "host_selftest.cpp")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    if not _newer(out, srcs + headers):
+        _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined",
+              "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-I" + INCLUDE, "-I" + CSRC] + srcs + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
