@@ -13,6 +13,7 @@ import shutil
 import sys
 
 tag, kt, fd, wd = sys.argv[1:5]
+sqd = sys.argv[5] if len(sys.argv) > 5 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -42,4 +43,13 @@ for k in sorted(set(fetch) | set(write)):
                   "hbm_bytes_per_launch": 2.0 * fr + wr, "launches_sampled": fetch.get(k, (0, 0))[1]}
 with open(os.path.join(out, "%s_pmc_hbm_traffic.json" % tag), "w") as f:
     json.dump(summary, f, indent=1)
-print(json.dumps(summary, indent=1))
+print(json.dumps(summary, indent=1)[:3000])
+if sqd:
+    sq = {}
+    for counter in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"):
+        for k, (v, n) in mean_counter(sqd, counter).items():
+            if k.startswith("void cuadmm") or k.startswith("cuadmm"):
+                sq.setdefault(k, {})[counter] = v
+                sq[k]["launches_sampled"] = n
+    with open(os.path.join(out, "%s_pmc_sq_counters.json" % tag), "w") as f:
+        json.dump(sq, f, indent=1)
