@@ -184,7 +184,7 @@ static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_
 template <int NP>
 static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t st) {
   if (count <= 0) return CUADMM_OK;
-  const size_t lds = sizeof(double) * 3 * NP * SignLdsCfg<NP>::LD;
+  const size_t lds = sizeof(double) * 2 * NP * SignLdsCfg<NP>::LD;
   auto kern = psd_sign_lds_kernel<NP>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {

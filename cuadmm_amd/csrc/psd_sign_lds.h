@@ -1,6 +1,6 @@
 // PSD projection of blocks with 32 < n <= 64: the matrix-sign iteration of psd_large.hip with the WHOLE iteration
-// resident in LDS -- one workgroup (6 or 10 wavefronts) per block, three NP x NP matrices (S, S^2, next S) in LDS, one
-// launch, no global traffic between the svec read and the svec write.
+// resident in LDS -- one workgroup (6 or 10 wavefronts) per block, two NP x NP matrices (S, S^2) in LDS and the next S in
+// accumulator registers, one launch, no global traffic between the svec read and the svec write.
 //
 // Why not the register-resident eigensolver (psd_small_reg.h) that serves n <= 32: at n = 33..64 it runs one block
 // per wavefront and is bound by the dependent rotation chain (0.7 us/block at n = 45 in bulk, 0.84 ms latency for a
@@ -99,9 +99,13 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
                                                   double* smem, int* steps_out) {
   using Cfg = SignLdsCfg<NP>;
   constexpr int LD = Cfg::LD;
+  // TWO matrices in LDS (S and Y); the next iterate T lives in the accumulator registers of the wavefront that owns the
+  // sub-tile and overwrites S in place once every wavefront has finished reading S (the barrier the statistics exchange
+  // needs anyway).  Three resident matrices (round 1) limited a CU to 2 (NP = 48) / 1 (NP = 64) workgroups; two allow
+  // 4 / 2, and the exposed LDS / barrier latency of one block is covered by the others (the kernel ran at ~30 % of the
+  // fp64 matrix-core peak on the n = 45 blocks of C4).
   double* S = smem;
   double* Y = S + NP * LD;
-  double* T = Y + NP * LD;
   __shared__ double red[64];
   __shared__ double stat[3 * 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
     for (int r = 0; r < 4; ++r) { const double d = e[r] - z[r]; pg += d * d; }
     pg = wave_sum(pg) * wgt;
     if (lane == 0) { stat[wave] = pa; stat[16 + wave] = pb; stat[32 + wave] = pg; }
-    __syncthreads();
+    __syncthreads();                                                                 // statistics visible; all reads of S done
     double ta = 0.0, tb = 0.0, tg = 0.0;
 #pragma unroll
     for (int w = 0; w < Cfg::NU; ++w) { ta += stat[w]; tb += stat[16 + w]; tg += stat[32 + w]; }
@@ -153,28 +157,28 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
     sl_v4f64 t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = alpha * z[r] + beta * e[r];                   // T = 1.5 mu S - 0.5 mu^3 S*Y
-    sl_store<NP>(T, t, ti, tj, lane);
+    sl_store<NP>(S, t, ti, tj, lane);                                                // in place: the sub-tile and its mirror image
     __syncthreads();
-    double* sw = S; S = T; T = sw;
   }
   if (steps_out && tid == 0) *steps_out = sched.steps;
-  // P = 0.5 * (X0 + X0 * S): X0 is unpacked again (three matrices fit in LDS, four do not at NP = 64)
+  // P = 0.5 * (X0 + X0 * S): X0 is unpacked again into Y; the result replaces S after a barrier
   sl_unpack<NP>(in, n, Y, tid);
+  sl_v4f64 t;
   {
     const sl_v4f64 z = sl_mma<NP>(Y, S, ti, tj, lane);
     const sl_v4f64 e = sl_tile<NP>(Y, ti, tj, lane);
-    sl_v4f64 t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = 0.5 * z[r] + 0.5 * e[r];
-    sl_store<NP>(T, t, ti, tj, lane);
   }
+  __syncthreads();
+  sl_store<NP>(S, t, ti, tj, lane);
   __syncthreads();
   const int len = n * (n + 1) / 2;
   bool bad = false;
   for (int e = tid; e < len; e += Cfg::THREADS) {
     int i, j;
     tri_decode(e, i, j);
-    const double v = T[j * LD + i];
+    const double v = S[j * LD + i];
     bad |= !(fabs(v) <= 1.7976931348623157e308);
     out[e] = (i == j) ? v : v * kSqrt2;
   }
