@@ -69,6 +69,7 @@ PROTOTYPES = {
     "cuadmm_mex_result_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "cuadmm_mex_result_free": (None, [C.c_void_p]),
     "cuadmm_get_psd_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "cuadmm_sign_sched_simulate_hint": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_int_p]),
     "cuadmm_sign_sched_simulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
     "cuadmm_op_psd_project_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cuadmm_op_psd_project_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -187,7 +187,7 @@ struct cuadmm_solver {
   SpmvLongRows A_long;         // rows of A much longer than the average (trace / all-ones constraints)
   DevBuf<double> At_v, A_v;
   DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
-  DevBuf<int> steps_d;
+  DevBuf<int> steps_d, hint_d;
   // Where the kernels write [A*X | sums | A*(S-C)]: the device buffer out_d when it has to be all-reduced, otherwise the
   // pinned host buffer h_out itself through its device mapping -- the results cross PCIe as the kernels produce them and
   // fetch_out is a stream synchronisation without a copy.
@@ -657,6 +657,15 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->plan.eig_rank = s->eig_rank > 0 ? s->eig_rank : 0;
   rc = s->plan.build(s->blk_local.data(), (int)s->blk_local.size());
   s->plan.overlap = true;
+  if (!rc && !s->blk_local.empty() && getenv("CUADMM_PSD_HINT") && atoi(getenv("CUADMM_PSD_HINT")) == 1) {
+    // Schedule warm start of the sign kernels (lift steps each block needed in the previous projection), OPT-IN: measured
+    // C2 12.0 -> 11.4 steps (-4 % projection time), C4 11.0 -> 10.5, but C3 17 -> 18 (+5 %): the recorded count includes the
+    // overshoot of the previous run's bursts and only decays every 16th projection, and a failed first probe costs 4 steps.
+    if ((rc = s->hint_d.alloc(s->blk_local.size()))) return rc;
+    CUADMM_HIP_TRY(hipMemset(s->hint_d.p, 0, sizeof(int) * s->blk_local.size()));
+    s->plan.d_hint = s->hint_d.p;
+    s->plan.sign.d_hint = s->hint_d.p;
+  }
   if (!rc && s->psd_steps && !s->blk_local.empty()) {
     if ((rc = s->steps_d.alloc(s->blk_local.size()))) return rc;
     CUADMM_HIP_TRY(hipMemset(s->steps_d.p, 0, sizeof(int) * s->blk_local.size()));

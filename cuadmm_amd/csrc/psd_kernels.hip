@@ -42,6 +42,7 @@ struct PsdArgs {
   const long long* ws_off; // GLOBAL variant: workspace offset per member
   long long* dbg;          // developer aid: per-workgroup phase timestamps (CUADMM_PSD_DEBUG)
   int* steps;              // developer aid: Newton-Schulz steps taken per block (sign kernels; may be null)
+  int* hint;               // per block, in/out: lift steps the previous projection needed (schedule warm start; may be null)
   int eig_rank;            // > 0: rank-limited projection, only the eig_rank largest eigenvalues survive (eigensolver kernels)
 };
 
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(P
   extern __shared__ double sign_smem[];
   const int m = first + (int)blockIdx.x;
   const int id = a.ids ? a.ids[m] : m;
-  psd_sign_lds_body<NP>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, a.steps ? a.steps + id : nullptr);
+  psd_sign_lds_body<NP>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, a.steps ? a.steps + id : nullptr,
+                        a.hint ? a.hint + id : nullptr);
 }
 
 // n <= 32 (projection only): one wavefront per block (psd_sign_lds.h, SignWave32); WPG wavefronts per workgroup.
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(P
     if (m >= count) return;                                                                                                         \
     const int id = a.ids ? a.ids[first + m] : first + m;                                                                            \
     psd_sign_wave32_body<DBG>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sw_smem + w * SignWave32::PER_WAVE,          \
-                              a.steps ? a.steps + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr);                       \
+                              a.steps ? a.steps + id : nullptr, a.hint ? a.hint + id : nullptr,                                    \
+                              a.dbg ? a.dbg + 10 * (long long)m : nullptr);                                                         \
   }
 // two register budgets of the same kernel: 4 wavefronts per SIMD (<= 128 VGPRs, a few spills outside the iteration) and 3
 // (<= 168, no spills); CUADMM_PSD_W32_OCC=3|4 selects, the default is the measured winner
@@ -339,7 +342,17 @@ static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
 // Size classes are independent: with `overlap` (engine-owned plans) every class and the sign path run on their own
 // stream between a fork and a join event on `st`, so small classes (a moment relaxation has a handful of blocks per
 // size) overlap instead of queueing behind each other.
+// schedule hints age: one lift step fewer every 16th projection, so that a block whose spectrum got easier finds out
+__global__ void hint_decay_kernel(int* hint, int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n && hint[i] > 1) hint[i] -= 1;
+}
+
 int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
+  if (d_hint && (++n_project & 15) == 0) {
+    hipLaunchKernelGGL(hint_decay_kernel, dim3((nblk + 255) / 256), dim3(256), 0, st, d_hint, nblk);
+    CUADMM_HIP_TRY(hipGetLastError());
+  }
   static const bool psd_debug = getenv("CUADMM_PSD_DEBUG") != nullptr;     // environment read once, not per projection
   static const bool no_overlap = (getenv("CUADMM_PSD_OVERLAP") && atoi(getenv("CUADMM_PSD_OVERLAP")) == 0) || psd_debug;
   int lanes = sign.empty() ? 0 : 1;
@@ -368,6 +381,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
     a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff; a.steps = d_steps;
     a.eig_rank = (eig_rank > 0 && rank_active) ? eig_rank : 0;
+    a.hint = d_hint;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
     if (c == 3 && psd_debug && sign32 && eig_rank == 0) {   // phase cycles of the one-wavefront-per-block sign kernel

@@ -11,6 +11,7 @@ struct SignPsd {
   std::vector<Group> groups;                 // same padded size N, bounded workspace
   int* d_ids = nullptr;                      // block ids, group after group
   int* d_steps = nullptr;                    // not owned; when set: Newton-Schulz steps taken per block
+  int* d_hint = nullptr;                     // not owned; schedule warm start per block (lift steps of the previous projection)
   double *X0 = nullptr, *S = nullptr, *Y = nullptr, *T = nullptr, *colsum = nullptr, *scale = nullptr;
   void* d_state = nullptr;                   // 2 x SignDevState per member of the largest group (adaptive schedule, sign_sched.h)
   void* d_done = nullptr;                    // SignDone per member

@@ -76,6 +76,8 @@ struct SignArgs {
   double* p1;               // [member][tile][2]: tr Y, ||Y||_F^2 of the current step
   double* p2;               // [parity][member][tile]: ||S - S Y||_F^2 of the step with that parity
   int* group;               // group[0]: members not finished, group[1]: largest step count (polled by the host)
+  int* hint;                // per block (all blocks of the plan), in/out: schedule warm start; may be null
+  const int* ids;           // member -> block id
   int count, step;
 };
 
@@ -112,6 +114,7 @@ __device__ __forceinline__ double lg_reduce_decide(const SignArgs& sa, int membe
       if (last) {
         sa.done[member].steps = v.sched.steps;
         sa.done[member].done_at = sa.step + 1;
+        if (sa.hint) sa.hint[sa.ids[member]] = v.sched.lifts;
         atomicMax(sa.group + 1, v.sched.steps);
         atomicSub(sa.group, 1);
       }
@@ -440,6 +443,7 @@ __global__ void lg_state_init_kernel(SignArgs sa, const int* __restrict__ ids, c
   if (m >= sa.count) return;
   SignDevState s;
   s.sched = SignSched();
+  if (sa.hint && sa.hint[ids[m]] > 0) s.sched.lift0 = sa.hint[ids[m]];
   s.mu = 1.0;
   s.n = bn[ids[m]];
   sa.st[m] = s;
@@ -565,6 +569,8 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     sa.p1 = d_part;
     sa.p2 = d_part + part_half;
     sa.group = d_group;
+    sa.hint = d_hint;
+    sa.ids = ids;
     sa.count = cnt;
     sa.step = 0;
     hipLaunchKernelGGL(lg_state_init_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, bn);

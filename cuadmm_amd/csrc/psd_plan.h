@@ -18,6 +18,8 @@ struct PsdPlan {
   int* d_n = nullptr;          // block sizes
   int* d_ids = nullptr;        // block ids grouped by class
   int* d_fail = nullptr;       // number of blocks whose QL iteration hit its cap (cumulative)
+  int* d_hint = nullptr;       // not owned; per block: lift steps the previous projection needed (sign_sched.h warm start)
+  mutable unsigned n_project = 0;
   int* d_steps = nullptr;      // not owned; when set, the sign kernels record their Newton-Schulz step count per block
   double* d_ws = nullptr;      // HBM workspace of the large-block path
   long long* d_wsoff = nullptr;

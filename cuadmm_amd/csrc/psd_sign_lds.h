@@ -96,7 +96,7 @@ __device__ __forceinline__ void sl_unpack(const double* __restrict__ src, int n,
 // anyway (+1 barrier per step between S Y and the combine), and every thread runs the same (uniform) state machine.
 template <int NP>
 __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
-                                                  double* smem, int* steps_out) {
+                                                  double* smem, int* steps_out, int* hint) {
   using Cfg = SignLdsCfg<NP>;
   constexpr int LD = Cfg::LD;
   // TWO matrices in LDS (S and Y); the next iterate T lives in the accumulator registers of the wavefront that owns the
@@ -128,6 +128,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   for (int e = tid; e < NP * LD; e += Cfg::THREADS) S[e] *= scale;
   __syncthreads();
   SignSched sched;
+  if (hint && *hint > 0) sched.lift0 = *hint;
   bool last = false;
   while (!last) {
     const sl_v4f64 y = sl_mma<NP>(S, S, ti, tj, lane);                               // Y = S*S
@@ -161,6 +162,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
     __syncthreads();
   }
   if (steps_out && tid == 0) *steps_out = sched.steps;
+  if (hint && tid == 0) *hint = sched.lifts;
   // P = 0.5 * (X0 + X0 * S): X0 is unpacked again into Y; the result replaces S after a barrier
   sl_unpack<NP>(in, n, Y, tid);
   sl_v4f64 t;
@@ -319,7 +321,7 @@ __device__ __forceinline__ void sw32_mma_regB(const double (&fa)[8][2], const sl
 // combine step reads anyway -- three wave reductions per step next to 48 MFMAs.
 template <bool DBG>
 __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
-                                                     double* S, int* steps_out, long long* dbg) {
+                                                     double* S, int* steps_out, int* hint, long long* dbg) {
 #define SW32_STAMP(k) do { if (DBG) { const long long now_ = (long long)__builtin_readcyclecounter(); ph[k] += now_ - tprev; tprev = now_; } } while (0)
   long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
   constexpr int LD = SignWave32::LD;
@@ -343,6 +345,7 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   wave_fence();
   double f[8][2];
   SignSched sched;
+  if (hint) { const int h = __builtin_amdgcn_readfirstlane(*hint); if (h > 0) sched.lift0 = h; }
   bool last = false;
   const long long c1 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   tprev = c1;
@@ -409,6 +412,7 @@ __device__ __forceinline__ void psd_sign_wave32_body(const double* __restrict__ 
   }
 #undef SW32_STAMP
   if (steps_out && lane == 0) *steps_out = sched.steps;
+  if (hint && lane == 0) *hint = sched.lifts;
   const long long c2 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   // P = 0.5 (X0 + S X0): A fragments of S from LDS, then LDS is reused for X0, whose sub-tiles are read in accumulator
   // layout (register B operand).  The lower sub-tile of X0 is read directly too (X0 is exactly symmetric in LDS).

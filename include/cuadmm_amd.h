@@ -321,6 +321,9 @@ int cuadmm_op_psd_project_steps(const double* Xb, double* Xproj, const int* blk_
  * s[n] = |eigenvalue| / ||X||_1 on entry, the sign estimates on exit; returns the number of steps the kernels would
  * take on that spectrum and, in *max_err_out, max_i s_i(0) |1 - s_i| / 2 (projection error relative to ||X||_1). */
 int cuadmm_sign_sched_simulate(double* s, int n, int lagged, double* max_err_out);
+/* same, with the schedule's warm start across ADMM iterations: lift0 = lift steps the previous projection of the block needed
+ * (0: none), *lifts_out = the hint this run leaves */
+int cuadmm_sign_sched_simulate_hint(double* s, int n, int lagged, int lift0, double* max_err_out, int* lifts_out);
 /* perform_permutation (src/kernels/permutation.cu:12-33): v1[perm[i]] = v2[i] */
 int cuadmm_op_permute(double* v1, const double* v2, const int* perm, int n, void* stream);
 /* get_normA (src/kernels/sparse_matrix_norm.cu:11-44): per CSC column norm=max(1,||col||), col/=norm */

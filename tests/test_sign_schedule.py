@@ -99,3 +99,31 @@ def test_random_spectra_fuzz():
             assert err <= 2.5e-13, (trial, lag, steps, err)
             worst = max(worst, steps)
     assert worst <= 64
+
+
+def test_schedule_warm_start_hint_costs_steps_only():
+    """lift0 = the number of lift steps the previous projection needed (any value is safe): the resolution contract holds for
+    every hint, the right hint saves steps, and the hint a run leaves reproduces its own step count."""
+    lib = cuadmm_amd.load()
+    rng = np.random.default_rng(21)
+    saved = 0
+    for trial in range(300):
+        n = int(rng.integers(2, 65))
+        w = rng.standard_normal(n) if trial % 2 else 10.0 ** rng.uniform(-15, 0, n)
+        w = np.abs(w) / (np.abs(w).max() * rng.uniform(1.0, 4.0))
+        base, err0, _ = _run(w)
+        hint_next = None
+        for lift0 in (1, 2, 5, 9, 20, 40, 64):
+            s = np.ascontiguousarray(w, dtype=np.float64).copy()
+            err, lifts = C.c_double(), C.c_int()
+            steps = lib.cuadmm_sign_sched_simulate_hint(s.ctypes.data_as(C.c_void_p), n, 0, lift0, C.byref(err), C.byref(lifts))
+            assert 1 <= steps <= 64 and err.value <= 2.5e-13, (trial, lift0, steps, err.value)
+        # self-consistency: run with the hint the default run leaves
+        s = np.ascontiguousarray(w, dtype=np.float64).copy()
+        err, lifts = C.c_double(), C.c_int()
+        lib.cuadmm_sign_sched_simulate_hint(s.ctypes.data_as(C.c_void_p), n, 0, 0, C.byref(err), C.byref(lifts))
+        s = np.ascontiguousarray(w, dtype=np.float64).copy()
+        steps2 = lib.cuadmm_sign_sched_simulate_hint(s.ctypes.data_as(C.c_void_p), n, 0, lifts.value, C.byref(err), C.byref(lifts))
+        assert err.value <= 2.5e-13
+        saved += base - steps2
+    assert saved > 0                      # on average the warm start is a gain

@@ -64,7 +64,7 @@ def spectra_from_oracle(problem, iters, sample_every=10):
     def eig_fn(bidx, xb):
         x, eigs = orc.psd_project_svec(bidx, xb, return_eigs=True)
         eig_fn.k += 1
-        if eig_fn.k % sample_every == 1:
+        if (eig_fn.k - 1) % sample_every == 0:
             mats = bidx.unpack(xb)
             n1 = [np.abs(M).sum(axis=1).max(axis=1) for M in mats]
             out.append((eig_fn.k, eigs, n1))
