@@ -57,6 +57,8 @@ PROTOTYPES = {
     "cuadmm_set_XyS": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "cuadmm_get_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "cuadmm_get_shard": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_int_p, c_int_p]),
+    "cuadmm_aat_factor_arrays": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4),
+    "cuadmm_aat_forest": (C.c_int, [C.c_void_p, c_int_p, c_int_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "cuadmm_mex_call": (C.c_int, [C.c_int, C.c_int, C.c_double,
                                    C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -44,6 +44,10 @@ struct cuadmm_aat {
   std::vector<int> schur_col;
   std::vector<double> schur_val;
   double analyze_s = 0, factor_s = 0;
+  // elimination forest as lists of columns per tree (cuadmm_aat_forest): tree t owns forest_cols[forest_ptr[t] .. forest_ptr[t+1]),
+  // ascending; the sweeps of a solve never leave a tree
+  std::vector<int> forest_ptr, forest_cols;
+  int forest_max = 0;
 };
 
 namespace {
@@ -491,6 +495,45 @@ int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f) { return f ? f->Lp[f->m] : 0;
 const int64_t* cuadmm_aat_factor_colptr(const cuadmm_aat* f) { return f ? f->Lp.data() : nullptr; }
 
 int cuadmm_aat_tail_k(const cuadmm_aat* f) { return f ? f->tail_k : 0; }
+
+int cuadmm_aat_factor_arrays(const cuadmm_aat* f, const int64_t** Lp, const int** Li, const double** Lx, const double** D) {
+  if (!f || !Lp || !Li || !Lx || !D) { set_error("aat_factor_arrays: null argument"); return CUADMM_ERR_INVALID; }
+  *Lp = f->Lp.data(); *Li = f->Li.data(); *Lx = f->Lx.data(); *D = f->D.data();
+  return CUADMM_OK;
+}
+
+// The elimination forest of the factor: parent(j) = smallest row index of column j of L.  Independent trees never exchange
+// data in a solve, so many small trees (block-diagonal A A^T: one tree per group of coupled constraints) can be solved by
+// one GPU thread each (engine.hip: forest_solve_kernel) with the arithmetic order of the serial host sweeps.
+int cuadmm_aat_forest(cuadmm_aat* f, int* n_trees, int* max_cols, const int** tree_ptr, const int** tree_cols) {
+  if (!f || !n_trees || !max_cols || !tree_ptr || !tree_cols) { set_error("aat_forest: null argument"); return CUADMM_ERR_INVALID; }
+  if (f->tail_k > 0) { set_error("aat_forest: the factor is split"); return CUADMM_ERR_INVALID; }
+  const int m = f->m;
+  if (f->forest_ptr.empty()) {
+    std::vector<int> root((size_t)m), parent((size_t)m, -1);
+    for (int j = 0; j < m; ++j) {
+      int pmin = -1;
+      for (int64_t p = f->Lp[j]; p < f->Lp[j + 1]; ++p) if (pmin < 0 || f->Li[p] < pmin) pmin = f->Li[p];
+      parent[j] = pmin;
+    }
+    for (int j = m - 1; j >= 0; --j) root[j] = parent[j] < 0 ? j : root[parent[j]];   // parent(j) > j
+    std::vector<int> tree_of_root((size_t)m, -1), count;
+    for (int j = 0; j < m; ++j) {
+      if (tree_of_root[root[j]] < 0) { tree_of_root[root[j]] = (int)count.size(); count.push_back(0); }
+      count[tree_of_root[root[j]]]++;
+    }
+    f->forest_ptr.assign(count.size() + 1, 0);
+    for (size_t t = 0; t < count.size(); ++t) { f->forest_ptr[t + 1] = f->forest_ptr[t] + count[t]; f->forest_max = std::max(f->forest_max, count[t]); }
+    f->forest_cols.resize((size_t)m);
+    std::vector<int> fill(f->forest_ptr.begin(), f->forest_ptr.end() - 1);
+    for (int j = 0; j < m; ++j) f->forest_cols[fill[tree_of_root[root[j]]]++] = j;     // ascending inside every tree
+  }
+  *n_trees = (int)f->forest_ptr.size() - 1;
+  *max_cols = f->forest_max;
+  *tree_ptr = f->forest_ptr.data();
+  *tree_cols = f->forest_cols.data();
+  return CUADMM_OK;
+}
 int cuadmm_aat_tail_schur(const cuadmm_aat* f, const int64_t** row_ptr, const int** col, const double** val) {
   if (!f || !row_ptr || !col || !val) { set_error("aat_tail_schur: null argument"); return CUADMM_ERR_INVALID; }
   if (f->tail_k == 0 || f->schur_ptr.empty()) { set_error("aat_tail_schur: no Schur complement (factor not split, or released)"); return CUADMM_ERR_INVALID; }

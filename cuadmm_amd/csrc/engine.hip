@@ -158,10 +158,18 @@ struct cuadmm_solver {
   double ov_nb = 0, ov_nc = 0, ov_nb2 = 0;
   DevBuf<double> scal_d, yfull_d, b_d, normA_d;
   PinnedBuf<double> h_scal;
+  double* h_scal_dev = nullptr;   // device mapping of h_scal
   // owned-constraints mode over > 1 ranks: the four scalars of the stopping test are formed on the device (rp_stats_kernel),
   // all-reduced on the stream and copied down with the result vector: one stream synchronisation per iteration, no
   // H2D -> collective -> D2H -> sync round trip of their own
   bool dev_scalars = false;
+  // Device-side y-solve (forest_solve_kernel) when the elimination forest of the factor is many small trees (block-diagonal
+  // A A^T: C2, C4, ros_2000 ...): y, A X, A(S-C), b stay in HBM, the host fetches only the four scalars of the stopping test.
+  bool dev_solve = false;
+  int forest_trees = 0;
+  DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
+  DevBuf<long long> f_Lp;
+  DevBuf<double> f_Lx, f_D, y_best_d;
   std::vector<double> y_full;
   cuadmm_aat* fac = nullptr;
   TailSolve tail;              // dense trailing triangle of L on the GPU (tail.k == 0: whole solve on the host)
@@ -275,6 +283,13 @@ struct cuadmm_solver {
   int host_solve() {  // y_p = (P(AA^T+eps I)P^T)^-1 rhs_p
     double t0 = wall_s();
     const double isig = 1 / sig;
+    if (dev_solve) {   // everything it needs is in HBM (out_d: [A X | sums | A(S-C)]); y_d is the result
+      prof_begin(K_TAIL);
+      int rc = launch_forest_solve(forest_trees, f_tree_ptr.p, f_tree_cols.p, f_Lp.p, f_Li.p, f_Lx.p, f_D.p, out_d.p, out_d.p + (size_t)m + 2,
+                                   b_d.p, isig, y_d.p, st);
+      prof_end(K_TAIL, 0.0);
+      return rc;
+    }
     // the right-hand side is formed in y_p from the pinned result buffer (A(S-C) lives at h_out[m+2..) since the last
     // fetch) and solved in place: no copies of m-vectors on the critical path between two GPU phases
     const double* asmc = h_out.p + (size_t)m + 2;
@@ -297,7 +312,8 @@ struct cuadmm_solver {
     return rc;
   }
 
-  int upload_y() {
+  int upload_y(bool force = false) {
+    if (dev_solve && !force) return CUADMM_OK;     // y is produced on the device
     prof_begin(K_COPY);
     // y_p is registered (page-locked) at init: the copy engine reads it directly; it is not written again before the
     // next fetch_out has synchronised the stream
@@ -313,12 +329,21 @@ struct cuadmm_solver {
     if (!out_mapped) {
       int rc = do_allreduce(out_d.p + first, count);
       if (rc) return rc;
-      if (dev_scalars && first == 0) {     // [||Rp||^2, b.y, sum Rd^2, <C,X>] of this rank -> sum over ranks, on the stream
-        if ((rc = launch_rp_stats(m, out_d.p, b_d.p, normA_d.p, y_d.p, bscale, out_d.p + (size_t)m, scal_d.p, st))) return rc;
-        if ((rc = comm_allreduce(scal_d.p, 4))) return rc;
-        CUADMM_HIP_TRY(hipMemcpyAsync(h_scal.p, scal_d.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+      if ((dev_scalars || dev_solve) && first == 0) {     // [||Rp||^2, b.y, sum Rd^2, <C,X>] (of this rank -> sum over ranks), on the stream
+        // without a collective in between the final stage writes the four scalars straight into the pinned host buffer
+        // through its device mapping: the fetch is then a stream synchronisation without a copy command
+        double* dst = (!dev_scalars && h_scal_dev) ? h_scal_dev : scal_d.p;
+        if ((rc = launch_rp_stats(m, out_d.p, b_d.p, normA_d.p, y_d.p, bscale, out_d.p + (size_t)m, scal_d.p + 8, dst, st))) return rc;
+        if (dev_scalars) {
+          if ((rc = comm_allreduce(scal_d.p, 4))) return rc;
+        }
+        if (dst == scal_d.p) CUADMM_HIP_TRY(hipMemcpyAsync(h_scal.p, scal_d.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
       }
-      CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+      if (dev_solve) {
+        if (first != 0) return CUADMM_OK;                 // sGS half step: A(S-C) is consumed on the device, nothing to wait for
+      } else {
+        CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+      }
     }
     CUADMM_HIP_TRY(hipStreamSynchronize(st));
     prof_collect();
@@ -765,24 +790,47 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   }
   if ((rc = s->Rd1.alloc(L)) || (rc = s->Xb.alloc(L)) || (rc = s->Xproj.alloc(L)) || (rc = s->y_d.alloc(std::max(m, 1))) ||
       (rc = s->out_d.alloc(2 * (size_t)m + 2)) || (rc = s->partials.alloc(2 * (size_t)post_grid(L) + 2)) ||
-      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8)))
+      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8 + 128)))
     return rc;
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
   std::memset(s->h_out.p, 0, sizeof(double) * (2 * (size_t)m + 2));
   s->out_w = s->out_d.p;
   s->dev_scalars = s->local_mode && s->comm_world > 1 && !getenv("CUADMM_HOST_SCALARS");
-  if (s->dev_scalars) {
+  // device-side y-solve: whole factor on the host side of the split (no GPU tail) and a forest of many small trees
+  s->dev_solve = false;
+  if (s->tail.k == 0 && m > 0 && !getenv("CUADMM_HOST_SOLVE")) {
+    int ntrees = 0, maxc = 0;
+    const int *tp = nullptr, *tc = nullptr;
+    if (cuadmm_aat_forest(s->fac, &ntrees, &maxc, &tp, &tc) == CUADMM_OK && ntrees >= 256 && maxc <= 64) {
+      const int64_t* Lp; const int* Li; const double* Lx; const double* D;
+      if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
+      const size_t lnz = (size_t)Lp[m];
+      std::vector<long long> lp64(Lp, Lp + m + 1);
+      if ((rc = s->f_tree_ptr.from(std::vector<int>(tp, tp + ntrees + 1))) || (rc = s->f_tree_cols.from(std::vector<int>(tc, tc + m))) ||
+          (rc = s->f_Lp.from(lp64)) || (rc = s->f_Li.from(std::vector<int>(Li, Li + lnz))) || (rc = s->f_Lx.from(std::vector<double>(Lx, Lx + lnz))) ||
+          (rc = s->f_D.from(std::vector<double>(D, D + m))))
+        return rc;
+      s->forest_trees = ntrees;
+      s->dev_solve = true;
+      if (s->local_mode && s->comm_world > 1) s->dev_scalars = true;
+      if (s->verbose) printf(" y-solve on the device: %d independent trees of the elimination forest (<= %d columns each)\n", ntrees, maxc);
+    }
+  }
+  if (s->dev_scalars || s->dev_solve) {
     if ((rc = s->b_d.alloc(std::max(m, 1))) || (rc = s->normA_d.alloc(std::max(m, 1))) || (rc = s->h_scal.alloc(4))) return rc;
     if ((rc = s->b_d.upload(s->b_p.data(), (size_t)m)) || (rc = s->normA_d.upload(s->normA_p.data(), (size_t)m))) return rc;
+    void* dp = nullptr;
+    if (!getenv("CUADMM_NO_MAPPED_OUT") && hipHostGetDevicePointer(&dp, s->h_scal.p, 0) == hipSuccess && dp) s->h_scal_dev = static_cast<double*>(dp);
+    else { hipError_t e = hipGetLastError(); (void)e; }
   }
-  if (s->world <= 1 && !s->force_comm && !s->dev_scalars && !getenv("CUADMM_NO_MAPPED_OUT")) {
+  if (s->world <= 1 && !s->force_comm && !s->dev_scalars && !s->dev_solve && !getenv("CUADMM_NO_MAPPED_OUT")) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, s->h_out.p, 0) == hipSuccess && dp) { s->out_w = static_cast<double*>(dp); s->out_mapped = true; }
     else { hipError_t e = hipGetLastError(); (void)e; }
   }
 
   // --- initial residuals (solver.cu:195-228)
-  if ((rc = s->upload_y())) return rc;
+  if ((rc = s->upload_y(true))) return rc;
   if ((rc = s->launch_aty(false))) return rc;                               // Rd1 = At*y - C
   if ((rc = launch_post(2, L, s->Xproj.p, s->Rd1.p, s->C.p, s->X.p, s->S.p, 1.0, 0.0, s->partials.p,
                         s->out_w + (size_t)m, s->st)))                      // Rd = Rd1 + S, sums (X untouched)
@@ -791,7 +839,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
   {
     double nr = 0, bty = 0;
-    for (int i = 0; i < m; ++i) {
+    for (int i = 0; i < m && !s->dev_solve; ++i) {
       s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i];
       double ro = s->normA_p[i] * s->Rp_p[i] * s->bscale;
       nr += ro * ro;
@@ -799,7 +847,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     }
     {
       double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
-      if (s->dev_scalars) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // summed over ranks on the device
+      if (s->dev_scalars || s->dev_solve) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // formed (and summed over ranks) on the device
       else if ((rc = s->allreduce_scalars(v, 4))) return rc;
       nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
     }
@@ -840,11 +888,12 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
 
   if (!if_first) {   // solver.cu:385-409: X,y,S currently hold UNSCALED values
     for (int i = 0; i < m; ++i) s->y_p[i] = (s->y_p[i] * s->normA_p[i]) * (1 / s->Cscale);
+    if (s->dev_solve && (rc = s->upload_y(true))) return rc;
     if ((rc = launch_scale(s->X.p, L, 1 / s->bscale, s->st))) return rc;
     if ((rc = launch_scale(s->S.p, L, 1 / s->Cscale, s->st))) return rc;
     if ((rc = s->launch_spmv(true, true))) return rc;
     if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
-    for (int i = 0; i < m; ++i) s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i];
+    for (int i = 0; i < m && !s->dev_solve; ++i) s->Rp_p[i] = -s->h_out.p[i] + s->b_p[i];
   }
 
   if (verbose) {
@@ -883,7 +932,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         CUADMM_HIP_TRY(hipMemcpyAsync(s->X.p, s->X_best.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         CUADMM_HIP_TRY(hipMemcpyAsync(s->S.p, s->S_best.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
-        std::copy(s->y_best_p.begin(), s->y_best_p.end(), s->y_p.begin());   // in place: y_p's storage is page-locked
+        if (s->dev_solve) CUADMM_HIP_TRY(hipMemcpy(s->y_d.p, s->y_best_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice));
+        else std::copy(s->y_best_p.begin(), s->y_best_p.end(), s->y_p.begin());   // in place: y_p's storage is page-locked
         if (verbose) printf("best max KKT residual after switch  = %2.1e \n", s->best_KKT);
       }
       break;
@@ -946,7 +996,12 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         CUADMM_HIP_TRY(hipMemcpyAsync(s->X_best.p, s->X.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         CUADMM_HIP_TRY(hipMemcpyAsync(s->S_best.p, s->S.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         s->prof_end(K_COPY, 32.0 * (double)L);
-        s->y_best_p = s->y_p;
+        if (s->dev_solve) {
+          if (!s->y_best_d.p && (rc = s->y_best_d.alloc(std::max(m, 1)))) return rc;
+          CUADMM_HIP_TRY(hipMemcpyAsync(s->y_best_d.p, s->y_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s->st));
+        } else {
+          s->y_best_p = s->y_p;
+        }
         s->have_best = true;
         if ((rc = s->launch_post_mode(2, tau))) return rc;
       } else {
@@ -962,7 +1017,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       double nr = 0, bty = 0;
       const double* ax = s->h_out.p;
       double part[2 * kHostChunks] = {0};
-      host_ranges(m, [&](int c, int lo, int hi) {
+      if (!s->dev_solve) host_ranges(m, [&](int c, int lo, int hi) {
         double a = 0, b = 0;
         for (int i = lo; i < hi; ++i) {
           const double rp = -ax[i] + s->b_p[i];
@@ -976,7 +1031,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       for (int c = 0; c < kHostChunks; ++c) { nr += part[2 * c]; bty += part[2 * c + 1]; }
       {
         double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
-        if (s->dev_scalars) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // summed over ranks on the device
+        if (s->dev_scalars || s->dev_solve) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // formed (and summed over ranks) on the device
         else if ((rc = s->allreduce_scalars(v, 4))) return rc;
         nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
       }
@@ -1005,6 +1060,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   // unscale (solver.cu:814-816)
   if ((rc = launch_scale(s->X.p, L, s->bscale, s->st))) return rc;
   if ((rc = launch_scale(s->S.p, L, s->Cscale, s->st))) return rc;
+  if (s->dev_solve && m > 0) CUADMM_HIP_TRY(hipMemcpyAsync(s->y_p.data(), s->y_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s->st));
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
   for (int i = 0; i < m; ++i) s->y_p[i] = s->y_p[i] / s->normA_p[i] * s->Cscale;
   if (s->local_mode) {   // y is replicated for the caller: gather the owned pieces once per solve

@@ -43,8 +43,11 @@ int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, con
                      const SpmvLongRows* long_rows = nullptr);
 
 int launch_scale(double* v, long long n, double s, hipStream_t st);
+// y = (L D L^T)^-1 (-A(S-C) + (b - A X) / sigma) on the device, one thread per tree of the elimination forest
+int launch_forest_solve(int ntrees, const int* tree_ptr, const int* tree_cols, const long long* Lp, const int* Li, const double* Lx,
+                        const double* D, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st);
 // owned-constraints sharding: [||Rp org||^2, b.y, sums[0], sums[1]] from A*X on the device (one workgroup, deterministic)
 int launch_rp_stats(int m, const double* ax, const double* b, const double* normA, const double* y, double bscale,
-                    const double* sums, double* out4, hipStream_t st);
+                    const double* sums, double* partials /* 128 doubles */, double* out4, hipStream_t st);
 
 }  // namespace cuadmm

@@ -151,22 +151,74 @@ __global__ __launch_bounds__(kVecThreads) void reduce_pairs_kernel(const double*
 //   out4[0] = sum_i (normA_i (b_i - (A X)_i) bscale)^2   (|| Rp org ||^2, solver.cu:768-772)
 //   out4[1] = sum_i b_i y_i                               (solver.cu:781)
 //   out4[2..3] = sums[0..1] (sum Rd^2, <C, X>: copied next to them)
-// One workgroup, fixed summation order: bit-reproducible.
-__global__ __launch_bounds__(kVecThreads) void rp_stats_kernel(int m, const double* __restrict__ ax, const double* __restrict__ b,
-                                                               const double* __restrict__ normA, const double* __restrict__ y,
-                                                               double bscale, const double* __restrict__ sums, double* __restrict__ out4) {
+// Two stages over a fixed grid, fixed summation order: bit-reproducible.
+__global__ __launch_bounds__(kVecThreads) void rp_stats_partial_kernel(int m, const double* __restrict__ ax, const double* __restrict__ b,
+                                                                       const double* __restrict__ normA, const double* __restrict__ y,
+                                                                       double bscale, double* __restrict__ partials) {
   double a = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+  for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < m; i += (int)(gridDim.x * blockDim.x)) {
     const double ro = normA[i] * (b[i] - ax[i]) * bscale;
     a += ro * ro;
     c += b[i] * y[i];
   }
   block_sum2<kVecThreads>(a, c);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = c; }
+}
+__global__ __launch_bounds__(kVecThreads) void rp_stats_final_kernel(const double* __restrict__ partials, int nparts, const double* __restrict__ sums,
+                                                                     double* __restrict__ out4) {
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) { a += partials[2 * i]; c += partials[2 * i + 1]; }
+  block_sum2<kVecThreads>(a, c);
   if (threadIdx.x == 0) { out4[0] = a; out4[1] = c; out4[2] = sums[0]; out4[3] = sums[1]; }
 }
+// two-stage, fixed grid (64 workgroups) and fixed summation order: bit-reproducible; `partials` holds 128 doubles
 int launch_rp_stats(int m, const double* ax, const double* b, const double* normA, const double* y, double bscale,
-                    const double* sums, double* out4, hipStream_t st) {
-  hipLaunchKernelGGL(rp_stats_kernel, dim3(1), dim3(kVecThreads), 0, st, m, ax, b, normA, y, bscale, sums, out4);
+                    const double* sums, double* partials, double* out4, hipStream_t st) {
+  constexpr int kGrid = 64;
+  hipLaunchKernelGGL(rp_stats_partial_kernel, dim3(kGrid), dim3(kVecThreads), 0, st, m, ax, b, normA, y, bscale, partials);
+  hipLaunchKernelGGL(rp_stats_final_kernel, dim3(1), dim3(kVecThreads), 0, st, partials, kGrid, sums, out4);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The y-solve of a block-diagonal A A^T on the device (engine option: automatic when the elimination forest of the factor
+// consists of many small trees): y = (L D L^T)^-1 rhs with rhs = -A(S-C) + (b - A X) / sigma (solver.cu:478-500), one
+// THREAD per tree.  The sweeps of a solve never leave a tree, and inside a tree this is the serial host algorithm
+// (aat_ldlt.cpp: columns ascending, x[i] -= L[i][j] x[j]; then x[j] / D[j] and the transposed sweep) with unfused
+// multiply-subtract, so y is bit-identical to the host solve.  y stays in HBM: no m-vector crosses PCIe in an iteration.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kVecThreads) void forest_solve_kernel(int ntrees, const int* __restrict__ tree_ptr, const int* __restrict__ tree_cols,
+                                                                   const long long* __restrict__ Lp, const int* __restrict__ Li,
+                                                                   const double* __restrict__ Lx, const double* __restrict__ D,
+                                                                   const double* __restrict__ ax, const double* __restrict__ asmc,
+                                                                   const double* __restrict__ b, double isig, double* __restrict__ x) {
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= ntrees) return;
+  const int c0 = tree_ptr[t], c1 = tree_ptr[t + 1];
+  for (int q = c0; q < c1; ++q) {
+    const int j = tree_cols[q];
+    const double rp = __dadd_rn(-ax[j], b[j]);                       // Rp = -A X + b
+    x[j] = __dadd_rn(-asmc[j], __dmul_rn(isig, rp));                 // rhs = -A(S-C) + Rp / sigma
+  }
+  for (int q = c0; q < c1; ++q) {                                    // L z = rhs
+    const int j = tree_cols[q];
+    const double xj = x[j];
+    if (xj != 0.0)
+      for (long long p = Lp[j]; p < Lp[j + 1]; ++p) x[Li[p]] = __dsub_rn(x[Li[p]], __dmul_rn(Lx[p], xj));
+  }
+  for (int q = c1 - 1; q >= c0; --q) {                               // D^-1, then L^T y = z
+    const int j = tree_cols[q];
+    double s = x[j] / D[j];
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p) s = __dsub_rn(s, __dmul_rn(Lx[p], x[Li[p]]));
+    x[j] = s;
+  }
+}
+int launch_forest_solve(int ntrees, const int* tree_ptr, const int* tree_cols, const long long* Lp, const int* Li, const double* Lx,
+                        const double* D, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st) {
+  if (ntrees <= 0) return CUADMM_OK;
+  hipLaunchKernelGGL(forest_solve_kernel, dim3((ntrees + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, st, ntrees, tree_ptr, tree_cols, Lp,
+                     Li, Lx, D, ax, asmc, b, isig, x);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }

@@ -240,6 +240,12 @@ int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k);
 int cuadmm_aat_create_split(int con_num, int vec_len, const int* A_col_ptrs, const int* A_row_ids,
                             const double* A_vals, double eps, int max_k, cuadmm_aat** out);
 int cuadmm_aat_tail_k(const cuadmm_aat* f);
+/* Whole (unsplit) factor for a device-side solve: the strict lower triangle of the unit factor L by columns (Lp[m+1], Li, Lx),
+ * the pivots D[m], and the elimination forest as lists of columns per tree (tree t: tree_cols[tree_ptr[t] .. tree_ptr[t+1]),
+ * ascending).  The sweeps of a solve never leave a tree, so a block-diagonal A A^T (one small tree per group of coupled
+ * constraints) is solved by one GPU thread per tree (engine: forest solve) in the arithmetic order of the host sweeps. */
+int cuadmm_aat_factor_arrays(const cuadmm_aat* f, const int64_t** Lp, const int** Li, const double** Lx, const double** D);
+int cuadmm_aat_forest(cuadmm_aat* f, int* n_trees, int* max_cols, const int** tree_ptr, const int** tree_cols);
 /* lower triangle with diagonal of the Schur complement by rows (CSR over the k tail rows, tail-local column indices,
  * not sorted within a row); pointers stay valid until _tail_schur_release / _free */
 int cuadmm_aat_tail_schur(const cuadmm_aat* f, const int64_t** row_ptr, const int** col, const double** val);

@@ -168,3 +168,29 @@ def test_duo_solver_front(problem_dirs):
         cuadmm_amd.SDPSolver(verbose=False).duo_init(True, 1, 15, 30, b.vec_len, b.con_num, b.At_csc_col_ptrs, b.At_csc_row_ids,
                                                      b.At_csc_vals, b.At_nnz, b.b_indices, b.b_vals, b.b_nnz, b.C_indices,
                                                      b.C_vals, b.C_nnz, b.blk_vals, b.mat_num)
+
+
+def test_device_side_y_solve_matches_the_host_solve(monkeypatch):
+    """Block-diagonal A A^T (every constraint touches one block): the elimination forest of the factor is one small tree per
+    block and the y-solve runs on the device, one thread per tree (forest_solve_kernel), with y, A X, A(S-C) and b resident
+    in HBM.  Inside a tree it is the serial host algorithm with unfused multiply-subtract, so the whole trajectory must be
+    identical to roundoff to the host solve (CUADMM_HOST_SOLVE=1) -- sGS phase, the switch and the ADMM phase included."""
+    from cuadmm_amd.synthetic import make_synthetic
+    p = make_synthetic([32] * 300 + [6] * 100 + [45] * 40, cons_per_block=4, seed=13)
+    prob = cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
+    runs = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("CUADMM_HOST_SOLVE", "1")
+        else:
+            monkeypatch.delenv("CUADMM_HOST_SOLVE", raising=False)
+        s = cuadmm_amd.SDPSolver(verbose=False, profile=1)
+        s.init_problem(prob)
+        s.solve(40, 0.0, 0, 10, 10, 15, 1.05)
+        s.solve(10, 0.0, 0, 10, 10, 0, 1.05, if_first=False)            # warm restart path
+        runs[mode] = (s.X, s.y, s.S, [s.info_arr(n) for n in ("pobj", "dobj", "errRp", "errRd", "relgap", "sig")], s.profile())
+    assert runs["device"][4]["host"]["ms"] < 0.2 * runs["host"][4]["host"]["ms"] + 1e-9       # the host solve is gone
+    for a, b in zip(runs["device"][:3], runs["host"][:3]):
+        assert np.max(np.abs(a - b)) <= 1e-12 * (1 + np.max(np.abs(b)))      # same operation order; the fp64 division differs in the last bit
+    for a, b in zip(runs["device"][3], runs["host"][3]):
+        assert np.max(np.abs(a - b) / (1e-300 + np.abs(b))) <= 1e-12      # scalars: device / host summation order of the norms
