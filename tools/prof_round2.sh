@@ -19,6 +19,7 @@ prof c3 python3 $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline 
 prof c4 python3 $R/bench.py --config c4 --steps 12 --warmup 2 --no-cpu-baseline --no-breakdown
 prof planarhand python3 $R/tools/run_real.py PlanarHand_N=1_MOMENT 60 0
 cd $R
+cp profiles/r02_*_kernel_stats.csv profiles/r02_*_pmc_*.json gpurun_out/ 2>/dev/null
 ls profiles | grep r02
 # the bench lines of the round, outside the profiler
 timeout 600 python3 bench.py 2>/dev/null | grep '^{' > gpurun_out/r02_bench_c2.json
@@ -26,5 +27,4 @@ timeout 600 python3 bench.py --config c3 2>/dev/null | grep '^{' > gpurun_out/r0
 timeout 600 python3 bench.py --config c4 2>/dev/null | grep '^{' > gpurun_out/r02_bench_c4.json
 timeout 600 python3 bench.py --mode sgs --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r02_bench_c2_sgs.json
 CUADMM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --sharding allreduce --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r02_bench_c2_allreduce_forced_1rank.json
-cp profiles/r02_* gpurun_out/ 2>/dev/null
 head -c 600 gpurun_out/r02_bench_c2.json
