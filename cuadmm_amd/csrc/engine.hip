@@ -24,6 +24,7 @@
 #include "device_util.h"
 #include "psd_plan.h"
 #include "tail_solve.h"
+#include "lead_solve.h"
 #include "vec_kernels.h"
 
 using namespace cuadmm;
@@ -166,6 +167,7 @@ struct cuadmm_solver {
   // Device-side y-solve (forest_solve_kernel) when the elimination forest of the factor is many small trees (block-diagonal
   // A A^T: C2, C4, ros_2000 ...): y, A X, A(S-C), b stay in HBM, the host fetches only the four scalars of the stopping test.
   bool dev_solve = false;
+  LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
   DevBuf<long long> f_Lp;
@@ -285,7 +287,7 @@ struct cuadmm_solver {
     const double isig = 1 / sig;
     if (dev_solve) {   // everything it needs is in HBM (out_d: [A X | sums | A(S-C)]); y_d is the result
       prof_begin(K_TAIL);
-      int rc = launch_forest_solve(forest_trees, f_tree_ptr.p, f_tree_cols.p, f_Lp.p, f_Li.p, f_Lx.p, f_D.p, out_d.p, out_d.p + (size_t)m + 2,
+      int rc = lead.ready ? lead.solve(out_d.p, out_d.p + (size_t)m + 2, b_d.p, isig, y_d.p, tail, st) : launch_forest_solve(forest_trees, f_tree_ptr.p, f_tree_cols.p, f_Lp.p, f_Li.p, f_Lx.p, f_D.p, out_d.p, out_d.p + (size_t)m + 2,
                                    b_d.p, isig, y_d.p, st);
       prof_end(K_TAIL, 0.0);
       return rc;
@@ -798,6 +800,21 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->dev_scalars = s->local_mode && s->comm_world > 1 && !getenv("CUADMM_HOST_SCALARS");
   // device-side y-solve: whole factor on the host side of the split (no GPU tail) and a forest of many small trees
   s->dev_solve = false;
+  if (s->tail.k > 0 && !getenv("CUADMM_HOST_SOLVE")) {
+    // split factor: leading sweeps on the device too when the leading elimination forest is shallow enough (cost model:
+    // the deepest tree decides the kernel; host: 1.2 ns per leading nonzero for both sweeps + the PCIe hops of the tail)
+    const int64_t* Lp; const int* Li; const double* Lx; const double* D;
+    if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
+    if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D))) return rc;
+    const double host_us = 1.2e-3 * (double)Lp[m - s->tail.k] + 150.0;
+    if (s->lead.ready && s->lead.est_us < 0.7 * host_us) {
+      s->dev_solve = true;
+      if (s->local_mode && s->comm_world > 1) s->dev_scalars = true;
+      if (s->verbose) printf(" y-solve on the device: leading sweeps over %d trees (depth <= %d) around the GPU tail\n", s->lead.ntrees, s->lead.max_levels);
+    } else {
+      s->lead.release();
+    }
+  }
   if (s->tail.k == 0 && m > 0 && !getenv("CUADMM_HOST_SOLVE")) {
     int ntrees = 0, maxc = 0;
     const int *tp = nullptr, *tc = nullptr;

@@ -1,0 +1,44 @@
+// Device-side sweeps over the sparse LEADING columns of a split A A^T factor (the dense tail is tail_solve.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace cuadmm {
+
+struct TailSolve;
+
+// With the leading sweeps on the device the whole y-solve of a split factor runs without a PCIe hop:
+//   forward  (per tree of the leading elimination forest, level by level, row gather):  z1 = L11^-1 rhs1
+//   tail rhs (SpMV over the tail rows of the leading columns):                          z2 = rhs2 - L21 z1  -> TailSolve::vin
+//   tail     (tail_solve.hip, two triangular GEMVs):                                    x2 = L22^-T D2^-1 L22^-1 z2
+//   backward (per tree, levels in reverse, column gather):                              x1 = L11^-T (D1^-1 z1 - L21^T x2 ...)
+// rhs = -A(S-C) + (b - A X) / sigma is formed on the fly from vectors resident in HBM (solver.cu:478-482).
+struct LeadSolve {
+  int m = 0, n1 = 0, k = 0, ntrees = 0, max_levels = 0, max_nodes = 0;
+  size_t lds_bytes = 0;
+  // tail rows of the leading columns (k rows, columns < n1), CSR: z2 = rhs2 - L21 z1
+  long long* rp21 = nullptr; int* ci21 = nullptr; double* v21 = nullptr;
+  // sweep streams in processing order (slot idx = position in nodes_*), LOCAL indices inside the tree:
+  long long* fptr = nullptr; int* fci = nullptr; double* fv_ = nullptr;     // forward: row of L11 of the node in the slot
+  long long* bptr = nullptr; int* bci = nullptr; double* bv_ = nullptr;     // backward: leading rows of its column
+  long long* tptr = nullptr; int* tri = nullptr; double* tv_ = nullptr;     // tail rows of every leading column (w = L21^T x2)
+  double* D1 = nullptr;
+  double* wvec = nullptr;
+  // trees: nodes ordered by level inside each tree, per sweep direction
+  int* nodes_f = nullptr; int* nodes_b = nullptr;
+  int* lvl_ptr_f = nullptr; int* lvl_ptr_b = nullptr;      // offsets into lvl_off_* per tree (ntrees + 1)
+  int* lvl_off_f = nullptr; int* lvl_off_b = nullptr;      // level boundaries in nodes_* (levels + 1 entries per tree)
+  int* lvl_g_f = nullptr; int* lvl_g_b = nullptr;          // lanes per row of each level (power of two, from its mean row length)
+  bool ready = false;
+  double est_us = 0;            // cost model used to decide (per solve)
+
+  // Lp / Li / Lx / D: the split factor (cuadmm_aat_factor_arrays), k = its tail size
+  int build(int m, int k, const int64_t* Lp, const int* Li, const double* Lx, const double* D);
+  // y <- (L D L^T)^-1 (-asmc + (b - ax) * isig): everything on `st`, nothing synchronises
+  int solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const;
+  void release();
+  ~LeadSolve() { release(); }
+};
+
+}  // namespace cuadmm

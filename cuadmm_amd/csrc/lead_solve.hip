@@ -1,0 +1,325 @@
+// Device-side sweeps over the sparse leading columns of a split A A^T factor (see lead_solve.h).
+//
+// The reference solves with CHOLMOD on the host (include/cuadmm/cholesky_cpu.h:146-155) between a D2H and an H2D copy of
+// the m-vector (src/solver.cu:489-499); round 1 kept the sparse leading columns there and moved the dense trailing
+// triangle to the GPU.  On moment relaxations the host part became the largest share of an iteration (pendulum N=80:
+// 1.5 of 2.4 ms).  The leading columns of such factors form a forest of a few thousand shallow trees (PlanarHand_N=1:
+// 2365 trees, depth <= 66; pendulum: 2071 trees, depth <= 60), so the sweeps are done here, one WAVEFRONT per tree, level by
+// level, in gather form (deterministic: every sum has a fixed order, no atomics).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+#include "device_util.h"
+#include "lead_solve.h"
+#include "psd_device.h"
+#include "tail_solve.h"
+
+namespace cuadmm {
+
+namespace {
+
+template <class T>
+int to_device(T*& d, const std::vector<T>& h) {
+  CUADMM_HIP_TRY(hipMalloc(&d, sizeof(T) * std::max<size_t>(h.size(), 1)));
+  if (!h.empty()) CUADMM_HIP_TRY(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  return CUADMM_OK;
+}
+
+__device__ __forceinline__ double lead_rhs(const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b,
+                                           double isig, int i) {
+  return -asmc[i] + isig * (-ax[i] + b[i]);      // solver.cu:478-482
+}
+
+// sum over a group of G lanes (G a power of two <= 64, groups aligned)
+__device__ __forceinline__ double group_sum(double s, int G) {
+  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+// One wavefront per tree, level by level.  The tree's solution values live in LDS under LOCAL indices (position in the
+// tree's processing order), so the only level-to-level dependency -- the gather x[col] -- is an LDS access; the index /
+// value streams (ptr, ci, v) are stored in processing order and do not depend on x.  G = lvl_g[l] lanes share a row (from
+// the level's mean row length: root levels have few long rows, leaf levels many empty ones).
+// Dynamic LDS per workgroup: xs[max_nodes] doubles | s_off[max_levels + 1] ints | s_g[max_levels] ints.
+//
+// forward:  x[i] = rhs[i] - sum_{j < i} L11[i][j] x[j]
+__global__ __launch_bounds__(64) void lead_forward_kernel(const int* __restrict__ lvl_ptr, const int* __restrict__ lvl_off, const int* __restrict__ lvl_g,
+                                                          const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
+                                                          const double* __restrict__ v, const double* __restrict__ ax, const double* __restrict__ asmc,
+                                                          const double* __restrict__ b, double isig, double* __restrict__ x, int max_nodes,
+                                                          int max_levels) {
+  extern __shared__ double lead_smem[];
+  double* xs = lead_smem;
+  int* s_off = reinterpret_cast<int*>(xs + max_nodes);
+  int* s_g = s_off + max_levels + 1;
+  const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
+  const int l0 = lvl_ptr[t], nlev = lvl_ptr[t + 1] - 1 - l0;
+  for (int l = lane; l <= nlev; l += 64) s_off[l] = lvl_off[l0 + l];
+  for (int l = lane; l < nlev; l += 64) s_g[l] = lvl_g[l0 + l];
+  wave_fence();
+  const int first = s_off[0];
+  for (int l = 0; l < nlev; ++l) {
+    const int G = s_g[l], sub = lane & (G - 1), grp = lane / G, ngrp = 64 / G;
+    const int beg = s_off[l], end = s_off[l + 1];
+    for (int base = beg; base < end; base += ngrp) {       // uniform trip count: the shuffles need every lane
+      const int idx = base + grp;
+      double s = 0.0;
+      if (idx < end)
+        for (long long q = ptr[idx] + sub; q < ptr[idx + 1]; q += G) s += v[q] * xs[ci[q]];
+      s = group_sum(s, G);
+      if (idx < end && sub == 0) {
+        const int i = nodes[idx];
+        const double xi = lead_rhs(ax, asmc, b, isig, i) - s;
+        xs[idx - first] = xi;
+        x[i] = xi;
+      }
+    }
+    wave_fence();                                          // the next level reads xs written by this one
+  }
+}
+
+// z2[i] = rhs[n1 + i] - sum_j L21[i][j] z1[j]  -> the tail's input vector (8 lanes per tail row, fixed summation order)
+__global__ __launch_bounds__(256) void lead_tail_rhs_kernel(int k, int n1, const long long* __restrict__ rp, const int* __restrict__ ci,
+                                                            const double* __restrict__ v, const double* __restrict__ ax, const double* __restrict__ asmc,
+                                                            const double* __restrict__ b, double isig, const double* __restrict__ z1,
+                                                            double* __restrict__ z2) {
+  const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int i = gt >> 3, sub = gt & 7;
+  if (i >= k) return;
+  double s = 0.0;
+  for (long long q = rp[i] + sub; q < rp[i + 1]; q += 8) s += v[q] * z1[ci[q]];
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  if (sub == 0) z2[i] = lead_rhs(ax, asmc, b, isig, n1 + i) - s;
+}
+
+// w[j] = sum over the TAIL rows of column j:  L21[i][j] x2[i]   (8 lanes per leading column; independent of the sweeps)
+__global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long* __restrict__ tp, const int* __restrict__ tr, const double* __restrict__ tv,
+                                                        const double* __restrict__ x2, double* __restrict__ w) {
+  const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int j = gt >> 3, sub = gt & 7;
+  if (j >= n1) return;
+  double s = 0.0;
+  for (long long q = tp[j] + sub; q < tp[j + 1]; q += 8) s += tv[q] * x2[tr[q]];
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  if (sub == 0) w[j] = s;
+}
+
+// backward, levels root side first:  x[j] = x[j] / D[j] - w[j] - sum_{leading i > j} L11[i][j] x[i]
+__global__ __launch_bounds__(64) void lead_backward_kernel(const int* __restrict__ lvl_ptr, const int* __restrict__ lvl_off, const int* __restrict__ lvl_g,
+                                                           const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
+                                                           const double* __restrict__ v, const double* __restrict__ D, const double* __restrict__ w,
+                                                           double* __restrict__ x, int max_nodes, int max_levels) {
+  extern __shared__ double lead_smem[];
+  double* xs = lead_smem;
+  int* s_off = reinterpret_cast<int*>(xs + max_nodes);
+  int* s_g = s_off + max_levels + 1;
+  const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
+  const int l0 = lvl_ptr[t], nlev = lvl_ptr[t + 1] - 1 - l0;
+  for (int l = lane; l <= nlev; l += 64) s_off[l] = lvl_off[l0 + l];
+  for (int l = lane; l < nlev; l += 64) s_g[l] = lvl_g[l0 + l];
+  wave_fence();
+  const int first = s_off[0];
+  for (int l = 0; l < nlev; ++l) {
+    const int G = s_g[l], sub = lane & (G - 1), grp = lane / G, ngrp = 64 / G;
+    const int beg = s_off[l], end = s_off[l + 1];
+    for (int base = beg; base < end; base += ngrp) {
+      const int idx = base + grp;
+      double s = 0.0;
+      if (idx < end)
+        for (long long q = ptr[idx] + sub; q < ptr[idx + 1]; q += G) s += v[q] * xs[ci[q]];
+      s = group_sum(s, G);
+      if (idx < end && sub == 0) {
+        const int j = nodes[idx];
+        const double xj = x[j] / D[j] - w[j] - s;
+        xs[idx - first] = xj;
+        x[j] = xj;
+      }
+    }
+    wave_fence();
+  }
+}
+
+}  // namespace
+
+void LeadSolve::release() {
+  for (void* p : {(void*)rp21, (void*)ci21, (void*)v21, (void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)tptr,
+                  (void*)tri, (void*)tv_, (void*)D1, (void*)wvec, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f, (void*)lvl_ptr_b, (void*)lvl_off_f,
+                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b})
+    if (p) { hipError_t e = hipFree(p); (void)e; }
+  rp21 = fptr = bptr = tptr = nullptr; ci21 = fci = bci = tri = nullptr; v21 = fv_ = bv_ = tv_ = D1 = wvec = nullptr;
+  nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
+  ready = false;
+}
+
+int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D) {
+  release();
+  m = m_; k = k_; n1 = m - k;
+  if (n1 <= 0 || k <= 0) return CUADMM_OK;
+  const long long nnz = (long long)Lp[n1];
+  // CSR of L11 and of L21 by counting sort over the leading columns (rows ascending inside a column => columns ascending inside a row)
+  std::vector<long long> r11((size_t)n1 + 1, 0), r21((size_t)k + 1, 0);
+  for (long long p = 0; p < nnz; ++p) { const int i = Li[p]; if (i < n1) r11[(size_t)i + 1]++; else r21[(size_t)(i - n1) + 1]++; }
+  for (int i = 0; i < n1; ++i) r11[(size_t)i + 1] += r11[i];
+  for (int i = 0; i < k; ++i) r21[(size_t)i + 1] += r21[i];
+  std::vector<int> c11((size_t)r11[n1]), c21((size_t)r21[k]);
+  std::vector<double> w11((size_t)r11[n1]), w21((size_t)r21[k]);
+  {
+    std::vector<long long> f11(r11.begin(), r11.end() - 1), f21(r21.begin(), r21.end() - 1);
+    for (int j = 0; j < n1; ++j)
+      for (long long p = Lp[j]; p < Lp[j + 1]; ++p) {
+        const int i = Li[p];
+        if (i < n1) { const long long q = f11[i]++; c11[(size_t)q] = j; w11[(size_t)q] = Lx[p]; }
+        else { const long long q = f21[i - n1]++; c21[(size_t)q] = j; w21[(size_t)q] = Lx[p]; }
+      }
+  }
+  // elimination forest of the leading block, levels of both sweeps
+  std::vector<int> parent((size_t)n1, -1), root((size_t)n1), lev_f((size_t)n1, 0), lev_b((size_t)n1, 0);
+  for (int j = 0; j < n1; ++j) {
+    int pmin = -1;
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p) if (Li[p] < n1 && (pmin < 0 || Li[p] < pmin)) pmin = Li[p];
+    parent[j] = pmin;
+  }
+  for (int j = n1 - 1; j >= 0; --j) root[j] = parent[j] < 0 ? j : root[parent[j]];
+  for (int i = 0; i < n1; ++i) {          // forward: a row waits for every column it gathers from
+    int lv = 0;
+    for (long long q = r11[i]; q < r11[i + 1]; ++q) lv = std::max(lv, lev_f[c11[(size_t)q]] + 1);
+    lev_f[i] = lv;
+  }
+  for (int j = n1 - 1; j >= 0; --j) {     // backward: a column waits for every leading row it gathers from
+    int lv = 0;
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p) if (Li[p] < n1) lv = std::max(lv, lev_b[Li[p]] + 1);
+    lev_b[j] = lv;
+  }
+  std::vector<int> tree_of((size_t)n1, -1);
+  ntrees = 0;
+  for (int j = 0; j < n1; ++j) if (root[j] == j) tree_of[j] = ntrees++;
+  for (int j = 0; j < n1; ++j) tree_of[j] = tree_of[root[j]];
+  auto order = [&](const std::vector<int>& lev, std::vector<int>& nodes, std::vector<int>& lvl_ptr, std::vector<int>& lvl_off, int& maxlev,
+                   const std::vector<long long>& len_ptr, std::vector<int>& lvl_g) {
+    nodes.resize((size_t)n1);
+    std::iota(nodes.begin(), nodes.end(), 0);
+    std::stable_sort(nodes.begin(), nodes.end(), [&](int a, int b) {
+      if (tree_of[a] != tree_of[b]) return tree_of[a] < tree_of[b];
+      return lev[a] < lev[b];
+    });
+    lvl_ptr.assign((size_t)ntrees + 1, 0);
+    lvl_off.clear();
+    int cur_tree = -1, cur_lev = -1;
+    for (int idx = 0; idx < n1; ++idx) {
+      const int a = nodes[idx];
+      if (tree_of[a] != cur_tree) {
+        if (cur_tree >= 0) lvl_off.push_back(idx);         // sentinel of the previous tree
+        cur_tree = tree_of[a]; cur_lev = -1;
+        lvl_ptr[cur_tree] = (int)lvl_off.size();
+      }
+      if (lev[a] != cur_lev) { lvl_off.push_back(idx); cur_lev = lev[a]; maxlev = std::max(maxlev, cur_lev + 1); }
+    }
+    lvl_off.push_back(n1);
+    lvl_ptr[ntrees] = (int)lvl_off.size();
+    // lanes per row of a level: the power of two next to the level's mean number of nonzeros per node (1 .. 64)
+    lvl_g.assign(lvl_off.size(), 1);
+    for (size_t l = 0; l + 1 < lvl_off.size(); ++l) {
+      const int cnt = lvl_off[l + 1] - lvl_off[l];
+      if (cnt <= 0) continue;
+      long long tot = 0;
+      for (int idx = lvl_off[l]; idx < lvl_off[l + 1]; ++idx) tot += len_ptr[(size_t)nodes[idx] + 1] - len_ptr[nodes[idx]];
+      const double mean = (double)tot / cnt;
+      int g = 1;
+      while (g < 64 && g < mean) g <<= 1;
+      lvl_g[l] = g;
+    }
+  };
+  std::vector<int> nf, nb, lpf, lpb, lof, lob, lgf, lgb;
+  int mlf = 0, mlb = 0;
+  // per-node entry counts of the two sweeps: forward = row of L11, backward = leading rows of the column
+  std::vector<long long> cnt_b((size_t)n1 + 1, 0);
+  for (int j = 0; j < n1; ++j) {
+    long long c = 0;
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p) c += Li[p] < n1;
+    cnt_b[(size_t)j + 1] = cnt_b[j] + c;
+  }
+  order(lev_f, nf, lpf, lof, mlf, r11, lgf);
+  order(lev_b, nb, lpb, lob, mlb, cnt_b, lgb);
+  max_levels = std::max(mlf, mlb);
+  // local index of a node = its position inside its tree in the sweep's processing order
+  std::vector<int> tree_first((size_t)ntrees, 0);
+  max_nodes = 0;
+  {
+    std::vector<int> cnt((size_t)ntrees, 0);
+    for (int j = 0; j < n1; ++j) cnt[tree_of[j]]++;
+    int acc = 0;
+    for (int t = 0; t < ntrees; ++t) { tree_first[t] = acc; acc += cnt[t]; max_nodes = std::max(max_nodes, cnt[t]); }
+  }
+  std::vector<int> pos_f((size_t)n1), pos_b((size_t)n1);
+  for (int idx = 0; idx < n1; ++idx) { pos_f[nf[idx]] = idx - tree_first[tree_of[nf[idx]]]; pos_b[nb[idx]] = idx - tree_first[tree_of[nb[idx]]]; }
+  // forward stream: row of L11 of the node in slot idx, local column indices
+  std::vector<long long> fp((size_t)n1 + 1, 0), bp((size_t)n1 + 1, 0), tp((size_t)n1 + 1, 0);
+  std::vector<int> fc((size_t)r11[n1]), bc((size_t)cnt_b[n1]), tr((size_t)r21[k]);
+  std::vector<double> fv((size_t)r11[n1]), bv((size_t)cnt_b[n1]), tv((size_t)r21[k]);
+  for (int idx = 0; idx < n1; ++idx) {
+    const int i = nf[idx];
+    long long q = fp[idx];
+    for (long long r = r11[i]; r < r11[i + 1]; ++r, ++q) { fc[(size_t)q] = pos_f[c11[(size_t)r]]; fv[(size_t)q] = w11[(size_t)r]; }
+    fp[(size_t)idx + 1] = q;
+  }
+  // backward stream: leading rows of the column of the node in slot idx, local row indices; tail rows by column for w
+  for (int idx = 0; idx < n1; ++idx) {
+    const int j = nb[idx];
+    long long q = bp[idx];
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p)
+      if (Li[p] < n1) { bc[(size_t)q] = pos_b[Li[p]]; bv[(size_t)q] = Lx[p]; ++q; }
+    bp[(size_t)idx + 1] = q;
+  }
+  for (int j = 0; j < n1; ++j) {
+    long long q = tp[j];
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p)
+      if (Li[p] >= n1) { tr[(size_t)q] = Li[p] - n1; tv[(size_t)q] = Lx[p]; ++q; }
+    tp[(size_t)j + 1] = q;
+  }
+  // cost model: per level two dependent global-memory latencies (~2 us) in the deepest tree, per sweep, plus the streaming part
+  est_us = 2.0 * 2.0 * max_levels + 40.0 + (double)nnz * 2e-4;
+  if (max_nodes > 6144 || max_levels > 2048) { est_us = 1e30; return CUADMM_OK; }     // LDS budget of one wavefront's tree
+  lds_bytes = sizeof(double) * (size_t)max_nodes + sizeof(int) * (2 * (size_t)max_levels + 2);
+  int rc;
+  if ((rc = to_device(rp21, r21)) || (rc = to_device(ci21, c21)) || (rc = to_device(v21, w21)) ||
+      (rc = to_device(fptr, fp)) || (rc = to_device(fci, fc)) || (rc = to_device(fv_, fv)) ||
+      (rc = to_device(bptr, bp)) || (rc = to_device(bci, bc)) || (rc = to_device(bv_, bv)) ||
+      (rc = to_device(tptr, tp)) || (rc = to_device(tri, tr)) || (rc = to_device(tv_, tv)) ||
+      (rc = to_device(D1, std::vector<double>(D, D + n1))) || (rc = to_device(nodes_f, nf)) || (rc = to_device(nodes_b, nb)) ||
+      (rc = to_device(lvl_ptr_f, lpf)) || (rc = to_device(lvl_ptr_b, lpb)) || (rc = to_device(lvl_off_f, lof)) || (rc = to_device(lvl_off_b, lob)) ||
+      (rc = to_device(lvl_g_f, lgf)) || (rc = to_device(lvl_g_b, lgb)))
+    return rc;
+  CUADMM_HIP_TRY(hipMalloc(&wvec, sizeof(double) * (size_t)n1));
+  if (lds_bytes > 48 * 1024) {
+    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
+  ready = true;
+  return CUADMM_OK;
+}
+
+int LeadSolve::solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const {
+  if (!ready) { set_error("lead_solve: not built"); return CUADMM_ERR_INVALID; }
+  hipLaunchKernelGGL(lead_forward_kernel, dim3(ntrees), dim3(64), lds_bytes, st, lvl_ptr_f, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, y,
+                     max_nodes, max_levels);
+  hipLaunchKernelGGL(lead_tail_rhs_kernel, dim3((k * 8 + 255) / 256), dim3(256), 0, st, k, n1, rp21, ci21, v21, ax, asmc, b, isig, y, tail.vin);
+  CUADMM_HIP_TRY(hipGetLastError());
+  int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
+  if (rc) return rc;
+  hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
+  hipLaunchKernelGGL(lead_backward_kernel, dim3(ntrees), dim3(64), lds_bytes, st, lvl_ptr_b, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_, D1, wvec, y,
+                     max_nodes, max_levels);
+  CUADMM_HIP_TRY(hipGetLastError());
+  CUADMM_HIP_TRY(hipMemcpyAsync(y + n1, tail.vin, sizeof(double) * (size_t)k, hipMemcpyDeviceToDevice, st));
+  return CUADMM_OK;
+}
+
+}  // namespace cuadmm

@@ -14,6 +14,7 @@ struct TailSolve {
   int alloc(int k);
   int invert(const double* dL, hipStream_t st);
   int solve(double* z2, hipStream_t st);
+  int solve_device(hipStream_t st);      // in place on the device vector `vin` (k entries, zero padding kept); asynchronous
   void release();
   ~TailSolve() { release(); }
 };

@@ -448,4 +448,13 @@ int TailSolve::solve(double* z2, hipStream_t st) {
   return CUADMM_OK;
 }
 
+// the same on a right-hand side that is already in `vin` (written by lead_tail_rhs_kernel): nothing crosses PCIe
+int TailSolve::solve_device(hipStream_t st) {
+  if (!W) { set_error("tail_solve: not built"); return CUADMM_ERR_INVALID; }
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 }  // namespace cuadmm
