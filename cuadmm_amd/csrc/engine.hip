@@ -167,6 +167,9 @@ struct cuadmm_solver {
   // Device-side y-solve (forest_solve_kernel) when the elimination forest of the factor is many small trees (block-diagonal
   // A A^T: C2, C4, ros_2000 ...): y, A X, A(S-C), b stay in HBM, the host fetches only the four scalars of the stopping test.
   bool dev_solve = false;
+  // Fused iteration (psd_fuse.h): the projection kernels of the 17 <= n <= 64 blocks form Xb themselves and apply the S / X
+  // updates to their svec ranges; the stand-alone vector kernels visit only the rest of the svec (plan.d_rest).
+  bool fuse = false;
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -369,6 +372,25 @@ struct cuadmm_solver {
     prof_begin(K_PSD);
     int rc = plan.project(Xb.p, Xproj.p, st);
     prof_end(K_PSD, 16.0 * (double)L);
+    return rc;
+  }
+  // Step 2 of a fused iteration: Rd1 / Xb on the rest of the svec, then the projection whose fused blocks also do the
+  // post step `mode` (0: S, X, sums; 1: S only) on their own ranges, then the post step on the rest (+ the sums).
+  int launch_fused_step(int mode, double tau) {
+    int rc;
+    prof_begin(K_ATY);
+    rc = launch_aty_xb_idx(plan.n_rest, plan.d_rest, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st);
+    prof_end(K_ATY, 36.0 * (double)plan.n_rest);
+    if (rc) return rc;
+    SignFuse fz{At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, Rd1.p, S.p, partials.p, sig, 1 / sig, tau * sig, mode};
+    prof_begin(K_PSD);
+    rc = plan.project(Xb.p, Xproj.p, st, &fz);
+    prof_end(K_PSD, 68.0 * (double)(L - plan.n_rest) + 16.0 * (double)plan.n_rest);
+    if (rc) return rc;
+    prof_begin(K_POST);
+    rc = launch_post_rest(mode, plan.n_rest, plan.d_rest, plan.fused_blocks(), Xproj.p, Rd1.p, C.p, X.p, S.p, 1 / sig, tau * sig, partials.p,
+                          out_w + (size_t)m, st);
+    prof_end(K_POST, (mode == 0 ? 48.0 : 32.0) * (double)plan.n_rest);
     return rc;
   }
   int launch_post_mode(int mode, double tau) {
@@ -791,12 +813,19 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     if ((rc = s->S.from(tmp))) return rc;
   }
   if ((rc = s->Rd1.alloc(L)) || (rc = s->Xb.alloc(L)) || (rc = s->Xproj.alloc(L)) || (rc = s->y_d.alloc(std::max(m, 1))) ||
-      (rc = s->out_d.alloc(2 * (size_t)m + 2)) || (rc = s->partials.alloc(2 * (size_t)post_grid(L) + 2)) ||
+      (rc = s->out_d.alloc(2 * (size_t)m + 2)) || (rc = s->partials.alloc(2 * (size_t)post_grid(L) + 2 + 2 * (size_t)s->plan.fused_blocks())) ||
       (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8 + 128)))
     return rc;
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
   std::memset(s->h_out.p, 0, sizeof(double) * (2 * (size_t)m + 2));
   s->out_w = s->out_d.p;
+  // fused iteration: needs the one-wavefront-per-block sign kernels and no long rows of A^T (they are summed by their own kernel)
+  s->fuse = s->plan.fusable() && s->At_long.nlong == 0 && !getenv("CUADMM_DEBUG_EIG") &&
+            !(getenv("CUADMM_FUSE") && atoi(getenv("CUADMM_FUSE")) == 0);
+  if (s->fuse && (rc = s->plan.build_rest_index())) return rc;
+  if (s->fuse && s->verbose)
+    printf(" fused iteration: %d blocks form Xb and apply the S / X updates inside their projection kernel (%lld of %lld svec entries outside)\n",
+           s->plan.fused_blocks(), s->plan.n_rest, L);
   s->dev_scalars = s->local_mode && s->comm_world > 1 && !getenv("CUADMM_HOST_SCALARS");
   // device-side y-solve: whole factor on the host side of the split (no GPU tail) and a forest of many small trees
   s->dev_solve = false;
@@ -956,26 +985,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       break;
     }
 
-    // ---- Step 2 (solver.cu:514-656)
-    if ((rc = s->upload_y())) return rc;
-    if ((rc = s->launch_aty(true))) return rc;
-    s->plan.rank_active = s->eig_rank > 0 && (iter >= s->eig_rank_begin_iter || s->maxfeas < s->eig_rank_maxfeas);   // duo_solver.cu:844
-    if ((rc = s->launch_project())) return rc;
-    static const char* const debug_eig_dir = getenv("CUADMM_DEBUG_EIG");   // read once, not per iteration
-    if (debug_eig_dir) {   // developer aid: dump the projection input when a block hits the QL cap
-      int f = s->plan.fail_count(s->st);
-      if (f != s->eig_fail_total) {
-        fprintf(stderr, "[cuadmm debug] iter %d: QL cap hits %d -> %d\n", iter, s->eig_fail_total, f);
-        std::vector<double> h((size_t)L);
-        if (hipMemcpy(h.data(), s->Xb.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost) == hipSuccess) {
-          char fn[256];
-          snprintf(fn, sizeof fn, "%s/xb_fail_iter%d.bin", debug_eig_dir, iter);
-          if (FILE* fp = fopen(fn, "wb")) { fwrite(h.data(), sizeof(double), (size_t)L, fp); fclose(fp); }
-        }
-        s->eig_fail_total = f;
-      }
-    }
-
+    // ---- Step 2 (solver.cu:514-656).  The host-side decisions of this iteration (tau, snapshot) depend only on the previous
+    // iteration's scalars, so they are taken first: the fused projection needs to know which post step follows it.
     double tau = (iter < switch_admm) ? 1.95 : 1.618;                    // solver.cu:747-754
     if (s->errRd < stop_tol) tau = std::max(1.618, tau / 1.1);
 
@@ -994,9 +1005,33 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       snapshot = true;
     }
 
+    const int post_mode_after_proj = (iter < switch_admm || snapshot) ? 1 : 0;
+    if ((rc = s->upload_y())) return rc;
+    if (s->fuse) {
+      if ((rc = s->launch_fused_step(post_mode_after_proj, tau))) return rc;
+    } else {
+      if ((rc = s->launch_aty(true))) return rc;
+      s->plan.rank_active = s->eig_rank > 0 && (iter >= s->eig_rank_begin_iter || s->maxfeas < s->eig_rank_maxfeas);   // duo_solver.cu:844
+      if ((rc = s->launch_project())) return rc;
+      static const char* const debug_eig_dir = getenv("CUADMM_DEBUG_EIG");   // read once, not per iteration
+      if (debug_eig_dir) {   // developer aid: dump the projection input when a block hits the QL cap
+        int f = s->plan.fail_count(s->st);
+        if (f != s->eig_fail_total) {
+          fprintf(stderr, "[cuadmm debug] iter %d: QL cap hits %d -> %d\n", iter, s->eig_fail_total, f);
+          std::vector<double> h((size_t)L);
+          if (hipMemcpy(h.data(), s->Xb.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost) == hipSuccess) {
+            char fn[256];
+            snprintf(fn, sizeof fn, "%s/xb_fail_iter%d.bin", debug_eig_dir, iter);
+            if (FILE* fp = fopen(fn, "wb")) { fwrite(h.data(), sizeof(double), (size_t)L, fp); fclose(fp); }
+          }
+          s->eig_fail_total = f;
+        }
+      }
+    }
+
     if (iter < switch_admm) {
       // sGS half step: S^{k+1}, second solve with it, Rd1 from the new y (solver.cu:693-729)
-      if ((rc = s->launch_post_mode(1, tau))) return rc;
+      if (!s->fuse && (rc = s->launch_post_mode(1, tau))) return rc;     // fused: done with the projection
       if ((rc = s->launch_spmv(false, true))) return rc;
       if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
       if ((rc = s->host_solve())) return rc;
@@ -1008,7 +1043,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     } else {
       if (snapshot) {
         if (!s->X_best.p && L > 0) { if ((rc = s->X_best.alloc(L)) || (rc = s->S_best.alloc(L))) return rc; }
-        if ((rc = s->launch_post_mode(1, tau))) return rc;
+        if (!s->fuse && (rc = s->launch_post_mode(1, tau))) return rc;
         s->prof_begin(K_COPY);
         CUADMM_HIP_TRY(hipMemcpyAsync(s->X_best.p, s->X.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
         CUADMM_HIP_TRY(hipMemcpyAsync(s->S_best.p, s->S.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToDevice, s->st));
@@ -1021,7 +1056,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         }
         s->have_best = true;
         if ((rc = s->launch_post_mode(2, tau))) return rc;
-      } else {
+      } else if (!s->fuse) {
         if ((rc = s->launch_post_mode(0, tau))) return rc;
       }
       if ((rc = s->launch_spmv(true, true))) return rc;

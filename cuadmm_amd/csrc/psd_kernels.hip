@@ -25,6 +25,7 @@
 #include "psd_plan.h"
 #include "psd_small_reg.h"
 #include "psd_sign_lds.h"
+#include "psd_sign_wave.h"
 
 namespace cuadmm {
 
@@ -168,15 +169,59 @@ CUADMM_SW32_KERNEL(psd_sign_wave32_occ3_kernel, 3, false)
 CUADMM_SW32_KERNEL(psd_sign_wave32_dbg_kernel, 3, true)     // CUADMM_PSD_DEBUG: per-phase cycle stamps inside the step
 #undef CUADMM_SW32_KERNEL
 
-static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_t st) {
+// one WAVEFRONT per block (psd_sign_wave.h): NT = 3 (n <= 48, two wavefronts per SIMD), NT = 4 (n <= 64, one); NT = 2 is the
+// A/B twin of psd_sign_wave32_kernel with column-pair loads (CUADMM_PSD_W32_GEN=<waves per SIMD>)
+template <int NT, int OCC, bool FUSED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_wave_kernel(PsdArgs a, SignFuse fz, int first, int count, int slot0) {
+  extern __shared__ double swt_smem[];
+  const int m = (int)blockIdx.x;
+  if (m >= count) return;
+  const int id = a.ids ? a.ids[first + m] : first + m;
+  const long long off = a.boff[id];
+  psd_sign_wave_body<NT, FUSED>(a.in + off, a.out + off, a.bn[id], a.info, swt_smem, a.steps ? a.steps + id : nullptr,
+                                a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, slot0 + m);
+}
+
+// fz != nullptr: the fused variant (SignFuse, psd_sign_wave.h); slot0 = partial-sum slot of the first member of this launch
+template <int NT, int OCC>
+static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t st, const SignFuse* fz = nullptr, int slot0 = 0) {
+  if (count <= 0) return CUADMM_OK;
+  if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count, slot0);
+  else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count, 0);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// A/B switches of the projection kernels, read from the environment once
+struct PsdKnobs {
+  bool debug, sign32, mid_eig, mid_lds, w64;
+  int gen;   // n <= 32: 3 | 4 = psd_sign_wave_kernel<2> at that many wavefronts per SIMD, 0 = the hand-unrolled SignWave32 kernel
+  PsdKnobs() {
+    auto is = [](const char* name, const char* val) { const char* e = getenv(name); return e && std::string(e) == val; };
+    debug = getenv("CUADMM_PSD_DEBUG") != nullptr;
+    sign32 = !is("CUADMM_PSD_N32", "eig");
+    mid_eig = is("CUADMM_PSD_MID", "eig");
+    mid_lds = is("CUADMM_PSD_MID", "lds");
+    w64 = !(getenv("CUADMM_PSD_W64") && atoi(getenv("CUADMM_PSD_W64")) == 0);
+    gen = getenv("CUADMM_PSD_W32_GEN") ? atoi(getenv("CUADMM_PSD_W32_GEN")) : 4;
+    if (gen != 3 && gen != 4) gen = 0;
+  }
+};
+static const PsdKnobs& psd_knobs() { static const PsdKnobs k; return k; }
+
+static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_t st, const SignFuse* fz = nullptr, int slot0 = 0) {
   if (count <= 0) return CUADMM_OK;
   static const int wpg = getenv("CUADMM_PSD_W32_WPG") ? atoi(getenv("CUADMM_PSD_W32_WPG")) : 1;
   static const int occ = getenv("CUADMM_PSD_W32_OCC") ? atoi(getenv("CUADMM_PSD_W32_OCC")) : 3;
+  const int gen = psd_knobs().gen;
+  if (gen == 3 && (!a.dbg || fz)) return launch_sign_wave<2, 3>(a, first, count, st, fz, slot0);
+  if ((gen == 4 && !a.dbg) || fz) return launch_sign_wave<2, 4>(a, first, count, st, fz, slot0);
+  static const int pad = getenv("CUADMM_PSD_W32_PAD") ? atoi(getenv("CUADMM_PSD_W32_PAD")) : 0;   // occupancy experiments: unused dynamic LDS
   if (a.dbg) {
-    hipLaunchKernelGGL(psd_sign_wave32_dbg_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
+    hipLaunchKernelGGL(psd_sign_wave32_dbg_kernel<1>, dim3(count), dim3(64), pad, st, a, first, count);
   } else if (occ == 3) {
     if (wpg == 4) hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<4>, dim3((count + 3) / 4), dim3(256), 0, st, a, first, count);
-    else hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
+    else hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<1>, dim3(count), dim3(64), pad, st, a, first, count);
   } else {
     hipLaunchKernelGGL(psd_sign_wave32_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
   }
@@ -221,6 +266,7 @@ int psd_class_of(int n) {
 int PsdPlan::build(const int* blk, int mat_num) {
   release();
   nblk = mat_num;
+  h_blk.assign(blk, blk + mat_num);
   std::vector<long long> off((size_t)mat_num + 1, 0);
   std::vector<long long> free_off, free_len;   // unconstrained blocks (negative size): identity "projection"
   for (int k = 0; k < mat_num; ++k) {
@@ -290,8 +336,9 @@ int PsdPlan::build(const int* blk, int mat_num) {
 }
 
 void PsdPlan::release() {
-  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len})
+  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len, (void*)d_rest})
     if (p) { hipError_t e = hipFree(p); (void)e; }
+  d_rest = nullptr; n_rest = 0;
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
   d_free_off = d_free_len = nullptr; n_free = 0;
   sign.release();
@@ -348,13 +395,42 @@ __global__ void hint_decay_kernel(int* hint, int n) {
   if (i < n && hint[i] > 1) hint[i] -= 1;
 }
 
-int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
+// Blocks of the one-wavefront-per-block sign kernels (classes 3 and 4) can take the iteration's vector work with them
+bool PsdPlan::fusable() const {
+  const PsdKnobs& k = psd_knobs();
+  return eig_rank == 0 && !k.debug && k.sign32 && k.gen != 0 && !k.mid_eig && !k.mid_lds && k.w64 && fused_blocks() > 0 &&
+         vec_len < 0x7fffffffLL;
+}
+
+// svec elements outside the fused blocks, ascending (the stand-alone vector kernels run over this list)
+int PsdPlan::build_rest_index() {
+  if (d_rest) { hipError_t e = hipFree(d_rest); (void)e; d_rest = nullptr; }
+  std::vector<int> rest;
+  long long off = 0;
+  for (int k = 0; k < nblk; ++k) {
+    const long long len = blk_svec_len(h_blk[k]);
+    const int c = h_blk[k] > 0 && h_blk[k] < sign_min ? psd_class_of(h_blk[k]) : -1;
+    if (c != 3 && c != 4)
+      for (long long i = off; i < off + len; ++i) rest.push_back((int)i);
+    off += len;
+  }
+  n_rest = (long long)rest.size();
+  if (n_rest > 0) {
+    CUADMM_HIP_TRY(hipMalloc(&d_rest, sizeof(int) * rest.size()));
+    CUADMM_HIP_TRY(hipMemcpy(d_rest, rest.data(), sizeof(int) * rest.size(), hipMemcpyHostToDevice));
+  }
+  return CUADMM_OK;
+}
+
+int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const SignFuse* fz) const {
   if (d_hint && (++n_project & 15) == 0) {
     hipLaunchKernelGGL(hint_decay_kernel, dim3((nblk + 255) / 256), dim3(256), 0, st, d_hint, nblk);
     CUADMM_HIP_TRY(hipGetLastError());
   }
-  static const bool psd_debug = getenv("CUADMM_PSD_DEBUG") != nullptr;     // environment read once, not per projection
+  const PsdKnobs& knobs = psd_knobs();                                      // environment read once, not per projection
+  const bool psd_debug = knobs.debug;
   static const bool no_overlap = (getenv("CUADMM_PSD_OVERLAP") && atoi(getenv("CUADMM_PSD_OVERLAP")) == 0) || psd_debug;
+  if (fz && !fusable()) { set_error("psd: fused projection requested on a plan that cannot fuse"); return CUADMM_ERR_INVALID; }
   int lanes = sign.empty() ? 0 : 1;
   for (int c = 0; c < kNumPsdClasses; ++c) lanes += cls_count[c] > 0;
   const bool fork = overlap && !no_overlap && st != nullptr && lanes > 1;
@@ -369,7 +445,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
   hipStream_t main_st = st;
   // 16 < n <= 32: CUADMM_PSD_N32 = eig (register eigensolver, psd_small_reg.h) | sign (one wavefront per block, psd_sign_lds.h)
   // Default sign: 0.805 ms vs 0.92 ms per 10 000 x 32 blocks (MI355X), and 0.16 ms vs 0.35 ms latency for a single block.
-  static const bool sign32 = !(getenv("CUADMM_PSD_N32") && std::string(getenv("CUADMM_PSD_N32")) == "eig");
+  const bool sign32 = knobs.sign32;
   for (int c = 0; c < kNumPsdClasses; ++c) {
     if (cls_count[c] == 0) continue;
     if (fork) {   // the sign path keeps the main stream (it is the longest chain)
@@ -409,12 +485,15 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st) const {
       a.dbg = dbg;
     }
     int rc;
-    static const bool no_sign_lds = getenv("CUADMM_PSD_MID") && std::string(getenv("CUADMM_PSD_MID")) == "eig";   // A/B: register eigensolver
-    if (c == 4 && !no_sign_lds && eig_rank == 0) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
-      rc = launch_sign_lds<64>(a, 0, cls4_big, st);
-      if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st);
+    if (c == 4 && !knobs.mid_eig && eig_rank == 0) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
+      // one wavefront per block (psd_sign_wave.h); CUADMM_PSD_MID=lds restores the one-workgroup-per-block kernels (A/B),
+      // CUADMM_PSD_MID=eig the register eigensolver.  Fused: partial-sum slots follow those of class 3.
+      const bool mid_lds = knobs.mid_lds, w64 = knobs.w64;
+      rc = (w64 && !mid_lds) ? launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz, cls_count[3]) : launch_sign_lds<64>(a, 0, cls4_big, st);
+      if (!rc) rc = mid_lds ? launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st)
+                            : launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz, cls_count[3] + cls4_big);
     } else if (c == 3 && sign32 && eig_rank == 0) {
-      rc = launch_sign_wave32(a, 0, cls_count[c], st);
+      rc = launch_sign_wave32(a, 0, cls_count[c], st, fz, 0);
     } else {
       rc = launch_class<0>(c, a, cls_maxn[c], st);
     }

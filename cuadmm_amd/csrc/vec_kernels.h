@@ -25,6 +25,14 @@ int post_grid(long long L);
 int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, const double* C, double* X, double* S,
                 double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st);
 
+// Fused iteration (psd_fuse.h): the same two steps restricted to a list of svec rows (those outside the fused blocks); the
+// mode-0 reduction also folds in the per-block partial pairs the projection kernels wrote to partials[0, 2 nfused).
+// partials: 2 * (nfused + post_grid(nidx)) doubles.
+int launch_aty_xb_idx(long long nidx, const int* idx, const int* rp, const int* ci, const double* av, const double* y, const double* C,
+                      const double* X, double sig, double* Rd1, double* Xb, hipStream_t st);
+int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const double* Xproj, const double* Rd1, const double* C, double* X,
+                     double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st);
+
 // Rows of A with more than `cap` nonzeros (a trace / all-ones constraint): their tail is summed in segments by extra
 // workgroups and added in segment order (reproducible), so one row cannot serialise the SpMV.
 struct SpmvLongRows {

@@ -76,6 +76,22 @@ __global__ __launch_bounds__(kVecThreads) void aty_xb_kernel(long long L, const 
   }
 }
 
+// the same over a LIST of svec rows (fused iteration: the rows outside the blocks whose projection kernel does this itself)
+__global__ __launch_bounds__(kVecThreads) void aty_xb_idx_kernel(long long nidx, const int* __restrict__ idx, const int* __restrict__ rp,
+                                                                 const int* __restrict__ ci, const double* __restrict__ av,
+                                                                 const double* __restrict__ y, const double* __restrict__ C,
+                                                                 const double* __restrict__ X, double sig,
+                                                                 double* __restrict__ Rd1, double* __restrict__ Xb) {
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nidx; k += (long long)gridDim.x * blockDim.x) {
+    const int i = idx[k];
+    double t = 0.0;
+    for (int p = rp[i]; p < rp[i + 1]; ++p) t += av[p] * y[ci[p]];
+    const double r = t - C[i];
+    Rd1[i] = r;
+    Xb[i] = X[i] + r * sig;
+  }
+}
+
 // one workgroup per long row (two-stage sum in a fixed order: reproducible)
 template <bool WRITE_XB>
 __global__ __launch_bounds__(kVecThreads) void aty_xb_long_kernel(const int* __restrict__ long_rows, const int* __restrict__ rp,
@@ -132,6 +148,34 @@ __global__ __launch_bounds__(kVecThreads) void post_kernel(long long L, const do
     }
   }
   if (MODE != 1) {
+    block_sum2<kVecThreads>(s_rd, s_cx);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_rd; partials[2 * blockIdx.x + 1] = s_cx; }
+  }
+}
+
+// post_kernel<0|1> over a LIST of svec rows (fused iteration); partial sums at partials[2 * blockIdx.x]
+template <int MODE>
+__global__ __launch_bounds__(kVecThreads) void post_idx_kernel(long long nidx, const int* __restrict__ idx, const double* __restrict__ Xproj,
+                                                               const double* __restrict__ Rd1, const double* __restrict__ C,
+                                                               double* __restrict__ X, double* __restrict__ S,
+                                                               double inv_sig, double tau_sig, double* __restrict__ partials) {
+  double s_rd = 0.0, s_cx = 0.0;
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nidx; k += (long long)gridDim.x * blockDim.x) {
+    const int i = idx[k];
+    const double x = X[i];
+    const double r1 = Rd1[i];
+    const double xdiff = Xproj[i] - x;
+    const double s = inv_sig * xdiff - r1;
+    S[i] = s;
+    if (MODE == 0) {
+      const double rd = r1 + s;
+      const double xn = x + tau_sig * rd;
+      X[i] = xn;
+      s_rd += rd * rd;
+      s_cx += C[i] * xn;
+    }
+  }
+  if (MODE == 0) {
     block_sum2<kVecThreads>(s_rd, s_cx);
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_rd; partials[2 * blockIdx.x + 1] = s_cx; }
   }
@@ -317,6 +361,14 @@ int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, cons
   return CUADMM_OK;
 }
 
+int launch_aty_xb_idx(long long nidx, const int* idx, const int* rp, const int* ci, const double* av, const double* y, const double* C,
+                      const double* X, double sig, double* Rd1, double* Xb, hipStream_t st) {
+  if (nidx <= 0) return CUADMM_OK;
+  hipLaunchKernelGGL(aty_xb_idx_kernel, dim3(grid_for(nidx, kVecThreads, 256 * 16)), dim3(kVecThreads), 0, st, nidx, idx, rp, ci, av, y, C, X, sig, Rd1, Xb);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 int AtyLongRows::build(long long L, const int* rp_host) {
   release();
   std::vector<int> lr;
@@ -347,6 +399,24 @@ int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, c
   CUADMM_HIP_TRY(hipGetLastError());
   if (mode != 1) {
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(kVecThreads), 0, st, partials, grid, sums_out);
+    CUADMM_HIP_TRY(hipGetLastError());
+  }
+  return CUADMM_OK;
+}
+
+// Fused iteration: the projection kernels left one partial pair per fused block in partials[0, 2 nfused); the rows of `idx`
+// add their grid's pairs behind them, and (mode 0) everything is summed in slot order.
+int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const double* Xproj, const double* Rd1, const double* C, double* X,
+                     double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st) {
+  const int grid = nidx > 0 ? post_grid(nidx) : 0;
+  if (nidx > 0) {
+    double* part = partials + 2 * (size_t)nfused;
+    if (mode == 0) hipLaunchKernelGGL(post_idx_kernel<0>, dim3(grid), dim3(kVecThreads), 0, st, nidx, idx, Xproj, Rd1, C, X, S, inv_sig, tau_sig, part);
+    else hipLaunchKernelGGL(post_idx_kernel<1>, dim3(grid), dim3(kVecThreads), 0, st, nidx, idx, Xproj, Rd1, C, X, S, inv_sig, tau_sig, part);
+    CUADMM_HIP_TRY(hipGetLastError());
+  }
+  if (mode == 0) {
+    hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(kVecThreads), 0, st, partials, nfused + grid, sums_out);
     CUADMM_HIP_TRY(hipGetLastError());
   }
   return CUADMM_OK;

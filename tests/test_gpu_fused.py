@@ -1,0 +1,78 @@
+"""GPU parity of the FUSED iteration (psd_fuse.h: the projection kernels of the 17 <= n <= 64 blocks form Xb themselves and
+apply the S / X updates to their svec ranges) against the stand-alone kernels (CUADMM_FUSE=0) and the oracle.
+
+Element by element the fused path evaluates the same expressions as aty_xb_kernel / post_kernel; only the order of the two
+sums of an iteration differs.  Tolerance: per-iteration scalars <= 1e-9 relative over the run, sigma exact, X / y / S <= 1e-9.
+"""
+import numpy as np
+import pytest
+
+import cuadmm_amd
+from cuadmm_amd import synthetic
+from oracle import cuadmm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(blk, cons_per_block=3, seed=7):
+    p = synthetic.make_synthetic(blk, cons_per_block=cons_per_block, seed=seed)
+    return p, cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
+
+
+def _run(prob, iters, sw, monkeypatch, fuse, stop_tol=0.0):
+    monkeypatch.setenv("CUADMM_FUSE", "1" if fuse else "0")
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.init_problem(prob)
+    s.solve(iters, stop_tol, 0, 50, 100, sw, 1.05)
+    return s
+
+
+def _same(a, b, rtol=1e-9, atol=1e-12):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape
+    assert np.max(np.abs(a - b) / (atol / rtol + np.abs(b))) <= rtol
+
+
+BLKS = {
+    "all32": [32] * 300,
+    "mixed_c4": [3, 6, 10, 15, 28, 45] * 60,
+    "every_class": [1, 4, 8, 16, 17, 31, 32, 33, 40, 48, 49, 57, 63, 64, 70, 100] * 6,
+    "only_mid": [45] * 40 + [64] * 10 + [50] * 10,
+}
+
+
+@pytest.mark.parametrize("name", sorted(BLKS))
+@pytest.mark.parametrize("sw", [0, 8, 1000])          # ADMM only | sGS then the switch (snapshots) | sGS only
+def test_fused_iteration_equals_standalone_kernels(name, sw, monkeypatch):
+    _, prob = _problem(BLKS[name])
+    iters = 25
+    a = _run(prob, iters, sw, monkeypatch, fuse=True)
+    b = _run(prob, iters, sw, monkeypatch, fuse=False)
+    assert a.info_iter_num == b.info_iter_num == iters
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+        _same(a.info_arr(nm), b.info_arr(nm))
+    assert np.array_equal(a.info_arr("sig"), b.info_arr("sig"))
+    for va, vb in ((a.X, b.X), (a.y, b.y), (a.S, b.S)):
+        assert np.max(np.abs(va - vb)) <= 1e-9 * (1 + np.max(np.abs(vb)))
+
+
+def test_fused_iteration_vs_oracle(monkeypatch):
+    """The fused engine against the numpy oracle on a mixed problem (20 iterations, both phases)."""
+    p, prob = _problem([3, 6, 10, 15, 28, 45, 33, 64] * 12, seed=11)
+    iters, sw = 20, 10
+    s = _run(prob, iters, sw, monkeypatch, fuse=True)
+    op = orc.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
+    o = orc.OracleSolver().init_problem(op)
+    info = o.solve(iters, 0.0, 0, 50, 100, sw, 1.05)
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+        _same(s.info_arr(nm), np.asarray(getattr(info, nm), float), rtol=1e-8, atol=1e-11)
+    assert np.max(np.abs(s.X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))
+
+
+def test_fused_runs_are_bit_reproducible(monkeypatch):
+    _, prob = _problem(BLKS["mixed_c4"], seed=3)
+    a = _run(prob, 15, 0, monkeypatch, fuse=True)
+    b = _run(prob, 15, 0, monkeypatch, fuse=True)
+    for nm in ("errRp", "errRd", "pobj", "dobj"):
+        assert np.array_equal(a.info_arr(nm), b.info_arr(nm))
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.S, b.S)

@@ -282,3 +282,26 @@ def test_project_mid_sizes_in_bulk_properties(n, count):
         sl = slice(int(bidx.off[k]), int(bidx.off[k + 1]))
         ref = orc.psd_project_svec(orc.BlockIndex([n]), x[sl])
         assert np.max(np.abs(p1[sl] - ref)) <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("kind", ["randn", "lowrank", "graded", "psd", "nsd", "clustered"])
+def test_project_every_mid_size_one_wavefront_per_block(kind):
+    """Every size 33 ... 64 (the one-wavefront-per-block sign kernels of psd_sign_wave.h and the one-workgroup kernel above
+    48: column-pair svec loads, odd sizes, the n = 63 / 64 corner of the pairing) on the spectra families of the sign path,
+    three blocks per size in one call, plus an exactly zero block."""
+    sizes = np.repeat(np.arange(33, 65), 3)
+    rng = np.random.default_rng(77 + len(kind))
+    sizes = sizes[rng.permutation(sizes.size)]
+    blk = sizes.astype(np.int32)
+    bidx = orc.BlockIndex(blk)
+    mats = [_spectrum_matrix(int(n), kind, rng) for n in sizes]
+    zero_k = 5
+    mats[zero_k] = np.zeros_like(mats[zero_k])
+    x = np.concatenate([orc.BlockIndex([M.shape[0]]).pack([M[None]]) for M in mats])
+    got = psd_project_gpu(x, blk)
+    ref = orc.psd_project_svec(bidx, x)
+    for k, M in enumerate(mats):
+        sl = slice(int(bidx.off[k]), int(bidx.off[k + 1]))
+        nrm = max(np.linalg.norm(M, 2), 1e-300)
+        assert np.max(np.abs(got[sl] - ref[sl])) <= 2e-12 * nrm * np.sqrt(2), (k, M.shape[0])
+    assert np.all(got[int(bidx.off[zero_k]):int(bidx.off[zero_k + 1])] == 0.0)
