@@ -196,13 +196,13 @@ int cuadmm_partition_blocks(const int* blk, int mat_num, int world, int* first_b
 // host model of the adaptive matrix-sign schedule (sign_sched.h): the kernels run the same state machine per block
 int cuadmm_sign_sched_simulate(double* s, int n, int lagged, double* max_err_out) {
   if (!s || n < 0) { set_error("sign_sched_simulate: bad arguments"); return CUADMM_ERR_INVALID; }
-  return sign_sched_simulate(s, n, lagged != 0, max_err_out);
+  return sign_sched_simulate(s, n, lagged, max_err_out);
 }
 
 // the same with the schedule's warm start: lift0 = the hint (lift steps of the previous projection), *lifts_out = the next hint
 int cuadmm_sign_sched_simulate_hint(double* s, int n, int lagged, int lift0, double* max_err_out, int* lifts_out) {
   if (!s || n < 0) { set_error("sign_sched_simulate: bad arguments"); return CUADMM_ERR_INVALID; }
-  return sign_sched_simulate(s, n, lagged != 0, max_err_out, lift0, lifts_out);
+  return sign_sched_simulate(s, n, lagged, max_err_out, lift0, lifts_out);
 }
 
 }  // extern "C"

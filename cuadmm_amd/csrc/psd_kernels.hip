@@ -45,6 +45,7 @@ struct PsdArgs {
   int* steps;              // developer aid: Newton-Schulz steps taken per block (sign kernels; may be null)
   int* hint;               // per block, in/out: lift steps the previous projection needed (schedule warm start; may be null)
   int eig_rank;            // > 0: rank-limited projection, only the eig_rank largest eigenvalues survive (eigensolver kernels)
+  const PsdDesc* desc;     // class member -> (svec offset, size, block id) in ONE 16-byte load (the sign kernels' first dependent access)
 };
 
 // register-resident variant (psd_small_reg.h): the production path for n <= 32
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   extern __shared__ double swt_smem[];
   const int m = (int)blockIdx.x;
   if (m >= count) return;
-  const int id = a.ids ? a.ids[first + m] : first + m;
-  const long long off = a.boff[id];
-  psd_sign_wave_body<NT, FUSED>(a.in + off, a.out + off, a.bn[id], a.info, swt_smem, a.steps ? a.steps + id : nullptr,
+  const PsdDesc d = a.desc[first + m];
+  const int id = d.id;
+  const long long off = d.off;
+  psd_sign_wave_body<NT, FUSED>(a.in + off, a.out + off, d.n, a.info, swt_smem, a.steps ? a.steps + id : nullptr,
                                 a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, slot0 + m);
 }
 
@@ -320,6 +322,12 @@ int PsdPlan::build(const int* blk, int mat_num) {
   CUADMM_HIP_TRY(hipMemcpy(d_n, blk, sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
   if (!ids.empty()) CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
   {
+    std::vector<PsdDesc> desc(std::max<size_t>(ids.size(), 1));
+    for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q]};
+    CUADMM_HIP_TRY(hipMalloc(&d_desc, sizeof(PsdDesc) * desc.size()));
+    CUADMM_HIP_TRY(hipMemcpy(d_desc, desc.data(), sizeof(PsdDesc) * desc.size(), hipMemcpyHostToDevice));
+  }
+  {
     int rc = sign.build(blk, sign_members);
     if (rc) return rc;
   }
@@ -336,9 +344,9 @@ int PsdPlan::build(const int* blk, int mat_num) {
 }
 
 void PsdPlan::release() {
-  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len, (void*)d_rest})
+  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len, (void*)d_rest, (void*)d_desc})
     if (p) { hipError_t e = hipFree(p); (void)e; }
-  d_rest = nullptr; n_rest = 0;
+  d_rest = nullptr; n_rest = 0; d_desc = nullptr;
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
   d_free_off = d_free_len = nullptr; n_free = 0;
   sign.release();
@@ -454,7 +462,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     }
     PsdArgs a{};
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
-    a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n;
+    a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n; a.desc = d_desc + cls_begin[c];
     a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff; a.steps = d_steps;
     a.eig_rank = (eig_rank > 0 && rank_active) ? eig_rank : 0;
     a.hint = d_hint;

@@ -13,6 +13,13 @@ namespace cuadmm {
 constexpr int kNumPsdClasses = 7;   // n<=4, <=8, <=16, <=32, <=64 (register kernels) | LDS workgroup | HBM workgroup
 int psd_class_of(int n);
 
+// class member -> block, 16 bytes
+struct PsdDesc {
+  long long off;   // svec offset
+  int n;           // size
+  int id;          // block id
+};
+
 struct PsdPlan {
   int nblk = 0;
   long long vec_len = 0;
@@ -20,6 +27,7 @@ struct PsdPlan {
   long long* d_off = nullptr;  // nblk+1 svec offsets
   int* d_n = nullptr;          // block sizes
   int* d_ids = nullptr;        // block ids grouped by class
+  PsdDesc* d_desc = nullptr;   // the same order, (off, n, id) per member
   int* d_fail = nullptr;       // number of blocks whose QL iteration hit its cap (cumulative)
   int* d_hint = nullptr;       // not owned; per block: lift steps the previous projection needed (sign_sched.h warm start)
   mutable unsigned n_project = 0;

@@ -108,9 +108,10 @@ __device__ __forceinline__ void swt_frags(const double* __restrict__ M, int r16,
 }
 
 // lower sub-tiles of a symmetric matrix whose upper sub-tiles sit in accumulator layout: t[b][j] (b > j) = t[j][b]^T through
-// NT (NT - 1) / 2 scratch tiles of 16 x 17 doubles
+// NT (NT - 1) / 2 scratch tiles of 16 x 17 doubles -- in two halves, so that the products that need no lower sub-tile run
+// while the transposed tiles are on their way through LDS
 template <int NT>
-__device__ __forceinline__ void swt_fill_lower(double* __restrict__ scr, int r16, int kk, sl_v4f64 (&t)[NT][NT]) {
+__device__ __forceinline__ void swt_lower_write(double* __restrict__ scr, int r16, int kk, const sl_v4f64 (&t)[NT][NT]) {
   constexpr int SL = SignWaveT<NT>::SCR_LD;
   int slot = 0;
 #pragma unroll
@@ -122,7 +123,11 @@ __device__ __forceinline__ void swt_fill_lower(double* __restrict__ scr, int r16
       ++slot;
     }
   wave_fence();
-  slot = 0;
+}
+template <int NT>
+__device__ __forceinline__ void swt_lower_read(const double* __restrict__ scr, int r16, int kk, sl_v4f64 (&t)[NT][NT]) {
+  constexpr int SL = SignWaveT<NT>::SCR_LD;
+  int slot = 0;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -131,18 +136,20 @@ __device__ __forceinline__ void swt_fill_lower(double* __restrict__ scr, int r16
       for (int r = 0; r < 4; ++r) t[j][i][r] = scr[slot * 16 * SL + (kk + 4 * r) * SL + r16];
       ++slot;
     }
-  wave_fence();
 }
 
-// acc(upper sub-tiles) = A * B: A symmetric, given by its fragments; B by all its sub-tiles in accumulator layout
-template <int NT>
+// acc(upper sub-tiles) (+)= A * B over the row blocks [B0, B1) of B: A symmetric, given by its fragments; B by its sub-tiles
+// in accumulator layout.  Row block 0 of B needs no lower sub-tile.
+template <int NT, int B0, int B1>
 __device__ __forceinline__ void swt_mma_regB(const double (&fa)[4 * NT][NT], const sl_v4f64 (&yb)[NT][NT], sl_v4f64 (&acc)[NT][NT]) {
+  if (B0 == 0) {
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = i; j < NT; ++j) acc[i][j] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
+      for (int j = i; j < NT; ++j) acc[i][j] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
+  }
 #pragma unroll
-  for (int b = 0; b < NT; ++b)
+  for (int b = B0; b < B1; ++b)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -234,33 +241,43 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = i; j < NT; ++j) y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][i], f[s][j], y[i][j], 0, 0, 0);
-    // tr Y and ||Y||_F^2 (off-diagonal sub-tiles count twice)
+    // tr Y and ||Y||_F^2 (off-diagonal sub-tiles count twice) -- only when the schedule will look at them
+    const bool stats = sched.needs_stats();                 // wave-uniform
     double pa = 0.0, pb = 0.0;
+    if (stats) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = i; j < NT; ++j)
+        for (int j = i; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (i == j && kk + 4 * r == r16) pa += y[i][j][r];
-          pb += (i == j ? 1.0 : 2.0) * (y[i][j][r] * y[i][j][r]);
-        }
-    swt_fill_lower<NT>(S, r16, kk, y);
+          for (int r = 0; r < 4; ++r) {
+            if (i == j && kk + 4 * r == r16) pa += y[i][j][r];
+            pb += (i == j ? 1.0 : 2.0) * (y[i][j][r] * y[i][j][r]);
+          }
+    }
     sl_v4f64 z[NT][NT];
-    swt_mma_regB<NT>(f, y, z);
-    const double ta = wave_sum(pa), tb = wave_sum(pb);
-    double pg = 0.0;
+    swt_lower_write<NT>(S, r16, kk, y);
+    swt_mma_regB<NT, 0, 1>(f, y, z);                        // row block 0 of Y: upper sub-tiles only
+    swt_lower_read<NT>(S, r16, kk, y);
+    swt_mma_regB<NT, 1, NT>(f, y, z);
+    double mu;
+    if (stats) {
+      const double ta = wave_sum(pa), tb = wave_sum(pb);
+      double pg = 0.0;
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = i; j < NT; ++j)
+        for (int j = i; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double d = f[4 * i + r][j] - z[i][j][r];     // f[4 i + r][j] = S(16 i + 4 r + kk, 16 j + r16): accumulator layout
-          pg += (i == j ? 1.0 : 2.0) * (d * d);
-        }
-    const double tg = wave_sum(pg);
-    const double mu = sched.decide<false>(n, ta, tb, tg, last);
+          for (int r = 0; r < 4; ++r) {
+            const double d = f[4 * i + r][j] - z[i][j][r];     // f[4 i + r][j] = S(16 i + 4 r + kk, 16 j + r16): accumulator layout
+            pg += (i == j ? 1.0 : 2.0) * (d * d);
+          }
+      const double tg = wave_sum(pg);
+      mu = sched.decide<false>(n, ta, tb, tg, last);
+    } else {
+      mu = sched.decide<false>(n, 0.0, 0.0, 0.0, last);    // a branch that does not read them
+    }
     const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -268,7 +285,8 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       for (int j = i; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[i][j][r] = alpha * z[i][j][r] + beta * f[4 * i + r][j];
-    swt_store_mirrored<NT>(S, r16, kk, z);                   // the scratch tiles were consumed before the second product
+    wave_fence();                                            // the scratch tiles have been read
+    swt_store_mirrored<NT>(S, r16, kk, z);
     wave_fence();
   }
   if (steps_out && lane == 0) *steps_out = sched.steps;
@@ -302,7 +320,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xb[b][j][r] = S[(16 * b + kk + 4 * r) * LD + 16 * j + r16];
-  swt_mma_regB<NT>(f, xb, p);
+  swt_mma_regB<NT, 0, NT>(f, xb, p);
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll

@@ -30,6 +30,13 @@
 // LAGGED variant (batched-GEMM path, psd_large.hip): there g2 of iterate k is only complete after the launch that
 // applies mu_k, so decisions at step k use (a_k, b_k) and g2 of iterate k-1 (plain phase: g_k <= 0.75 g_{k-1}^2).
 //
+// DEFERRED variant (one wavefront per block, psd_sign_wave.h): decide<true> for step k is evaluated while the iterate of
+// step k - 1 is on its way through LDS, i.e. with (a, b) AND g of iterate k - 1 (step 0 is decided in place: its b sets the
+// normalisation).  (a, b) only enter through step 0, through the test d2 < 0.5 -- which, once true, stays true: [0.5, 1]
+// is invariant -- and through the heuristics; every exit test works from g of the previous iterate, as in the lagged
+// variant.  So the deferral costs at most a step, never accuracy, and takes the reductions and this state machine off the
+// critical path of a step (they were a third of it).
+//
 // Compiles for host and device: tests/test_sign_schedule.py drives it on the CPU through cuadmm_sign_sched_simulate.
 #pragma once
 #include <cmath>
@@ -72,6 +79,15 @@ struct SignSched {
     double x = sh > 1e-300 ? sh : 1e-300, g = G;
     while (x * kSlope <= 0.45 && g * kTol < 0.5 && c < kCap) { x *= kSlope; g *= kSlope; ++c; }
     return c > 1 ? c : 1;
+  }
+
+  // Does the next decision read its statistics at all?  Inside a lift phase or a burst (k > 0) and on the two probe steps the
+  // scale is fixed in advance: the one-wavefront kernels then skip the three wave reductions and call decide with zeros
+  // (same decisions, same step counts -- a third of a step's latency on two steps out of three).
+  CUADMM_SCHED_HD bool needs_stats() const {
+    if (steps == 0 || fin > 0 || plain) return true;
+    if (k > 0 && G * kTol < 0.5) return false;
+    return !(j == 0 || j == 1);
   }
 
   // One decision per Newton-Schulz step.  n: true block size; a, b from Y = S^2 of the CURRENT iterate; g2: ||S - SY||_F^2
@@ -167,14 +183,15 @@ struct SignSched {
 
 // Scalar model of the iteration on a spectrum (the iteration acts on eigenvalues independently): used by the CPU tests
 // and by tools/sign_schedule_sim.py.  s[i] = |lambda_i| / ||X||_1 on entry, the sign estimates on exit.
-inline int sign_sched_simulate(double* s, int n, bool lag, double* err_out, int lift0 = 0, int* lifts_out = nullptr) {
+// lag: 0 = decisions from the current iterate, 1 = lagged (g of the previous iterate), 2 = deferred ((a, b, g) of the previous one)
+inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int lift0 = 0, int* lifts_out = nullptr) {
   SignSched st;
   if (lift0 > 0) st.lift0 = lift0;
   double orig_max_err = 0.0;
   double* s0 = new double[n > 0 ? n : 1];
   for (int i = 0; i < n; ++i) s0[i] = s[i];
   bool last = false;
-  double g2_prev = 0.0;
+  double g2_prev = 0.0, a_prev = 0.0, b_prev = 0.0;
   while (!last) {
     double a = 0, b = 0, g2 = 0;
     for (int i = 0; i < n; ++i) {
@@ -184,11 +201,13 @@ inline int sign_sched_simulate(double* s, int n, bool lag, double* err_out, int 
     double mu;
     if (lag) {
       st.gprev = st.steps == 0 ? -1.0 : sqrt(g2_prev);
-      mu = st.decide<true>(n, a, b, 0.0, last);
+      if (lag == 2 && st.steps > 0) mu = st.decide<true>(n, a_prev, b_prev, 0.0, last);
+      else mu = st.decide<true>(n, a, b, 0.0, last);
     } else {
-      mu = st.decide<false>(n, a, b, g2, last);
+      // as the one-wavefront kernels call it: without statistics where needs_stats() says they are not read
+      mu = st.needs_stats() ? st.decide<false>(n, a, b, g2, last) : st.decide<false>(n, 0.0, 0.0, 0.0, last);
     }
-    g2_prev = g2;
+    g2_prev = g2; a_prev = a; b_prev = b;
     for (int i = 0; i < n; ++i) s[i] = 1.5 * mu * s[i] - 0.5 * mu * mu * mu * s[i] * s[i] * s[i];
   }
   for (int i = 0; i < n; ++i) {
