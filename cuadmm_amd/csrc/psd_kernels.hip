@@ -196,12 +196,13 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
 
 // A/B switches of the projection kernels, read from the environment once
 struct PsdKnobs {
-  bool debug, sign32, mid_eig, mid_lds, w64;
+  bool debug, sign32, sign16, mid_eig, mid_lds, w64;
   int gen;   // n <= 32: 3 | 4 = psd_sign_wave_kernel<2> at that many wavefronts per SIMD, 0 = the hand-unrolled SignWave32 kernel
   PsdKnobs() {
     auto is = [](const char* name, const char* val) { const char* e = getenv(name); return e && std::string(e) == val; };
     debug = getenv("CUADMM_PSD_DEBUG") != nullptr;
     sign32 = !is("CUADMM_PSD_N32", "eig");
+    sign16 = !is("CUADMM_PSD_N16", "eig");
     mid_eig = is("CUADMM_PSD_MID", "eig");
     mid_lds = is("CUADMM_PSD_MID", "lds");
     w64 = !(getenv("CUADMM_PSD_W64") && atoi(getenv("CUADMM_PSD_W64")) == 0);
@@ -269,6 +270,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
   release();
   nblk = mat_num;
   h_blk.assign(blk, blk + mat_num);
+  sign16 = psd_knobs().sign16 && psd_knobs().gen != 0;
   std::vector<long long> off((size_t)mat_num + 1, 0);
   std::vector<long long> free_off, free_len;   // unconstrained blocks (negative size): identity "projection"
   for (int k = 0; k < mat_num; ++k) {
@@ -418,7 +420,7 @@ int PsdPlan::build_rest_index() {
   for (int k = 0; k < nblk; ++k) {
     const long long len = blk_svec_len(h_blk[k]);
     const int c = h_blk[k] > 0 && h_blk[k] < sign_min ? psd_class_of(h_blk[k]) : -1;
-    if (c != 3 && c != 4)
+    if (!(c == 3 || c == 4 || (c == 2 && sign16)))
       for (long long i = off; i < off + len; ++i) rest.push_back((int)i);
     off += len;
   }
@@ -497,11 +499,15 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       // one wavefront per block (psd_sign_wave.h); CUADMM_PSD_MID=lds restores the one-workgroup-per-block kernels (A/B),
       // CUADMM_PSD_MID=eig the register eigensolver.  Fused: partial-sum slots follow those of class 3.
       const bool mid_lds = knobs.mid_lds, w64 = knobs.w64;
-      rc = (w64 && !mid_lds) ? launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz, cls_count[3]) : launch_sign_lds<64>(a, 0, cls4_big, st);
+      rc = (w64 && !mid_lds) ? launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz, fused_blocks() - cls_count[4]) : launch_sign_lds<64>(a, 0, cls4_big, st);
       if (!rc) rc = mid_lds ? launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st)
-                            : launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz, cls_count[3] + cls4_big);
+                            : launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz, fused_blocks() - cls_count[4] + cls4_big);
     } else if (c == 3 && sign32 && eig_rank == 0) {
-      rc = launch_sign_wave32(a, 0, cls_count[c], st, fz, 0);
+      rc = launch_sign_wave32(a, 0, cls_count[c], st, fz, sign16 ? cls_count[2] : 0);
+    } else if (c == 2 && sign16 && eig_rank == 0 && !psd_debug) {
+      // 9 <= n <= 16: the same iteration on ONE 16 x 16 sub-tile, eight wavefronts per SIMD (the register eigensolver needs
+      // ~20 us of dependent rotations per block; here a block is 8 MFMAs per step)
+      rc = launch_sign_wave<1, 8>(a, 0, cls_count[c], st, fz, 0);
     } else {
       rc = launch_class<0>(c, a, cls_maxn[c], st);
     }

@@ -52,14 +52,15 @@ struct PsdPlan {
   mutable hipStream_t aux[kNumPsdClasses] = {};
   int cls_begin[kNumPsdClasses] = {0}, cls_count[kNumPsdClasses] = {0}, cls_maxn[kNumPsdClasses] = {0};
 
-  // Fused iteration (SignFuse, psd_sign_wave.h): the blocks of classes 3 and 4 (17 <= n <= 64, one wavefront per block) form
+  // Fused iteration (SignFuse, psd_sign_wave.h): the blocks of classes 2, 3 and 4 (9 <= n <= 64, one wavefront per block) form
   // Xb from X / A^T y / C themselves and apply the S / X updates to their own svec ranges; the stand-alone vector kernels
   // then only visit the REST of the svec (d_rest: element indices outside those blocks).
   std::vector<int> h_blk;      // host copy of the block sizes
   int* d_rest = nullptr;
   long long n_rest = 0;
   bool fusable() const;
-  int fused_blocks() const { return cls_count[3] + cls_count[4]; }
+  int fused_blocks() const { return (sign16 ? cls_count[2] : 0) + cls_count[3] + cls_count[4]; }
+  bool sign16 = true;          // 9 <= n <= 16 on the one-wavefront sign kernel too (CUADMM_PSD_N16=eig: register eigensolver)
   int build_rest_index();
 
   int build(const int* blk, int mat_num);

@@ -34,10 +34,10 @@ struct SignWaveT {
   static constexpr int NP = 16 * NT, LD = NP + 1, KS = 4 * NT;
   static constexpr int NU = NT * (NT + 1) / 2;                 // sub-tiles on or above the diagonal
   // svec <-> lanes by COLUMN PAIRS (swt_slot): W lanes serve one pair, G pairs per load
-  static constexpr int W = NT <= 2 ? 32 : 64, G = 64 / W, MC = W - 1;
+  static constexpr int W = NT == 1 ? 16 : (NT == 2 ? 32 : 64), G = 64 / W, MC = W - 1;
   static constexpr bool EXTRA = NP > MC;                       // n = W: column W - 1 takes one more load
   static constexpr int NPAIRS = (NP / 2 < (MC + 1) / 2 ? NP / 2 : (MC + 1) / 2);
-  static constexpr int NQ = (NPAIRS + G - 1) / G + (EXTRA ? 1 : 0);   // global loads per lane (NT = 2: 9, 3: 24, 4: 33)
+  static constexpr int NQ = (NPAIRS + G - 1) / G + (EXTRA ? 1 : 0);   // global loads per lane (NT = 1: 3, 2: 9, 3: 24, 4: 33)
   static constexpr size_t LDS_BYTES = sizeof(double) * NP * LD;
   static constexpr int SCR_LD = 17;                            // transposition tiles (alias the region of S)
 };

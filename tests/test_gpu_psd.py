@@ -286,10 +286,10 @@ def test_project_mid_sizes_in_bulk_properties(n, count):
 
 @pytest.mark.parametrize("kind", ["randn", "lowrank", "graded", "psd", "nsd", "clustered"])
 def test_project_every_mid_size_one_wavefront_per_block(kind):
-    """Every size 33 ... 64 (the one-wavefront-per-block sign kernels of psd_sign_wave.h and the one-workgroup kernel above
-    48: column-pair svec loads, odd sizes, the n = 63 / 64 corner of the pairing) on the spectra families of the sign path,
-    three blocks per size in one call, plus an exactly zero block."""
-    sizes = np.repeat(np.arange(33, 65), 3)
+    """Every size 9 ... 64 (the one-wavefront-per-block sign kernels of psd_sign_wave.h, NT = 1 ... 4: column-pair svec loads,
+    odd sizes, the n = 15 / 16, 31 / 32 and 63 / 64 corners of the pairing) on the spectra families of the sign path, three
+    blocks per size in one call, plus an exactly zero block."""
+    sizes = np.repeat(np.arange(9, 65), 3)
     rng = np.random.default_rng(77 + len(kind))
     sizes = sizes[rng.permutation(sizes.size)]
     blk = sizes.astype(np.int32)
