@@ -34,6 +34,7 @@ BLOCKS_PER_GPU = 10000
 BLOCK_N = 32
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak (256 CU x 128 FLOP/clk x 2.4 GHz)
+SUSTAINED_FP64_MFMA_TFLOPS = 67.9   # measured: every SIMD issuing independent v_mfma_f64_16x16x4_f64 only (tools/ubench/mfma_sustained.hip)
 
 
 def cpu_baseline(prob, threads, budget_s=20.0):
@@ -105,14 +106,15 @@ def usable_cpus():
     return max(1, n)
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no summary is present."""
+def pmc_traffic(kernel_substr, config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this configuration
+    (profiles/rNN_<config>_pmc_hbm_traffic.json, latest round; separate --pmc passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950); None when no summary is present."""
     best = None
     prof = os.path.join(ROOT, "profiles")
     if os.path.isdir(prof):
         for fn in sorted(os.listdir(prof)):
-            if fn.endswith("_pmc_hbm_traffic.json"):
+            if fn.endswith("_%s_pmc_hbm_traffic.json" % config):
                 try:
                     d = json.load(open(os.path.join(prof, fn)))
                 except Exception:
@@ -125,12 +127,15 @@ def pmc_traffic(kernel_substr):
 
 def issued_mfma_flops(blk, steps):
     """fp64 flops the projection kernels issue on the matrix cores for the measured per-block step counts
-    (v_mfma_f64_16x16x4_f64 = 2048 flop): n <= 32: 48 MFMA per step + 24 (psd_sign_lds.h, SignWave32); n <= 48 / 64:
-    6 / 10 upper sub-tiles x NP/4 MFMA per product (psd_sign_lds.h); larger: upper-triangle tiles of the batched GEMMs
-    (psd_large.hip).  Blocks served by the register eigensolver (n <= 16) issue 0 here (their rebuild is a few MFMAs)."""
+    (v_mfma_f64_16x16x4_f64 = 2048 flop), one-wavefront kernels of psd_sign_wave.h: NT (NT + 1) / 2 upper sub-tiles x 4 NT
+    MFMA per product, two products per step + the final one (n <= 16: 8 per step + 4; n <= 32: 48 + 24; n <= 48: 144 + 72;
+    n <= 64: 320 + 160); larger: upper-triangle tiles of the batched GEMMs (psd_large.hip).  Blocks served by the register
+    eigensolver (n <= 8) issue 0 here (their rebuild is a few MFMAs)."""
     blk = np.asarray(blk, np.int64)
     steps = np.asarray(steps, np.float64)
     fl = np.zeros(blk.size)
+    m = (blk > 8) & (blk <= 16)
+    fl[m] = (steps[m] * 8 + 4) * 2048.0
     m = (blk > 16) & (blk <= 32)
     fl[m] = (steps[m] * 48 + 24) * 2048.0
     m = (blk > 32) & (blk <= 48)
@@ -289,14 +294,20 @@ def main():
         psd = prof["psd_project"]
         psd_ms = psd["ms"] / max(psd["launches"], 1)
         L_local = int(np.sum(blk_local.astype(np.int64) * (blk_local + 1) // 2))
-        alg_bytes = 16.0 * L_local                         # read Xb + write Xproj, 8 B each per svec element
+        # read Xb + write Xproj, 8 B each per svec element; blocks of the FUSED iteration (9 <= n <= 64, psd_fuse.h)
+        # also carry the vector work of aty_xb / post: row pointer 4 + C 8 + X 8 read, Rd1 8 write | X 8 + Rd1 8 + C 8 read,
+        # S 8 + X 8 write = 68 B per svec element, and Xb / Xproj never reach HBM
+        fused = os.environ.get("CUADMM_FUSE", "1") != "0"
+        fb = blk_local[(blk_local > 8) & (blk_local <= 64)].astype(np.int64)
+        L_fused = int(np.sum(fb * (fb + 1) // 2)) if fused else 0
+        alg_bytes = 68.0 * L_fused + 16.0 * (L_local - L_fused)
         nominal_flops = (32.0 / 3.0) * float(np.sum(blk_local.astype(np.float64) ** 3))
         issued_flops = issued_mfma_flops(blk_local, steps_blk)
-        sign_blocks = blk_local > 16
-        kernel = {"c2": "psd_sign_wave32_kernel (fused svec -> adaptive matrix-sign projection -> svec, one wavefront per block)",
+        sign_blocks = blk_local > 8
+        kernel = {"c2": "psd_sign_wave_kernel<2, 4, fused> (X / A^T y / C -> adaptive matrix-sign projection -> S, X updates; one wavefront per block)",
                   "c3": "lg_gemm_sym_kernel (adaptive matrix-sign projection of the n=2000 block as batched upper-triangle fp64-MFMA GEMMs)",
-                  "c4": "psd_project phase: psd_sign_lds_kernel<48> (n=45) | psd_sign_wave32_kernel (n=28) | psd_small_reg_kernel (n<=15), concurrent streams"}[args.config]
-        kname = {"c2": "psd_sign_wave32_kernel", "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_lds_kernel"}[args.config]
+                  "c4": "psd_project phase: psd_sign_wave_kernel<3, 2> (n=45) | <2, 4> (n=28) | <1, 8> (n=10, 15), fused | psd_small_reg_kernel (n<=6), concurrent streams"}[args.config]
+        kname = {"c2": "psd_sign_wave_kernel<2", "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_wave_kernel<3"}[args.config]
         per_s = psd_ms * 1e-3
         shard_iters = (world if (args.scaling == "weak" or replicas) else 1) * args.steps
         out = {
@@ -326,7 +337,11 @@ def main():
                          "achieved": nominal_flops / per_s / 1e12 if per_s > 0 else 0.0,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (nominal_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
-                         "traffic": pmc_traffic(kname), "avg_launch_ms": psd_ms,
+                         "traffic": pmc_traffic(kname, args.config), "avg_launch_ms": psd_ms,
+                         # what the matrix cores deliver when EVERY SIMD runs nothing but independent v_mfma_f64_16x16x4_f64
+                         # (tools/ubench/mfma_sustained.hip, profiles/r02_mfma_sustained.log): the achievable ceiling
+                         "sustained_mfma_peak_measured": SUSTAINED_FP64_MFMA_TFLOPS,
+                         "mfma_issued_frac_of_sustained": (issued_flops / per_s / 1e12 / SUSTAINED_FP64_MFMA_TFLOPS) if per_s > 0 else 0.0,
                          "algorithmic_flops_per_launch": nominal_flops,
                          "mfma_issued_tflops": issued_flops / per_s / 1e12 if per_s > 0 else 0.0,
                          "mfma_pipe_util": (issued_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
@@ -335,7 +350,8 @@ def main():
                                                  "note": "per-block adaptive schedule (csrc/sign_sched.h); round 1 ran a fixed 44"},
                          "hbm_gbs": alg_bytes / per_s / 1e9 if per_s > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64 matrix-core bound (DESIGN.md section 4); traffic = FETCH_SIZE*2 + WRITE_SIZE from the "
-                                 "committed rocprofv3 PMC passes (profiles/), algorithmic bytes 16 B per svec element",
+                                 "committed rocprofv3 PMC passes (profiles/); algorithmic bytes 68 B per svec element of a fused block "
+                                 "(the launch also does the aty_xb / post vector work), 16 B elsewhere",
                          "blocks_per_s": blk_local.size / per_s if per_s > 0 else 0.0},
             "final_state": {k: st[k] for k in ("errRp", "errRd", "relgap", "sig")},
         }

@@ -170,6 +170,15 @@ struct cuadmm_solver {
   // Fused iteration (psd_fuse.h): the projection kernels of the 17 <= n <= 64 blocks form Xb themselves and apply the S / X
   // updates to their svec ranges; the stand-alone vector kernels visit only the rest of the svec (plan.d_rest).
   bool fuse = false;
+  // ... and the constraint rows whose nonzeros all lie in one fused block are evaluated there too (SignFuse::lc_*); the
+  // stand-alone SpMV then only visits the other rows (compact CSR + the constraint index of each row)
+  struct LocalRows {
+    bool active = false;
+    int nlocal = 0, nrest = 0;
+    double rest_avg = 1.0;
+    DevBuf<int> ptr, row, nzptr, e, rest_rp, rest_ci, rest_map;
+    DevBuf<double> v, rest_v;
+  } lrows;
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -361,7 +370,16 @@ struct cuadmm_solver {
     prof_end(K_ATY, (write_xb ? 32.0 : 16.0) * (double)L + 4.0 * (double)L);
     return rc;
   }
-  int launch_spmv(bool doX, bool doS) {
+  // after_fused: the local rows were written by the fused projection kernels of this step -- only the other rows are left
+  int launch_spmv(bool doX, bool doS, bool after_fused = false) {
+    if (after_fused && lrows.active) {
+      if (lrows.nrest == 0) return CUADMM_OK;
+      prof_begin(K_SPMV);
+      int rc = launch_spmv_rows(lrows.nrest, lrows.rest_avg, lrows.rest_rp.p, lrows.rest_ci.p, lrows.rest_v.p, X.p, S.p, C.p, doX ? out_w : nullptr,
+                                doS ? out_w + m + 2 : nullptr, st, nullptr, lrows.rest_map.p);
+      prof_end(K_SPMV, 12.0 * (double)lrows.rest_v.n + 8.0 * lrows.nrest * ((doX ? 1 : 0) + (doS ? 1 : 0)));
+      return rc;
+    }
     prof_begin(K_SPMV);
     int rc = launch_spmv_rows(m, A_avg_nnz, A_rp.p, A_ci.p, A_v.p, X.p, S.p, C.p, doX ? out_w : nullptr,
                               doS ? out_w + m + 2 : nullptr, st, &A_long);
@@ -382,7 +400,13 @@ struct cuadmm_solver {
     rc = launch_aty_xb_idx(plan.n_rest, plan.d_rest, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st);
     prof_end(K_ATY, 36.0 * (double)plan.n_rest);
     if (rc) return rc;
-    SignFuse fz{At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, Rd1.p, S.p, partials.p, sig, 1 / sig, tau * sig, mode};
+    SignFuse fz{At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, Rd1.p, S.p, partials.p, sig, 1 / sig, tau * sig, mode,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (lrows.active) {
+      fz.lc_ptr = lrows.ptr.p; fz.lc_row = lrows.row.p; fz.lc_nzptr = lrows.nzptr.p; fz.lc_e = lrows.e.p; fz.lc_v = lrows.v.p;
+      fz.outX = mode == 0 ? out_w : nullptr;
+      fz.outS = out_w + m + 2;
+    }
     prof_begin(K_PSD);
     rc = plan.project(Xb.p, Xproj.p, st, &fz);
     prof_end(K_PSD, 68.0 * (double)(L - plan.n_rest) + 16.0 * (double)plan.n_rest);
@@ -749,6 +773,75 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     }
     s->A_avg_nnz = m > 0 ? (double)aci.size() / m : 1.0;
     if ((rc = s->A_long.build(m, arp.data()))) return rc;
+    // fused iteration: needs the one-wavefront-per-block sign kernels and no long rows of A^T (they are summed by their own kernel)
+    s->fuse = s->plan.fusable() && s->At_long.nlong == 0 && !getenv("CUADMM_DEBUG_EIG") &&
+              !(getenv("CUADMM_FUSE") && atoi(getenv("CUADMM_FUSE")) == 0);
+    s->lrows.active = false; s->lrows.nlocal = s->lrows.nrest = 0;
+    if (s->fuse && s->A_long.nlong == 0 && m > 0 && !(getenv("CUADMM_FUSE_ROWS") && atoi(getenv("CUADMM_FUSE_ROWS")) == 0)) {
+      // constraint rows local to one fused block -> that block's kernel (psd_fuse.h)
+      std::vector<int> slot_of;
+      s->plan.fused_slots(slot_of);                                    // block -> partial-sum slot, -1: not fused
+      const int nslots = s->plan.fused_blocks();
+      std::vector<long long> boff((size_t)s->blk_local.size() + 1, 0);
+      for (size_t k = 0; k < s->blk_local.size(); ++k) boff[k + 1] = boff[k] + blk_svec_len(s->blk_local[k]);
+      std::vector<int> row_slot((size_t)m, -1);
+      std::vector<int> cnt((size_t)nslots + 1, 0);
+      int nlocal = 0;
+      for (int r = 0; r < m; ++r) {
+        if (arp[r + 1] == arp[r]) continue;
+        const long long c0 = aci[arp[r]];
+        const int k = (int)(std::upper_bound(boff.begin(), boff.end(), c0) - boff.begin()) - 1;
+        if (slot_of[k] < 0) continue;
+        bool in = true;
+        for (int p = arp[r]; p < arp[r + 1] && in; ++p) in = aci[p] >= boff[k] && aci[p] < boff[k + 1];
+        if (!in) continue;
+        row_slot[r] = slot_of[k];
+      }
+      {   // a block keeps its local rows only if their nonzeros fit the free part of its LDS tile (psd_fuse.h)
+        std::vector<long long> nz_of((size_t)nslots, 0);
+        std::vector<int> n_of((size_t)nslots, 0);
+        for (size_t k = 0; k < s->blk_local.size(); ++k) if (slot_of[k] >= 0) n_of[slot_of[k]] = s->blk_local[k];
+        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) nz_of[row_slot[r]] += arp[r + 1] - arp[r];
+        for (int r = 0; r < m; ++r) {
+          if (row_slot[r] < 0) continue;
+          if (nz_of[row_slot[r]] > fuse_rows_capacity(n_of[row_slot[r]])) { row_slot[r] = -1; continue; }
+          cnt[row_slot[r] + 1]++;
+          ++nlocal;
+        }
+      }
+      if (nlocal > 0) {
+        for (int q = 0; q < nslots; ++q) cnt[q + 1] += cnt[q];
+        std::vector<int> lrow((size_t)nlocal), lnz((size_t)nlocal + 1, 0), le, fill(cnt.begin(), cnt.end() - 1);
+        std::vector<double> lval;
+        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) lrow[fill[row_slot[r]]++] = r;      // rows ascending inside a slot
+        std::vector<long long> slot_off((size_t)nslots, 0);
+        for (size_t k = 0; k < s->blk_local.size(); ++k) if (slot_of[k] >= 0) slot_off[slot_of[k]] = boff[k];
+        for (int q = 0; q < nlocal; ++q) {
+          const int r = lrow[q];
+          for (int p = arp[r]; p < arp[r + 1]; ++p) { le.push_back((int)(aci[p] - slot_off[row_slot[r]])); lval.push_back(av[p]); }
+          lnz[q + 1] = (int)le.size();
+        }
+        std::vector<int> rrp{0}, rci, rmap;
+        std::vector<double> rv2;
+        for (int r = 0; r < m; ++r) {
+          if (row_slot[r] >= 0) continue;
+          for (int p = arp[r]; p < arp[r + 1]; ++p) { rci.push_back(aci[p]); rv2.push_back(av[p]); }
+          rrp.push_back((int)rci.size());
+          rmap.push_back(r);
+        }
+        auto& lr = s->lrows;
+        lr.nlocal = nlocal; lr.nrest = (int)rmap.size();
+        lr.rest_avg = rmap.empty() ? 1.0 : (double)rci.size() / (double)rmap.size();
+        if ((rc = lr.ptr.from(cnt)) || (rc = lr.row.from(lrow)) || (rc = lr.nzptr.from(lnz)) || (rc = lr.e.from(le)) || (rc = lr.v.from(lval))) return rc;
+        if (lr.nrest > 0) {
+          if ((rc = lr.rest_rp.from(rrp)) || (rc = lr.rest_map.from(rmap)) || (rc = lr.rest_ci.alloc(std::max<size_t>(rci.size(), 1))) ||
+              (rc = lr.rest_v.alloc(std::max<size_t>(rv2.size(), 1))) || (rc = lr.rest_ci.upload(rci.data(), rci.size())) ||
+              (rc = lr.rest_v.upload(rv2.data(), rv2.size())))
+            return rc;
+        }
+        lr.active = true;
+      }
+    }
     if (s->A_long.nlong > 0) {   // the average that picks the threads-per-row of the main kernel should not count the capped tails
       long long capped = 0;
       for (int i = 0; i < m; ++i) capped += std::min(arp[i + 1] - arp[i], s->A_long.cap);
@@ -819,13 +912,10 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
   std::memset(s->h_out.p, 0, sizeof(double) * (2 * (size_t)m + 2));
   s->out_w = s->out_d.p;
-  // fused iteration: needs the one-wavefront-per-block sign kernels and no long rows of A^T (they are summed by their own kernel)
-  s->fuse = s->plan.fusable() && s->At_long.nlong == 0 && !getenv("CUADMM_DEBUG_EIG") &&
-            !(getenv("CUADMM_FUSE") && atoi(getenv("CUADMM_FUSE")) == 0);
   if (s->fuse && (rc = s->plan.build_rest_index())) return rc;
   if (s->fuse && s->verbose)
-    printf(" fused iteration: %d blocks form Xb and apply the S / X updates inside their projection kernel (%lld of %lld svec entries outside)\n",
-           s->plan.fused_blocks(), s->plan.n_rest, L);
+    printf(" fused iteration: %d blocks form Xb and apply the S / X updates inside their projection kernel (%lld of %lld svec entries outside); "
+           "%d of %d constraint rows are local to one of them\n", s->plan.fused_blocks(), s->plan.n_rest, L, s->lrows.nlocal, m);
   s->dev_scalars = s->local_mode && s->comm_world > 1 && !getenv("CUADMM_HOST_SCALARS");
   // device-side y-solve: whole factor on the host side of the split (no GPU tail) and a forest of many small trees
   s->dev_solve = false;
@@ -1032,7 +1122,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     if (iter < switch_admm) {
       // sGS half step: S^{k+1}, second solve with it, Rd1 from the new y (solver.cu:693-729)
       if (!s->fuse && (rc = s->launch_post_mode(1, tau))) return rc;     // fused: done with the projection
-      if ((rc = s->launch_spmv(false, true))) return rc;
+      if ((rc = s->launch_spmv(false, true, s->fuse))) return rc;
       if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
       if ((rc = s->host_solve())) return rc;
       if ((rc = s->upload_y())) return rc;
@@ -1059,7 +1149,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       } else if (!s->fuse) {
         if ((rc = s->launch_post_mode(0, tau))) return rc;
       }
-      if ((rc = s->launch_spmv(true, true))) return rc;
+      if ((rc = s->launch_spmv(true, true, s->fuse && !snapshot))) return rc;
       if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
     }
 

@@ -309,6 +309,11 @@ int PsdPlan::build(const int* blk, int mat_num) {
     }
     cls_count[c] = (int)ids.size() - cls_begin[c];
   }
+  {
+    const PsdKnobs& kn = psd_knobs();
+    const int wave4_min = getenv("CUADMM_PSD_WAVE4_MIN") ? atoi(getenv("CUADMM_PSD_WAVE4_MIN")) : 1024;   // read per plan: tests set it
+    wave4 = kn.w64 && !kn.mid_lds && !kn.mid_eig && kn.gen != 0 && cls_count[4] >= wave4_min;
+  }
   n_free = (int)free_off.size();
   if (n_free > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_free_off, sizeof(long long) * free_off.size()));
@@ -323,6 +328,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
   CUADMM_HIP_TRY(hipMemcpy(d_off, off.data(), sizeof(long long) * ((size_t)mat_num + 1), hipMemcpyHostToDevice));
   CUADMM_HIP_TRY(hipMemcpy(d_n, blk, sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
   if (!ids.empty()) CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
+  h_ids = ids;
   {
     std::vector<PsdDesc> desc(std::max<size_t>(ids.size(), 1));
     for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q]};
@@ -408,8 +414,18 @@ __global__ void hint_decay_kernel(int* hint, int n) {
 // Blocks of the one-wavefront-per-block sign kernels (classes 3 and 4) can take the iteration's vector work with them
 bool PsdPlan::fusable() const {
   const PsdKnobs& k = psd_knobs();
-  return eig_rank == 0 && !k.debug && k.sign32 && k.gen != 0 && !k.mid_eig && !k.mid_lds && k.w64 && fused_blocks() > 0 &&
+  return eig_rank == 0 && !k.debug && k.sign32 && k.gen != 0 && !k.mid_eig && fused_blocks() > 0 &&
          vec_len < 0x7fffffffLL;
+}
+
+// partial-sum slots in launch order: class 2 (when it runs the sign kernel), 3, 4 -- as PsdPlan::project hands them out
+void PsdPlan::fused_slots(std::vector<int>& slot_of) const {
+  slot_of.assign((size_t)nblk, -1);
+  int slot = 0;
+  for (int c = 2; c <= 4; ++c) {
+    if ((c == 2 && !sign16) || (c == 4 && !wave4)) continue;
+    for (int q = 0; q < cls_count[c]; ++q) slot_of[h_ids[cls_begin[c] + q]] = slot++;
+  }
 }
 
 // svec elements outside the fused blocks, ascending (the stand-alone vector kernels run over this list)
@@ -420,7 +436,7 @@ int PsdPlan::build_rest_index() {
   for (int k = 0; k < nblk; ++k) {
     const long long len = blk_svec_len(h_blk[k]);
     const int c = h_blk[k] > 0 && h_blk[k] < sign_min ? psd_class_of(h_blk[k]) : -1;
-    if (!(c == 3 || c == 4 || (c == 2 && sign16)))
+    if (!(c == 3 || (c == 4 && wave4) || (c == 2 && sign16)))
       for (long long i = off; i < off + len; ++i) rest.push_back((int)i);
     off += len;
   }
@@ -498,10 +514,13 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     if (c == 4 && !knobs.mid_eig && eig_rank == 0) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
       // one wavefront per block (psd_sign_wave.h); CUADMM_PSD_MID=lds restores the one-workgroup-per-block kernels (A/B),
       // CUADMM_PSD_MID=eig the register eigensolver.  Fused: partial-sum slots follow those of class 3.
-      const bool mid_lds = knobs.mid_lds, w64 = knobs.w64;
-      rc = (w64 && !mid_lds) ? launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz, fused_blocks() - cls_count[4]) : launch_sign_lds<64>(a, 0, cls4_big, st);
-      if (!rc) rc = mid_lds ? launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st)
-                            : launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz, fused_blocks() - cls_count[4] + cls4_big);
+      if (wave4) {
+        rc = launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz, fused_blocks() - cls_count[4]);
+        if (!rc) rc = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz, fused_blocks() - cls_count[4] + cls4_big);
+      } else {
+        rc = launch_sign_lds<64>(a, 0, cls4_big, st);
+        if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st);
+      }
     } else if (c == 3 && sign32 && eig_rank == 0) {
       rc = launch_sign_wave32(a, 0, cls_count[c], st, fz, sign16 ? cls_count[2] : 0);
     } else if (c == 2 && sign16 && eig_rank == 0 && !psd_debug) {

@@ -59,9 +59,15 @@ struct PsdPlan {
   int* d_rest = nullptr;
   long long n_rest = 0;
   bool fusable() const;
-  int fused_blocks() const { return (sign16 ? cls_count[2] : 0) + cls_count[3] + cls_count[4]; }
+  int fused_blocks() const { return (sign16 ? cls_count[2] : 0) + cls_count[3] + (wave4 ? cls_count[4] : 0); }
+  // 32 < n <= 64 on the one-wavefront kernels (throughput: 1.3x the one-workgroup kernels in bulk) only when there are enough
+  // blocks to fill the chip; a handful of blocks (moment relaxations) is a LATENCY problem, and there six / ten wavefronts per
+  // block win (measured crossover: ~1000 blocks at n = 45 and at n = 64; CUADMM_PSD_WAVE4_MIN moves it)
+  bool wave4 = false;
   bool sign16 = true;          // 9 <= n <= 16 on the one-wavefront sign kernel too (CUADMM_PSD_N16=eig: register eigensolver)
   int build_rest_index();
+  void fused_slots(std::vector<int>& slot_of) const;   // block -> partial-sum slot of the fused launches (-1: not fused)
+  std::vector<int> h_ids;      // host copy of d_ids
 
   int build(const int* blk, int mat_num);
   void release();

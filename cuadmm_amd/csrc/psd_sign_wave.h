@@ -333,7 +333,19 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   bool bad = false;
   if (FUSED) {
     double s_rd = 0.0, s_cx = 0.0;
-    const bool upd = fz.mode == 0;
+    const bool upd = fz.mode == 0, local_rows = fz.lc_ptr != nullptr;
+    // local constraint rows: their index data is requested first (one lane per nonzero, one per row; more than 64 of either
+    // are fetched later), so that the round trip overlaps the slot loads below
+    int k0 = 0, k1 = 0, z0 = 0, z1 = 0, ze = 0, kb = 0, ke = 0, krow = 0;
+    double zv = 0.0;
+    if (local_rows) {
+      k0 = fz.lc_ptr[slot]; k1 = fz.lc_ptr[slot + 1];                 // wave-uniform
+      if (k0 < k1) {
+        z0 = fz.lc_nzptr[k0]; z1 = fz.lc_nzptr[k1];
+        if (z0 + lane < z1) { ze = fz.lc_e[z0 + lane]; zv = fz.lc_v[z0 + lane]; }
+        if (k0 + lane < k1) { kb = fz.lc_nzptr[k0 + lane]; ke = fz.lc_nzptr[k0 + lane + 1]; krow = fz.lc_row[k0 + lane]; }
+      }
+    }
     // straight-line loads again (masked afterwards), so that the slots' X / Rd1 / C are all in flight together
     double xq[Cfg::NQ], rq[Cfg::NQ], cq[Cfg::NQ], pq[Cfg::NQ];
 #pragma unroll
@@ -342,7 +354,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       const bool ok = swt_slot<NT>(q, lane, n, r, c);
       const long long i = off + (ok ? c * (c + 1) / 2 + r : 0);
       xq[q] = fz.X[i]; rq[q] = fz.Rd1[i];
-      cq[q] = upd ? fz.C[i] : 0.0;
+      cq[q] = (upd || local_rows) ? fz.C[i] : 0.0;
       pq[q] = S[ok ? r * LD + c : 0];
     }
 #pragma unroll
@@ -357,12 +369,44 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       const double xdiff = xp - x;
       const double sv = fz.inv_sig * xdiff - r1;
       if (ok) fz.S[i] = sv;
+      rq[q] = sv - cq[q];                                    // S - C (local rows)
       if (upd) {
         const double rd = r1 + sv;
         const double xn = x + fz.tau_sig * rd;
         if (ok) fz.X[i] = xn;
+        xq[q] = xn;
         s_rd += ok ? rd * rd : 0.0;
         s_cx += ok ? cq[q] * xn : 0.0;
+      }
+    }
+    if (local_rows && k0 < k1) {
+      // the tile region is free now: the block's svec (new X, then S - C) in packed order, the products behind it
+      const int len = n * (n + 1) / 2;
+      double* __restrict__ PR = S + len;
+#pragma unroll 1
+      for (int pass = (upd && fz.outX) ? 0 : 1; pass < 2; ++pass) {
+        double* __restrict__ dst = pass == 0 ? fz.outX : fz.outS;
+        if (!dst) continue;
+        wave_fence();
+#pragma unroll
+        for (int q = 0; q < Cfg::NQ; ++q) {
+          int r, c;
+          if (swt_slot<NT>(q, lane, n, r, c)) S[c * (c + 1) / 2 + r] = pass == 0 ? xq[q] : rq[q];
+        }
+        wave_fence();
+        if (z0 + lane < z1) PR[lane] = zv * S[ze];
+        for (int z = z0 + 64 + lane; z < z1; z += 64) PR[z - z0] = fz.lc_v[z] * S[fz.lc_e[z]];
+        wave_fence();
+        if (k0 + lane < k1) {
+          double acc = 0.0;
+          for (int p = kb; p < ke; ++p) acc += PR[p - z0];
+          dst[krow] = acc;
+        }
+        for (int k = k0 + 64 + lane; k < k1; k += 64) {
+          double acc = 0.0;
+          for (int p = fz.lc_nzptr[k]; p < fz.lc_nzptr[k + 1]; ++p) acc += PR[p - z0];
+          dst[fz.lc_row[k]] = acc;
+        }
       }
     }
     if (fz.mode == 0) {

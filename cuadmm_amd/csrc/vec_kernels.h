@@ -48,7 +48,7 @@ struct SpmvLongRows {
 // outX = A*X, outS = A*(S-C) over the rows of A (either output may be null)
 int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, const double* av, const double* X,
                      const double* S, const double* C, double* outX, double* outS, hipStream_t st,
-                     const SpmvLongRows* long_rows = nullptr);
+                     const SpmvLongRows* long_rows = nullptr, const int* rowmap = nullptr);   // rowmap: compact row -> output slot
 
 int launch_scale(double* v, long long n, double s, hipStream_t st);
 // y = (L D L^T)^-1 (-A(S-C) + (b - A X) / sigma) on the device, one thread per tree of the elimination forest

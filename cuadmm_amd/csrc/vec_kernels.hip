@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kVecThreads) void spmv_rows_kernel(int rows, const 
                                                                 const int* __restrict__ ci, const double* __restrict__ av,
                                                                 const double* __restrict__ X, const double* __restrict__ S,
                                                                 const double* __restrict__ C, double* __restrict__ outX,
-                                                                double* __restrict__ outS, int cap) {
+                                                                double* __restrict__ outS, int cap, const int* __restrict__ rowmap) {
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int sub = (int)(threadIdx.x & (T - 1));
   const long long nsub = (long long)gridDim.x * blockDim.x / T;
@@ -313,8 +313,9 @@ __global__ __launch_bounds__(kVecThreads) void spmv_rows_kernel(int rows, const 
       as += __shfl_xor(as, o, 64);
     }
     if (sub == 0) {
-      if (doX) outX[row] = ax;
-      if (doS) outS[row] = as;
+      const long long orow = rowmap ? rowmap[row] : row;     // compact row list (fused iteration): the constraint's own slot
+      if (doX) outX[orow] = ax;
+      if (doS) outS[orow] = as;
     }
   }
 }
@@ -433,14 +434,14 @@ int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const
 }
 
 int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, const double* av, const double* X,
-                     const double* S, const double* C, double* outX, double* outS, hipStream_t st, const SpmvLongRows* lr) {
+                     const double* S, const double* C, double* outX, double* outS, hipStream_t st, const SpmvLongRows* lr, const int* rowmap) {
   if (rows <= 0) return CUADMM_OK;
   const int cap = (lr && lr->nlong > 0) ? lr->cap : 0;
   int T = 1;
   while (T < 64 && T < avg_nnz) T <<= 1;
   const int grid = grid_for((long long)rows * T, kVecThreads, 256 * 16);
 #define CUADMM_SPMV_CASE(TT) \
-  case TT: hipLaunchKernelGGL(spmv_rows_kernel<TT>, dim3(grid), dim3(kVecThreads), 0, st, rows, rp, ci, av, X, S, C, outX, outS, cap); break;
+  case TT: hipLaunchKernelGGL(spmv_rows_kernel<TT>, dim3(grid), dim3(kVecThreads), 0, st, rows, rp, ci, av, X, S, C, outX, outS, cap, rowmap); break;
   switch (T) {
     CUADMM_SPMV_CASE(1) CUADMM_SPMV_CASE(2) CUADMM_SPMV_CASE(4) CUADMM_SPMV_CASE(8)
     CUADMM_SPMV_CASE(16) CUADMM_SPMV_CASE(32) CUADMM_SPMV_CASE(64)

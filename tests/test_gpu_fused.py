@@ -19,8 +19,32 @@ def _problem(blk, cons_per_block=3, seed=7):
     return p, cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
 
 
-def _run(prob, iters, sw, monkeypatch, fuse, stop_tol=0.0):
+def _coupled_problem(blk, n_couple, seed=5):
+    """make_synthetic plus n_couple constraints whose nonzeros span TWO blocks: those rows are not local to a fused block
+    and stay with the stand-alone SpMV (compact row list), next to the local ones evaluated inside the projection kernels."""
+    p = synthetic.make_synthetic(blk, cons_per_block=2, seed=seed)
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(np.asarray(p.blk, np.int64) * (np.asarray(p.blk, np.int64) + 1) // 2)])
+    cp, rows, vals = list(p.At_col_ptrs), list(p.At_row_ids), list(p.At_vals)
+    b_idx, b_vals = list(p.b_idx), list(p.b_vals)
+    m = p.con_num
+    for _ in range(n_couple):
+        k1, k2 = rng.choice(len(p.blk), 2, replace=False)
+        sl = sorted(set(int(off[k1] + rng.integers(0, off[k1 + 1] - off[k1])) for _ in range(3)) |
+                    set(int(off[k2] + rng.integers(0, off[k2 + 1] - off[k2])) for _ in range(3)))
+        rows += sl
+        vals += list(rng.standard_normal(len(sl)))
+        cp.append(len(rows))
+        b_idx.append(m); b_vals.append(float(rng.standard_normal()))
+        m += 1
+    return cuadmm_amd.Problem(p.vec_len, m, p.blk, np.array(cp, np.int32), np.array(rows, np.int32), np.array(vals), np.array(b_idx, np.int32),
+                              np.array(b_vals), p.C_idx, p.C_vals)
+
+
+def _run(prob, iters, sw, monkeypatch, fuse, stop_tol=0.0, rows=True):
+    monkeypatch.setenv("CUADMM_PSD_WAVE4_MIN", "1")        # the one-wavefront kernels for 32 < n <= 64 whatever the block count
     monkeypatch.setenv("CUADMM_FUSE", "1" if fuse else "0")
+    monkeypatch.setenv("CUADMM_FUSE_ROWS", "1" if rows else "0")
     s = cuadmm_amd.SDPSolver(verbose=False)
     s.init_problem(prob)
     s.solve(iters, stop_tol, 0, 50, 100, sw, 1.05)
@@ -76,3 +100,20 @@ def test_fused_runs_are_bit_reproducible(monkeypatch):
     for nm in ("errRp", "errRd", "pobj", "dobj"):
         assert np.array_equal(a.info_arr(nm), b.info_arr(nm))
     assert np.array_equal(a.X, b.X) and np.array_equal(a.S, b.S)
+
+
+@pytest.mark.parametrize("sw", [0, 6, 1000])
+def test_local_constraint_rows_inside_the_projection_kernel(sw, monkeypatch):
+    """Rows of A local to one fused block are evaluated by that block's kernel (SignFuse::lc_*), the coupled ones by the
+    stand-alone SpMV over a compact row list: same trajectories as with CUADMM_FUSE_ROWS=0 and as without any fusion."""
+    prob = _coupled_problem([32] * 40 + [45] * 12 + [12] * 30 + [6] * 20 + [70] * 2, n_couple=25)
+    iters = 20
+    a = _run(prob, iters, sw, monkeypatch, fuse=True, rows=True)
+    b = _run(prob, iters, sw, monkeypatch, fuse=True, rows=False)
+    c = _run(prob, iters, sw, monkeypatch, fuse=False)
+    for other in (b, c):
+        for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+            _same(a.info_arr(nm), other.info_arr(nm))
+        assert np.array_equal(a.info_arr("sig"), other.info_arr("sig"))
+        for va, vb in ((a.X, other.X), (a.y, other.y), (a.S, other.S)):
+            assert np.max(np.abs(va - vb)) <= 1e-9 * (1 + np.max(np.abs(vb)))

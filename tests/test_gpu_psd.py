@@ -284,11 +284,13 @@ def test_project_mid_sizes_in_bulk_properties(n, count):
         assert np.max(np.abs(p1[sl] - ref)) <= 1e-12 * scale
 
 
+@pytest.mark.parametrize("wave4_min", ["1", "1024"])      # 32 < n <= 64: one wavefront per block | one workgroup per block
 @pytest.mark.parametrize("kind", ["randn", "lowrank", "graded", "psd", "nsd", "clustered"])
-def test_project_every_mid_size_one_wavefront_per_block(kind):
+def test_project_every_mid_size_one_wavefront_per_block(kind, wave4_min, monkeypatch):
     """Every size 9 ... 64 (the one-wavefront-per-block sign kernels of psd_sign_wave.h, NT = 1 ... 4: column-pair svec loads,
     odd sizes, the n = 15 / 16, 31 / 32 and 63 / 64 corners of the pairing) on the spectra families of the sign path, three
     blocks per size in one call, plus an exactly zero block."""
+    monkeypatch.setenv("CUADMM_PSD_WAVE4_MIN", wave4_min)
     sizes = np.repeat(np.arange(9, 65), 3)
     rng = np.random.default_rng(77 + len(kind))
     sizes = sizes[rng.permutation(sizes.size)]
