@@ -176,7 +176,8 @@ struct cuadmm_solver {
     bool active = false;
     int nlocal = 0, nrest = 0;
     double rest_avg = 1.0;
-    DevBuf<int> ptr, row, nzptr, e, rest_rp, rest_ci, rest_map;
+    DevBuf<LcDesc> desc;
+    DevBuf<int> row, nzptr, e, rest_rp, rest_ci, rest_map;
     DevBuf<double> v, rest_v;
   } lrows;
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
@@ -403,7 +404,7 @@ struct cuadmm_solver {
     SignFuse fz{At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, Rd1.p, S.p, partials.p, sig, 1 / sig, tau * sig, mode,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (lrows.active) {
-      fz.lc_ptr = lrows.ptr.p; fz.lc_row = lrows.row.p; fz.lc_nzptr = lrows.nzptr.p; fz.lc_e = lrows.e.p; fz.lc_v = lrows.v.p;
+      fz.lc = lrows.desc.p; fz.lc_row = lrows.row.p; fz.lc_nzptr = lrows.nzptr.p; fz.lc_e = lrows.e.p; fz.lc_v = lrows.v.p;
       fz.outX = mode == 0 ? out_w : nullptr;
       fz.outS = out_w + m + 2;
     }
@@ -797,29 +798,39 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
         if (!in) continue;
         row_slot[r] = slot_of[k];
       }
-      {   // a block keeps its local rows only if their nonzeros fit the free part of its LDS tile (psd_fuse.h)
-        std::vector<long long> nz_of((size_t)nslots, 0);
-        std::vector<int> n_of((size_t)nslots, 0);
-        for (size_t k = 0; k < s->blk_local.size(); ++k) if (slot_of[k] >= 0) n_of[slot_of[k]] = s->blk_local[k];
-        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) nz_of[row_slot[r]] += arp[r + 1] - arp[r];
+      {   // a block keeps its local rows only if one lane per row and one per nonzero suffice (psd_fuse.h)
+        std::vector<long long> nz_of((size_t)nslots, 0), rows_of((size_t)nslots, 0);
+        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) { nz_of[row_slot[r]] += arp[r + 1] - arp[r]; rows_of[row_slot[r]]++; }
         for (int r = 0; r < m; ++r) {
           if (row_slot[r] < 0) continue;
-          if (nz_of[row_slot[r]] > fuse_rows_capacity(n_of[row_slot[r]])) { row_slot[r] = -1; continue; }
-          cnt[row_slot[r] + 1]++;
+          if (nz_of[row_slot[r]] > kFuseRowsMax || rows_of[row_slot[r]] > kFuseRowsMax) { row_slot[r] = -1; continue; }
           ++nlocal;
         }
       }
       if (nlocal > 0) {
-        for (int q = 0; q < nslots; ++q) cnt[q + 1] += cnt[q];
-        std::vector<int> lrow((size_t)nlocal), lnz((size_t)nlocal + 1, 0), le, fill(cnt.begin(), cnt.end() - 1);
+        // rows grouped by BLOCK (plan order of the blocks, rows ascending inside a block); lc[block] = {first row, rows |
+        // longest row << 16, first nonzero, nonzeros}
+        const size_t nb = s->blk_local.size();
+        std::vector<int> blk_of_slot((size_t)nslots, -1);
+        for (size_t k = 0; k < nb; ++k) if (slot_of[k] >= 0) blk_of_slot[slot_of[k]] = (int)k;
+        std::vector<int> bcnt(nb + 1, 0);
+        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) bcnt[(size_t)blk_of_slot[row_slot[r]] + 1]++;
+        for (size_t k = 0; k < nb; ++k) bcnt[k + 1] += bcnt[k];
+        std::vector<int> lrow((size_t)nlocal), lnz((size_t)nlocal + 1, 0), le, fill(bcnt.begin(), bcnt.end() - 1);
         std::vector<double> lval;
-        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) lrow[fill[row_slot[r]]++] = r;      // rows ascending inside a slot
-        std::vector<long long> slot_off((size_t)nslots, 0);
-        for (size_t k = 0; k < s->blk_local.size(); ++k) if (slot_of[k] >= 0) slot_off[slot_of[k]] = boff[k];
+        for (int r = 0; r < m; ++r) if (row_slot[r] >= 0) lrow[fill[blk_of_slot[row_slot[r]]]++] = r;
         for (int q = 0; q < nlocal; ++q) {
           const int r = lrow[q];
-          for (int p = arp[r]; p < arp[r + 1]; ++p) { le.push_back((int)(aci[p] - slot_off[row_slot[r]])); lval.push_back(av[p]); }
+          const long long base = boff[blk_of_slot[row_slot[r]]];
+          for (int p = arp[r]; p < arp[r + 1]; ++p) { le.push_back((int)(aci[p] - base)); lval.push_back(av[p]); }
           lnz[q + 1] = (int)le.size();
+        }
+        std::vector<LcDesc> lcd(nb, LcDesc{0, 0, 0, 0});
+        for (size_t k = 0; k < nb; ++k) {
+          const int k0 = bcnt[k], k1 = bcnt[k + 1];
+          int longest = 0;
+          for (int q = k0; q < k1; ++q) longest = std::max(longest, lnz[q + 1] - lnz[q]);
+          lcd[k] = LcDesc{k0, (k1 - k0) | (longest << 16), lnz[k0], lnz[k1] - lnz[k0]};
         }
         std::vector<int> rrp{0}, rci, rmap;
         std::vector<double> rv2;
@@ -832,7 +843,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
         auto& lr = s->lrows;
         lr.nlocal = nlocal; lr.nrest = (int)rmap.size();
         lr.rest_avg = rmap.empty() ? 1.0 : (double)rci.size() / (double)rmap.size();
-        if ((rc = lr.ptr.from(cnt)) || (rc = lr.row.from(lrow)) || (rc = lr.nzptr.from(lnz)) || (rc = lr.e.from(le)) || (rc = lr.v.from(lval))) return rc;
+        if ((rc = lr.desc.from(lcd)) || (rc = lr.row.from(lrow)) || (rc = lr.nzptr.from(lnz)) || (rc = lr.e.from(le)) || (rc = lr.v.from(lval))) return rc;
         if (lr.nrest > 0) {
           if ((rc = lr.rest_rp.from(rrp)) || (rc = lr.rest_map.from(rmap)) || (rc = lr.rest_ci.alloc(std::max<size_t>(rci.size(), 1))) ||
               (rc = lr.rest_v.alloc(std::max<size_t>(rv2.size(), 1))) || (rc = lr.rest_ci.upload(rci.data(), rci.size())) ||

@@ -20,18 +20,14 @@ struct SignFuse {
   // Constraint rows whose nonzeros all lie in ONE fused block ("local" rows: every row of a block-diagonal problem) are
   // evaluated by that block's kernel from the values it holds, instead of gathering them back from HBM in spmv_rows_kernel
   // (3 random 8-byte gathers per nonzero: 128 MB moved for 15 MB at C2): outX[row] = sum a X_new, outS[row] = sum a (S - C)
-  // (solver.cu:478,695,764).  lc_ptr[slot] .. lc_ptr[slot + 1]: the local rows of the block in partial-sum slot `slot`;
-  // row k: constraint lc_row[k], nonzeros lc_nzptr[k] .. lc_nzptr[k + 1]: (offset inside the block's svec, value).  One LANE
-  // per nonzero forms a * v into the free part of the tile, one lane per row adds its segment in order (deterministic); the
-  // host only marks rows local when the block's nonzeros fit there (fuse_rows_capacity).
-  const int* lc_ptr; const int* lc_row; const int* lc_nzptr; const int* lc_e; const double* lc_v;
+  // (solver.cu:478,695,764).  lc[block]: its local rows lc.x .. lc.x + (lc.y & 0xffff) (longest: lc.y >> 16 nonzeros) and
+  // their nonzeros lc.z .. lc.z + lc.w; row k: constraint lc_row[k], nonzeros lc_nzptr[k] .. lc_nzptr[k + 1]: (offset inside
+  // the block's svec, value).  One LANE per nonzero forms a * v, one lane per row adds its segment in order (deterministic):
+  // a block keeps its local rows only when it has at most 64 of them with at most 64 nonzeros in total (kFuseRowsMax).
+  const struct LcDesc* lc; const int* lc_row; const int* lc_nzptr; const int* lc_e; const double* lc_v;
   double* outX; double* outS;                         // null: not wanted (outX only with mode 0)
 };
-
-// doubles of LDS left for the products next to the packed svec of a block of size n (tile of the kernel that serves it)
-inline int fuse_rows_capacity(int n) {
-  const int np = n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 48 ? 48 : 64));
-  return np * (np + 1) - n * (n + 1) / 2;
-}
+struct LcDesc { int x, y, z, w; };
+constexpr int kFuseRowsMax = 64;
 
 }  // namespace cuadmm

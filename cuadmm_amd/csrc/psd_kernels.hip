@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   const int id = d.id;
   const long long off = d.off;
   psd_sign_wave_body<NT, FUSED>(a.in + off, a.out + off, d.n, a.info, swt_smem, a.steps ? a.steps + id : nullptr,
-                                a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, slot0 + m);
+                                a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, slot0 + m, id);
 }
 
 // fz != nullptr: the fused variant (SignFuse, psd_sign_wave.h); slot0 = partial-sum slot of the first member of this launch
@@ -486,6 +486,33 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     a.hint = d_hint;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
+    if (psd_debug && eig_rank == 0 && knobs.gen != 0 && ((c == 2 && sign16) || c == 3 || (c == 4 && wave4)) && getenv("CUADMM_PSD_DEBUG_GEN")) {
+      // phase ticks of the generic one-wavefront kernels (CUADMM_PSD_DEBUG=1 CUADMM_PSD_DEBUG_GEN=1), unfused
+      std::vector<long long> h((size_t)cls_count[c] * 10, 0);
+      long long* d = nullptr;
+      CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
+      CUADMM_HIP_TRY(hipMemset(d, 0, sizeof(long long) * h.size()));
+      a.dbg = d;
+      int rc2 = CUADMM_OK;
+      if (c == 2) rc2 = launch_sign_wave<1, 8>(a, 0, cls_count[c], st);
+      else if (c == 3) rc2 = launch_sign_wave<2, 4>(a, 0, cls_count[c], st);
+      else {
+        rc2 = launch_sign_wave<4, 1>(a, 0, cls4_big, st);
+        if (!rc2) rc2 = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st);
+      }
+      if (rc2) return rc2;
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 7; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
+      const double nw = cls_count[c];
+      fprintf(stderr, "[psd debug] class %d: %d blocks: ticks/block prologue %.0f (zero fill done at %.0f, first batch of loads back at %.0f, tile written at %.0f) "
+                      "iteration %.0f (%.1f steps, %.0f per step) epilogue %.0f\n",
+              c, cls_count[c], ph[0] / nw, ph[4] / nw, ph[5] / nw, ph[6] / nw, ph[1] / nw, ph[3] / nw, ph[1] / std::max(ph[3], 1.0), ph[2] / nw);
+      { hipError_t e = hipFree(d); (void)e; }
+      if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
+      continue;
+    }
     if (c == 3 && psd_debug && sign32 && eig_rank == 0) {   // phase cycles of the one-wavefront-per-block sign kernel
       std::vector<long long> h((size_t)cls_count[c] * 10);
       long long* d = nullptr;

@@ -29,73 +29,33 @@
 
 namespace cuadmm {
 
+// e -> (r, c) of the column-major upper triangle (e = c (c + 1) / 2 + r, r <= c), packed r | c << 8, for every e < 2080
+// (n <= 64).  The map does not depend on n, so ONE 4 KB table (L1-resident) serves every block: the svec is read and
+// written FLAT -- lane l takes elements l, l + 64, ... : fully coalesced 512-byte accesses, no index decoding (tri_decode
+// costs a float sqrt and two correction loops per element), and the loops over a block's svec are rolled in batches of U
+// loads.  (Round 2's first version walked column pairs with everything unrolled: the prologue and epilogue of a fused
+// n <= 48 block were 60 KB of straight-line code -- the instruction cache of a CU pair holds 64 KB -- and took 39 % of a
+// block's lifetime; measured with CUADMM_PSD_DEBUG_GEN.)
+struct SwtTab {
+  unsigned short v[2080];
+  constexpr SwtTab() : v() {
+    int e = 0;
+    for (int c = 0; c < 64; ++c)
+      for (int r = 0; r <= c; ++r) v[e++] = (unsigned short)(r | (c << 8));
+  }
+};
+__device__ const SwtTab g_swt_tab = SwtTab();
+
 template <int NT>
 struct SignWaveT {
   static constexpr int NP = 16 * NT, LD = NP + 1, KS = 4 * NT;
   static constexpr int NU = NT * (NT + 1) / 2;                 // sub-tiles on or above the diagonal
-  // svec <-> lanes by COLUMN PAIRS (swt_slot): W lanes serve one pair, G pairs per load
-  static constexpr int W = NT == 1 ? 16 : (NT == 2 ? 32 : 64), G = 64 / W, MC = W - 1;
-  static constexpr bool EXTRA = NP > MC;                       // n = W: column W - 1 takes one more load
-  static constexpr int NPAIRS = (NP / 2 < (MC + 1) / 2 ? NP / 2 : (MC + 1) / 2);
-  static constexpr int NQ = (NPAIRS + G - 1) / G + (EXTRA ? 1 : 0);   // global loads per lane (NT = 1: 3, 2: 9, 3: 24, 4: 33)
+  static constexpr int MAXLEN = NP * (NP + 1) / 2;
+  static constexpr int NSLOT = (MAXLEN + 63) / 64;             // svec elements per lane (NT = 1: 3, 2: 9, 3: 19, 4: 33)
+  static constexpr int U = NT == 1 ? 3 : (NT == 2 ? 9 : (NT == 3 ? 10 : 11));   // loads in flight per batch
   static constexpr size_t LDS_BYTES = sizeof(double) * NP * LD;
   static constexpr int SCR_LD = 17;                            // transposition tiles (alias the region of S)
 };
-
-// svec <-> lanes: column c of the upper triangle is the contiguous svec range [c (c + 1) / 2, + c + 1).  A group of W lanes
-// takes the column pair (p, m - 1 - p), m = min(n, W - 1): p + 1 + m - p = m + 1 <= W lanes, two coalesced runs, no index
-// decoding (tri_decode costs a float sqrt and two correction loops per element).  n = W: column W - 1 is one more load.
-// Returns whether the lane holds an element.
-template <int NT>
-__device__ __forceinline__ bool swt_slot(int q, int lane, int n, int& r, int& c) {
-  using Cfg = SignWaveT<NT>;
-  if (Cfg::EXTRA && q == Cfg::NQ - 1) { r = lane; c = Cfg::MC; return n > Cfg::MC && lane <= Cfg::MC; }
-  const int g = lane / Cfg::W, l = lane % Cfg::W;
-  const int m = n < Cfg::MC ? n : Cfg::MC;
-  const int c1 = q * Cfg::G + g, c2 = m - 1 - c1;
-  if (c1 > c2) return false;
-  if (l <= c1) { r = l; c = c1; return true; }
-  r = l - c1 - 1; c = c2;
-  return c2 != c1 && r <= c2;
-}
-
-template <int NT>
-__device__ __forceinline__ void swt_load(const double* __restrict__ src, int n, int lane, double (&v)[SignWaveT<NT>::NQ]) {
-#pragma unroll
-  for (int q = 0; q < SignWaveT<NT>::NQ; ++q) {
-    int r, c;
-    v[q] = swt_slot<NT>(q, lane, n, r, c) ? src[c * (c + 1) / 2 + r] : 0.0;
-  }
-}
-// M = scale * smat(v), both triangles.  M must have been zeroed where no element lands (padding rows / columns >= n).
-template <int NT>
-__device__ __forceinline__ void swt_tile_from(double* __restrict__ M, int n, int lane, const double (&v)[SignWaveT<NT>::NQ], double scale) {
-  constexpr int LD = SignWaveT<NT>::LD;
-#pragma unroll
-  for (int q = 0; q < SignWaveT<NT>::NQ; ++q) {
-    int r, c;
-    if (swt_slot<NT>(q, lane, n, r, c)) {
-      const double x = v[q] * (r == c ? scale : scale * kSqrt2Inv);
-      M[r * LD + c] = x;
-      M[c * LD + r] = x;
-    }
-  }
-}
-template <int NT>
-__device__ __forceinline__ bool swt_store_svec(const double* __restrict__ M, double* __restrict__ out, int n, int lane) {
-  constexpr int LD = SignWaveT<NT>::LD;
-  bool bad = false;
-#pragma unroll
-  for (int q = 0; q < SignWaveT<NT>::NQ; ++q) {
-    int r, c;
-    if (swt_slot<NT>(q, lane, n, r, c)) {
-      const double x = M[r * LD + c];
-      bad |= !(fabs(x) <= 1.7976931348623157e308);
-      out[c * (c + 1) / 2 + r] = (r == c) ? x : x * kSqrt2;
-    }
-  }
-  return bad;
-}
 
 // all operand fragments of the symmetric matrix in LDS: f[s][x] = M[4 s + kk][16 x + r16]
 template <int NT>
@@ -174,52 +134,78 @@ __device__ __forceinline__ void swt_store_mirrored(double* __restrict__ M, int r
       }
 }
 
-// FUSED: `in` / `out` are unused; fz carries the vectors, off = svec offset of the block, slot = its partial-sum slot
+// One batch of the flat svec walk: slot u of the batch is element e = base + 64 u + lane.  An invalid slot (e >= len) reads
+// element 0 of the block and is masked afterwards, so the loads of a batch are straight-line: one memory round trip per batch.
+#define CUADMM_SWT_SLOT(u)                                        \
+  const int e_ = base + 64 * (u) + lane;                          \
+  const bool ok_ = e_ < len;                                      \
+  const int ec_ = ok_ ? e_ : 0
+
+// FUSED: `in` / `out` are unused; fz carries the vectors, off = svec offset of the block, slot = its partial-sum slot,
+// id = its index in the plan (local constraint rows)
 template <int NT, bool FUSED>
 __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail, double* S,
-                                                   int* steps_out, int* hint, long long* dbg, const SignFuse& fz, long long off, int slot) {
+                                                   int* steps_out, int* hint, long long* dbg, const SignFuse& fz, long long off, int slot, int id) {
   using Cfg = SignWaveT<NT>;
-  constexpr int LD = Cfg::LD, NP = Cfg::NP;
+  constexpr int LD = Cfg::LD, NP = Cfg::NP, U = Cfg::U;
   const int lane = lane_id();
   const int r16 = lane & 15, kk = lane >> 4;
+  const int len = n * (n + 1) / 2;
+  const unsigned short* __restrict__ tab = g_swt_tab.v;
   const long long c0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
-  // S_0 = X / ||X||_F: the Frobenius norm is the 2-norm of the svec (the sqrt2 counts the off-diagonals twice)
-  {
-    double v[Cfg::NQ];
+  // ---- prologue: the tile takes X (fused: Xb = X + sigma (A^T y - C), formed here); ||X||_F is the 2-norm of the svec (the
+  // sqrt2 counts the off-diagonals twice) and goes onto the fragments of the first step
+#pragma unroll 1
+  for (int e = lane; e < NP * LD; e += 64) S[e] = 0.0;
+  if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[4] = (long long)__builtin_readcyclecounter() - c0; }
+  double ss = 0.0;
+#pragma unroll 1
+  for (int base = 0; base < len; base += 64 * U) {
+    double v[U];
+    int rc[U];
     if (FUSED) {
-      // Straight-line loads (an invalid slot reads the block's first element and is masked afterwards): all row pointers /
-      // C / X of the lane's slots are in flight before the first use; then the (mostly empty) rows of A^T.
-      int p0[Cfg::NQ], p1[Cfg::NQ];
-      double cq[Cfg::NQ];
+      int p0[U], p1[U];
+      double cq[U];
 #pragma unroll
-      for (int q = 0; q < Cfg::NQ; ++q) {
-        int r, c;
-        const bool ok = swt_slot<NT>(q, lane, n, r, c);
-        const long long i = off + (ok ? c * (c + 1) / 2 + r : 0);
-        p0[q] = fz.rp[i]; p1[q] = fz.rp[i + 1]; cq[q] = fz.C[i]; v[q] = fz.X[i];
+      for (int u = 0; u < U; ++u) {
+        CUADMM_SWT_SLOT(u);
+        const long long i = off + ec_;
+        rc[u] = tab[ec_];
+        p0[u] = fz.rp[i]; p1[u] = ok_ ? fz.rp[i + 1] : p0[u]; cq[u] = fz.C[i]; v[u] = fz.X[i];
       }
 #pragma unroll
-      for (int q = 0; q < Cfg::NQ; ++q) {
-        int r, c;
-        const bool ok = swt_slot<NT>(q, lane, n, r, c);
+      for (int u = 0; u < U; ++u) {
+        CUADMM_SWT_SLOT(u);
         double t = 0.0;
-        for (int p = p0[q]; p < (ok ? p1[q] : p0[q]); ++p) t += fz.av[p] * fz.y[fz.ci[p]];
-        const double r1 = t - cq[q];
-        if (ok) fz.Rd1[off + c * (c + 1) / 2 + r] = r1;
-        v[q] = ok ? v[q] + r1 * fz.sig : 0.0;
+        for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * fz.y[fz.ci[p]];
+        const double r1 = t - cq[u];
+        if (ok_) fz.Rd1[off + e_] = r1;
+        v[u] = ok_ ? v[u] + r1 * fz.sig : 0.0;
+        (void)ec_;
       }
     } else {
-      swt_load<NT>(in, n, lane, v);
-    }
-    for (int e = lane; e < NP * LD; e += 64) S[e] = 0.0;
-    double ss = 0.0;
 #pragma unroll
-    for (int q = 0; q < Cfg::NQ; ++q) ss += v[q] * v[q];
-    const double nrm = sqrt(wave_sum(ss));
-    const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);   // NaN propagates (flagged at the store)
-    wave_fence();
-    swt_tile_from<NT>(S, n, lane, v, scale);
+      for (int u = 0; u < U; ++u) {
+        CUADMM_SWT_SLOT(u);
+        rc[u] = tab[ec_];
+        const double x = in[ec_];
+        v[u] = ok_ ? x : 0.0;
+      }
+    }
+    if (dbg && base == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) dbg[5] = (long long)__builtin_readcyclecounter() - c0; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      CUADMM_SWT_SLOT(u);
+      (void)ec_;
+      ss += v[u] * v[u];
+      const int r = rc[u] & 255, c = rc[u] >> 8;
+      const double x = (r == c) ? v[u] : v[u] * kSqrt2Inv;
+      if (ok_) { S[r * LD + c] = x; S[c * LD + r] = x; }
+    }
   }
+  if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[6] = (long long)__builtin_readcyclecounter() - c0; }
+  const double nrm = sqrt(wave_sum(ss));
+  const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);   // NaN propagates (flagged at the store)
   wave_fence();
   double f[4 * NT][NT];
   SignSched sched;
@@ -228,6 +214,12 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   const long long c1 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   while (!last) {
     swt_frags<NT>(S, r16, kk, f);
+    if (sched.steps == 0) {                                // S_0 = X / ||X||_F: the tile holds X, the scale goes onto its fragments
+#pragma unroll
+      for (int s = 0; s < 4 * NT; ++s)
+#pragma unroll
+        for (int x = 0; x < NT; ++x) f[s][x] *= scale;
+    }
     wave_fence();                                          // the region of S is scratch from here to the store of the next iterate
     // Y = S S on the upper sub-tiles
     sl_v4f64 y[NT][NT];
@@ -291,131 +283,140 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   }
   if (steps_out && lane == 0) *steps_out = sched.steps;
   if (hint && lane == 0) *hint = sched.lifts;
+  if (steps_out && lane == 0) *steps_out = sched.steps;
+  if (hint && lane == 0) *hint = sched.lifts;
   const long long c2 = dbg ? (long long)__builtin_readcyclecounter() : 0;
-  // P = 0.5 (X0 + S X0): A fragments of S from LDS, then LDS takes X0 again (L2-hot), whose sub-tiles are read in
-  // accumulator layout (register B operand; X0 is exactly symmetric in LDS, so the lower sub-tiles are read directly)
-  {
-    double v[Cfg::NQ];
-    if (FUSED) {                                             // Xb again from X and Rd1 (bit-identical to the prologue's value)
+  // ---- epilogue: P = 0.5 (X0 + S X0).  A fragments of S from LDS, then the tile takes X0 again (fused: rebuilt from X and
+  // Rd1, bit-identical), whose sub-tiles are read in accumulator layout (register B operand; X0 is exactly symmetric in LDS)
+  swt_frags<NT>(S, r16, kk, f);
+  wave_fence();
+#pragma unroll 1
+  for (int base = 0; base < len; base += 64 * U) {
+    double v[U];
+    int rc[U];
 #pragma unroll
-      for (int q = 0; q < Cfg::NQ; ++q) {
-        int r, c;
-        const bool ok = swt_slot<NT>(q, lane, n, r, c);
-        const long long i = off + (ok ? c * (c + 1) / 2 + r : 0);
-        const double xb = fz.X[i] + fz.Rd1[i] * fz.sig;
-        v[q] = ok ? xb : 0.0;
-      }
-    } else {
-      swt_load<NT>(in, n, lane, v);                          // issued first: the latency overlaps the fragment reads
+    for (int u = 0; u < U; ++u) {
+      CUADMM_SWT_SLOT(u);
+      (void)ok_;
+      rc[u] = tab[ec_];
+      v[u] = FUSED ? fz.X[off + ec_] + fz.Rd1[off + ec_] * fz.sig : in[ec_];
     }
-    swt_frags<NT>(S, r16, kk, f);
-    wave_fence();
-    swt_tile_from<NT>(S, n, lane, v, 1.0);                   // same positions as in the prologue: the zero padding is still there
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      CUADMM_SWT_SLOT(u);
+      (void)ec_;
+      const int r = rc[u] & 255, c = rc[u] >> 8;
+      const double x = (r == c) ? v[u] : v[u] * kSqrt2Inv;
+      if (ok_) { S[r * LD + c] = x; S[c * LD + r] = x; }     // same positions as in the prologue: the zero padding is still there
+    }
   }
   wave_fence();
-  sl_v4f64 xb[NT][NT], p[NT][NT];
+  {
+    sl_v4f64 xb[NT][NT], p[NT][NT];
 #pragma unroll
-  for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xb[b][j][r] = S[(16 * b + kk + 4 * r) * LD + 16 * j + r16];
-  swt_mma_regB<NT, 0, NT>(f, xb, p);
+        for (int r = 0; r < 4; ++r) xb[b][j][r] = S[(16 * b + kk + 4 * r) * LD + 16 * j + r16];
+    swt_mma_regB<NT, 0, NT>(f, xb, p);
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = i; j < NT; ++j)
+      for (int j = i; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[i][j][r] = 0.5 * p[i][j][r] + 0.5 * xb[i][j][r];
+        for (int r = 0; r < 4; ++r) p[i][j][r] = 0.5 * p[i][j][r] + 0.5 * xb[i][j][r];
+    wave_fence();
+    swt_store_mirrored<NT>(S, r16, kk, p);
+  }
   wave_fence();
-  swt_store_mirrored<NT>(S, r16, kk, p);
-  wave_fence();
+  // ---- the projection leaves through the flat walk again.  Fused: S, Rd, X updates and the two sums on the way (the
+  // expressions of post_kernel); the slot of P(r, c) in the tile then takes S - C and its mirror image (the pad column for a
+  // diagonal element) the new X -- the staging the local constraint rows read.
   bool bad = false;
-  if (FUSED) {
-    double s_rd = 0.0, s_cx = 0.0;
-    const bool upd = fz.mode == 0, local_rows = fz.lc_ptr != nullptr;
-    // local constraint rows: their index data is requested first (one lane per nonzero, one per row; more than 64 of either
-    // are fetched later), so that the round trip overlaps the slot loads below
-    int k0 = 0, k1 = 0, z0 = 0, z1 = 0, ze = 0, kb = 0, ke = 0, krow = 0;
-    double zv = 0.0;
-    if (local_rows) {
-      k0 = fz.lc_ptr[slot]; k1 = fz.lc_ptr[slot + 1];                 // wave-uniform
-      if (k0 < k1) {
-        z0 = fz.lc_nzptr[k0]; z1 = fz.lc_nzptr[k1];
-        if (z0 + lane < z1) { ze = fz.lc_e[z0 + lane]; zv = fz.lc_v[z0 + lane]; }
-        if (k0 + lane < k1) { kb = fz.lc_nzptr[k0 + lane]; ke = fz.lc_nzptr[k0 + lane + 1]; krow = fz.lc_row[k0 + lane]; }
-      }
-    }
-    // straight-line loads again (masked afterwards), so that the slots' X / Rd1 / C are all in flight together
-    double xq[Cfg::NQ], rq[Cfg::NQ], cq[Cfg::NQ], pq[Cfg::NQ];
-#pragma unroll
-    for (int q = 0; q < Cfg::NQ; ++q) {
-      int r, c;
-      const bool ok = swt_slot<NT>(q, lane, n, r, c);
-      const long long i = off + (ok ? c * (c + 1) / 2 + r : 0);
-      xq[q] = fz.X[i]; rq[q] = fz.Rd1[i];
-      cq[q] = (upd || local_rows) ? fz.C[i] : 0.0;
-      pq[q] = S[ok ? r * LD + c : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < Cfg::NQ; ++q) {
-      int r, c;
-      const bool ok = swt_slot<NT>(q, lane, n, r, c);
-      const long long i = off + (ok ? c * (c + 1) / 2 + r : 0);
-      const double pm = pq[q];
-      bad |= ok && !(fabs(pm) <= 1.7976931348623157e308);
-      const double xp = (r == c) ? pm : pm * kSqrt2;         // Xproj[i]
-      const double x = xq[q], r1 = rq[q];
-      const double xdiff = xp - x;
-      const double sv = fz.inv_sig * xdiff - r1;
-      if (ok) fz.S[i] = sv;
-      rq[q] = sv - cq[q];                                    // S - C (local rows)
-      if (upd) {
-        const double rd = r1 + sv;
-        const double xn = x + fz.tau_sig * rd;
-        if (ok) fz.X[i] = xn;
-        xq[q] = xn;
-        s_rd += ok ? rd * rd : 0.0;
-        s_cx += ok ? cq[q] * xn : 0.0;
-      }
-    }
-    if (local_rows && k0 < k1) {
-      // the tile region is free now: the block's svec (new X, then S - C) in packed order, the products behind it
-      const int len = n * (n + 1) / 2;
-      double* __restrict__ PR = S + len;
+  double s_rd = 0.0, s_cx = 0.0;
+  const bool upd = FUSED && fz.mode == 0, local_rows = FUSED && fz.lc != nullptr;
+  LcDesc lcd = {0, 0, 0, 0};
+  int ze = 0, kb = 0, ke = 0, krow = 0;
+  double zv = 0.0;
+  if (local_rows) {                      // index data of the local rows first: the round trip overlaps the walk below
+    lcd = fz.lc[id];                     // {first row, rows | longest row << 16, first nonzero, nonzeros}: wave-uniform
+    if (lane < lcd.w) { ze = fz.lc_e[lcd.z + lane]; zv = fz.lc_v[lcd.z + lane]; }
+    if (lane < (lcd.y & 0xffff)) { kb = fz.lc_nzptr[lcd.x + lane] - lcd.z; ke = fz.lc_nzptr[lcd.x + lane + 1] - lcd.z; krow = fz.lc_row[lcd.x + lane]; }
+  }
 #pragma unroll 1
-      for (int pass = (upd && fz.outX) ? 0 : 1; pass < 2; ++pass) {
-        double* __restrict__ dst = pass == 0 ? fz.outX : fz.outS;
-        if (!dst) continue;
-        wave_fence();
+  for (int base = 0; base < len; base += 64 * U) {
+    double pq[U], xq[U], rq[U], cq[U];
+    int rc[U];
 #pragma unroll
-        for (int q = 0; q < Cfg::NQ; ++q) {
-          int r, c;
-          if (swt_slot<NT>(q, lane, n, r, c)) S[c * (c + 1) / 2 + r] = pass == 0 ? xq[q] : rq[q];
-        }
-        wave_fence();
-        if (z0 + lane < z1) PR[lane] = zv * S[ze];
-        for (int z = z0 + 64 + lane; z < z1; z += 64) PR[z - z0] = fz.lc_v[z] * S[fz.lc_e[z]];
-        wave_fence();
-        if (k0 + lane < k1) {
-          double acc = 0.0;
-          for (int p = kb; p < ke; ++p) acc += PR[p - z0];
-          dst[krow] = acc;
-        }
-        for (int k = k0 + 64 + lane; k < k1; k += 64) {
-          double acc = 0.0;
-          for (int p = fz.lc_nzptr[k]; p < fz.lc_nzptr[k + 1]; ++p) acc += PR[p - z0];
-          dst[fz.lc_row[k]] = acc;
-        }
+    for (int u = 0; u < U; ++u) {
+      CUADMM_SWT_SLOT(u);
+      (void)ok_;
+      rc[u] = tab[ec_];
+      if (FUSED) {
+        xq[u] = fz.X[off + ec_]; rq[u] = fz.Rd1[off + ec_];
+        cq[u] = (upd || local_rows) ? fz.C[off + ec_] : 0.0;
       }
     }
-    if (fz.mode == 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) pq[u] = S[(rc[u] & 255) * LD + (rc[u] >> 8)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      CUADMM_SWT_SLOT(u);
+      (void)ec_;
+      const int r = rc[u] & 255, c = rc[u] >> 8;
+      const double pm = pq[u];
+      bad |= ok_ && !(fabs(pm) <= 1.7976931348623157e308);
+      const double xp = (r == c) ? pm : pm * kSqrt2;         // Xproj[e]
+      if (FUSED) {
+        const long long i = off + e_;
+        const double x = xq[u], r1 = rq[u];
+        const double xdiff = xp - x;
+        const double sv = fz.inv_sig * xdiff - r1;
+        if (ok_) fz.S[i] = sv;
+        double xn = x;
+        if (upd) {
+          const double rd = r1 + sv;
+          xn = x + fz.tau_sig * rd;
+          if (ok_) fz.X[i] = xn;
+          s_rd += ok_ ? rd * rd : 0.0;
+          s_cx += ok_ ? cq[u] * xn : 0.0;
+        }
+        if (local_rows && ok_) {
+          S[r * LD + c] = sv - cq[u];
+          S[r == c ? r * LD + NP : c * LD + r] = xn;
+        }
+      } else {
+        if (ok_) out[e_] = xp;
+      }
+    }
+  }
+  if (FUSED) {
+    if (local_rows && lcd.w > 0) {
+      // one lane per nonzero forms a * v from the staging, one lane per row adds its segment in order (host: a block keeps its
+      // local rows only when it has at most 64 of them with at most 64 nonzeros in total)
+      wave_fence();
+      const int zt = tab[ze];
+      const int zr = zt & 255, zc = zt >> 8;
+      const double ps = zv * S[zr * LD + zc];
+      const double px = zv * S[zr == zc ? zr * LD + NP : zc * LD + zr];
+      const int maxlen = lcd.y >> 16;
+      double as = 0.0, ax = 0.0;
+      for (int t = 0; t < maxlen; ++t) {
+        const int src = (kb + t) & 63;
+        const double vs = __shfl(ps, src, 64), vx = __shfl(px, src, 64);
+        if (kb + t < ke) { as += vs; ax += vx; }
+      }
+      if (lane < (lcd.y & 0xffff)) {
+        if (fz.outS) fz.outS[krow] = as;
+        if (upd && fz.outX) fz.outX[krow] = ax;
+      }
+    }
+    if (upd) {
       s_rd = wave_sum(s_rd);
       s_cx = wave_sum(s_cx);
       if (lane == 0) { fz.partials[2 * (long long)slot] = s_rd; fz.partials[2 * (long long)slot + 1] = s_cx; }
     }
-  } else {
-    bad = swt_store_svec<NT>(S, out, n, lane);
   }
   if (bad && fail) atomicAdd(fail, 1);
   if (dbg && lane == 0) {   // developer aid (CUADMM_PSD_DEBUG): cycles of prologue / iteration / epilogue, steps
@@ -423,5 +424,6 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
     dbg[0] = c1 - c0; dbg[1] = c2 - c1; dbg[2] = c3 - c2; dbg[3] = sched.steps;
   }
 }
+#undef CUADMM_SWT_SLOT
 
 }  // namespace cuadmm

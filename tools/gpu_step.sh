@@ -7,3 +7,4 @@ for e in "$@"; do
   env $e timeout 300 python bench.py --no-cpu-baseline 2>&1 | grep '^{' | pl "c2 $e"
   env $e timeout 300 python bench.py --config c4 --no-cpu-baseline 2>&1 | grep '^{' | pl "c4 $e"
 done
+export CUADMM_PSD_DEBUG=1 CUADMM_PSD_DEBUG_GEN=1; for n in 15 32 45 64; do python tools/probe_w32_occ.py $n 16667 1 2>&1 | grep "psd debug" | tail -1; done
