@@ -211,6 +211,8 @@ struct cuadmm_solver {
   DevBuf<double> At_v, A_v;
   DevBuf<double> X, S, C, Rd1, Xb, Xproj, y_d, out_d, partials, X_best, S_best;
   DevBuf<int> steps_d, hint_d;
+  std::vector<int> steps_h;
+  long long lpt_next = 3, lpt_iters = 0;       // longest-block-first reordering: next event, iterations so far
   // Where the kernels write [A*X | sums | A*(S-C)]: the device buffer out_d when it has to be all-reduced, otherwise the
   // pinned host buffer h_out itself through its device mapping -- the results cross PCIe as the kernels produce them and
   // fetch_out is a stream synchronisation without a copy.
@@ -740,7 +742,8 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     s->plan.d_hint = s->hint_d.p;
     s->plan.sign.d_hint = s->hint_d.p;
   }
-  if (!rc && s->psd_steps && !s->blk_local.empty()) {
+  static const bool lpt_on = !(getenv("CUADMM_PSD_LPT") && atoi(getenv("CUADMM_PSD_LPT")) == 0);
+  if (!rc && (s->psd_steps || (lpt_on && s->plan.fusable())) && !s->blk_local.empty()) {
     if ((rc = s->steps_d.alloc(s->blk_local.size()))) return rc;
     CUADMM_HIP_TRY(hipMemset(s->steps_d.p, 0, sizeof(int) * s->blk_local.size()));
     s->plan.d_steps = s->steps_d.p;
@@ -1048,6 +1051,9 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     std::cout << " -------------------------------------------------------------------------------" << std::endl;
   }
 
+  static const bool lpt_enabled = !(getenv("CUADMM_PSD_LPT") && atoi(getenv("CUADMM_PSD_LPT")) == 0);
+  long long& lpt_ev = s->lpt_next;             // counts iterations over all solve calls of this solver
+  if (!lpt_enabled) lpt_ev = 0;
   for (int iter = 1; iter <= max_iter + 1; ++iter) {
     // ---- Step 0 (solver.cu:419-467)
     if (std::max(s->maxfeas, s->relgap) < stop_tol) { breakyes = true; final_msg = "Solver ended: converged."; }
@@ -1208,6 +1214,14 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     s->info[CUADMM_INFO_RELGAP].push_back(s->relgap); s->info[CUADMM_INFO_SIG].push_back(s->sig);
     s->info[CUADMM_INFO_BSCALE].push_back(s->bscale); s->info[CUADMM_INFO_CSCALE].push_back(s->Cscale);
     s->info_iter_num++;
+    // longest block first (PsdPlan::reorder_by_steps): at iterations 3, 24, 192, ... of this solve the stream is idle here
+    if (s->fuse && lpt_ev > 0 && ++s->lpt_iters == lpt_ev && s->steps_d.p) {
+      s->steps_h.resize(s->steps_d.n);
+      CUADMM_HIP_TRY(hipMemcpyAsync(s->steps_h.data(), s->steps_d.p, sizeof(int) * s->steps_d.n, hipMemcpyDeviceToHost, s->st));
+      CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+      if ((rc = s->plan.reorder_by_steps(s->steps_h.data(), s->st))) return rc;
+      lpt_ev *= 8;
+    }
   }
 
   // unscale (solver.cu:814-816)

@@ -334,6 +334,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q]};
     CUADMM_HIP_TRY(hipMalloc(&d_desc, sizeof(PsdDesc) * desc.size()));
     CUADMM_HIP_TRY(hipMemcpy(d_desc, desc.data(), sizeof(PsdDesc) * desc.size(), hipMemcpyHostToDevice));
+    h_desc = desc;
   }
   {
     int rc = sign.build(blk, sign_members);
@@ -416,6 +417,31 @@ bool PsdPlan::fusable() const {
   const PsdKnobs& k = psd_knobs();
   return eig_rank == 0 && !k.debug && k.sign32 && k.gen != 0 && !k.mid_eig && fused_blocks() > 0 &&
          vec_len < 0x7fffffffLL;
+}
+
+int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
+  // ranges served by the one-wavefront kernels: class 2 (sign16), class 3, class 4 (wave4: the n > 48 members and the others)
+  std::vector<std::pair<int, int>> ranges;
+  if (sign16 && cls_count[2] > 0) ranges.push_back({cls_begin[2], cls_count[2]});
+  if (cls_count[3] > 0) ranges.push_back({cls_begin[3], cls_count[3]});
+  if (wave4 && cls_count[4] > 0) {
+    if (cls4_big > 0) ranges.push_back({cls_begin[4], cls4_big});
+    if (cls_count[4] > cls4_big) ranges.push_back({cls_begin[4] + cls4_big, cls_count[4] - cls4_big});
+  }
+  std::vector<PsdDesc> tmp;
+  for (auto& rg : ranges) {   // counting sort by steps (<= SignSched::kCap), descending, stable
+    constexpr int K = SignSched::kCap + 2;
+    int cnt[K + 1] = {0};
+    auto key = [&](const PsdDesc& d) { const int st = steps_host[d.id]; return K - 1 - (st < 0 ? 0 : (st > K - 1 ? K - 1 : st)); };
+    for (int q = 0; q < rg.second; ++q) cnt[key(h_desc[rg.first + q]) + 1]++;
+    for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+    tmp.resize((size_t)rg.second);
+    for (int q = 0; q < rg.second; ++q) tmp[(size_t)cnt[key(h_desc[rg.first + q])]++] = h_desc[rg.first + q];
+    std::copy(tmp.begin(), tmp.end(), h_desc.begin() + rg.first);
+    CUADMM_HIP_TRY(hipMemcpyAsync(d_desc + rg.first, &h_desc[rg.first], sizeof(PsdDesc) * (size_t)rg.second, hipMemcpyHostToDevice, st));
+  }
+  CUADMM_HIP_TRY(hipStreamSynchronize(st));     // h_desc is pageable: the copies are staged, but keep the ordering explicit
+  return CUADMM_OK;
 }
 
 // partial-sum slots in launch order: class 2 (when it runs the sign kernel), 3, 4 -- as PsdPlan::project hands them out

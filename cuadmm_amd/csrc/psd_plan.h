@@ -66,6 +66,11 @@ struct PsdPlan {
   bool wave4 = false;
   bool sign16 = true;          // 9 <= n <= 16 on the one-wavefront sign kernel too (CUADMM_PSD_N16=eig: register eigensolver)
   int build_rest_index();
+  // Longest block first: a launch ends with blocks running alone on their SIMD, and a block that needs 19 steps started last
+  // keeps the chip waiting.  The step count of a block barely moves from one ADMM iteration to the next, so the engine now and
+  // then re-sorts the members of the one-wavefront classes by the steps of the previous projection (descending, stable).
+  int reorder_by_steps(const int* steps_host, hipStream_t st);
+  std::vector<PsdDesc> h_desc;
   void fused_slots(std::vector<int>& slot_of) const;   // block -> partial-sum slot of the fused launches (-1: not fused)
   std::vector<int> h_ids;      // host copy of d_ids
 
