@@ -179,7 +179,18 @@ struct cuadmm_solver {
     DevBuf<LcDesc> desc;
     DevBuf<int> row, nzptr, e, rest_rp, rest_ci, rest_map;
     DevBuf<double> v, rest_v;
+    std::vector<LcDesc> h_desc;      // host copies for the closed-block solve set-up
+    std::vector<int> h_row, h_At_ci;
   } lrows;
+  // closed blocks (psd_fuse.h): every constraint is local to one fused block and no block has more than kClosedMaxRows of
+  // them -> the blocks solve for their own multipliers and add their share of ||Rp||^2, b^T y inside the projection kernel
+  struct ClosedSolve {
+    bool active = false;
+    DevBuf<double> L, partials2;
+    DevBuf<int> off, ci_local;
+  } closed;
+  bool stats_fused = false;        // this iteration's four scalars were formed by launch_reduce_quads
+  int fused_nparts = 0;
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -297,9 +308,11 @@ struct cuadmm_solver {
     return CUADMM_OK;
   }
 
-  int host_solve() {  // y_p = (P(AA^T+eps I)P^T)^-1 rhs_p
+  // in_fused_step: the projection launch that follows solves for y itself (closed blocks)
+  int host_solve(bool in_fused_step = false) {  // y_p = (P(AA^T+eps I)P^T)^-1 rhs_p
     double t0 = wall_s();
     const double isig = 1 / sig;
+    if (in_fused_step && closed.active) return CUADMM_OK;
     if (dev_solve) {   // everything it needs is in HBM (out_d: [A X | sums | A(S-C)]); y_d is the result
       prof_begin(K_TAIL);
       int rc = lead.ready ? lead.solve(out_d.p, out_d.p + (size_t)m + 2, b_d.p, isig, y_d.p, tail, st) : launch_forest_solve(forest_trees, f_tree_ptr.p, f_tree_cols.p, f_Lp.p, f_Li.p, f_Lx.p, f_D.p, out_d.p, out_d.p + (size_t)m + 2,
@@ -350,7 +363,8 @@ struct cuadmm_solver {
         // without a collective in between the final stage writes the four scalars straight into the pinned host buffer
         // through its device mapping: the fetch is then a stream synchronisation without a copy command
         double* dst = (!dev_scalars && h_scal_dev) ? h_scal_dev : scal_d.p;
-        if ((rc = launch_rp_stats(m, out_d.p, b_d.p, normA_d.p, y_d.p, bscale, out_d.p + (size_t)m, scal_d.p + 8, dst, st))) return rc;
+        if (stats_fused) stats_fused = false;               // formed by launch_reduce_quads in this iteration's fused step
+        else if ((rc = launch_rp_stats(m, out_d.p, b_d.p, normA_d.p, y_d.p, bscale, out_d.p + (size_t)m, scal_d.p + 8, dst, st))) return rc;
         if (dev_scalars) {
           if ((rc = comm_allreduce(scal_d.p, 4))) return rc;
         }
@@ -404,19 +418,33 @@ struct cuadmm_solver {
     prof_end(K_ATY, 36.0 * (double)plan.n_rest);
     if (rc) return rc;
     SignFuse fz{At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, Rd1.p, S.p, partials.p, sig, 1 / sig, tau * sig, mode,
-                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0};
     if (lrows.active) {
       fz.lc = lrows.desc.p; fz.lc_row = lrows.row.p; fz.lc_nzptr = lrows.nzptr.p; fz.lc_e = lrows.e.p; fz.lc_v = lrows.v.p;
       fz.outX = mode == 0 ? out_w : nullptr;
       fz.outS = out_w + m + 2;
+    }
+    if (closed.active) {
+      fz.cs_L = closed.L.p; fz.cs_off = closed.off.p; fz.cs_D = f_D.p; fz.ci_local = closed.ci_local.p;
+      fz.b = b_d.p; fz.normA = normA_d.p; fz.y_out = y_d.p;
+      fz.ax_old = out_d.p; fz.as_old = out_d.p + (size_t)m + 2;
+      fz.partials2 = closed.partials2.p;
+      fz.isig = 1 / sig; fz.bscale = bscale;
     }
     prof_begin(K_PSD);
     rc = plan.project(Xb.p, Xproj.p, st, &fz);
     prof_end(K_PSD, 68.0 * (double)(L - plan.n_rest) + 16.0 * (double)plan.n_rest);
     if (rc) return rc;
     prof_begin(K_POST);
+    stats_fused = closed.active && mode == 0;
+    int nparts = 0;
     rc = launch_post_rest(mode, plan.n_rest, plan.d_rest, plan.fused_blocks(), Xproj.p, Rd1.p, C.p, X.p, S.p, 1 / sig, tau * sig, partials.p,
-                          out_w + (size_t)m, st);
+                          out_w + (size_t)m, st, stats_fused ? &nparts : nullptr);
+    if (!rc && stats_fused) {   // all four scalars of the stopping test in one launch (rp_stats is not needed this iteration)
+      double* dst = (!dev_scalars && h_scal_dev) ? h_scal_dev : scal_d.p;
+      rc = launch_reduce_quads(partials.p, nparts, closed.partials2.p, plan.fused_blocks(), dst, out_w + (size_t)m, st);
+    }
     prof_end(K_POST, (mode == 0 ? 48.0 : 32.0) * (double)plan.n_rest);
     return rc;
   }
@@ -846,6 +874,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
         auto& lr = s->lrows;
         lr.nlocal = nlocal; lr.nrest = (int)rmap.size();
         lr.rest_avg = rmap.empty() ? 1.0 : (double)rci.size() / (double)rmap.size();
+        lr.h_desc = lcd; lr.h_row = lrow; lr.h_At_ci = lci;
         if ((rc = lr.desc.from(lcd)) || (rc = lr.row.from(lrow)) || (rc = lr.nzptr.from(lnz)) || (rc = lr.e.from(le)) || (rc = lr.v.from(lval))) return rc;
         if (lr.nrest > 0) {
           if ((rc = lr.rest_rp.from(rrp)) || (rc = lr.rest_map.from(rmap)) || (rc = lr.rest_ci.alloc(std::max<size_t>(rci.size(), 1))) ||
@@ -966,6 +995,54 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       if (s->verbose) printf(" y-solve on the device: %d independent trees of the elimination forest (<= %d columns each)\n", ntrees, maxc);
     }
   }
+  s->closed.active = false;
+  // Default: only when no block with rows is smaller than 17 -- the solve adds two dependent memory round trips to a block's
+  // prologue: < 4 % of the lifetime of an n >= 17 block (C2: 0.307 -> 0.300 ms per iteration, the solve and statistics kernels
+  // gone), but 15 % of an n <= 16 block's (C4 with its 67 000 tiny blocks: 1.89 -> 1.91).  CUADMM_FUSE_SOLVE=1 / 0 forces it.
+  bool want_closed = true;
+  if (const char* e = getenv("CUADMM_FUSE_SOLVE")) want_closed = atoi(e) != 0;
+  else
+    for (size_t k = 0; k < s->lrows.h_desc.size() && want_closed; ++k)
+      if ((s->lrows.h_desc[k].y & 0xffff) > 0 && s->blk_local[k] < 17) want_closed = false;
+  if (want_closed && s->fuse && s->lrows.active && s->lrows.nrest == 0 && s->forest_trees > 0 && s->lrows.nlocal == m) {
+    const auto& hd = s->lrows.h_desc;
+    const auto& hrow = s->lrows.h_row;
+    const size_t nb = hd.size();
+    bool ok = true;
+    for (const auto& d : hd) ok = ok && (d.y & 0xffff) <= kClosedMaxRows;
+    if (ok) {
+      const int64_t* Lp; const int* Li; const double* Lx; const double* D;
+      if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
+      std::vector<int> pos((size_t)m, -1), blk_of_row((size_t)m, -1), loff(nb + 1, 0);
+      for (size_t k = 0; k < nb; ++k) {
+        const int nk = hd[k].y & 0xffff;
+        loff[k + 1] = loff[k] + nk * nk;
+        for (int q = 0; q < nk; ++q) { pos[hrow[hd[k].x + q]] = q; blk_of_row[hrow[hd[k].x + q]] = (int)k; }
+      }
+      std::vector<double> Ld((size_t)std::max(loff[nb], 1), 0.0);
+      for (size_t k = 0; k < nb && ok; ++k) {
+        const int nk = hd[k].y & 0xffff;
+        for (int a = 0; a < nk && ok; ++a) {
+          const int j = hrow[hd[k].x + a];
+          for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
+            const int i = Li[p];
+            if (blk_of_row[i] != (int)k || pos[i] <= a) { ok = false; break; }     // fill outside the block: not closed after all
+            Ld[(size_t)loff[k] + (size_t)pos[i] * nk + a] = Lx[p];
+          }
+        }
+      }
+      if (ok) {
+        std::vector<int> cil(s->lrows.h_At_ci.size());
+        for (size_t p = 0; p < cil.size(); ++p) cil[p] = pos[s->lrows.h_At_ci[p]];
+        loff.pop_back();
+        if ((rc = s->closed.L.from(Ld)) || (rc = s->closed.off.from(loff)) || (rc = s->closed.ci_local.from(cil)) ||
+            (rc = s->closed.partials2.alloc(2 * (size_t)s->plan.fused_blocks() + 2)))
+          return rc;
+        s->closed.active = true;
+        if (s->verbose) printf(" closed blocks: each block solves for its own multipliers (<= %d rows) inside the projection kernel\n", kClosedMaxRows);
+      }
+    }
+  }
   if (s->dev_scalars || s->dev_solve) {
     if ((rc = s->b_d.alloc(std::max(m, 1))) || (rc = s->normA_d.alloc(std::max(m, 1))) || (rc = s->h_scal.alloc(4))) return rc;
     if ((rc = s->b_d.upload(s->b_p.data(), (size_t)m)) || (rc = s->normA_d.upload(s->normA_p.data(), (size_t)m))) return rc;
@@ -1077,8 +1154,9 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       s->total_time = wall_s() - s->t_init0;
     }
 
-    // ---- Step 1 (solver.cu:478-500): y = (AA^T)^-1 (Rp/sig - A(S-C))
-    if ((rc = s->host_solve())) return rc;
+    // ---- Step 1 (solver.cu:478-500): y = (AA^T)^-1 (Rp/sig - A(S-C)); with closed blocks the fused projection of this
+    // iteration solves it (not on the last pass through the loop, which stops before the projection)
+    if ((rc = s->host_solve(s->fuse && !breakyes))) return rc;
 
     if (breakyes) {   // solver.cu:567-576
       if (iter > switch_admm && s->have_best) {

@@ -26,8 +26,22 @@ struct SignFuse {
   // a block keeps its local rows only when it has at most 64 of them with at most 64 nonzeros in total (kFuseRowsMax).
   const struct LcDesc* lc; const int* lc_row; const int* lc_nzptr; const int* lc_e; const double* lc_v;
   double* outX; double* outS;                         // null: not wanted (outX only with mode 0)
+  // CLOSED blocks (every constraint that touches the block is one of its local rows, at most kClosedMaxRows of them: the
+  // block-diagonal configurations): the block also SOLVES for its own multipliers in the prologue -- rhs from the rows of
+  // [A X | A (S - C)] it wrote in the previous iteration, the dense unit-lower factor of its diagonal block of A A^T (cut
+  // out of the host factor, same elimination order, same unfused arithmetic as forest_solve_kernel: bit-identical y;
+  // solver.cu:478-500) -- gathers A^T y from those values, and in mode 0 adds its rows' share of ||Rp||^2 and b^T y
+  // (solver.cu:768-772,781) to a second partial pair.  cs_L == null: y comes from y[] as before.
+  const double* cs_L; const int* cs_off;              // dense nk x nk factor of block `id` at cs_L + cs_off[id], row-major
+  const double* cs_D; const int* ci_local;            // D by constraint; for every nonzero of A^T: its row's position in the block
+  const double* b; const double* normA;
+  double* y_out;                                      // y (all constraints, the factor's order)
+  const double* ax_old; const double* as_old;         // [A X], [A (S - C)] of the previous iteration
+  double* partials2;                                  // 2 doubles per fused block: sum (normA (b - A X) bscale)^2, sum b y
+  double isig, bscale;
 };
 struct LcDesc { int x, y, z, w; };
 constexpr int kFuseRowsMax = 64;
+constexpr int kClosedMaxRows = 8;
 
 }  // namespace cuadmm

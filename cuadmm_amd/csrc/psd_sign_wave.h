@@ -158,6 +158,43 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
 #pragma unroll 1
   for (int e = lane; e < NP * LD; e += 64) S[e] = 0.0;
   if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[4] = (long long)__builtin_readcyclecounter() - c0; }
+  const bool local_rows = FUSED && fz.lc != nullptr, closed = FUSED && fz.cs_L != nullptr;
+  LcDesc lcd = {0, 0, 0, 0};
+  if (local_rows) lcd = fz.lc[id];       // {first row, rows | longest row << 16, first nonzero, nonzeros}: wave-uniform
+  const int nk = lcd.y & 0xffff;
+  double yk = 0.0;                       // closed block: the multiplier of the lane's row (kept for the epilogue's b^T y)
+  if (closed && nk > 0) {
+    // y_B = (L D L^T)^-1 rhs_B, one lane per row, the serial order of forest_solve_kernel (columns ascending, then descending)
+    const bool mine = lane < nk;
+    const int row = fz.lc_row[lcd.x + (mine ? lane : 0)];
+    const double* __restrict__ Lb = fz.cs_L + fz.cs_off[id];
+    double lrow[kClosedMaxRows], lcol[kClosedMaxRows];
+#pragma unroll
+    for (int q = 0; q < kClosedMaxRows; ++q) {
+      lrow[q] = (mine && q < lane) ? Lb[lane * nk + q] : 0.0;               // L[lane][q]
+      lcol[q] = (mine && q > lane && q < nk) ? Lb[q * nk + lane] : 0.0;     // L[q][lane]
+    }
+    const double rp = __dadd_rn(-fz.ax_old[row], fz.b[row]);               // Rp = -A X + b
+    double x = mine ? __dadd_rn(-fz.as_old[row], __dmul_rn(fz.isig, rp)) : 0.0;
+    const double dk = fz.cs_D[row];
+#pragma unroll
+    for (int j = 0; j < kClosedMaxRows; ++j) {                              // L z = rhs
+      const double xj = __shfl(x, j, 64);
+      if (j < nk && lane > j) x = __dsub_rn(x, __dmul_rn(lrow[j], xj));
+    }
+    double yv = x / dk;                                                     // D^-1, then L^T y = z
+#pragma unroll
+    for (int j = kClosedMaxRows - 2; j >= 0; --j) {
+#pragma unroll
+      for (int i = j + 1; i < kClosedMaxRows; ++i) {
+        const double yi = __shfl(yv, i, 64);
+        if (lane == j && i < nk) yv = __dsub_rn(yv, __dmul_rn(lcol[i], yi));
+      }
+    }
+    yk = mine ? yv : 0.0;
+    if (mine) { fz.y_out[row] = yv; S[lane * LD + NP] = yv; }               // pad column of the tile: the gather below reads it
+    wave_fence();
+  }
   double ss = 0.0;
 #pragma unroll 1
   for (int base = 0; base < len; base += 64 * U) {
@@ -177,7 +214,8 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       for (int u = 0; u < U; ++u) {
         CUADMM_SWT_SLOT(u);
         double t = 0.0;
-        for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * fz.y[fz.ci[p]];
+        if (closed) { for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * S[fz.ci_local[p] * LD + NP]; }
+        else { for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * fz.y[fz.ci[p]]; }
         const double r1 = t - cq[u];
         if (ok_) fz.Rd1[off + e_] = r1;
         v[u] = ok_ ? v[u] + r1 * fz.sig : 0.0;
@@ -335,12 +373,11 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   // diagonal element) the new X -- the staging the local constraint rows read.
   bool bad = false;
   double s_rd = 0.0, s_cx = 0.0;
-  const bool upd = FUSED && fz.mode == 0, local_rows = FUSED && fz.lc != nullptr;
-  LcDesc lcd = {0, 0, 0, 0};
+  const bool upd = FUSED && fz.mode == 0;
   int ze = 0, kb = 0, ke = 0, krow = 0;
-  double zv = 0.0;
+  double zv = 0.0, kb_b = 0.0, kb_n = 0.0;
   if (local_rows) {                      // index data of the local rows first: the round trip overlaps the walk below
-    lcd = fz.lc[id];                     // {first row, rows | longest row << 16, first nonzero, nonzeros}: wave-uniform
+    if (closed && upd && lane < nk) { const int row = fz.lc_row[lcd.x + lane]; kb_b = fz.b[row]; kb_n = fz.normA[row]; }
     if (lane < lcd.w) { ze = fz.lc_e[lcd.z + lane]; zv = fz.lc_v[lcd.z + lane]; }
     if (lane < (lcd.y & 0xffff)) { kb = fz.lc_nzptr[lcd.x + lane] - lcd.z; ke = fz.lc_nzptr[lcd.x + lane + 1] - lcd.z; krow = fz.lc_row[lcd.x + lane]; }
   }
@@ -411,6 +448,15 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
         if (fz.outS) fz.outS[krow] = as;
         if (upd && fz.outX) fz.outX[krow] = ax;
       }
+      if (closed && upd) {               // the rows' share of the stopping test's constraint-space sums (rp_stats_partial_kernel)
+        const double ro = kb_n * (kb_b - ax) * fz.bscale;
+        double pr = lane < nk ? ro * ro : 0.0, pby = lane < nk ? kb_b * yk : 0.0;
+        pr = wave_sum(pr);
+        pby = wave_sum(pby);
+        if (lane == 0) { fz.partials2[2 * (long long)slot] = pr; fz.partials2[2 * (long long)slot + 1] = pby; }
+      }
+    } else if (closed && upd && lane == 0) {
+      fz.partials2[2 * (long long)slot] = 0.0; fz.partials2[2 * (long long)slot + 1] = 0.0;
     }
     if (upd) {
       s_rd = wave_sum(s_rd);

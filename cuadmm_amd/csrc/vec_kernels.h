@@ -31,7 +31,9 @@ int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, c
 int launch_aty_xb_idx(long long nidx, const int* idx, const int* rp, const int* ci, const double* av, const double* y, const double* C,
                       const double* X, double sig, double* Rd1, double* Xb, hipStream_t st);
 int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const double* Xproj, const double* Rd1, const double* C, double* X,
-                     double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st);
+                     double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st, int* nparts_out = nullptr);
+// all four scalars of the stopping test from the per-block partial pairs of a fused iteration with closed blocks
+int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, hipStream_t st);
 
 // Rows of A with more than `cap` nonzeros (a trace / all-ones constraint): their tail is summed in segments by extra
 // workgroups and added in segment order (reproducible), so one row cannot serialise the SpMV.

@@ -200,6 +200,33 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pairs_kernel(const doub
   if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
 }
 
+// Fused iteration with closed blocks (psd_fuse.h): the projection kernels left BOTH partial pairs per block -- (sum Rd^2,
+// <C, X>) in p1 (followed by the pairs of the stand-alone post step) and (||Rp org||^2, b^T y) in p2 -- and this one
+// workgroup forms all four scalars of the stopping test: out4 = [||Rp||^2, b.y, sum Rd^2, <C,X>], sums_out = out4[2..3].
+__global__ __launch_bounds__(kReduceThreads) void reduce_quads_kernel(const double* __restrict__ p1, int n1, const double* __restrict__ p2, int n2,
+                                                                     double* __restrict__ out4, double* __restrict__ sums_out) {
+  const double2* __restrict__ q1 = reinterpret_cast<const double2*>(p1);
+  const double2* __restrict__ q2 = reinterpret_cast<const double2*>(p2);
+  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, c0 = 0.0, d0 = 0.0, c1 = 0.0, d1 = 0.0;
+  int i = threadIdx.x;
+  for (; i + kReduceThreads < n1; i += 2 * kReduceThreads) { const double2 u = q1[i], v = q1[i + kReduceThreads]; a0 += u.x; b0 += u.y; a1 += v.x; b1 += v.y; }
+  for (; i < n1; i += kReduceThreads) { const double2 u = q1[i]; a0 += u.x; b0 += u.y; }
+  i = threadIdx.x;
+  for (; i + kReduceThreads < n2; i += 2 * kReduceThreads) { const double2 u = q2[i], v = q2[i + kReduceThreads]; c0 += u.x; d0 += u.y; c1 += v.x; d1 += v.y; }
+  for (; i < n2; i += kReduceThreads) { const double2 u = q2[i]; c0 += u.x; d0 += u.y; }
+  double a = a0 + a1, b = b0 + b1, c = c0 + c1, d = d0 + d1;
+  block_sum2<kReduceThreads>(a, b);
+  __syncthreads();
+  block_sum2<kReduceThreads>(c, d);
+  if (threadIdx.x == 0) { out4[0] = c; out4[1] = d; out4[2] = a; out4[3] = b; sums_out[0] = a; sums_out[1] = b; }
+}
+
+int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_quads_kernel, dim3(1), dim3(kReduceThreads), 0, st, p1, n1, p2, n2, out4, sums_out);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 // Owned-constraints sharding: the two constraint-space sums of the stopping test, formed on the device from A*X so that
 // all four scalars of an iteration travel in ONE small all-reduce enqueued on the stream (no host round trip):
 //   out4[0] = sum_i (normA_i (b_i - (A X)_i) bscale)^2   (|| Rp org ||^2, solver.cu:768-772)
@@ -418,7 +445,7 @@ int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, c
 // Fused iteration: the projection kernels left one partial pair per fused block in partials[0, 2 nfused); the rows of `idx`
 // add their grid's pairs behind them, and (mode 0) everything is summed in slot order.
 int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const double* Xproj, const double* Rd1, const double* C, double* X,
-                     double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st) {
+                     double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st, int* nparts_out) {
   const int grid = nidx > 0 ? post_grid(nidx) : 0;
   if (nidx > 0) {
     double* part = partials + 2 * (size_t)nfused;
@@ -426,6 +453,7 @@ int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const
     else hipLaunchKernelGGL(post_idx_kernel<1>, dim3(grid), dim3(kVecThreads), 0, st, nidx, idx, Xproj, Rd1, C, X, S, inv_sig, tau_sig, part);
     CUADMM_HIP_TRY(hipGetLastError());
   }
+  if (nparts_out) { *nparts_out = nfused + grid; return CUADMM_OK; }    // the caller reduces (launch_reduce_quads)
   if (mode == 0) {
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(kReduceThreads), 0, st, partials, nfused + grid, sums_out);
     CUADMM_HIP_TRY(hipGetLastError());

@@ -41,7 +41,8 @@ def _coupled_problem(blk, n_couple, seed=5):
                               np.array(b_vals), p.C_idx, p.C_vals)
 
 
-def _run(prob, iters, sw, monkeypatch, fuse, stop_tol=0.0, rows=True):
+def _run(prob, iters, sw, monkeypatch, fuse, stop_tol=0.0, rows=True, solve=True):
+    monkeypatch.setenv("CUADMM_FUSE_SOLVE", "1" if solve else "0")
     monkeypatch.setenv("CUADMM_PSD_WAVE4_MIN", "1")        # the one-wavefront kernels for 32 < n <= 64 whatever the block count
     monkeypatch.setenv("CUADMM_FUSE", "1" if fuse else "0")
     monkeypatch.setenv("CUADMM_FUSE_ROWS", "1" if rows else "0")
@@ -117,3 +118,20 @@ def test_local_constraint_rows_inside_the_projection_kernel(sw, monkeypatch):
         assert np.array_equal(a.info_arr("sig"), other.info_arr("sig"))
         for va, vb in ((a.X, other.X), (a.y, other.y), (a.S, other.S)):
             assert np.max(np.abs(va - vb)) <= 1e-9 * (1 + np.max(np.abs(vb)))
+
+
+@pytest.mark.parametrize("sw", [0, 7, 1000])
+@pytest.mark.parametrize("cons", [1, 3, 8])
+def test_closed_blocks_solve_for_their_own_multipliers(cons, sw, monkeypatch):
+    """Block-diagonal problems with at most 8 constraints per block: the projection kernel solves the block's part of
+    A A^T y = rhs itself (same elimination order and unfused arithmetic as forest_solve_kernel) and adds its rows' share of
+    ||Rp||^2 and b^T y -- same trajectories as with the stand-alone solve / statistics kernels (CUADMM_FUSE_SOLVE=0)."""
+    _, prob = _problem([32] * 50 + [45] * 10 + [12] * 20 + [20] * 20, cons_per_block=cons, seed=13)
+    iters = 30
+    a = _run(prob, iters, sw, monkeypatch, fuse=True, solve=True)
+    b = _run(prob, iters, sw, monkeypatch, fuse=True, solve=False)
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+        _same(a.info_arr(nm), b.info_arr(nm), rtol=1e-10)
+    assert np.array_equal(a.info_arr("sig"), b.info_arr("sig"))
+    for va, vb in ((a.X, b.X), (a.y, b.y), (a.S, b.S)):
+        assert np.max(np.abs(va - vb)) <= 1e-11 * (1 + np.max(np.abs(vb)))
