@@ -1221,8 +1221,17 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
       if ((rc = s->host_solve())) return rc;
       if ((rc = s->upload_y())) return rc;
-      if ((rc = s->launch_aty(false))) return rc;
-      if ((rc = s->launch_post_mode(2, tau))) return rc;
+      static const bool aty_post2 = !getenv("CUADMM_NO_ATY_POST2");
+      if (s->At_long.nlong == 0 && aty_post2) {   // one pass, Rd1 not stored (vec_kernels.hip)
+        s->prof_begin(K_POST);
+        rc = launch_aty_post2(L, s->At_rp.p, s->At_ci.p, s->At_v.p, s->y_d.p, s->C.p, s->S.p, s->X.p, tau * s->sig, s->partials.p,
+                              s->out_w + (size_t)m, s->st);
+        s->prof_end(K_POST, 40.0 * (double)L);
+        if (rc) return rc;
+      } else {
+        if ((rc = s->launch_aty(false))) return rc;
+        if ((rc = s->launch_post_mode(2, tau))) return rc;
+      }
       if ((rc = s->launch_spmv(true, false))) return rc;
       if ((rc = s->fetch_out(0, (size_t)m + 2))) return rc;            // [A*X | sums]; A*(S-C) unchanged since the half step
     } else {

@@ -25,6 +25,10 @@ int post_grid(long long L);
 int launch_post(int mode, long long L, const double* Xproj, const double* Rd1, const double* C, double* X, double* S,
                 double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st);
 
+// sGS second half in one pass: Rd1 = At*y - C (not stored), Rd = Rd1 + S, X += tau_sig*Rd, sums (no long rows of At)
+int launch_aty_post2(long long L, const int* rp, const int* ci, const double* av, const double* y, const double* C, const double* S, double* X,
+                     double tau_sig, double* partials, double* sums_out, hipStream_t st);
+
 // Fused iteration (psd_fuse.h): the same two steps restricted to a list of svec rows (those outside the fused blocks); the
 // mode-0 reduction also folds in the per-block partial pairs the projection kernels wrote to partials[0, 2 nfused).
 // partials: 2 * (nfused + post_grid(nidx)) doubles.

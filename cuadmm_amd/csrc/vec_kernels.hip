@@ -92,6 +92,29 @@ __global__ __launch_bounds__(kVecThreads) void aty_xb_idx_kernel(long long nidx,
   }
 }
 
+// Second half of an sGS iteration in ONE pass (solver.cu:707-729,746-758,774-776): Rd1 = A^T y - C with the new y, Rd = Rd1 + S,
+// X += tau sigma Rd, sum Rd^2, <C, X> -- aty_xb_kernel<false> followed by post_kernel<2> wrote and re-read Rd1 (16 B per svec
+// element of 76) and took two launches.  Same expressions; Rd1 is not stored (the next iteration forms its own).
+__global__ __launch_bounds__(kVecThreads) void aty_post2_kernel(long long L, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                                const double* __restrict__ av, const double* __restrict__ y,
+                                                                const double* __restrict__ C, const double* __restrict__ S,
+                                                                double* __restrict__ X, double tau_sig, double* __restrict__ partials) {
+  double s_rd = 0.0, s_cx = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
+    double t = 0.0;
+    for (int p = rp[i]; p < rp[i + 1]; ++p) t += av[p] * y[ci[p]];
+    const double c = C[i];
+    const double r1 = t - c;
+    const double rd = r1 + S[i];
+    const double xn = X[i] + tau_sig * rd;
+    X[i] = xn;
+    s_rd += rd * rd;
+    s_cx += c * xn;
+  }
+  block_sum2<kVecThreads>(s_rd, s_cx);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s_rd; partials[2 * blockIdx.x + 1] = s_cx; }
+}
+
 // one workgroup per long row (two-stage sum in a fixed order: reproducible)
 template <bool WRITE_XB>
 __global__ __launch_bounds__(kVecThreads) void aty_xb_long_kernel(const int* __restrict__ long_rows, const int* __restrict__ rp,
@@ -403,6 +426,15 @@ int launch_aty_xb_idx(long long nidx, const int* idx, const int* rp, const int* 
                       const double* X, double sig, double* Rd1, double* Xb, hipStream_t st) {
   if (nidx <= 0) return CUADMM_OK;
   hipLaunchKernelGGL(aty_xb_idx_kernel, dim3(grid_for(nidx, kVecThreads, 256 * 16)), dim3(kVecThreads), 0, st, nidx, idx, rp, ci, av, y, C, X, sig, Rd1, Xb);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+int launch_aty_post2(long long L, const int* rp, const int* ci, const double* av, const double* y, const double* C, const double* S, double* X,
+                     double tau_sig, double* partials, double* sums_out, hipStream_t st) {
+  const int grid = post_grid(L);
+  hipLaunchKernelGGL(aty_post2_kernel, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, S, X, tau_sig, partials);
+  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(kReduceThreads), 0, st, partials, grid, sums_out);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
