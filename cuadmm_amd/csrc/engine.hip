@@ -417,9 +417,10 @@ struct cuadmm_solver {
     rc = launch_aty_xb_idx(plan.n_rest, plan.d_rest, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st);
     prof_end(K_ATY, 36.0 * (double)plan.n_rest);
     if (rc) return rc;
-    SignFuse fz{At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, Rd1.p, S.p, partials.p, sig, 1 / sig, tau * sig, mode,
-                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0};
+    SignFuse fz{};                                     // every optional part (local rows, closed blocks) off
+    fz.rp = At_rp.p; fz.ci = At_ci.p; fz.av = At_v.p; fz.y = y_d.p; fz.C = C.p;
+    fz.X = X.p; fz.Rd1 = Rd1.p; fz.S = S.p; fz.partials = partials.p;
+    fz.sig = sig; fz.inv_sig = 1 / sig; fz.tau_sig = tau * sig; fz.mode = mode;
     if (lrows.active) {
       fz.lc = lrows.desc.p; fz.lc_row = lrows.row.p; fz.lc_nzptr = lrows.nzptr.p; fz.lc_e = lrows.e.p; fz.lc_v = lrows.v.p;
       fz.outX = mode == 0 ? out_w : nullptr;
@@ -770,8 +771,8 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     s->plan.d_hint = s->hint_d.p;
     s->plan.sign.d_hint = s->hint_d.p;
   }
-  static const bool lpt_on = !(getenv("CUADMM_PSD_LPT") && atoi(getenv("CUADMM_PSD_LPT")) == 0);
-  if (!rc && (s->psd_steps || (lpt_on && s->plan.fusable())) && !s->blk_local.empty()) {
+  // step counts per block: for cuadmm_get_psd_steps and for the longest-block-first reordering of the fused launches
+  if (!rc && (s->psd_steps || s->plan.fusable()) && !s->blk_local.empty()) {
     if ((rc = s->steps_d.alloc(s->blk_local.size()))) return rc;
     CUADMM_HIP_TRY(hipMemset(s->steps_d.p, 0, sizeof(int) * s->blk_local.size()));
     s->plan.d_steps = s->steps_d.p;
@@ -817,7 +818,6 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       std::vector<long long> boff((size_t)s->blk_local.size() + 1, 0);
       for (size_t k = 0; k < s->blk_local.size(); ++k) boff[k + 1] = boff[k] + blk_svec_len(s->blk_local[k]);
       std::vector<int> row_slot((size_t)m, -1);
-      std::vector<int> cnt((size_t)nslots + 1, 0);
       int nlocal = 0;
       for (int r = 0; r < m; ++r) {
         if (arp[r + 1] == arp[r]) continue;

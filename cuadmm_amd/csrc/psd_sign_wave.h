@@ -1,23 +1,26 @@
-// PSD projection of blocks with 32 < n <= 64 by the matrix-sign iteration with ONE WAVEFRONT PER BLOCK (NT = 3: n <= 48,
-// NT = 4: n <= 64) -- the generalisation of the n <= 32 kernel of psd_sign_lds.h (SignWave32).
+// PSD projection of blocks with 9 <= n <= 64 by the matrix-sign iteration with ONE WAVEFRONT PER BLOCK (NT x NT sub-tiles of
+// 16 x 16: NT = 1: n <= 16, 2: n <= 32, 3: n <= 48, 4: n <= 64), optionally FUSED with the vector work of the ADMM iteration
+// on the block's svec range (psd_fuse.h) -- the kernels of BASELINE configs[1] and [3].
 //
 // Replaces, per block (reference src/solver.cu:534-647): vector_to_matrices, the eigendecomposition, max(W, 0), V diag,
-// the DGEMM and matrices_to_vector.
+// the DGEMM and matrices_to_vector; fused: also solver.cu:514-527 (A^T y, Rd1, Xb), :652-656,746-758,774-776 (S, Rd, X
+// update, the two sums) and the block-local rows of :478,695,764 (A X, A (S - C)).
 //
-// Why: the one-workgroup-per-block kernel (psd_sign_lds_kernel, 6 / 10 wavefronts, operands read from LDS for every
-// MFMA) is bound by LDS bandwidth -- two fragment reads per MFMA, 35 % of the fp64 matrix-core peak on the n = 45
-// blocks that dominate BASELINE configs[3].  With one wavefront owning the whole block
+// Why one wavefront: the one-workgroup-per-block kernel (psd_sign_lds_kernel, 6 / 10 wavefronts, operands read from LDS
+// for every MFMA) is bound by LDS bandwidth -- two fragment reads per MFMA, 35 % of the fp64 matrix-core peak on the
+// n = 45 blocks that dominate configs[3].  With one wavefront owning the whole block
 //   * the 4 NT x NT operand fragments of S are read from LDS ONCE per step (f[s][x] = S[4 s + kk][16 x + r16]); they are the
 //     A fragments of both products (S symmetric), the B fragments of Y = S S, and -- register 4 i + r of column block j is
 //     element (16 i + 4 r + kk, 16 j + r16) -- the accumulator-layout copy of S that the combine step needs;
 //   * Y = S^2 stays in registers: the accumulator layout of v_mfma_f64_16x16x4_f64 is the B-operand layout, so the upper
 //     sub-tiles feed S Y directly; the lower ones are transposed through LDS (the region of S is dead once the fragments
 //     are loaded, so the scratch tiles alias it): 4 writes + 4 reads per off-diagonal sub-tile instead of 4 NT MFMAs;
-//   * only sub-tiles on or above the diagonal are computed (6 of 9 / 10 of 16) and the next iterate is stored mirrored
+//   * only sub-tiles on or above the diagonal are computed (1 / 3 / 6 / 10) and the next iterate is stored mirrored
 //     (exactly symmetric iterate, psd_large.hip explains why that matters).
-// Per step and block: 2 * NU * 4 NT MFMAs (NT = 3: 144) against 4 NT^2 + 8 NL LDS reads and <= 8 NU + 4 NL writes --
-// the matrix cores are the only busy unit.  Registers: fragments 8 NT^2, Y 8 NT^2, S Y 8 NU VGPRs (NT = 3: 72 + 72 + 48
-// -> two wavefronts per SIMD; NT = 4: 128 + 128 + 80 -> one).  LDS: NP x (NP + 1) doubles per block (18.4 / 32.5 KB).
+// Per step and block: 2 * NU * 4 NT MFMAs (NT = 3: 144) against 4 NT^2 + 8 NL LDS reads and <= 8 NU + 4 NL writes.
+// Registers: fragments 8 NT^2, Y 8 NT^2, S Y 8 NU VGPRs -> eight / four / two / one wavefront per SIMD.  LDS: NP x (NP + 1)
+// doubles per block.  A handful of 33 <= n <= 64 blocks is served by the one-workgroup kernels instead (latency; the
+// planner switches by block count).
 #pragma once
 #include <hip/hip_runtime.h>
 
