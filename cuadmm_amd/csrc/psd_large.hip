@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
   } while (0)
   LG_LOAD(pa0, pa1, pb0, pb1);
   ap += kstep; bp += kstep;
-  LG_LOAD(qa0, qa1, qb0, qb1);                            // N / BK is even (N is a multiple of 64)
+  if (N > BK) LG_LOAD(qa0, qa1, qb0, qb1);               // N is a multiple of BK; an odd number of k-tiles ends after a first half
   double2* sa = reinterpret_cast<double2*>(As + lk * LDS + lc);
   double2* sb2 = reinterpret_cast<double2*>(Bs + lk * LDS + lc);
 #define LG_COMPUTE()                                                                                              \
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
     __syncthreads();
     if (k0 + 2 * BK < N) { ap += kstep; bp += kstep; LG_LOAD(pa0, pa1, pb0, pb1); }
     LG_COMPUTE();
+    if (k0 + BK >= N) break;                              // odd number of k-tiles (N a multiple of BK only): uniform
     __syncthreads();
     LG_STORE(qa0, qa1, qb0, qb1);
     __syncthreads();
@@ -470,9 +471,20 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   size_t max_elems = 0, max_cols = 0;
   int max_count = 0;
   for (auto& kv : by_pad) {
-    const int N = kv.first;
+    int N = kv.first;
     const size_t per = (size_t)N * N * sizeof(double) * 4;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(ws_cap / per, 65535));
+    // A group on the 32 x 32 tiles only needs a multiple of 32: when every member fits N - 32 the padding shrinks (n = 2000:
+    // 2016 instead of 2048 is 4.6 % fewer flops per product; n = 861: 864 instead of 896 is 10 %)
+    {
+      int nmax = 0;
+      for (int k : kv.second) nmax = std::max(nmax, blk[k]);
+      const int cnt = (int)std::min<size_t>((size_t)chunk, kv.second.size());
+      static const bool pad32 = !(getenv("CUADMM_LG_PAD32") && atoi(getenv("CUADMM_LG_PAD32")) == 0);
+      if (pad32 && nmax <= N - 32 && lg_small_tiles(true, N, cnt) && lg_small_tiles(true, N - 32, cnt) &&
+          lg_small_tiles(true, N - 32, (int)(kv.second.size() % (size_t)chunk ? kv.second.size() % (size_t)chunk : cnt)))
+        N -= 32;
+    }
     for (size_t b = 0; b < kv.second.size(); b += (size_t)chunk) {
       Group g;
       g.N = N;

@@ -209,7 +209,7 @@ def _spectrum_matrix(n, kind, rng):
     return (M + M.T) / 2
 
 
-@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 500])
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 270, 410, 500])     # 270, 410: padded to 288 / 416 (odd number of 32-wide k-tiles)
 @pytest.mark.parametrize("kind", ["randn", "lowrank", "graded", "psd", "nsd", "clustered"])
 def test_project_sign_path_spectra(n, kind):
     rng = np.random.default_rng(1000 * n + len(kind))
