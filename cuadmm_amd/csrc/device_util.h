@@ -15,6 +15,12 @@
   } while (0)
 
 namespace cuadmm {
+// Blocking copies between PAGEABLE host memory and the device through the library's own page-locked staging buffers
+// (staging.hip explains why the runtime must never get to register caller memory).  `after`: a stream to drain first.
+int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t after = nullptr);
+int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t after = nullptr);
+int staged_h2d_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, hipStream_t after = nullptr);
+
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB LDS per CU / per workgroup
 constexpr int kMaxBlockSize = 4000;           // single-workgroup HBM-resident path limit (5n doubles of LDS)
 // Explicit eigendecomposition (cuadmm_op_batch_eig, rank-limited projection) of a block beyond this size is refused unless

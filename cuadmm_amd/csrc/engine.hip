@@ -46,8 +46,7 @@ struct DevBuf {
   }
   int upload(const T* h, size_t count) {
     if (count == 0) return CUADMM_OK;
-    CUADMM_HIP_TRY(hipMemcpy(p, h, sizeof(T) * count, hipMemcpyHostToDevice));
-    return CUADMM_OK;
+    return staged_h2d(p, h, sizeof(T) * count);   // never hipMemcpy on caller / vector memory (staging.hip)
   }
   int from(const std::vector<T>& h) {
     int rc = alloc(h.size());
@@ -1304,8 +1303,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     // longest block first (PsdPlan::reorder_by_steps): at iterations 3, 24, 192, ... of this solve the stream is idle here
     if (s->fuse && lpt_ev > 0 && ++s->lpt_iters == lpt_ev && s->steps_d.p) {
       s->steps_h.resize(s->steps_d.n);
-      CUADMM_HIP_TRY(hipMemcpyAsync(s->steps_h.data(), s->steps_d.p, sizeof(int) * s->steps_d.n, hipMemcpyDeviceToHost, s->st));
-      CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+      if ((rc = staged_d2h(s->steps_h.data(), s->steps_d.p, sizeof(int) * s->steps_d.n, s->st))) return rc;
       if ((rc = s->plan.reorder_by_steps(s->steps_h.data(), s->st))) return rc;
       lpt_ev *= 8;
     }
@@ -1322,10 +1320,9 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     for (int i = 0; i < m; ++i) s->y_full[s->cons_local[s->perm[i]]] = s->y_p[i];
     if (s->comm_world > 1 && s->m_full > 0) {
       if (!s->yfull_d.p && (rc = s->yfull_d.alloc((size_t)s->m_full))) return rc;
-      CUADMM_HIP_TRY(hipMemcpyAsync(s->yfull_d.p, s->y_full.data(), sizeof(double) * (size_t)s->m_full, hipMemcpyHostToDevice, s->st));
+      if ((rc = staged_h2d(s->yfull_d.p, s->y_full.data(), sizeof(double) * (size_t)s->m_full, s->st))) return rc;
       if ((rc = s->comm_allreduce(s->yfull_d.p, (size_t)s->m_full))) return rc;
-      CUADMM_HIP_TRY(hipMemcpyAsync(s->y_full.data(), s->yfull_d.p, sizeof(double) * (size_t)s->m_full, hipMemcpyDeviceToHost, s->st));
-      CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+      if ((rc = staged_d2h(s->y_full.data(), s->yfull_d.p, sizeof(double) * (size_t)s->m_full, s->st))) return rc;
     }
   }
   s->eig_fail_total = s->plan.fail_count(s->st);
@@ -1390,7 +1387,7 @@ static int get_vec(cuadmm_solver* s, const DevBuf<double>& v, double* out) {
   int rc = check_device(s->device);
   if (rc) return rc;
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
-  if (s->L > 0) CUADMM_HIP_TRY(hipMemcpy(out, v.p, sizeof(double) * (size_t)s->L, hipMemcpyDeviceToHost));
+  if (s->L > 0) { int rc2 = staged_d2h(out, v.p, sizeof(double) * (size_t)s->L, s->st); if (rc2) return rc2; }
   return CUADMM_OK;
 }
 // world>1: writes this rank's shard (length svec_end - svec_begin) at out[0..)
@@ -1411,8 +1408,8 @@ int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const dou
   if (!s || !s->initialised) { set_error("set_XyS: not initialised"); return CUADMM_ERR_INVALID; }
   int rc = check_device(s->device);
   if (rc) return rc;
-  if (X && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->X.p, X + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
-  if (S && s->L > 0) CUADMM_HIP_TRY(hipMemcpy(s->S.p, S + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, hipMemcpyHostToDevice));
+  if (X && s->L > 0) { int rc2 = staged_h2d(s->X.p, X + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, s->st); if (rc2) return rc2; }
+  if (S && s->L > 0) { int rc2 = staged_h2d(s->S.p, S + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, s->st); if (rc2) return rc2; }
   if (y) for (int i = 0; i < s->m; ++i) s->y_p[i] = s->local_mode ? y[s->cons_local[s->perm[i]]] : y[s->perm[i]];
   if (sig > 0) s->sig = sig;
   return CUADMM_OK;
@@ -1462,7 +1459,7 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap) {
   if (!s->steps_d.p) { set_error("get_psd_steps: set option psd_steps=1 before init"); return CUADMM_ERR_INVALID; }
   const int n = (int)std::min<size_t>(s->steps_d.n, (size_t)std::max(cap, 0));
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
-  CUADMM_HIP_TRY(hipMemcpy(out, s->steps_d.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  { int rc2 = staged_d2h(out, s->steps_d.p, sizeof(int) * (size_t)n, s->st); if (rc2) return rc2; }
   return n;
 }
 int cuadmm_reset_profile(cuadmm_solver* s) {
@@ -1527,8 +1524,8 @@ int cuadmm_op_psd_project_ex(const double* Xb, double* Xproj, const int* blk_hos
 
 int cuadmm_dev_malloc(void** ptr, size_t bytes) { CUADMM_HIP_TRY(hipMalloc(ptr, bytes ? bytes : 8)); return CUADMM_OK; }
 int cuadmm_dev_free(void* ptr) { if (ptr) CUADMM_HIP_TRY(hipFree(ptr)); return CUADMM_OK; }
-int cuadmm_memcpy_h2d(void* dst, const void* src, size_t bytes) { if (bytes) CUADMM_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return CUADMM_OK; }
-int cuadmm_memcpy_d2h(void* dst, const void* src, size_t bytes) { if (bytes) CUADMM_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return CUADMM_OK; }
+int cuadmm_memcpy_h2d(void* dst, const void* src, size_t bytes) { return staged_h2d(dst, src, bytes); }
+int cuadmm_memcpy_d2h(void* dst, const void* src, size_t bytes) { return staged_d2h(dst, src, bytes); }
 int cuadmm_dev_sync(void) { CUADMM_HIP_TRY(hipDeviceSynchronize()); return CUADMM_OK; }
 
 // ------------------------------------------------------------------------------------------

@@ -25,8 +25,7 @@ namespace {
 template <class T>
 int to_device(T*& d, const std::vector<T>& h) {
   CUADMM_HIP_TRY(hipMalloc(&d, sizeof(T) * std::max<size_t>(h.size(), 1)));
-  if (!h.empty()) CUADMM_HIP_TRY(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
-  return CUADMM_OK;
+  return h.empty() ? CUADMM_OK : staged_h2d(d, h.data(), sizeof(T) * h.size());
 }
 
 __device__ __forceinline__ double lead_rhs(const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b,

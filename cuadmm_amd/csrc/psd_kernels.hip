@@ -318,22 +318,22 @@ int PsdPlan::build(const int* blk, int mat_num) {
   if (n_free > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_free_off, sizeof(long long) * free_off.size()));
     CUADMM_HIP_TRY(hipMalloc(&d_free_len, sizeof(long long) * free_len.size()));
-    CUADMM_HIP_TRY(hipMemcpy(d_free_off, free_off.data(), sizeof(long long) * free_off.size(), hipMemcpyHostToDevice));
-    CUADMM_HIP_TRY(hipMemcpy(d_free_len, free_len.data(), sizeof(long long) * free_len.size(), hipMemcpyHostToDevice));
+    { int rc_ = staged_h2d(d_free_off, free_off.data(), sizeof(long long) * free_off.size()); if (rc_) return rc_; }
+    { int rc_ = staged_h2d(d_free_len, free_len.data(), sizeof(long long) * free_len.size()); if (rc_) return rc_; }
   }
   CUADMM_HIP_TRY(hipMalloc(&d_off, sizeof(long long) * ((size_t)mat_num + 1)));
   CUADMM_HIP_TRY(hipMalloc(&d_n, sizeof(int) * (size_t)std::max(mat_num, 1)));
   CUADMM_HIP_TRY(hipMalloc(&d_ids, sizeof(int) * (size_t)std::max(mat_num, 1)));
   CUADMM_HIP_TRY(hipMalloc(&d_fail, sizeof(int)));
-  CUADMM_HIP_TRY(hipMemcpy(d_off, off.data(), sizeof(long long) * ((size_t)mat_num + 1), hipMemcpyHostToDevice));
-  CUADMM_HIP_TRY(hipMemcpy(d_n, blk, sizeof(int) * (size_t)mat_num, hipMemcpyHostToDevice));
-  if (!ids.empty()) CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
+  { int rc_ = staged_h2d(d_off, off.data(), sizeof(long long) * ((size_t)mat_num + 1)); if (rc_) return rc_; }
+  { int rc_ = staged_h2d(d_n, blk, sizeof(int) * (size_t)mat_num); if (rc_) return rc_; }
+  if (!ids.empty()) { int rc_ = staged_h2d(d_ids, ids.data(), sizeof(int) * ids.size()); if (rc_) return rc_; }
   h_ids = ids;
   {
     std::vector<PsdDesc> desc(std::max<size_t>(ids.size(), 1));
     for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q]};
     CUADMM_HIP_TRY(hipMalloc(&d_desc, sizeof(PsdDesc) * desc.size()));
-    CUADMM_HIP_TRY(hipMemcpy(d_desc, desc.data(), sizeof(PsdDesc) * desc.size(), hipMemcpyHostToDevice));
+    { int rc_ = staged_h2d(d_desc, desc.data(), sizeof(PsdDesc) * desc.size()); if (rc_) return rc_; }
     h_desc = desc;
   }
   {
@@ -344,7 +344,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
   if (ws_total > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_ws, sizeof(double) * (size_t)ws_total));
     CUADMM_HIP_TRY(hipMalloc(&d_wsoff, sizeof(long long) * wsoff.size()));
-    CUADMM_HIP_TRY(hipMemcpy(d_wsoff, wsoff.data(), sizeof(long long) * wsoff.size(), hipMemcpyHostToDevice));
+    { int rc_ = staged_h2d(d_wsoff, wsoff.data(), sizeof(long long) * wsoff.size()); if (rc_) return rc_; }
   }
   // nominal flops 10.67 n^3 per block, GEMM-shaped part 2 n^3
   sum_n3 = 0;
@@ -438,9 +438,9 @@ int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
     tmp.resize((size_t)rg.second);
     for (int q = 0; q < rg.second; ++q) tmp[(size_t)cnt[key(h_desc[rg.first + q])]++] = h_desc[rg.first + q];
     std::copy(tmp.begin(), tmp.end(), h_desc.begin() + rg.first);
-    CUADMM_HIP_TRY(hipMemcpyAsync(d_desc + rg.first, &h_desc[rg.first], sizeof(PsdDesc) * (size_t)rg.second, hipMemcpyHostToDevice, st));
+    int rc = staged_h2d(d_desc + rg.first, &h_desc[rg.first], sizeof(PsdDesc) * (size_t)rg.second, st);
+    if (rc) return rc;
   }
-  CUADMM_HIP_TRY(hipStreamSynchronize(st));     // h_desc is pageable: the copies are staged, but keep the ordering explicit
   return CUADMM_OK;
 }
 
@@ -469,7 +469,7 @@ int PsdPlan::build_rest_index() {
   n_rest = (long long)rest.size();
   if (n_rest > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_rest, sizeof(int) * rest.size()));
-    CUADMM_HIP_TRY(hipMemcpy(d_rest, rest.data(), sizeof(int) * rest.size(), hipMemcpyHostToDevice));
+    { int rc_ = staged_h2d(d_rest, rest.data(), sizeof(int) * rest.size()); if (rc_) return rc_; }
   }
   return CUADMM_OK;
 }
@@ -647,7 +647,7 @@ int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream
     for (int i = 0; i < count; ++i) off[i] = (long long)i * n * (n | 1);
     CUADMM_HIP_TRY(hipMalloc(&ws, sizeof(double) * (size_t)count * n * (n | 1)));
     CUADMM_HIP_TRY(hipMalloc(&wsoff, sizeof(long long) * (size_t)count));
-    CUADMM_HIP_TRY(hipMemcpy(wsoff, off.data(), sizeof(long long) * (size_t)count, hipMemcpyHostToDevice));
+    { int rc_ = staged_h2d(wsoff, off.data(), sizeof(long long) * (size_t)count); if (rc_) return rc_; }
     a.workspace = ws; a.ws_off = wsoff;
   }
   int rc = launch_class<1>(c, a, n, st);

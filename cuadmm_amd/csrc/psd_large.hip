@@ -498,7 +498,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
     }
   }
   CUADMM_HIP_TRY(hipMalloc(&d_ids, sizeof(int) * ids.size()));
-  CUADMM_HIP_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
+  { int rc_ = staged_h2d(d_ids, ids.data(), sizeof(int) * ids.size()); if (rc_) return rc_; }
   CUADMM_HIP_TRY(hipMalloc(&X0, sizeof(double) * max_elems));
   CUADMM_HIP_TRY(hipMalloc(&S, sizeof(double) * max_elems));
   CUADMM_HIP_TRY(hipMalloc(&Y, sizeof(double) * max_elems));
@@ -629,7 +629,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       std::vector<SignDone> hs((size_t)cnt);
-      CUADMM_HIP_TRY(hipMemcpy(hs.data(), sa.done, sizeof(SignDone) * (size_t)cnt, hipMemcpyDeviceToHost));
+      { int rc_ = staged_d2h(hs.data(), sa.done, sizeof(SignDone) * (size_t)cnt, st); if (rc_) return rc_; }
       double steps = 0;
       int smax = 0;
       for (const SignDone& x : hs) { steps += x.steps; smax = std::max(smax, x.steps); }

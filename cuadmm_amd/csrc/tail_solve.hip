@@ -364,13 +364,14 @@ int TailSolve::build(const double* L22, const double* D2, int k_, hipStream_t st
   CUADMM_HIP_TRY(hipMalloc(&dL, sizeof(double) * sz));
   // upload: rows of L22 (leading dimension k) into the padded matrix (identity in the padding)
   CUADMM_HIP_TRY(hipMemsetAsync(dL, 0, sizeof(double) * sz, st));
-  CUADMM_HIP_TRY(hipMemcpy2DAsync(dL, sizeof(double) * (size_t)ld, L22, sizeof(double) * (size_t)k, sizeof(double) * (size_t)k, (size_t)k,
-                                  hipMemcpyHostToDevice, st));
+  if ((rc = staged_h2d_2d(dL, sizeof(double) * (size_t)ld, L22, sizeof(double) * (size_t)k, sizeof(double) * (size_t)k, (size_t)k, st))) {
+    hipError_t e = hipFree(dL); (void)e;
+    return rc;
+  }
   {
     std::vector<double> di((size_t)K, 1.0);
     for (int i = 0; i < k; ++i) di[i] = 1.0 / D2[i];
-    CUADMM_HIP_TRY(hipMemcpyAsync(dinv, di.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
-    CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = staged_h2d(dinv, di.data(), sizeof(double) * (size_t)K, st))) { hipError_t e = hipFree(dL); (void)e; return rc; }
   }
   rc = invert(dL, st);   // the padding rows of dL are zero: the diagonal is implicit
   { hipError_t e = hipFree(dL); (void)e; }
@@ -404,9 +405,10 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   if (e == hipSuccess) e = hipMalloc(&dflag, sizeof(int));
   if (e == hipSuccess) e = hipMemsetAsync(dS, 0, sizeof(double) * sz, st);
   if (e == hipSuccess) e = hipMemsetAsync(dflag, 0, sizeof(int), st);
-  if (e == hipSuccess) e = hipMemcpyAsync(drp, row_ptr, sizeof(long long) * ((size_t)k + 1), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(dci, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(dval, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && (staged_h2d(drp, row_ptr, sizeof(long long) * ((size_t)k + 1), st) ||
+                          (nnz > 0 && (staged_h2d(dci, col, sizeof(int) * (size_t)nnz, st) || staged_h2d(dval, val, sizeof(double) * (size_t)nnz, st))))) {
+    cleanup(); release(); return CUADMM_ERR_NO_DEVICE;
+  }
   if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return e == hipErrorOutOfMemory ? CUADMM_ERR_INVALID : CUADMM_ERR_NO_DEVICE; }
   hipLaunchKernelGGL(ts_scatter_csr_kernel, dim3(K), dim3(256), 0, st, drp, dci, dval, k, dS, ld);
   const int nbk = K / 64;

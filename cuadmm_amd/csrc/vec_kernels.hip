@@ -447,7 +447,7 @@ int AtyLongRows::build(long long L, const int* rp_host) {
   nlong = (int)lr.size();
   if (nlong == 0) return CUADMM_OK;
   CUADMM_HIP_TRY(hipMalloc(&rows, sizeof(int) * lr.size()));
-  CUADMM_HIP_TRY(hipMemcpy(rows, lr.data(), sizeof(int) * lr.size(), hipMemcpyHostToDevice));
+  { int rc_ = staged_h2d(rows, lr.data(), sizeof(int) * lr.size()); if (rc_) return rc_; }
   return CUADMM_OK;
 }
 void AtyLongRows::release() {
@@ -539,10 +539,10 @@ int SpmvLongRows::build(int rows, const int* rp_host) {
   CUADMM_HIP_TRY(hipMalloc(&seg_begin, sizeof(int) * sb.size()));
   CUADMM_HIP_TRY(hipMalloc(&seg_end, sizeof(int) * se.size()));
   CUADMM_HIP_TRY(hipMalloc(&partial, sizeof(double) * 2 * sb.size()));
-  CUADMM_HIP_TRY(hipMemcpy(long_row, lrow.data(), sizeof(int) * lrow.size(), hipMemcpyHostToDevice));
-  CUADMM_HIP_TRY(hipMemcpy(long_seg0, lseg0.data(), sizeof(int) * lseg0.size(), hipMemcpyHostToDevice));
-  CUADMM_HIP_TRY(hipMemcpy(seg_begin, sb.data(), sizeof(int) * sb.size(), hipMemcpyHostToDevice));
-  CUADMM_HIP_TRY(hipMemcpy(seg_end, se.data(), sizeof(int) * se.size(), hipMemcpyHostToDevice));
+  { int rc_ = staged_h2d(long_row, lrow.data(), sizeof(int) * lrow.size()); if (rc_) return rc_; }
+  { int rc_ = staged_h2d(long_seg0, lseg0.data(), sizeof(int) * lseg0.size()); if (rc_) return rc_; }
+  { int rc_ = staged_h2d(seg_begin, sb.data(), sizeof(int) * sb.size()); if (rc_) return rc_; }
+  { int rc_ = staged_h2d(seg_end, se.data(), sizeof(int) * se.size()); if (rc_) return rc_; }
   return CUADMM_OK;
 }
 void SpmvLongRows::release() {
