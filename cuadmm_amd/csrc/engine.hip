@@ -918,6 +918,10 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->Cscale = 1 + std::sqrt(nc);
   s->objscale = s->bscale * s->Cscale;
   const double ibs = 1 / s->bscale, ics = 1 / s->Cscale;   // *_div_scalar multiply by 1/s (dense_scalar.cu:77-81)
+  if (s->y_registered) {   // a second init on the same handle: the registration must not outlive the storage it names
+    hipError_t e = hipHostUnregister(s->y_p.data()); (void)e;
+    s->y_registered = false;
+  }
   s->normA_p.resize(m); s->b_p.resize(m); s->y_p.assign(m, 0.0); s->Rp_p.assign(m, 0.0);
   s->y_best_p.assign(m, 0.0);
   if (m > 0 && hipHostRegister(s->y_p.data(), sizeof(double) * (size_t)m, hipHostRegisterDefault) == hipSuccess) s->y_registered = true;
