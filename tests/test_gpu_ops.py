@@ -216,3 +216,21 @@ def test_tail_factor_solve_op_dense_ldlt_on_gpu(k):
         zz = np.ones(3)
         check(lib.cuadmm_op_tail_factor_solve(P(Z.indptr.astype(np.int64)), P(Z.indices.astype(np.int32)), P(Z.data.astype(np.float64)), 3, P(zz), 1))
     assert "Factorization fails" in str(e.value)
+
+
+@pytest.mark.parametrize("nbytes", [8, 4096, (16 << 20) - 8, 16 << 20, (16 << 20) + 8, 40 << 20])
+def test_staged_copies_round_trip(nbytes):
+    """cuadmm_memcpy_h2d / _d2h go through the library's page-locked staging halves (csrc/staging.hip: 2 x 16 MB) -- never
+    hipMemcpy on caller memory: sizes around the chunk boundaries, freshly allocated and freed host arrays in between (the
+    pattern that made the runtime's cached registrations go stale)."""
+    rng = np.random.default_rng(nbytes % 1000)
+    n = nbytes // 8
+    for rep in range(3):
+        x = rng.standard_normal(n)
+        want = x.copy()
+        d = Dev(x)
+        del x                                   # the source array is gone before the next allocation / copy
+        junk = np.full(n + 1024 * rep, float(rep))   # the freed range goes to another owner
+        y = d.get()
+        assert y.shape == (n,) and np.array_equal(y, want)
+        del junk, d
