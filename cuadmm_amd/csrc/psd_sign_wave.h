@@ -158,8 +158,10 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   const long long c0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   // ---- prologue: the tile takes X (fused: Xb = X + sigma (A^T y - C), formed here); ||X||_F is the 2-norm of the svec (the
   // sqrt2 counts the off-diagonals twice) and goes onto the fragments of the first step
+  if (n < NP) {                          // a full-size block writes every entry of the tile itself
 #pragma unroll 1
-  for (int e = lane; e < NP * LD; e += 64) S[e] = 0.0;
+    for (int e = lane; e < NP * LD; e += 64) S[e] = 0.0;
+  }
   if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[4] = (long long)__builtin_readcyclecounter() - c0; }
   const bool local_rows = FUSED && fz.lc != nullptr, closed = FUSED && fz.cs_L != nullptr;
   LcDesc lcd = {0, 0, 0, 0};
