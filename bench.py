@@ -145,7 +145,7 @@ def issued_mfma_flops(blk, steps):
     m = blk > 64
     if m.any():
         N = (blk[m] + 63) // 64 * 64
-        tm = np.where((N >= 256) & (N <= 3000), 32, 64)      # lg_small_tiles (single large matrix / small groups)
+        tm = np.where((N >= 128) & (N <= 3000), 32, 64)      # lg_small_tiles (single large matrix / small groups)
         N = np.where((tm == 32) & (blk[m] <= N - 32), N - 32, N)   # 32 x 32 tiles: the padding is a multiple of 32 (SignPsd::build)
         nb = N // tm
         fl[m] = (steps[m] * 2 + 1) * 2.0 * N * tm * tm * (nb * (nb + 1) // 2)

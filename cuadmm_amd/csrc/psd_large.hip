@@ -410,7 +410,10 @@ static bool lg_small_tiles(bool mirror, int N, int count) {
   static const int tile_force = getenv("CUADMM_LG_TILE") ? atoi(getenv("CUADMM_LG_TILE")) : 0;
   const int nb64 = N / 64;
   const long long tiles64 = (long long)(mirror ? nb64 * (nb64 + 1) / 2 : nb64 * nb64) * count;
-  return tile_force ? tile_force == 32 : (mirror && N >= 256 && tiles64 < 1300);   // measured: better up to N ~ 3000
+  // measured: better up to N ~ 3000, and down to N = 128 (a moment relaxation's handful of 65 <= n <= 128 blocks: the launch
+  // is a few workgroups deep, and four times as many, four times smaller ones finish sooner -- PlanarHand_N=1: projection
+  // 1.41 -> 1.02 ms)
+  return tile_force ? tile_force == 32 : (mirror && N >= 128 && tiles64 < 1300);
 }
 
 template <int ROLE>
