@@ -171,7 +171,7 @@ CUADMM_SW32_KERNEL(psd_sign_wave32_dbg_kernel, 3, true)     // CUADMM_PSD_DEBUG:
 #undef CUADMM_SW32_KERNEL
 
 // one WAVEFRONT per block (psd_sign_wave.h): NT = 3 (n <= 48, two wavefronts per SIMD), NT = 4 (n <= 64, one); NT = 2 is the
-// A/B twin of psd_sign_wave32_kernel with column-pair loads (CUADMM_PSD_W32_GEN=<waves per SIMD>)
+// successor of psd_sign_wave32_kernel (CUADMM_PSD_W32_GEN=3|4: waves per SIMD; 0 = the hand-unrolled kernel)
 template <int NT, int OCC, bool FUSED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_wave_kernel(PsdArgs a, SignFuse fz, int first, int count, int slot0) {
   extern __shared__ double swt_smem[];
