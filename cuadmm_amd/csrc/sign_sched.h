@@ -183,7 +183,9 @@ struct SignSched {
 
 // Scalar model of the iteration on a spectrum (the iteration acts on eigenvalues independently): used by the CPU tests
 // and by tools/sign_schedule_sim.py.  s[i] = |lambda_i| / ||X||_1 on entry, the sign estimates on exit.
-// lag: 0 = decisions from the current iterate, 1 = lagged (g of the previous iterate), 2 = deferred ((a, b, g) of the previous one)
+// lag: 0 = decisions from the current iterate (statistics skipped where needs_stats() says so, as the kernels do), 1 = lagged
+// (g of the previous iterate), 2 = deferred ((a, b, g) of the previous one: measured and rejected), 3 = as 0 but with the
+// statistics passed on every step (the reference for the claim that skipping them changes nothing)
 inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int lift0 = 0, int* lifts_out = nullptr) {
   SignSched st;
   if (lift0 > 0) st.lift0 = lift0;
@@ -199,7 +201,9 @@ inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int l
       a += y; b += y * y; g2 += r * r;
     }
     double mu;
-    if (lag) {
+    if (lag == 3) {
+      mu = st.decide<false>(n, a, b, g2, last);
+    } else if (lag) {
       st.gprev = st.steps == 0 ? -1.0 : sqrt(g2_prev);
       if (lag == 2 && st.steps > 0) mu = st.decide<true>(n, a_prev, b_prev, 0.0, last);
       else mu = st.decide<true>(n, a, b, 0.0, last);

@@ -127,3 +127,27 @@ def test_schedule_warm_start_hint_costs_steps_only():
         assert err.value <= 2.5e-13
         saved += base - steps2
     assert saved > 0                      # on average the warm start is a gain
+
+
+def test_skipping_the_statistics_changes_no_decision():
+    """The one-wavefront kernels skip the three wave reductions on the steps whose scale is fixed in advance
+    (SignSched::needs_stats: lift phases, bursts, the two probe steps).  Mode 0 of the host model calls the state machine
+    the same way; mode 3 passes the statistics on every step: identical step counts and identical iterates, bit for bit."""
+    rng = np.random.default_rng(2024)
+    specs = list(_spectra(rng).values())
+    for _ in range(300):
+        n = int(rng.integers(2, 65))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            w = rng.standard_normal(n)
+        elif kind == 1:
+            w = 10.0 ** rng.uniform(-16, 0, n) * rng.choice([-1.0, 1.0], n)
+        elif kind == 2:
+            w = rng.standard_normal(n); w[: n // 2] = 0.0
+        else:
+            w = rng.standard_normal(n) * 1e-9; w[:2] = rng.uniform(0.3, 1.0, 2)
+        specs.append(w / max(np.sqrt((w * w).sum()), 1e-300))
+    for w in specs:
+        st0, e0, s0 = _run(w, 0)
+        st3, e3, s3 = _run(w, 3)
+        assert st0 == st3 and e0 == e3 and np.array_equal(s0, s3)
