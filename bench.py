@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--sharding", choices=["owned", "allreduce"], default="owned")
     ap.add_argument("--mode", choices=["admm", "sgs"], default="admm")
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch")
+    ap.add_argument("--batch", type=int, default=None, help="ADMM iterations per launch on closed blocks (engine option 'batch'; 0 = one launch per iteration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -224,7 +225,8 @@ def main():
     eng_world, eng_rank = (1, 0) if replicas else (world, rank)
     use_comm = (world > 1 and not replicas) or force_dist
     solver = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, profile=2,
-                                  force_comm=force_dist, psd_steps=True)
+                                  force_comm=force_dist, psd_steps=True,
+                                  options={} if args.batch is None else {"batch": args.batch})
 
     keep = []
     if use_comm:
@@ -293,7 +295,9 @@ def main():
 
     if rank == 0:
         psd = prof["psd_project"]
-        psd_ms = psd["ms"] / max(psd["launches"], 1)
+        launches = max(psd["launches"], 1)
+        iters_per_launch = args.steps / launches          # > 1 when the engine runs several iterations per launch (option "batch")
+        psd_ms = psd["ms"] / args.steps                   # projection time per ITERATION; a launch takes psd_ms * iters_per_launch
         L_local = int(np.sum(blk_local.astype(np.int64) * (blk_local + 1) // 2))
         # read Xb + write Xproj, 8 B each per svec element; blocks of the FUSED iteration (9 <= n <= 64, psd_fuse.h)
         # also carry the vector work of aty_xb / post: row pointer 4 + C 8 + X 8 read, Rd1 8 write | X 8 + Rd1 8 + C 8 read,
@@ -338,24 +342,26 @@ def main():
                          "achieved": nominal_flops / per_s / 1e12 if per_s > 0 else 0.0,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (nominal_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
-                         "traffic": pmc_traffic(kname, args.config), "avg_launch_ms": psd_ms,
+                         "traffic": pmc_traffic(kname, args.config), "avg_launch_ms": psd_ms * iters_per_launch,
+                         "launches": int(launches), "iterations_per_launch": iters_per_launch, "ms_per_iteration": psd_ms,
                          # what the matrix cores deliver when EVERY SIMD runs nothing but independent v_mfma_f64_16x16x4_f64
                          # (tools/ubench/mfma_sustained.hip, profiles/r02_mfma_sustained.log): the achievable ceiling
                          "sustained_mfma_peak_measured": SUSTAINED_FP64_MFMA_TFLOPS,
                          "mfma_issued_frac_of_sustained": (issued_flops / per_s / 1e12 / SUSTAINED_FP64_MFMA_TFLOPS) if per_s > 0 else 0.0,
-                         "algorithmic_flops_per_launch": nominal_flops,
+                         "algorithmic_flops_per_launch": nominal_flops * iters_per_launch,
                          "mfma_issued_tflops": issued_flops / per_s / 1e12 if per_s > 0 else 0.0,
                          "mfma_pipe_util": (issued_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
                          "newton_schulz_steps": {"mean": float(steps_blk[sign_blocks].mean()) if sign_blocks.any() else 0.0,
                                                  "max": int(steps_blk.max()) if steps_blk.size else 0,
                                                  "note": "per-block adaptive schedule (csrc/sign_sched.h); round 1 ran a fixed 44"},
-                         "hbm_gbs": alg_bytes / per_s / 1e9 if per_s > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes,
+                         "hbm_gbs": alg_bytes / per_s / 1e9 if per_s > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes * iters_per_launch,
                          "note": "fp64 matrix-core bound (DESIGN.md section 4); traffic = FETCH_SIZE*2 + WRITE_SIZE from the "
                                  "committed rocprofv3 PMC passes (profiles/); algorithmic bytes 68 B per svec element of a fused block "
                                  "(the launch also does the aty_xb / post vector work), 16 B elsewhere",
                          "blocks_per_s": blk_local.size / per_s if per_s > 0 else 0.0},
             "final_state": {k: st[k] for k in ("errRp", "errRd", "relgap", "sig")},
         }
+        out["engine_plan"] = solver.counters()
         if breakdown is not None:
             out["breakdown_ms_per_iter"] = breakdown      # psd_project / aty_xb / post_proj / spmv_A / copies / comm / host / tail_solve
         if world == 1 and not args.no_cpu_baseline:

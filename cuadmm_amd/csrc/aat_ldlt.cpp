@@ -15,12 +15,17 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <numeric>
 #include <thread>
+
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include "common.h"
 
@@ -182,8 +187,10 @@ class HostPool {
     }
     job = &f;
     pending.store(T - 1, std::memory_order_relaxed);
-    gen.fetch_add(1, std::memory_order_release);
-    if (sleepers.load(std::memory_order_acquire) > 0) {
+    // store-buffer pattern with the worker's (sleepers++ ; read gen): both sides sequentially consistent, or on a weakly
+    // ordered host each could miss the other (worker asleep, no notify, caller spinning on `pending` for ever)
+    gen.fetch_add(1, std::memory_order_seq_cst);
+    if (sleepers.load(std::memory_order_seq_cst) > 0) {
       std::lock_guard<std::mutex> lk(mu);      // pairs with the predicate check of a worker about to block
       cv_start.notify_all();
     }
@@ -217,8 +224,8 @@ class HostPool {
       }
       if (!got) {
         std::unique_lock<std::mutex> lk(mu);
-        sleepers.fetch_add(1, std::memory_order_acq_rel);
-        cv_start.wait(lk, [&] { return stop.load() || gen.load(std::memory_order_acquire) != seen; });
+        sleepers.fetch_add(1, std::memory_order_seq_cst);
+        cv_start.wait(lk, [&] { return stop.load() || gen.load(std::memory_order_seq_cst) != seen; });
         sleepers.fetch_sub(1, std::memory_order_acq_rel);
         if (stop.load()) return;
       }
@@ -238,14 +245,39 @@ class HostPool {
   std::atomic<bool> stop{false};
 };
 
-// CUADMM_HOST_THREADS (default 8, 1 = serial).  Created on first use, lives until process exit.
+// CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 hardware threads
+// under a 16-CPU quota: eight ranks with eight spinning threads each would be 64 busy threads on 16 CPUs).
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+#if defined(__linux__)
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = c; }
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[64] = {0};
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", quota, &period) == 2 && quota[0] != 'm' && period > 0) {
+      const long long q = atoll(quota);
+      if (q > 0) n = std::min<long long>(n, std::max<long long>(1, (q + period / 2) / period));
+    }
+    fclose(f);
+  }
+#endif
+  return std::max(1, n);
+}
+
+// Threads of the host pool: CUADMM_HOST_THREADS if set (1 = serial), else min(8, usable CPUs / ranks on this node) -- the
+// launcher's LOCAL_WORLD_SIZE (torch.distributed.run) or cuadmm_host_pool_hint() say how many ranks share the node.  Created on
+// first use, lives until process exit.
+static std::atomic<int> g_pool_ranks_hint{0};
 HostPool& host_pool() {
   static HostPool pool([] {
     const char* e = getenv("CUADMM_HOST_THREADS");
-    int t = e ? atoi(e) : 8;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0) t = std::min(t, hw);
-    return std::max(1, t);
+    if (e) return std::max(1, atoi(e));
+    int ranks = g_pool_ranks_hint.load();
+    if (ranks <= 0) { const char* l = getenv("LOCAL_WORLD_SIZE"); ranks = l ? atoi(l) : 1; }
+    ranks = std::max(1, ranks);
+    return std::max(1, std::min(8, usable_cpus() / ranks));
   }());
   return pool;
 }
@@ -673,6 +705,10 @@ int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
 }
 
 void cuadmm_aat_free(cuadmm_aat* f) { delete f; }
+
+// how many ranks share this node's CPUs (before the pool's first use; later calls are ignored)
+void cuadmm_host_pool_hint(int ranks_on_node) { if (ranks_on_node > 0) g_pool_ranks_hint.store(ranks_on_node); }
+int cuadmm_host_pool_threads(void) { return host_pool().size(); }
 
 // fn(chunk, ctx) for chunk = 0..nchunks-1 on the host pool (CUADMM_HOST_THREADS); chunks are handed out statically
 // (chunk c runs on thread c mod T), so anything reduced per chunk and combined in chunk order is reproducible.

@@ -56,3 +56,5 @@ void partition_blocks(const int* blk, int mat_num, int world, std::vector<int>& 
 
 // host thread pool of aat_ldlt.cpp (internal): fn(chunk, ctx) for chunk = 0..nchunks-1
 extern "C" void cuadmm_host_parallel_for(int nchunks, void (*fn)(int, void*), void* ctx);
+extern "C" void cuadmm_host_pool_hint(int ranks_on_node);
+extern "C" int cuadmm_host_pool_threads(void);

@@ -48,9 +48,11 @@ struct DevBuf {
     if (count == 0) return CUADMM_OK;
     return staged_h2d(p, h, sizeof(T) * count);   // never hipMemcpy on caller / vector memory (staging.hip)
   }
-  int from(const std::vector<T>& h) {
-    int rc = alloc(h.size());
+  int from(const std::vector<T>& h, size_t pad = 0) {   // pad: extra (zeroed) elements behind the data
+    int rc = alloc(h.size() + pad);
     if (rc) return rc;
+    n = h.size();
+    if (pad) CUADMM_HIP_TRY(hipMemset(p + h.size(), 0, sizeof(T) * pad));
     return upload(h.data(), h.size());
   }
   void release() {
@@ -81,6 +83,7 @@ struct PinnedBuf {
 // Host loops over the m constraints: serial below kHostParMin, else kHostChunks fixed index ranges on the host pool
 // (aat_ldlt.cpp).  Sums are formed per range and combined in range order: reproducible for any thread count.
 constexpr int kHostParMin = 20000, kHostChunks = 32;
+constexpr size_t kSvecPad = 64 * 40;       // >= 64 * U * batches of every tile geometry (psd_sign_closed.h)
 template <class F>
 static void host_ranges(int m, F&& body) {   // body(chunk, lo, hi)
   if (m < kHostParMin) { body(0, 0, m); return; }
@@ -178,18 +181,38 @@ struct cuadmm_solver {
     DevBuf<LcDesc> desc;
     DevBuf<int> row, nzptr, e, rest_rp, rest_ci, rest_map;
     DevBuf<double> v, rest_v;
-    std::vector<LcDesc> h_desc;      // host copies for the closed-block solve set-up
-    std::vector<int> h_row, h_At_ci;
+    std::vector<LcDesc> h_desc;      // host copies for the closed-block set-up
+    std::vector<int> h_row, h_nzptr, h_e;
+    std::vector<double> h_v;
   } lrows;
   // closed blocks (psd_fuse.h): every constraint is local to one fused block and no block has more than kClosedMaxRows of
   // them -> the blocks solve for their own multipliers and add their share of ||Rp||^2, b^T y inside the projection kernel
   struct ClosedSolve {
     bool active = false;
-    DevBuf<double> L, partials2;
-    DevBuf<int> off, ci_local;
+    DevBuf<ClosedRec> rec;         // one record per fused slot (psd_fuse.h)
+    DevBuf<double> partials2, cl_out;
+    bool out_dirty = true;         // a stand-alone kernel rewrote [A X | A (S - C)] by row: refresh the per-block copy first
   } closed;
   bool stats_fused = false;        // this iteration's four scalars were formed by launch_reduce_quads
   int fused_nparts = 0;
+  // Several iterations per launch (SignFuse::iters; closed blocks, ADMM phase): option "batch" = most iterations per launch
+  // (0 / 1: off).  bt_p1 / bt_p2: the per-iteration partial arrays, bt_h: the four scalars of every iteration of the batch
+  // (pinned, written by the reduction through its device mapping when no collective is needed), ck_*: the checkpoint a batch
+  // starts from (restored when the stopping test or the tau rule fires inside it).
+  struct Batch {
+    int max_iters = 32;
+    DevBuf<double> p1, p2, scal_d, ck_X, ck_S, ck_y, ck_out;
+    PinnedBuf<double> h;
+    double* h_dev = nullptr;
+    long long pstride = 0;
+    int len = 0, pos = 0;          // iterations launched / consumed by the host loop
+    double tau = 0, sig = 0;
+    long long launches = 0, iters = 0, rollbacks = 0;
+  } bt;
+  // X, S (device) and y hold SCALED values after a solve until somebody looks at them (materialise): a second solve with
+  // if_first = false then simply continues, instead of unscaling and rescaling three vectors and recomputing A X, A (S - C)
+  bool pending_unscale = false;
+  int lazy_unscale = 1;
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -223,6 +246,8 @@ struct cuadmm_solver {
   DevBuf<int> steps_d, hint_d;
   std::vector<int> steps_h;
   long long lpt_next = 3, lpt_iters = 0;       // longest-block-first reordering: next event, iterations so far
+  PinnedBuf<int> steps_pin;                    // batched launches: step counts fetched behind one batch, sorted during the next
+  bool lpt_steps_ready = false;
   // Where the kernels write [A*X | sums | A*(S-C)]: the device buffer out_d when it has to be all-reduced, otherwise the
   // pinned host buffer h_out itself through its device mapping -- the results cross PCIe as the kernels produce them and
   // fetch_out is a stream synchronisation without a copy.
@@ -299,11 +324,14 @@ struct cuadmm_solver {
   // owned-constraints mode: v[0..n) <- sum over ranks (host values through a small device buffer; blocks)
   int allreduce_scalars(double* v, int n) {
     if (!local_mode || comm_world <= 1) return CUADMM_OK;
-    CUADMM_HIP_TRY(hipMemcpyAsync(scal_d.p, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    // through the page-locked h_scal: the runtime must never register stack or caller memory (staging.hip)
+    for (int q = 0; q < n; ++q) h_scal.p[q] = v[q];
+    CUADMM_HIP_TRY(hipMemcpyAsync(scal_d.p, h_scal.p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
     int rc = comm_allreduce(scal_d.p, (size_t)n);
     if (rc) return rc;
-    CUADMM_HIP_TRY(hipMemcpyAsync(v, scal_d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    CUADMM_HIP_TRY(hipMemcpyAsync(h_scal.p, scal_d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
     CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < n; ++q) v[q] = h_scal.p[q];
     return CUADMM_OK;
   }
 
@@ -388,6 +416,7 @@ struct cuadmm_solver {
   }
   // after_fused: the local rows were written by the fused projection kernels of this step -- only the other rows are left
   int launch_spmv(bool doX, bool doS, bool after_fused = false) {
+    if (!(after_fused && lrows.active && lrows.nrest == 0)) closed.out_dirty = true;
     if (after_fused && lrows.active) {
       if (lrows.nrest == 0) return CUADMM_OK;
       prof_begin(K_SPMV);
@@ -410,7 +439,7 @@ struct cuadmm_solver {
   }
   // Step 2 of a fused iteration: Rd1 / Xb on the rest of the svec, then the projection whose fused blocks also do the
   // post step `mode` (0: S, X, sums; 1: S only) on their own ranges, then the post step on the rest (+ the sums).
-  int launch_fused_step(int mode, double tau) {
+  int launch_fused_step(int mode, double tau, int iters = 1) {
     int rc;
     prof_begin(K_ATY);
     rc = launch_aty_xb_idx(plan.n_rest, plan.d_rest, At_rp.p, At_ci.p, At_v.p, y_d.p, C.p, X.p, sig, Rd1.p, Xb.p, st);
@@ -426,11 +455,29 @@ struct cuadmm_solver {
       fz.outS = out_w + m + 2;
     }
     if (closed.active) {
-      fz.cs_L = closed.L.p; fz.cs_off = closed.off.p; fz.cs_D = f_D.p; fz.ci_local = closed.ci_local.p;
-      fz.b = b_d.p; fz.normA = normA_d.p; fz.y_out = y_d.p;
-      fz.ax_old = out_d.p; fz.as_old = out_d.p + (size_t)m + 2;
+      fz.rec = closed.rec.p; fz.cl_out = closed.cl_out.p; fz.y_out = y_d.p;
       fz.partials2 = closed.partials2.p;
       fz.isig = 1 / sig; fz.bscale = bscale;
+      if (closed.out_dirty) {
+        if ((rc = launch_closed_gather_out(closed.rec.p, plan.fused_blocks(), out_d.p, out_d.p + (size_t)m + 2, closed.cl_out.p, st))) return rc;
+        closed.out_dirty = false;
+      }
+    }
+    if (iters > 1) {   // batch: every block is closed and fused (can_batch), nothing runs beside the projection launches
+      fz.iters = iters; fz.pstride = bt.pstride; fz.partials = bt.p1.p; fz.partials2 = bt.p2.p;
+      prof_begin(K_PSD);
+      rc = plan.project(Xb.p, Xproj.p, st, &fz);
+      prof_end(K_PSD, 68.0 * (double)L * iters);
+      if (rc) return rc;
+      prof_begin(K_POST);
+      double* dst = (!dev_scalars && bt.h_dev) ? bt.h_dev : bt.scal_d.p;
+      rc = launch_reduce_quads_batch(bt.p1.p, bt.p2.p, plan.fused_blocks(), bt.pstride, iters, dst, st);
+      prof_end(K_POST, 0.0);
+      if (rc) return rc;
+      if (dev_scalars && (rc = comm_allreduce(bt.scal_d.p, 4 * (size_t)iters))) return rc;
+      if (dst == bt.scal_d.p) CUADMM_HIP_TRY(hipMemcpyAsync(bt.h.p, bt.scal_d.p, sizeof(double) * 4 * (size_t)iters, hipMemcpyDeviceToHost, st));
+      bt.launches++; bt.iters += iters;
+      return CUADMM_OK;
     }
     prof_begin(K_PSD);
     rc = plan.project(Xb.p, Xproj.p, st, &fz);
@@ -448,6 +495,55 @@ struct cuadmm_solver {
     prof_end(K_POST, (mode == 0 ? 48.0 : 32.0) * (double)plan.n_rest);
     return rc;
   }
+  // --- several iterations per launch ---------------------------------------------------------------------------------
+  bool can_batch() const {
+    return bt.max_iters >= 2 && fuse && closed.active && dev_solve && !lead.ready && plan.n_rest == 0 && eig_rank == 0 && !out_mapped &&
+           plan.fused_blocks() > 0;
+  }
+  int batch_alloc() {
+    if (bt.p1.p) return CUADMM_OK;
+    bt.pstride = 2 * (long long)plan.fused_blocks() + 2;
+    int rc;
+    if ((rc = bt.p1.alloc((size_t)bt.pstride * bt.max_iters)) || (rc = bt.p2.alloc((size_t)bt.pstride * bt.max_iters)) ||
+        (rc = bt.scal_d.alloc(4 * (size_t)bt.max_iters)) || (rc = bt.h.alloc(4 * (size_t)bt.max_iters)) || (rc = bt.ck_X.alloc(L)) ||
+        (rc = bt.ck_S.alloc(L)) || (rc = bt.ck_y.alloc(std::max(m, 1))) || (rc = bt.ck_out.alloc(2 * (size_t)m + 2)))
+      return rc;
+    void* dp = nullptr;
+    if (!getenv("CUADMM_NO_MAPPED_OUT") && hipHostGetDevicePointer(&dp, bt.h.p, 0) == hipSuccess && dp) bt.h_dev = static_cast<double*>(dp);
+    else { hipError_t e = hipGetLastError(); (void)e; }
+    return CUADMM_OK;
+  }
+  int batch_copy(bool save) {   // checkpoint of everything an iteration reads and writes: X, S, y, [A X | sums | A (S - C)]
+    prof_begin(K_COPY);
+    struct { double* live; double* ck; size_t n; } v[4] = {{X.p, bt.ck_X.p, (size_t)L}, {S.p, bt.ck_S.p, (size_t)L}, {y_d.p, bt.ck_y.p, (size_t)m},
+                                                           {out_d.p, bt.ck_out.p, 2 * (size_t)m + 2}};
+    for (auto& q : v)
+      if (q.n) CUADMM_HIP_TRY(hipMemcpyAsync(save ? q.ck : q.live, save ? q.live : q.ck, sizeof(double) * q.n, hipMemcpyDeviceToDevice, st));
+    prof_end(K_COPY, 16.0 * (2.0 * (double)L + 3.0 * m + 2));
+    return CUADMM_OK;
+  }
+  // the device ran bt.len iterations, the host schedule accepts only the first `keep` of them: back to the checkpoint and
+  // forward again by `keep` iterations (bit-identical: same kernels, same inputs)
+  int batch_rollback(int keep) {
+    int rc = batch_copy(false);
+    if (rc) return rc;
+    closed.out_dirty = true;
+    const double sig_now = sig;
+    sig = bt.sig;
+    if (keep == 1) rc = launch_fused_step(0, bt.tau);
+    else if (keep > 1) rc = launch_fused_step(0, bt.tau, keep);
+    sig = sig_now;
+    if (rc) return rc;
+    CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    prof_collect();
+    stats_fused = false;
+    bt.len = bt.pos = 0;
+    bt.rollbacks++;
+    return CUADMM_OK;
+  }
+  // X, S, y back in the caller's units (solver.cu:814-816); a no-op unless a solve left them scaled
+  int materialise();
+
   int launch_post_mode(int mode, double tau) {
     prof_begin(K_POST);
     int rc = launch_post(mode, L, Xproj.p, Rd1.p, C.p, X.p, S.p, 1 / sig, tau * sig, partials.p, out_w + (size_t)m, st);
@@ -500,6 +596,8 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "eig_rank_begin_iter") s->eig_rank_begin_iter = (int)value;
   else if (k == "eig_rank_maxfeas") s->eig_rank_maxfeas = value;
   else if (k == "psd_steps") s->psd_steps = (int)value;       // record the sign kernels' step count per block (cuadmm_get_psd_steps)
+  else if (k == "batch") s->bt.max_iters = std::max(0, std::min(256, (int)value));   // iterations per launch, closed blocks (0 / 1: off)
+  else if (k == "lazy_unscale") s->lazy_unscale = (int)value;                            // 0: unscale X, y, S at the end of every solve
   else if (k == "graph") {}
   else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
   return CUADMM_OK;
@@ -557,6 +655,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   for (int p = 0; p < At_nnz; ++p)
     if (At_ri[p] < 0 || At_ri[p] >= vec_len) { set_error("init: At row index %d out of range at %d", At_ri[p], p); return CUADMM_ERR_INVALID; }
 
+  if (s->world > 1) cuadmm_host_pool_hint(s->world);       // the ranks of a job share the node's CPUs (before the pool's first use)
   if (s->world > 1 && !s->local_mode && !getenv("CUADMM_NO_LOCAL_CONSTRAINTS")) {
     // does every constraint live inside one rank's block range?
     std::vector<int> first;
@@ -873,7 +972,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
         auto& lr = s->lrows;
         lr.nlocal = nlocal; lr.nrest = (int)rmap.size();
         lr.rest_avg = rmap.empty() ? 1.0 : (double)rci.size() / (double)rmap.size();
-        lr.h_desc = lcd; lr.h_row = lrow; lr.h_At_ci = lci;
+        lr.h_desc = lcd; lr.h_row = lrow; lr.h_nzptr = lnz; lr.h_e = le; lr.h_v = lval;
         if ((rc = lr.desc.from(lcd)) || (rc = lr.row.from(lrow)) || (rc = lr.nzptr.from(lnz)) || (rc = lr.e.from(le)) || (rc = lr.v.from(lval))) return rc;
         if (lr.nrest > 0) {
           if ((rc = lr.rest_rp.from(rrp)) || (rc = lr.rest_map.from(rmap)) || (rc = lr.rest_ci.alloc(std::max<size_t>(rci.size(), 1))) ||
@@ -943,17 +1042,20 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
         Cl[C_idx[i] - s->sv_begin] = C_vals[i] * ics;
       }
     }
-    if ((rc = s->C.from(Cl))) return rc;
+    // kSvecPad: the closed-block kernels read whole batches of the flat svec walk past a block's last element without a
+    // bounds clamp (psd_sign_closed.h); the values are never used
+    if ((rc = s->C.from(Cl, kSvecPad))) return rc;
     std::vector<double> tmp((size_t)L, 0.0);
     if (X0) for (long long i = 0; i < L; ++i) tmp[i] = X0[s->sv_begin + i] * ibs;
-    if ((rc = s->X.from(tmp))) return rc;
+    if ((rc = s->X.from(tmp, kSvecPad))) return rc;
     if (S0) for (long long i = 0; i < L; ++i) tmp[i] = S0[s->sv_begin + i] * ics;
     else std::fill(tmp.begin(), tmp.end(), 0.0);
-    if ((rc = s->S.from(tmp))) return rc;
+    if ((rc = s->S.from(tmp, kSvecPad))) return rc;
   }
   if ((rc = s->Rd1.alloc(L)) || (rc = s->Xb.alloc(L)) || (rc = s->Xproj.alloc(L)) || (rc = s->y_d.alloc(std::max(m, 1))) ||
       (rc = s->out_d.alloc(2 * (size_t)m + 2)) || (rc = s->partials.alloc(2 * (size_t)post_grid(L) + 2 + 2 * (size_t)s->plan.fused_blocks())) ||
-      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8 + 128)))
+      (rc = s->h_out.alloc(2 * (size_t)m + 2)) || (rc = s->h_y.alloc(std::max(m, 1))) || (rc = s->scal_d.alloc(8 + 128)) ||
+      (rc = s->h_scal.alloc(8)))
     return rc;
   CUADMM_HIP_TRY(hipMemset(s->out_d.p, 0, sizeof(double) * (2 * (size_t)m + 2)));
   std::memset(s->h_out.p, 0, sizeof(double) * (2 * (size_t)m + 2));
@@ -1007,7 +1109,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   else
     for (size_t k = 0; k < s->lrows.h_desc.size() && want_closed; ++k)
       if ((s->lrows.h_desc[k].y & 0xffff) > 0 && s->blk_local[k] < 17) want_closed = false;
-  if (want_closed && s->fuse && s->lrows.active && s->lrows.nrest == 0 && s->forest_trees > 0 && s->lrows.nlocal == m) {
+  if (want_closed && s->fuse && s->lrows.active && s->lrows.nrest == 0 && s->dev_solve && !s->lead.ready && s->forest_trees > 0 && s->lrows.nlocal == m) {
     const auto& hd = s->lrows.h_desc;
     const auto& hrow = s->lrows.h_row;
     const size_t nb = hd.size();
@@ -1016,38 +1118,70 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     if (ok) {
       const int64_t* Lp; const int* Li; const double* Lx; const double* D;
       if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
-      std::vector<int> pos((size_t)m, -1), blk_of_row((size_t)m, -1), loff(nb + 1, 0);
+      std::vector<int> pos((size_t)m, -1), blk_of_row((size_t)m, -1);
       for (size_t k = 0; k < nb; ++k) {
         const int nk = hd[k].y & 0xffff;
-        loff[k + 1] = loff[k] + nk * nk;
         for (int q = 0; q < nk; ++q) { pos[hrow[hd[k].x + q]] = q; blk_of_row[hrow[hd[k].x + q]] = (int)k; }
       }
-      std::vector<double> Ld((size_t)std::max(loff[nb], 1), 0.0);
+      // one ClosedRec per fused slot (psd_fuse.h): rows, their b / normA / D, the dense factor, the block's nonzeros of A in
+      // local-row order with the round in which each is applied to its svec slot
+      std::vector<int> slot_of;
+      s->plan.fused_slots(slot_of);
+      std::vector<ClosedRec> recs((size_t)std::max(s->plan.fused_blocks(), 1));
+      std::memset(recs.data(), 0, sizeof(ClosedRec) * recs.size());
       for (size_t k = 0; k < nb && ok; ++k) {
+        if (slot_of[k] < 0) continue;
+        ClosedRec& R = recs[(size_t)slot_of[k]];
         const int nk = hd[k].y & 0xffff;
+        R.nk = nk; R.nnz = hd[k].w;
+        if (R.nnz > kFuseRowsMax || nk > kClosedMaxRows) { ok = false; break; }
         for (int a = 0; a < nk && ok; ++a) {
           const int j = hrow[hd[k].x + a];
+          R.rows[a] = j;
+          R.D[a] = D[j]; R.b[a] = s->b_p[j]; R.normA[a] = s->normA_p[j];
           for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
             const int i = Li[p];
             if (blk_of_row[i] != (int)k || pos[i] <= a) { ok = false; break; }     // fill outside the block: not closed after all
-            Ld[(size_t)loff[k] + (size_t)pos[i] * nk + a] = Lx[p];
+            R.L[pos[i] * kClosedMaxRows + a] = Lx[p];
           }
         }
       }
       if (ok) {
-        std::vector<int> cil(s->lrows.h_At_ci.size());
-        for (size_t p = 0; p < cil.size(); ++p) cil[p] = pos[s->lrows.h_At_ci[p]];
-        loff.pop_back();
-        if ((rc = s->closed.L.from(Ld)) || (rc = s->closed.off.from(loff)) || (rc = s->closed.ci_local.from(cil)) ||
+        // nonzeros: s->lrows kept e / v / nzptr on the device only; rebuild them here from the host copies made above
+        const auto& le = s->lrows.h_e; const auto& lval = s->lrows.h_v; const auto& lnz = s->lrows.h_nzptr;
+        for (size_t k = 0; k < nb; ++k) {
+          if (slot_of[k] < 0) continue;
+          ClosedRec& R = recs[(size_t)slot_of[k]];
+          const int k0 = hd[k].x, nk = R.nk, z0 = hd[k].z;
+          int maxmult = 0;
+          for (int a = 0; a <= nk; ++a) R.nzp[a] = (unsigned char)(lnz[k0 + a] - z0);
+          for (int q = 0; q < R.nnz; ++q) {
+            R.e[q] = (unsigned short)le[z0 + q];
+            R.v[q] = lval[z0 + q];
+            int rowpos = 0;
+            while (rowpos + 1 <= nk && (int)R.nzp[rowpos + 1] <= q) ++rowpos;
+            int mult = 0;
+            for (int q2 = 0; q2 < q; ++q2) mult += le[z0 + q2] == le[z0 + q];
+            R.rk[q] = (unsigned char)(rowpos | (mult << 3));
+            maxmult = std::max(maxmult, mult + 1);
+            if (mult > 31) ok = false;
+          }
+          R.nrounds = maxmult;
+        }
+      }
+      if (ok) {
+        if ((rc = s->closed.rec.from(recs)) || (rc = s->closed.cl_out.alloc(16 * recs.size())) ||
             (rc = s->closed.partials2.alloc(2 * (size_t)s->plan.fused_blocks() + 2)))
           return rc;
+        CUADMM_HIP_TRY(hipMemset(s->closed.cl_out.p, 0, sizeof(double) * 16 * recs.size()));
         s->closed.active = true;
+        s->closed.out_dirty = true;
         if (s->verbose) printf(" closed blocks: each block solves for its own multipliers (<= %d rows) inside the projection kernel\n", kClosedMaxRows);
       }
     }
   }
   if (s->dev_scalars || s->dev_solve) {
-    if ((rc = s->b_d.alloc(std::max(m, 1))) || (rc = s->normA_d.alloc(std::max(m, 1))) || (rc = s->h_scal.alloc(4))) return rc;
+    if ((rc = s->b_d.alloc(std::max(m, 1))) || (rc = s->normA_d.alloc(std::max(m, 1)))) return rc;
     if ((rc = s->b_d.upload(s->b_p.data(), (size_t)m)) || (rc = s->normA_d.upload(s->normA_p.data(), (size_t)m))) return rc;
     void* dp = nullptr;
     if (!getenv("CUADMM_NO_MAPPED_OUT") && hipHostGetDevicePointer(&dp, s->h_scal.p, 0) == hipSuccess && dp) s->h_scal_dev = static_cast<double*>(dp);
@@ -1116,7 +1250,11 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     printf("\n norm of C = %2.1e, norm of b = %2.1e\n", s->norm_Corg, s->norm_borg);
   }
 
-  if (!if_first) {   // solver.cu:385-409: X,y,S currently hold UNSCALED values
+  if (if_first && s->pending_unscale && (rc = s->materialise())) return rc;   // the reference's X, y, S are unscaled after a solve
+  if (!if_first && s->pending_unscale) {
+    // the previous solve left X, y, S scaled and [A X | A (S - C)], Rp as its last iteration formed them: nothing to redo
+    s->pending_unscale = false;
+  } else if (!if_first) {   // solver.cu:385-409: X,y,S currently hold UNSCALED values
     for (int i = 0; i < m; ++i) s->y_p[i] = (s->y_p[i] * s->normA_p[i]) * (1 / s->Cscale);
     if (s->dev_solve && (rc = s->upload_y(true))) return rc;
     if ((rc = launch_scale(s->X.p, L, 1 / s->bscale, s->st))) return rc;
@@ -1157,9 +1295,12 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       s->total_time = wall_s() - s->t_init0;
     }
 
+    // the device is ahead of the host schedule by the unconsumed iterations of a batch: back to the accepted state
+    if (breakyes && s->bt.len > 0 && (rc = s->batch_rollback(s->bt.pos))) return rc;
+
     // ---- Step 1 (solver.cu:478-500): y = (AA^T)^-1 (Rp/sig - A(S-C)); with closed blocks the fused projection of this
     // iteration solves it (not on the last pass through the loop, which stops before the projection)
-    if ((rc = s->host_solve(s->fuse && !breakyes))) return rc;
+    if (s->bt.len == 0 && (rc = s->host_solve(s->fuse && !breakyes))) return rc;
 
     if (breakyes) {   // solver.cu:567-576
       if (iter > switch_admm && s->have_best) {
@@ -1194,8 +1335,45 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     }
 
     const int post_mode_after_proj = (iter < switch_admm || snapshot) ? 1 : 0;
-    if ((rc = s->upload_y())) return rc;
-    if (s->fuse) {
+    // ---- several iterations in one launch (SignFuse::iters): ADMM phase without best-iterate bookkeeping, every block closed.
+    // A batch ends at the next iteration that may change sigma; tau changes only through the errRd < stop_tol rule, checked
+    // below on every consumed iteration.
+    if (s->bt.len > 0 && tau != s->bt.tau) {
+      // this iteration was run with the wrong step length: keep the consumed ones, continue one launch at a time
+      if ((rc = s->batch_rollback(s->bt.pos))) return rc;
+    }
+    if (s->bt.len == 0 && iter > switch_admm && !s->have_best && !snapshot && s->can_batch()) {
+      int K = std::min(s->bt.max_iters, max_iter - iter + 1);
+      for (int j = 0; j < K; ++j) {          // the batch may END on a sigma-update iteration, not contain one
+        const int i = iter + j;
+        if ((i <= sig_update_threshold && i % sig_update_stage_1 == 1) || (i > sig_update_threshold && i % sig_update_stage_2 == 1)) { K = j + 1; break; }
+      }
+      if (K >= 2) {
+        if ((rc = s->batch_alloc()) || (rc = s->batch_copy(true))) return rc;
+        s->bt.tau = tau; s->bt.sig = s->sig;
+        if ((rc = s->launch_fused_step(0, tau, K))) return rc;
+        if (lpt_ev > 0 && s->steps_d.p) {   // longest block first without a stall: fetch behind one batch, sort during the next
+          if (s->lpt_steps_ready) {
+            if ((rc = s->plan.reorder_by_steps_async(s->steps_pin.p, s->st))) return rc;
+            s->lpt_steps_ready = false;
+            lpt_ev *= 8;
+          } else if (s->lpt_iters + K >= lpt_ev) {
+            if (!s->steps_pin.p && (rc = s->steps_pin.alloc(s->steps_d.n))) return rc;
+            CUADMM_HIP_TRY(hipMemcpyAsync(s->steps_pin.p, s->steps_d.p, sizeof(int) * s->steps_d.n, hipMemcpyDeviceToHost, s->st));
+            s->lpt_steps_ready = true;     // valid once the stream has been synchronised (below)
+          }
+        }
+        CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
+        s->prof_collect();
+        s->bt.len = K; s->bt.pos = 0;
+      }
+    }
+    const bool from_batch = s->bt.len > 0;
+    if (from_batch) {
+      // consumed below (Step 5) from bt.h
+    } else if ((rc = s->upload_y())) return rc;
+    if (from_batch) {
+    } else if (s->fuse) {
       if ((rc = s->launch_fused_step(post_mode_after_proj, tau))) return rc;
     } else {
       if ((rc = s->launch_aty(true))) return rc;
@@ -1217,7 +1395,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       }
     }
 
-    if (iter < switch_admm) {
+    if (from_batch) {
+    } else if (iter < switch_admm) {
       // sGS half step: S^{k+1}, second solve with it, Rd1 from the new y (solver.cu:693-729)
       if (!s->fuse && (rc = s->launch_post_mode(1, tau))) return rc;     // fused: done with the projection
       if ((rc = s->launch_spmv(false, true, s->fuse))) return rc;
@@ -1280,7 +1459,10 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       for (int c = 0; c < kHostChunks; ++c) { nr += part[2 * c]; bty += part[2 * c + 1]; }
       {
         double v[4] = {nr, bty, s->h_out.p[(size_t)m], s->h_out.p[(size_t)m + 1]};
-        if (s->dev_scalars || s->dev_solve) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // formed (and summed over ranks) on the device
+        if (from_batch) {
+          for (int q = 0; q < 4; ++q) v[q] = s->bt.h.p[4 * (size_t)s->bt.pos + q];
+          if (++s->bt.pos == s->bt.len) s->bt.len = s->bt.pos = 0;
+        } else if (s->dev_scalars || s->dev_solve) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // formed (and summed over ranks) on the device
         else if ((rc = s->allreduce_scalars(v, 4))) return rc;
         nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
       }
@@ -1305,7 +1487,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     s->info[CUADMM_INFO_BSCALE].push_back(s->bscale); s->info[CUADMM_INFO_CSCALE].push_back(s->Cscale);
     s->info_iter_num++;
     // longest block first (PsdPlan::reorder_by_steps): at iterations 3, 24, 192, ... of this solve the stream is idle here
-    if (s->fuse && lpt_ev > 0 && ++s->lpt_iters == lpt_ev && s->steps_d.p) {
+    if (s->fuse && lpt_ev > 0) ++s->lpt_iters;
+    if (s->fuse && lpt_ev > 0 && s->lpt_iters >= lpt_ev && s->bt.len == 0 && s->steps_d.p && !s->can_batch()) {
       s->steps_h.resize(s->steps_d.n);
       if ((rc = staged_d2h(s->steps_h.data(), s->steps_d.p, sizeof(int) * s->steps_d.n, s->st))) return rc;
       if ((rc = s->plan.reorder_by_steps(s->steps_h.data(), s->st))) return rc;
@@ -1313,26 +1496,45 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     }
   }
 
-  // unscale (solver.cu:814-816)
-  if ((rc = launch_scale(s->X.p, L, s->bscale, s->st))) return rc;
-  if ((rc = launch_scale(s->S.p, L, s->Cscale, s->st))) return rc;
-  if (s->dev_solve && m > 0) CUADMM_HIP_TRY(hipMemcpyAsync(s->y_p.data(), s->y_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s->st));
-  CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
-  for (int i = 0; i < m; ++i) s->y_p[i] = s->y_p[i] / s->normA_p[i] * s->Cscale;
-  if (s->local_mode) {   // y is replicated for the caller: gather the owned pieces once per solve
-    s->y_full.assign((size_t)s->m_full, 0.0);
-    for (int i = 0; i < m; ++i) s->y_full[s->cons_local[s->perm[i]]] = s->y_p[i];
-    if (s->comm_world > 1 && s->m_full > 0) {
-      if (!s->yfull_d.p && (rc = s->yfull_d.alloc((size_t)s->m_full))) return rc;
-      if ((rc = staged_h2d(s->yfull_d.p, s->y_full.data(), sizeof(double) * (size_t)s->m_full, s->st))) return rc;
-      if ((rc = s->comm_allreduce(s->yfull_d.p, (size_t)s->m_full))) return rc;
-      if ((rc = staged_d2h(s->y_full.data(), s->yfull_d.p, sizeof(double) * (size_t)s->m_full, s->st))) return rc;
-    }
-  }
+  // unscale (solver.cu:814-816) -- deferred until somebody reads or replaces X, y, S (materialise): a following
+  // solve(if_first = false) continues from the scaled state.  With owned constraints over several ranks the y gather is a
+  // collective, so there it happens here, where every rank is.
+  s->pending_unscale = true;
+  if (s->lazy_unscale == 0 || (s->local_mode && s->comm_world > 1)) { if ((rc = s->materialise())) return rc; }
   s->eig_fail_total = s->plan.fail_count(s->st);
   if (s->eig_fail_total > 0) {
     set_error("solve: %d block projections hit the QL sweep cap", s->eig_fail_total);
     return CUADMM_ERR_EIG;
+  }
+  return CUADMM_OK;
+}
+
+int cuadmm_solver::materialise() {
+  if (!pending_unscale) return CUADMM_OK;
+  pending_unscale = false;
+  int rc;
+  if ((rc = check_device(device))) return rc;
+  if ((rc = launch_scale(X.p, L, bscale, st))) return rc;
+  if ((rc = launch_scale(S.p, L, Cscale, st))) return rc;
+  if (dev_solve && m > 0) {
+    if (y_registered) CUADMM_HIP_TRY(hipMemcpyAsync(y_p.data(), y_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, st));
+    else {   // never a runtime copy into pageable memory (staging.hip)
+      CUADMM_HIP_TRY(hipMemcpyAsync(h_y.p, y_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, st));
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      std::memcpy(y_p.data(), h_y.p, sizeof(double) * (size_t)m);
+    }
+  }
+  CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < m; ++i) y_p[i] = y_p[i] / normA_p[i] * Cscale;
+  if (local_mode) {   // y is replicated for the caller: gather the owned pieces once per solve
+    y_full.assign((size_t)m_full, 0.0);
+    for (int i = 0; i < m; ++i) y_full[cons_local[perm[i]]] = y_p[i];
+    if (comm_world > 1 && m_full > 0) {
+      if (!yfull_d.p && (rc = yfull_d.alloc((size_t)m_full))) return rc;
+      if ((rc = staged_h2d(yfull_d.p, y_full.data(), sizeof(double) * (size_t)m_full, st))) return rc;
+      if ((rc = comm_allreduce(yfull_d.p, (size_t)m_full))) return rc;
+      if ((rc = staged_d2h(y_full.data(), yfull_d.p, sizeof(double) * (size_t)m_full, st))) return rc;
+    }
   }
   return CUADMM_OK;
 }
@@ -1390,6 +1592,7 @@ static int get_vec(cuadmm_solver* s, const DevBuf<double>& v, double* out) {
   if (!s || !s->initialised || !out) { set_error("get: bad arguments"); return CUADMM_ERR_INVALID; }
   int rc = check_device(s->device);
   if (rc) return rc;
+  if ((rc = s->materialise())) return rc;
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
   if (s->L > 0) { int rc2 = staged_d2h(out, v.p, sizeof(double) * (size_t)s->L, s->st); if (rc2) return rc2; }
   return CUADMM_OK;
@@ -1399,6 +1602,7 @@ int cuadmm_get_X(cuadmm_solver* s, double* out) { return get_vec(s, s->X, out); 
 int cuadmm_get_S(cuadmm_solver* s, double* out) { return get_vec(s, s->S, out); }
 int cuadmm_get_y(cuadmm_solver* s, double* out) {
   if (!s || !s->initialised || !out) { set_error("get_y: bad arguments"); return CUADMM_ERR_INVALID; }
+  { int rc = s->materialise(); if (rc) return rc; }
   if (s->local_mode) {
     if ((int)s->y_full.size() == s->m_full) std::copy(s->y_full.begin(), s->y_full.end(), out);   // gathered at the end of solve
     else { std::fill(out, out + s->m_full, 0.0); for (int i = 0; i < s->m; ++i) out[s->cons_local[s->perm[i]]] = s->y_p[i]; }
@@ -1412,6 +1616,7 @@ int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const dou
   if (!s || !s->initialised) { set_error("set_XyS: not initialised"); return CUADMM_ERR_INVALID; }
   int rc = check_device(s->device);
   if (rc) return rc;
+  if ((rc = s->materialise())) return rc;       // the vectors NOT replaced must be in the caller's units too
   if (X && s->L > 0) { int rc2 = staged_h2d(s->X.p, X + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, s->st); if (rc2) return rc2; }
   if (S && s->L > 0) { int rc2 = staged_h2d(s->S.p, S + s->sv_off + s->sv_begin, sizeof(double) * (size_t)s->L, s->st); if (rc2) return rc2; }
   if (y) for (int i = 0; i < s->m; ++i) s->y_p[i] = s->local_mode ? y[s->cons_local[s->perm[i]]] : y[s->perm[i]];
@@ -1421,6 +1626,7 @@ int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const dou
 
 int cuadmm_get_device_ptrs(cuadmm_solver* s, double** X, double** y, double** S) {
   if (!s || !s->initialised) { set_error("get_device_ptrs: not initialised"); return CUADMM_ERR_INVALID; }
+  { int rc = s->materialise(); if (rc) return rc; }
   if (X) *X = s->X.p;
   if (y) *y = s->y_d.p;
   if (S) *S = s->S.p;
@@ -1465,6 +1671,12 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap) {
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
   { int rc2 = staged_d2h(out, s->steps_d.p, sizeof(int) * (size_t)n, s->st); if (rc2) return rc2; }
   return n;
+}
+int cuadmm_get_counters(const cuadmm_solver* s, double o[8]) {
+  if (!s || !o) { set_error("get_counters: null"); return CUADMM_ERR_INVALID; }
+  o[0] = (double)s->bt.launches; o[1] = (double)s->bt.iters; o[2] = (double)s->bt.rollbacks; o[3] = (double)cuadmm_host_pool_threads();
+  o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? 1 : 0; o[7] = (double)s->tail.k;
+  return CUADMM_OK;
 }
 int cuadmm_reset_profile(cuadmm_solver* s) {
   if (!s) { set_error("reset_profile: null"); return CUADMM_ERR_INVALID; }

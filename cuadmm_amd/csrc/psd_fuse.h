@@ -27,21 +27,45 @@ struct SignFuse {
   const struct LcDesc* lc; const int* lc_row; const int* lc_nzptr; const int* lc_e; const double* lc_v;
   double* outX; double* outS;                         // null: not wanted (outX only with mode 0)
   // CLOSED blocks (every constraint that touches the block is one of its local rows, at most kClosedMaxRows of them: the
-  // block-diagonal configurations): the block also SOLVES for its own multipliers in the prologue -- rhs from the rows of
-  // [A X | A (S - C)] it wrote in the previous iteration, the dense unit-lower factor of its diagonal block of A A^T (cut
-  // out of the host factor, same elimination order, same unfused arithmetic as forest_solve_kernel: bit-identical y;
-  // solver.cu:478-500) -- gathers A^T y from those values, and in mode 0 adds its rows' share of ||Rp||^2 and b^T y
-  // (solver.cu:768-772,781) to a second partial pair.  cs_L == null: y comes from y[] as before.
-  const double* cs_L; const int* cs_off;              // dense nk x nk factor of block `id` at cs_L + cs_off[id], row-major
-  const double* cs_D; const int* ci_local;            // D by constraint; for every nonzero of A^T: its row's position in the block
-  const double* b; const double* normA;
+  // block-diagonal configurations) run psd_sign_closed.h instead: the block also SOLVES for its own multipliers -- rhs from its
+  // rows of [A X | A (S - C)] of the previous iteration, the dense unit-lower factor of its diagonal block of A A^T (cut out of
+  // the host factor, same elimination order, same unfused arithmetic as forest_solve_kernel: bit-identical y; solver.cu:478-500)
+  // -- scatters A^T y from those values, and in mode 0 adds its rows' share of ||Rp||^2 and b^T y (solver.cu:768-772,781) to a
+  // second partial pair.  rec == null: y comes from y[] (generic fused body).
   double* y_out;                                      // y (all constraints, the factor's order)
-  const double* ax_old; const double* as_old;         // [A X], [A (S - C)] of the previous iteration
   double* partials2;                                  // 2 doubles per fused block: sum (normA (b - A X) bscale)^2, sum b y
   double isig, bscale;
+  // SEVERAL ADMM iterations in one launch (closed blocks only, mode 0): between two sigma updates nothing couples the blocks of a
+  // block-diagonal problem except the four scalars of the stopping test, so a wavefront runs `iters` whole iterations on its
+  // block back to back (its X, S, y and rows of [A X | A (S - C)] go through HBM / L2 exactly as between two launches) and leaves
+  // one partial pair per iteration: iteration `it` writes partials + it * pstride and partials2 + it * pstride.  The engine
+  // forms the scalars of all `iters` iterations afterwards (reduce_quads_batch_kernel), replays the host-side schedule on them
+  // and, should the stopping test have fired inside the batch, restores its checkpoint and reruns the shorter batch -- the
+  // iterates are bit-identical to one launch per iteration.  No launch ramp / tail and no host round trip per iteration.
+  int iters;                                          // <= 1: one iteration
+  long long pstride;                                  // doubles between the partial arrays of consecutive iterations
+  // closed blocks, psd_sign_closed.h: the per-block records and the per-block copy of the block's rows of [A X | A (S - C)]
+  // (16 doubles per slot: A X of row k at 16 slot + k, A (S - C) at 16 slot + 8 + k; outX / outS keep the by-row copy)
+  const struct ClosedRec* rec;
+  double* cl_out;
 };
 struct LcDesc { int x, y, z, w; };
 constexpr int kFuseRowsMax = 64;
 constexpr int kClosedMaxRows = 8;
+
+// Everything static a CLOSED block's iteration needs, in one contiguous record addressed by the block's slot alone
+// (psd_sign_closed.h: one memory round trip instead of five dependent ones).  Nonzeros are ordered by local row (rows ascending
+// in the factor's order); rk = row position | round << 3, where `round` counts the earlier nonzeros on the same svec slot:
+// round k is applied after round k - 1, which reproduces the summation order of the CSR gather.
+struct alignas(64) ClosedRec {
+  int nk, nnz, nrounds, pad0;                 // local rows, their nonzeros, largest multiplicity of an svec slot
+  unsigned char nzp[16];                      // nonzeros of row k: nzp[k] .. nzp[k + 1]
+  int rows[kClosedMaxRows];                   // constraint index (the factor's order) of local row k
+  unsigned short e[kFuseRowsMax];             // svec offset inside the block
+  unsigned char rk[kFuseRowsMax];
+  double v[kFuseRowsMax];
+  double L[kClosedMaxRows * kClosedMaxRows];  // unit lower factor of the block's diagonal block of A A^T, row-major
+  double D[kClosedMaxRows], b[kClosedMaxRows], normA[kClosedMaxRows];
+};
 
 }  // namespace cuadmm

@@ -26,6 +26,7 @@
 #include "psd_small_reg.h"
 #include "psd_sign_lds.h"
 #include "psd_sign_wave.h"
+#include "psd_sign_closed.h"
 
 namespace cuadmm {
 
@@ -181,14 +182,108 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   const int id = d.id;
   const long long off = d.off;
   psd_sign_wave_body<NT, FUSED>(a.in + off, a.out + off, d.n, a.info, swt_smem, a.steps ? a.steps + id : nullptr,
-                                a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, slot0 + m, id);
+                                a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, d.slot, id);
+}
+
+// closed blocks (psd_sign_closed.h): the whole iteration of the block, one launch per iteration
+template <int NT, int OCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_closed_kernel(ClosedArgs a) {
+  extern __shared__ double swt_smem[];
+  const int m = (int)blockIdx.x;
+  if (m >= a.count) return;
+  const PsdDesc d = a.desc[a.first + m];
+  psd_sign_closed_body<NT>(a, d.n, swt_smem, a.steps ? a.steps + d.id : nullptr, a.hint ? a.hint + d.id : nullptr, nullptr, d.off, d.slot, 0);
+}
+
+// SEVERAL ADMM ITERATIONS PER LAUNCH (ClosedArgs::iters; closed blocks): one PERSISTENT WORKGROUP PER CU (WAVES = the CU's
+// wavefront slots at this kernel's register budget; n <= 16: two workgroups of 16) owns a fixed contiguous range of the class
+// members and runs the tasks (iteration it, member j), in the order it * nb + j, on whichever of its wavefronts is free: an LDS
+// counter hands them out, an LDS array `done[j]` = iterations completed on member j orders a task behind its predecessor (the
+// same member, one iteration earlier: nb tasks back in the queue with at most WAVES in flight, so the wait is almost never
+// taken).  What task (it, j) reads -- X, S, y and the member's rows of [A X | A (S - C)] -- was stored by a wavefront of the
+// SAME CU (same L1): a workgroup-scope release (s_waitcnt vmcnt(0)) before the flag and an acquire after it order the two.
+// Why: with one wavefront per block and one launch per iteration, 10 000 blocks on 4 096 wavefront slots are 2.44 rounds -- the
+// last one at 44 % occupancy -- plus a launch ramp, a tail and a host round trip every iteration; handing out (member,
+// iteration) pairs dynamically inside a CU keeps every SIMD at its four wavefronts until the last task of the batch.
+template <int NT, int WAVES, int OCC>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_closed_cu_kernel(ClosedArgs a) {
+  extern __shared__ double swt_smem[];
+  constexpr int TILE = SignWaveT<NT>::NP * SignWaveT<NT>::LD;
+  int* ctl = reinterpret_cast<int*>(swt_smem + (size_t)WAVES * TILE);      // [0]: next task; [1 + j]: iterations completed on member j
+  const int g = (int)blockIdx.x, G = (int)gridDim.x;
+  const int j0 = (int)((long long)a.count * g / G), nb = (int)((long long)a.count * (g + 1) / G) - j0;
+  for (int i = (int)threadIdx.x; i < nb + 1; i += 64 * WAVES) ctl[i] = 0;
+  __syncthreads();
+  const int ntask = nb * a.iters;
+  // The kernel arguments are re-read from the kernarg segment for every task (scalar loads, cached): held in SGPRs across the
+  // task loop they would be spilled at this kernel's register budget.
+  using KArgC = __attribute__((address_space(4))) const char;
+  KArgC* ka = (KArgC*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll 1
+  for (;;) {
+    int t = 0;
+    if (lane_id() == 0) t = atomicAdd(&ctl[0], 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= ntask) break;
+    const int it = t / nb, j = t - it * nb;
+    if (it > 0) {
+      volatile int* dn = ctl + 1 + j;
+      while (*dn < it) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(ka));                       // opaque: nothing loaded through it is kept across tasks
+    const ClosedArgs al = *reinterpret_cast<__attribute__((address_space(4))) const ClosedArgs*>(ka);
+#else
+    const ClosedArgs al = a;
+#endif
+    const PsdDesc d = al.desc[al.first + j0 + j];
+    int toff = ((int)threadIdx.x >> 6) * TILE;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(toff));                     // not hoisted out of the task loop (it would stay live across the body)
+#endif
+    double* tile = swt_smem + toff;
+    psd_sign_closed_body<NT, true>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
+                             al.dbg ? al.dbg + 10 * (long long)(j0 + j) : nullptr, d.off, d.slot, (long long)it * al.pstride);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane_id() == 0) { volatile int* dn = ctl + 1 + j; *dn = it + 1; }
+  }
 }
 
 // fz != nullptr: the fused variant (SignFuse, psd_sign_wave.h); slot0 = partial-sum slot of the first member of this launch
 template <int NT, int OCC>
 static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t st, const SignFuse* fz = nullptr, int slot0 = 0) {
   if (count <= 0) return CUADMM_OK;
-  if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count, slot0);
+  if (fz && fz->rec) {                                   // closed blocks: psd_sign_closed.h
+    ClosedArgs ca{};
+    ca.desc = a.desc; ca.steps = a.steps; ca.hint = a.hint; ca.fail = a.info; ca.dbg = a.dbg;
+    ca.X = fz->X; ca.S = fz->S; ca.Rd1 = fz->Rd1; ca.C = fz->C; ca.rec = fz->rec; ca.cl_out = fz->cl_out; ca.y_out = fz->y_out;
+    ca.outS = fz->outS; ca.outX = fz->outX; ca.partials = fz->partials; ca.partials2 = fz->partials2;
+    ca.sig = fz->sig; ca.inv_sig = fz->inv_sig; ca.tau_sig = fz->tau_sig; ca.isig = fz->isig; ca.bscale = fz->bscale;
+    ca.pstride = fz->pstride; ca.mode = fz->mode; ca.iters = fz->iters > 1 ? fz->iters : 1; ca.first = first; ca.count = count;
+    if (fz->iters > 1) {
+      constexpr int WAVES = 4 * OCC > 16 ? 16 : 4 * OCC, WG_PER_CU = 4 * OCC / WAVES;
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        CUADMM_HIP_TRY(hipGetDevice(&dev));
+        CUADMM_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      const int grid = std::min(count, n_cu * WG_PER_CU);
+      const size_t nb_max = ((size_t)count + grid - 1) / grid;
+      const size_t lds = WAVES * SignWaveT<NT>::LDS_BYTES + sizeof(int) * (nb_max + 2);
+      if (lds > kMaxLdsBytes) { set_error("psd: %d blocks per workgroup do not fit the batched launch", (int)nb_max); return CUADMM_ERR_INVALID; }
+      auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC>;
+      static bool attr_set = false;
+      if (!attr_set) { CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes)); attr_set = true; }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
+    } else {
+      hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
+    }
+  }
+  else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count, slot0);
   else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count, 0);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
@@ -331,7 +426,9 @@ int PsdPlan::build(const int* blk, int mat_num) {
   h_ids = ids;
   {
     std::vector<PsdDesc> desc(std::max<size_t>(ids.size(), 1));
-    for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q]};
+    std::vector<int> slot_of;
+    fused_slots(slot_of);
+    for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q], slot_of[ids[q]], {0, 0, 0}};
     CUADMM_HIP_TRY(hipMalloc(&d_desc, sizeof(PsdDesc) * desc.size()));
     { int rc_ = staged_h2d(d_desc, desc.data(), sizeof(PsdDesc) * desc.size()); if (rc_) return rc_; }
     h_desc = desc;
@@ -356,6 +453,7 @@ void PsdPlan::release() {
   for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len, (void*)d_rest, (void*)d_desc})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   d_rest = nullptr; n_rest = 0; d_desc = nullptr;
+  if (h_desc_pin) { hipError_t e = hipHostFree(h_desc_pin); (void)e; h_desc_pin = nullptr; }
   d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
   d_free_off = d_free_len = nullptr; n_free = 0;
   sign.release();
@@ -419,9 +517,9 @@ bool PsdPlan::fusable() const {
          vec_len < 0x7fffffffLL;
 }
 
-int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
+bool PsdPlan::sort_by_steps_host(const int* steps_host, std::vector<std::pair<int, int>>& ranges) {
   // ranges served by the one-wavefront kernels: class 2 (sign16), class 3, class 4 (wave4: the n > 48 members and the others)
-  std::vector<std::pair<int, int>> ranges;
+  ranges.clear();
   if (sign16 && cls_count[2] > 0) ranges.push_back({cls_begin[2], cls_count[2]});
   if (cls_count[3] > 0) ranges.push_back({cls_begin[3], cls_count[3]});
   if (wave4 && cls_count[4] > 0) {
@@ -438,9 +536,27 @@ int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
     tmp.resize((size_t)rg.second);
     for (int q = 0; q < rg.second; ++q) tmp[(size_t)cnt[key(h_desc[rg.first + q])]++] = h_desc[rg.first + q];
     std::copy(tmp.begin(), tmp.end(), h_desc.begin() + rg.first);
+  }
+  return !ranges.empty();
+}
+
+int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
+  std::vector<std::pair<int, int>> ranges;
+  sort_by_steps_host(steps_host, ranges);
+  for (auto& rg : ranges) {
     int rc = staged_h2d(d_desc + rg.first, &h_desc[rg.first], sizeof(PsdDesc) * (size_t)rg.second, st);
     if (rc) return rc;
   }
+  return CUADMM_OK;
+}
+
+int PsdPlan::reorder_by_steps_async(const int* steps_host, hipStream_t st) {
+  std::vector<std::pair<int, int>> ranges;
+  if (!sort_by_steps_host(steps_host, ranges)) return CUADMM_OK;
+  if (!h_desc_pin) CUADMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_desc_pin), sizeof(PsdDesc) * h_desc.size(), hipHostMallocDefault));
+  std::copy(h_desc.begin(), h_desc.end(), h_desc_pin);
+  for (auto& rg : ranges)
+    CUADMM_HIP_TRY(hipMemcpyAsync(d_desc + rg.first, h_desc_pin + rg.first, sizeof(PsdDesc) * (size_t)rg.second, hipMemcpyHostToDevice, st));
   return CUADMM_OK;
 }
 
@@ -535,6 +651,31 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       fprintf(stderr, "[psd debug] class %d: %d blocks: ticks/block prologue %.0f (zero fill done at %.0f, first batch of loads back at %.0f, tile written at %.0f) "
                       "iteration %.0f (%.1f steps, %.0f per step) epilogue %.0f\n",
               c, cls_count[c], ph[0] / nw, ph[4] / nw, ph[5] / nw, ph[6] / nw, ph[1] / nw, ph[3] / nw, ph[1] / std::max(ph[3], 1.0), ph[2] / nw);
+      { hipError_t e = hipFree(d); (void)e; }
+      if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
+      continue;
+    }
+    if (c == 3 && fz && fz->iters > 1 && getenv("CUADMM_CU_DBG")) {   // developer aid: phase ticks of the batched launches at full occupancy
+      std::vector<long long> h((size_t)cls_count[c] * 10, 0);
+      long long* d = nullptr;
+      CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
+      CUADMM_HIP_TRY(hipMemset(d, 0, sizeof(long long) * h.size()));
+      a.dbg = d;
+      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st, fz, 0);
+      if (rc2) return rc2;
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+      CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      double ph[10] = {0};
+      for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 10; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
+      const double nw = cls_count[c];
+      for (double& x : ph) x /= nw;
+      // stamps 4..9 are offsets from the start of the task; ph[0..2] are the phase lengths
+      const double it0 = ph[0], ep0 = ph[0] + ph[1];
+      fprintf(stderr, "[cu debug] %d blocks x %d iterations: ticks/task prologue %.0f [solve done %.0f, loads back %.0f, gather done %.0f] iteration %.0f (%.2f steps, %.0f per step) "
+                      "epilogue %.0f [Xb rebuilt +%.0f, P stored +%.0f, walk done +%.0f] total %.0f\n",
+              cls_count[c], fz->iters, ph[0], ph[4], ph[5], ph[6], ph[1], ph[3], ph[1] / std::max(ph[3], 1.0), ph[2], ph[7] - ep0, ph[8] - ep0, ph[9] - ep0,
+              ph[0] + ph[1] + ph[2]);
+      (void)it0;
       { hipError_t e = hipFree(d); (void)e; }
       if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
       continue;

@@ -13,11 +13,15 @@ namespace cuadmm {
 constexpr int kNumPsdClasses = 7;   // n<=4, <=8, <=16, <=32, <=64 (register kernels) | LDS workgroup | HBM workgroup
 int psd_class_of(int n);
 
-// class member -> block, 16 bytes
+// class member -> block, 32 bytes (one scalar load).  `slot`: the block's partial-sum slot in the fused iteration -- fixed at
+// build time, so the sums of an iteration do not depend on the order in which the members are launched (longest block first
+// reorders them; several iterations per launch hand them out dynamically): every variant leaves the same bits.
 struct PsdDesc {
   long long off;   // svec offset
   int n;           // size
   int id;          // block id
+  int slot;        // partial-sum slot of the fused launches (-1: not in a fused class)
+  int pad[3];
 };
 
 struct PsdPlan {
@@ -70,6 +74,11 @@ struct PsdPlan {
   // keeps the chip waiting.  The step count of a block barely moves from one ADMM iteration to the next, so the engine now and
   // then re-sorts the members of the one-wavefront classes by the steps of the previous projection (descending, stable).
   int reorder_by_steps(const int* steps_host, hipStream_t st);
+  // the same without draining the stream: the new order is sorted on the host while the device is busy and uploaded from a
+  // page-locked copy by a copy command queued on `st` (it takes effect for the launches queued after it)
+  int reorder_by_steps_async(const int* steps_host, hipStream_t st);
+  PsdDesc* h_desc_pin = nullptr;
+  bool sort_by_steps_host(const int* steps_host, std::vector<std::pair<int, int>>& ranges);
   std::vector<PsdDesc> h_desc;
   void fused_slots(std::vector<int>& slot_of) const;   // block -> partial-sum slot of the fused launches (-1: not fused)
   std::vector<int> h_ids;      // host copy of d_ids

@@ -21,6 +21,7 @@
 namespace cuadmm {
 
 typedef double sl_v4f64 __attribute__((ext_vector_type(4)));
+typedef double sl_v2f64 __attribute__((ext_vector_type(2)));
 
 
 template <int NP> struct SignLdsCfg;

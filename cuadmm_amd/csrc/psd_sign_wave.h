@@ -139,16 +139,21 @@ __device__ __forceinline__ void swt_store_mirrored(double* __restrict__ M, int r
 
 // One batch of the flat svec walk: slot u of the batch is element e = base + 64 u + lane.  An invalid slot (e >= len) reads
 // element 0 of the block and is masked afterwards, so the loads of a batch are straight-line: one memory round trip per batch.
+// developer aid (fused kernels, CUADMM_CU_DBG): tick stamp k after draining the memory counters, so that a phase owns its waits
+#define CUADMM_SWT_STAMP(k)                                                                                   \
+  if (FUSED && dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[k] = (long long)__builtin_readcyclecounter() - c0; }
 #define CUADMM_SWT_SLOT(u)                                        \
   const int e_ = base + 64 * (u) + lane;                          \
   const bool ok_ = e_ < len;                                      \
   const int ec_ = ok_ ? e_ : 0
 
 // FUSED: `in` / `out` are unused; fz carries the vectors, off = svec offset of the block, slot = its partial-sum slot,
-// id = its index in the plan (local constraint rows)
+// id = its index in the plan (local constraint rows), poff = offset of this iteration's partial arrays (several iterations
+// per launch: SignFuse::iters)
 template <int NT, bool FUSED>
 __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail, double* S,
-                                                   int* steps_out, int* hint, long long* dbg, const SignFuse& fz, long long off, int slot, int id) {
+                                                   int* steps_out, int* hint, long long* dbg, const SignFuse& fz, long long off, int slot, int id,
+                                                   long long poff = 0) {
   using Cfg = SignWaveT<NT>;
   constexpr int LD = Cfg::LD, NP = Cfg::NP, U = Cfg::U;
   const int lane = lane_id();
@@ -162,44 +167,10 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
 #pragma unroll 1
     for (int e = lane; e < NP * LD; e += 64) S[e] = 0.0;
   }
-  if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[4] = (long long)__builtin_readcyclecounter() - c0; }
-  const bool local_rows = FUSED && fz.lc != nullptr, closed = FUSED && fz.cs_L != nullptr;
+  if (dbg && !FUSED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[4] = (long long)__builtin_readcyclecounter() - c0; }
+  const bool local_rows = FUSED && fz.lc != nullptr;      // closed blocks have their own body (psd_sign_closed.h)
   LcDesc lcd = {0, 0, 0, 0};
   if (local_rows) lcd = fz.lc[id];       // {first row, rows | longest row << 16, first nonzero, nonzeros}: wave-uniform
-  const int nk = lcd.y & 0xffff;
-  double yk = 0.0;                       // closed block: the multiplier of the lane's row (kept for the epilogue's b^T y)
-  if (closed && nk > 0) {
-    // y_B = (L D L^T)^-1 rhs_B, one lane per row, the serial order of forest_solve_kernel (columns ascending, then descending)
-    const bool mine = lane < nk;
-    const int row = fz.lc_row[lcd.x + (mine ? lane : 0)];
-    const double* __restrict__ Lb = fz.cs_L + fz.cs_off[id];
-    double lrow[kClosedMaxRows], lcol[kClosedMaxRows];
-#pragma unroll
-    for (int q = 0; q < kClosedMaxRows; ++q) {
-      lrow[q] = (mine && q < lane) ? Lb[lane * nk + q] : 0.0;               // L[lane][q]
-      lcol[q] = (mine && q > lane && q < nk) ? Lb[q * nk + lane] : 0.0;     // L[q][lane]
-    }
-    const double rp = __dadd_rn(-fz.ax_old[row], fz.b[row]);               // Rp = -A X + b
-    double x = mine ? __dadd_rn(-fz.as_old[row], __dmul_rn(fz.isig, rp)) : 0.0;
-    const double dk = fz.cs_D[row];
-#pragma unroll
-    for (int j = 0; j < kClosedMaxRows; ++j) {                              // L z = rhs
-      const double xj = __shfl(x, j, 64);
-      if (j < nk && lane > j) x = __dsub_rn(x, __dmul_rn(lrow[j], xj));
-    }
-    double yv = x / dk;                                                     // D^-1, then L^T y = z
-#pragma unroll
-    for (int j = kClosedMaxRows - 2; j >= 0; --j) {
-#pragma unroll
-      for (int i = j + 1; i < kClosedMaxRows; ++i) {
-        const double yi = __shfl(yv, i, 64);
-        if (lane == j && i < nk) yv = __dsub_rn(yv, __dmul_rn(lcol[i], yi));
-      }
-    }
-    yk = mine ? yv : 0.0;
-    if (mine) { fz.y_out[row] = yv; S[lane * LD + NP] = yv; }               // pad column of the tile: the gather below reads it
-    wave_fence();
-  }
   double ss = 0.0;
 #pragma unroll 1
   for (int base = 0; base < len; base += 64 * U) {
@@ -215,17 +186,18 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
         rc[u] = tab[ec_];
         p0[u] = fz.rp[i]; p1[u] = ok_ ? fz.rp[i + 1] : p0[u]; cq[u] = fz.C[i]; v[u] = fz.X[i];
       }
+      if (base == 0) { CUADMM_SWT_STAMP(5); }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         CUADMM_SWT_SLOT(u);
         double t = 0.0;
-        if (closed) { for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * S[fz.ci_local[p] * LD + NP]; }
-        else { for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * fz.y[fz.ci[p]]; }
+        for (int p = p0[u]; p < p1[u]; ++p) t += fz.av[p] * fz.y[fz.ci[p]];
         const double r1 = t - cq[u];
         if (ok_) fz.Rd1[off + e_] = r1;
         v[u] = ok_ ? v[u] + r1 * fz.sig : 0.0;
         (void)ec_;
       }
+      if (base == 0) { CUADMM_SWT_STAMP(6); }
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -235,7 +207,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
         v[u] = ok_ ? x : 0.0;
       }
     }
-    if (dbg && base == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) dbg[5] = (long long)__builtin_readcyclecounter() - c0; }
+    if (dbg && !FUSED && base == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) dbg[5] = (long long)__builtin_readcyclecounter() - c0; }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       CUADMM_SWT_SLOT(u);
@@ -246,7 +218,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       if (ok_) { S[r * LD + c] = x; S[c * LD + r] = x; }
     }
   }
-  if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[6] = (long long)__builtin_readcyclecounter() - c0; }
+  if (dbg && !FUSED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[6] = (long long)__builtin_readcyclecounter() - c0; }
   const double nrm = sqrt(wave_sum(ss));
   const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);   // NaN propagates (flagged at the store)
   wave_fence();
@@ -326,8 +298,6 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   }
   if (steps_out && lane == 0) *steps_out = sched.steps;
   if (hint && lane == 0) *hint = sched.lifts;
-  if (steps_out && lane == 0) *steps_out = sched.steps;
-  if (hint && lane == 0) *hint = sched.lifts;
   const long long c2 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   // ---- epilogue: P = 0.5 (X0 + S X0).  A fragments of S from LDS, then the tile takes X0 again (fused: rebuilt from X and
   // Rd1, bit-identical), whose sub-tiles are read in accumulator layout (register B operand; X0 is exactly symmetric in LDS)
@@ -354,6 +324,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
     }
   }
   wave_fence();
+  CUADMM_SWT_STAMP(7);
   {
     sl_v4f64 xb[NT][NT], p[NT][NT];
 #pragma unroll
@@ -373,6 +344,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
     swt_store_mirrored<NT>(S, r16, kk, p);
   }
   wave_fence();
+  CUADMM_SWT_STAMP(8);
   // ---- the projection leaves through the flat walk again.  Fused: S, Rd, X updates and the two sums on the way (the
   // expressions of post_kernel); the slot of P(r, c) in the tile then takes S - C and its mirror image (the pad column for a
   // diagonal element) the new X -- the staging the local constraint rows read.
@@ -380,9 +352,8 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   double s_rd = 0.0, s_cx = 0.0;
   const bool upd = FUSED && fz.mode == 0;
   int ze = 0, kb = 0, ke = 0, krow = 0;
-  double zv = 0.0, kb_b = 0.0, kb_n = 0.0;
+  double zv = 0.0;
   if (local_rows) {                      // index data of the local rows first: the round trip overlaps the walk below
-    if (closed && upd && lane < nk) { const int row = fz.lc_row[lcd.x + lane]; kb_b = fz.b[row]; kb_n = fz.normA[row]; }
     if (lane < lcd.w) { ze = fz.lc_e[lcd.z + lane]; zv = fz.lc_v[lcd.z + lane]; }
     if (lane < (lcd.y & 0xffff)) { kb = fz.lc_nzptr[lcd.x + lane] - lcd.z; ke = fz.lc_nzptr[lcd.x + lane + 1] - lcd.z; krow = fz.lc_row[lcd.x + lane]; }
   }
@@ -433,6 +404,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       }
     }
   }
+  CUADMM_SWT_STAMP(9);
   if (FUSED) {
     if (local_rows && lcd.w > 0) {
       // one lane per nonzero forms a * v from the staging, one lane per row adds its segment in order (host: a block keeps its
@@ -453,20 +425,11 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
         if (fz.outS) fz.outS[krow] = as;
         if (upd && fz.outX) fz.outX[krow] = ax;
       }
-      if (closed && upd) {               // the rows' share of the stopping test's constraint-space sums (rp_stats_partial_kernel)
-        const double ro = kb_n * (kb_b - ax) * fz.bscale;
-        double pr = lane < nk ? ro * ro : 0.0, pby = lane < nk ? kb_b * yk : 0.0;
-        pr = wave_sum(pr);
-        pby = wave_sum(pby);
-        if (lane == 0) { fz.partials2[2 * (long long)slot] = pr; fz.partials2[2 * (long long)slot + 1] = pby; }
-      }
-    } else if (closed && upd && lane == 0) {
-      fz.partials2[2 * (long long)slot] = 0.0; fz.partials2[2 * (long long)slot + 1] = 0.0;
     }
     if (upd) {
       s_rd = wave_sum(s_rd);
       s_cx = wave_sum(s_cx);
-      if (lane == 0) { fz.partials[2 * (long long)slot] = s_rd; fz.partials[2 * (long long)slot + 1] = s_cx; }
+      if (lane == 0) { fz.partials[poff + 2 * (long long)slot] = s_rd; fz.partials[poff + 2 * (long long)slot + 1] = s_cx; }
     }
   }
   if (bad && fail) atomicAdd(fail, 1);
@@ -476,5 +439,6 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   }
 }
 #undef CUADMM_SWT_SLOT
+#undef CUADMM_SWT_STAMP
 
 }  // namespace cuadmm

@@ -93,14 +93,20 @@ struct SignSched {
   // One decision per Newton-Schulz step.  n: true block size; a, b from Y = S^2 of the CURRENT iterate; g2: ||S - SY||_F^2
   // of the current iterate (LAG = false) or of the previous one (LAG = true; ignored at the first step).
   // Returns mu of this step; `last` = this update is the final one.
+  // Which statistics does the next decision read?  needs_stats(): any at all; needs_ab(): tr Y and ||Y||_F^2 as well (the first
+  // step and the decision after a probe); in the plain and finishing phases only g2 is read -- one wave reduction, not three.
+  CUADMM_SCHED_HD bool needs_ab() const { return steps == 0 || (fin == 0 && !plain); }
+
   template <bool LAG>
   CUADMM_SCHED_HD double decide(int n, double a, double b, double g2, bool& last) {
-    const double d2 = (double)n - 2.0 * a + b;
-    double g = sqrt(g2 > 0.0 ? g2 : 0.0);
-    if (LAG) g = gprev;                 // iterate k-1
+    // exit tests compare g^2 with kGExit^2 (no square root on the steps that only test); g itself -- this iterate's, or the
+    // previous one's in the lagged variant -- is formed where a bound is derived from it
+    constexpr double kGExit2 = kGExit * kGExit;
+    const double g2c = g2 > 0.0 ? g2 : 0.0;
     double mu = 1.0;
     last = false;
     const bool was_plain = plain;
+    double g_now = -1.0;                // !LAG: sqrt(g2) once a branch below needed it (kept in gprev for the host model)
     if (steps == 0) {
       if (!(b > 0.0)) { last = true; }  // zero (or non-finite) block: one harmless update
       else {
@@ -113,10 +119,10 @@ struct SignSched {
     } else if (fin > 0) {
       --fin;
       last = fin == 0;
-      if (!LAG && g <= kGExit) last = true;
+      if (!LAG && g2c <= kGExit2) last = true;
     } else if (plain) {
       if (LAG) last = plain_prev && gprev >= 0.0 && 0.75 * gprev * gprev <= kGExit;
-      else last = g <= kGExit;
+      else last = g2c <= kGExit2;
     } else if (k > 0 && G * kTol < 0.5) {
       mu = kMu; --k; j = 0;
     } else if (j == 0) {
@@ -124,10 +130,13 @@ struct SignSched {
       mu = kMuP1; j = 1;
     } else if (j == 1) {
       mu = kMuP2; j = 2;
-    } else if (d2 < 0.5) {
+    } else if ((double)n - 2.0 * a + b < 0.5) {
       plain = true;
-      if (!LAG) last = g <= kGExit;
+      if (!LAG) last = g2c <= kGExit2;
     } else {
+      const double d2 = (double)n - 2.0 * a + b;
+      const double g = LAG ? gprev : sqrt(g2c);
+      g_now = g;
       // Unresolved eigenvalues exist.  Rigorous facts (no assumption on the spectrum): every eigenvalue satisfies
       // s (1 - s^2) <= g, i.e. it is either <= gb = g (1 + 1.5 g^2) or within gb / 2 of 1 (for g <= 0.3).
       double gb = -1.0, eb = 0.0;          // bounds for the CURRENT iterate: unresolved <= gb, basin error <= eb
@@ -173,7 +182,7 @@ struct SignSched {
     if (mu >= 0.999 * kMu) ++lifts;
     plain_prev = was_plain;
     muprev = mu;
-    if (!LAG) gprev = g;
+    if (!LAG) gprev = g_now;              // only where it was formed; the one-wavefront kernels never read it
     G *= 1.5 * mu;
     ++steps;
     if (steps >= kCap) last = true;

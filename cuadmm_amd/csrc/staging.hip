@@ -38,9 +38,20 @@ struct Staging {
   }
 };
 
-Staging& staging() {
-  static Staging s;   // process-wide, never freed (the runtime may already be gone at exit)
-  return s;
+// One staging state PER DEVICE (stream, events and buffers belong to the device that was current when they were made: a copy
+// for another device issued on this stream would not be covered by its events).  Process-wide, never freed (the runtime may
+// already be gone at exit).
+constexpr int kMaxDevices = 64;
+Staging* staging(int& rc) {
+  static Staging per_device[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("staging: no current HIP device (or more than %d devices)", kMaxDevices);
+    rc = CUADMM_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  rc = CUADMM_OK;
+  return &per_device[dev];
 }
 
 }  // namespace
@@ -56,11 +67,13 @@ static int drain(hipStream_t after) {
 // dst (device) <- src (pageable host).  Blocks until the data is on the device.
 int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t after) {
   if (bytes == 0) return CUADMM_OK;
-  { int rc0 = drain(after); if (rc0) return rc0; }
-  Staging& s = staging();
+  { int rc0 = drain(after); if (rc0) return rc0; }          // before the lock: another thread's solver may be waiting for it
+  int rc = CUADMM_OK;
+  Staging* sp = staging(rc);
+  if (!sp) return rc;
+  Staging& s = *sp;
   std::lock_guard<std::mutex> lk(s.mu);
-  int rc = s.ensure();
-  if (rc) return rc;
+  if ((rc = s.ensure())) return rc;
   size_t done = 0;
   for (int i = 0; done < bytes; i ^= 1) {
     const size_t n = std::min(kHalf, bytes - done);
@@ -77,12 +90,13 @@ int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t after) {
 // dst (pageable host) <- src (device); blocks
 int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t after) {
   if (bytes == 0) return CUADMM_OK;
-  (void)after;
-  Staging& s = staging();
+  { int rc0 = drain(after); if (rc0) return rc0; }          // the producers have finished (null: every stream of the device)
+  int rc = CUADMM_OK;
+  Staging* sp = staging(rc);
+  if (!sp) return rc;
+  Staging& s = *sp;
   std::lock_guard<std::mutex> lk(s.mu);
-  int rc = s.ensure();
-  if (rc) return rc;
-  CUADMM_HIP_TRY(hipDeviceSynchronize());                           // producers on any stream have finished
+  if ((rc = s.ensure())) return rc;
   size_t done = 0, copied = 0;
   size_t len[2] = {0, 0};
   for (int i = 0; copied < bytes; i ^= 1) {
@@ -107,10 +121,12 @@ int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t after) {
 int staged_h2d_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, hipStream_t after) {
   if (rows == 0 || width_bytes == 0) return CUADMM_OK;
   { int rc0 = drain(after); if (rc0) return rc0; }
-  Staging& s = staging();
+  int rc = CUADMM_OK;
+  Staging* sp = staging(rc);
+  if (!sp) return rc;
+  Staging& s = *sp;
   std::lock_guard<std::mutex> lk(s.mu);
-  int rc = s.ensure();
-  if (rc) return rc;
+  if ((rc = s.ensure())) return rc;
   if (width_bytes > kHalf) { set_error("staged_h2d_2d: row of %zu bytes exceeds the staging buffer", width_bytes); return CUADMM_ERR_INVALID; }
   const size_t per = std::max<size_t>(1, kHalf / width_bytes);
   size_t r0 = 0;

@@ -38,6 +38,11 @@ int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const
                      double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st, int* nparts_out = nullptr);
 // all four scalars of the stopping test from the per-block partial pairs of a fused iteration with closed blocks
 int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, hipStream_t st);
+// per-block copy of the closed blocks' rows of [A X | A (S - C)] from the by-row vectors (psd_sign_closed.h)
+struct ClosedRec;
+int launch_closed_gather_out(const ClosedRec* rec, int nslots, const double* ax, const double* as, double* cl_out, hipStream_t st);
+// several iterations per launch: out4[4 k ..] from the partial arrays of iteration k (p1 + k stride, p2 + k stride; n pairs each)
+int launch_reduce_quads_batch(const double* p1, const double* p2, int n, long long stride, int iters, double* out4, hipStream_t st);
 
 // Rows of A with more than `cap` nonzeros (a trace / all-ones constraint): their tail is summed in segments by extra
 // workgroups and added in segment order (reproducible), so one row cannot serialise the SpMV.

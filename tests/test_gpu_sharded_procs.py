@@ -30,3 +30,28 @@ def test_two_processes_one_gpu(kind, port, tmp_path):
     assert tuple(d["dims"]) == (d["X"].size, d["y"].size, 49)
     assert np.max(np.abs(d["X"] - d["Xref"])) <= 1e-9 * (1 + np.max(np.abs(d["Xref"])))
     assert np.max(np.abs(d["y"] - d["yref"])) <= 1e-8 * (1 + np.max(np.abs(d["yref"])))
+
+
+@pytest.mark.parametrize("name,port", [("pendulum_N=80", 29643), ("PlanarHand_N=1_MOMENT", 29644)])
+def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path):
+    """BASELINE configs[4] (pendulum N = 80) and configs[0] (PlanarHand) on TWO ranks: blocks sharded by index, coupled
+    constraints, the replicated y-solve with the GPU tail and the device-side leading sweeps on every rank -- against the
+    committed oracle trajectory (tests/golden/oracle_traj_moment.json), same tolerance as the one-rank test."""
+    import json
+    from tests.test_gpu_moment_parity import TOL, SIX, FLOOR
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_traj_moment.json")) as f:
+        rec = json.load(f)[name + "/switch=11000"]
+    out = tmp_path / "res.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "_sharded_worker.py"), str(out), name],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = np.load(out)
+    assert d["shard"][0] == 0 and 0 < d["shard"][1]                  # rank 0 holds a proper part of the svec
+    th = TOL[name + "/switch=11000"][0]
+    for nm in SIX:
+        ref = np.array([float(x) for x in rec[nm]])
+        dev = np.max(np.abs(d[nm][:ref.size] - ref) / (FLOOR[nm] + np.abs(ref)))
+        assert dev <= th, (nm, dev)
+    assert np.array_equal(d["sig"][:60], np.array([float(x) for x in rec["sig"]]))
