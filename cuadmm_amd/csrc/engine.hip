@@ -192,6 +192,7 @@ struct cuadmm_solver {
     DevBuf<ClosedRec> rec;         // one record per fused slot (psd_fuse.h)
     DevBuf<double> partials2, cl_out;
     bool out_dirty = true;         // a stand-alone kernel rewrote [A X | A (S - C)] by row: refresh the per-block copy first
+    long long iters_done = 0;      // fused closed iterations launched so far (ages the schedule hints deterministically)
   } closed;
   bool stats_fused = false;        // this iteration's four scalars were formed by launch_reduce_quads
   int fused_nparts = 0;
@@ -200,12 +201,15 @@ struct cuadmm_solver {
   // (pinned, written by the reduction through its device mapping when no collective is needed), ck_*: the checkpoint a batch
   // starts from (restored when the stopping test or the tau rule fires inside it).
   struct Batch {
-    int max_iters = 32;
+    int max_iters = 64;
     DevBuf<double> p1, p2, scal_d, ck_X, ck_S, ck_y, ck_out;
+    DevBuf<int> ck_hint;
+    long long ck_iters_done = 0;
     PinnedBuf<double> h;
     double* h_dev = nullptr;
     long long pstride = 0;
     int len = 0, pos = 0;          // iterations launched / consumed by the host loop
+    bool have_ck = false;          // this batch started from a checkpoint (taken whenever something could invalidate it)
     double tau = 0, sig = 0;
     long long launches = 0, iters = 0, rollbacks = 0;
   } bt;
@@ -213,6 +217,9 @@ struct cuadmm_solver {
   // if_first = false then simply continues, instead of unscaling and rescaling three vectors and recomputing A X, A (S - C)
   bool pending_unscale = false;
   int lazy_unscale = 1;
+  int opt_tiny_sign = getenv("CUADMM_TINY_SIGN") ? atoi(getenv("CUADMM_TINY_SIGN")) : 1;   // option "tiny_sign": 0 never, 1 closed candidates, 2 always
+  bool closed_candidate = false;
+  int opt_hint = getenv("CUADMM_PSD_HINT") ? atoi(getenv("CUADMM_PSD_HINT")) : 1;   // option "psd_hint": 0 off, 1 one-wavefront kernels, 2 all
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -456,6 +463,8 @@ struct cuadmm_solver {
     }
     if (closed.active) {
       fz.rec = closed.rec.p; fz.cl_out = closed.cl_out.p; fz.y_out = y_d.p;
+      fz.iter0 = (int)(closed.iters_done & 0x3fffffff);
+      closed.iters_done += iters > 1 ? iters : 1;
       fz.partials2 = closed.partials2.p;
       fz.isig = 1 / sig; fz.bscale = bscale;
       if (closed.out_dirty) {
@@ -498,7 +507,7 @@ struct cuadmm_solver {
   // --- several iterations per launch ---------------------------------------------------------------------------------
   bool can_batch() const {
     return bt.max_iters >= 2 && fuse && closed.active && dev_solve && !lead.ready && plan.n_rest == 0 && eig_rank == 0 && !out_mapped &&
-           plan.fused_blocks() > 0;
+           plan.fused_blocks() > 0 && plan.one_dominant_geometry();
   }
   int batch_alloc() {
     if (bt.p1.p) return CUADMM_OK;
@@ -517,14 +526,22 @@ struct cuadmm_solver {
     prof_begin(K_COPY);
     struct { double* live; double* ck; size_t n; } v[4] = {{X.p, bt.ck_X.p, (size_t)L}, {S.p, bt.ck_S.p, (size_t)L}, {y_d.p, bt.ck_y.p, (size_t)m},
                                                            {out_d.p, bt.ck_out.p, 2 * (size_t)m + 2}};
-    for (auto& q : v)
-      if (q.n) CUADMM_HIP_TRY(hipMemcpyAsync(save ? q.ck : q.live, save ? q.live : q.ck, sizeof(double) * q.n, hipMemcpyDeviceToDevice, st));
+    for (auto& q : v) {
+      int rc = launch_copy(save ? q.ck : q.live, save ? q.live : q.ck, (long long)q.n, st);
+      if (rc) return rc;
+    }
+    if (hint_d.p) {   // the schedule hints are part of the state an iteration reads and writes
+      if (!bt.ck_hint.p) { int rc = bt.ck_hint.alloc(hint_d.n); if (rc) return rc; }
+      CUADMM_HIP_TRY(hipMemcpyAsync(save ? bt.ck_hint.p : hint_d.p, save ? hint_d.p : bt.ck_hint.p, sizeof(int) * hint_d.n, hipMemcpyDeviceToDevice, st));
+    }
+    if (save) bt.ck_iters_done = closed.iters_done; else closed.iters_done = bt.ck_iters_done;
     prof_end(K_COPY, 16.0 * (2.0 * (double)L + 3.0 * m + 2));
     return CUADMM_OK;
   }
   // the device ran bt.len iterations, the host schedule accepts only the first `keep` of them: back to the checkpoint and
   // forward again by `keep` iterations (bit-identical: same kernels, same inputs)
   int batch_rollback(int keep) {
+    if (!bt.have_ck) { set_error("internal: batch invalidated without a checkpoint"); return CUADMM_ERR_INVALID; }
     int rc = batch_copy(false);
     if (rc) return rc;
     closed.out_dirty = true;
@@ -597,7 +614,9 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "eig_rank_maxfeas") s->eig_rank_maxfeas = value;
   else if (k == "psd_steps") s->psd_steps = (int)value;       // record the sign kernels' step count per block (cuadmm_get_psd_steps)
   else if (k == "batch") s->bt.max_iters = std::max(0, std::min(256, (int)value));   // iterations per launch, closed blocks (0 / 1: off)
-  else if (k == "lazy_unscale") s->lazy_unscale = (int)value;                            // 0: unscale X, y, S at the end of every solve
+  else if (k == "lazy_unscale") s->lazy_unscale = (int)value;
+  else if (k == "psd_hint") s->opt_hint = (int)value;
+  else if (k == "tiny_sign") s->opt_tiny_sign = (int)value;                               // n <= 8 on the sign kernel (before init)                                     // schedule warm start (before init)                            // 0: unscale X, y, S at the end of every solve
   else if (k == "graph") {}
   else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
   return CUADMM_OK;
@@ -858,16 +877,40 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->L = L;
   s->blk_local.assign(blk + s->blk_begin, blk + s->blk_end);
   s->plan.eig_rank = s->eig_rank > 0 ? s->eig_rank : 0;
+  {
+    // Closed-block candidate: every constraint lives in ONE block of this rank, no block has more than kClosedMaxRows of them or
+    // more than kFuseRowsMax nonzeros, every block fits a one-wavefront kernel (n <= 64).  Then the tiny blocks go through the sign
+    // kernel too (PsdPlan::tiny_sign), so that the whole iteration of every block can run in psd_sign_closed.h.
+    const auto& bl = s->blk_local;
+    bool cand = s->opt_tiny_sign != 0 && s->eig_rank == 0 && !bl.empty() && m > 0 && s->world == 1;
+    bool any_tiny = false;
+    for (size_t k = 0; k < bl.size() && cand; ++k) { cand = bl[k] > 0 && bl[k] <= 64; any_tiny = any_tiny || bl[k] <= 8; }
+    if (cand && any_tiny && s->opt_tiny_sign == 1) {
+      std::vector<long long> boff(bl.size() + 1, 0);
+      for (size_t k = 0; k < bl.size(); ++k) boff[k + 1] = boff[k] + blk_svec_len(bl[k]);
+      std::vector<int> rows_of(bl.size(), 0), nz_of(bl.size(), 0);
+      for (int j = 0; j < m && cand; ++j) {
+        if (At_cp[j] == At_cp[j + 1]) continue;
+        const long long r0 = At_ri[At_cp[j]];
+        const size_t k = (size_t)(std::upper_bound(boff.begin(), boff.end(), r0) - boff.begin()) - 1;
+        for (int p = At_cp[j]; p < At_cp[j + 1] && cand; ++p) cand = At_ri[p] >= boff[k] && At_ri[p] < boff[k + 1];
+        cand = cand && ++rows_of[k] <= kClosedMaxRows && (nz_of[k] += At_cp[j + 1] - At_cp[j]) <= kFuseRowsMax;
+      }
+    }
+    s->plan.tiny_sign = cand && any_tiny;
+    s->closed_candidate = cand;
+  }
   rc = s->plan.build(s->blk_local.data(), (int)s->blk_local.size());
   s->plan.overlap = true;
-  if (!rc && !s->blk_local.empty() && getenv("CUADMM_PSD_HINT") && atoi(getenv("CUADMM_PSD_HINT")) == 1) {
-    // Schedule warm start of the sign kernels (lift steps each block needed in the previous projection), OPT-IN: measured
-    // C2 12.0 -> 11.4 steps (-4 % projection time), C4 11.0 -> 10.5, but C3 17 -> 18 (+5 %): the recorded count includes the
-    // overshoot of the previous run's bursts and only decays every 16th projection, and a failed first probe costs 4 steps.
+  if (!rc && !s->blk_local.empty() && s->opt_hint != 0) {
+    // Schedule warm start of the ONE-WAVEFRONT sign kernels (lift steps each block needed in the previous projection): C2 12.0 ->
+    // 11.4 steps (+3 % iterations / s), C4 11.0 -> 10.5.  Not for the batched-GEMM path of the large blocks (C3: 17 -> 18 steps:
+    // the recorded count includes the overshoot of the previous run's bursts, and a failed first probe costs 4 steps there).
+    // The hint ages by one step every 16th projection (PsdPlan::project; inside the task loop of the batched launches).
     if ((rc = s->hint_d.alloc(s->blk_local.size()))) return rc;
     CUADMM_HIP_TRY(hipMemset(s->hint_d.p, 0, sizeof(int) * s->blk_local.size()));
     s->plan.d_hint = s->hint_d.p;
-    s->plan.sign.d_hint = s->hint_d.p;
+    if (s->opt_hint == 2) s->plan.sign.d_hint = s->hint_d.p;
   }
   // step counts per block: for cuadmm_get_psd_steps and for the longest-block-first reordering of the fused launches
   if (!rc && (s->psd_steps || s->plan.fusable()) && !s->blk_local.empty()) {
@@ -1104,11 +1147,10 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   // Default: only when no block with rows is smaller than 17 -- the solve adds two dependent memory round trips to a block's
   // prologue: < 4 % of the lifetime of an n >= 17 block (C2: 0.307 -> 0.300 ms per iteration, the solve and statistics kernels
   // gone), but 15 % of an n <= 16 block's (C4 with its 67 000 tiny blocks: 1.89 -> 1.91).  CUADMM_FUSE_SOLVE=1 / 0 forces it.
+  // (round 2 kept blocks with rows and n < 17 out: the solve added two dependent round trips to their prologue; with the block
+  // records of psd_sign_closed.h it rides in the one trip the prologue makes anyway)
   bool want_closed = true;
   if (const char* e = getenv("CUADMM_FUSE_SOLVE")) want_closed = atoi(e) != 0;
-  else
-    for (size_t k = 0; k < s->lrows.h_desc.size() && want_closed; ++k)
-      if ((s->lrows.h_desc[k].y & 0xffff) > 0 && s->blk_local[k] < 17) want_closed = false;
   if (want_closed && s->fuse && s->lrows.active && s->lrows.nrest == 0 && s->dev_solve && !s->lead.ready && s->forest_trees > 0 && s->lrows.nlocal == m) {
     const auto& hd = s->lrows.h_desc;
     const auto& hrow = s->lrows.h_row;
@@ -1349,7 +1391,9 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         if ((i <= sig_update_threshold && i % sig_update_stage_1 == 1) || (i > sig_update_threshold && i % sig_update_stage_2 == 1)) { K = j + 1; break; }
       }
       if (K >= 2) {
-        if ((rc = s->batch_alloc()) || (rc = s->batch_copy(true))) return rc;
+        // a batch can only be invalidated by the stopping test or the errRd < stop_tol rule for tau: no checkpoint without a tolerance
+        s->bt.have_ck = stop_tol > 0.0;
+        if ((rc = s->batch_alloc()) || (s->bt.have_ck && (rc = s->batch_copy(true)))) return rc;
         s->bt.tau = tau; s->bt.sig = s->sig;
         if ((rc = s->launch_fused_step(0, tau, K))) return rc;
         if (lpt_ev > 0 && s->steps_d.p) {   // longest block first without a stall: fetch behind one batch, sort during the next

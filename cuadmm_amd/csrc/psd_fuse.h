@@ -48,6 +48,7 @@ struct SignFuse {
   // (16 doubles per slot: A X of row k at 16 slot + k, A (S - C) at 16 slot + 8 + k; outX / outS keep the by-row copy)
   const struct ClosedRec* rec;
   double* cl_out;
+  int iter0;                                          // closed blocks: iterations run before this launch (ages the schedule hints)
 };
 struct LcDesc { int x, y, z, w; };
 constexpr int kFuseRowsMax = 64;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
 #endif
     double* tile = swt_smem + toff;
     psd_sign_closed_body<NT, true>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
-                             al.dbg ? al.dbg + 10 * (long long)(j0 + j) : nullptr, d.off, d.slot, (long long)it * al.pstride);
+                             al.dbg ? al.dbg + 10 * (long long)(j0 + j) : nullptr, d.off, d.slot, (long long)it * al.pstride, it);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane_id() == 0) { volatile int* dn = ctl + 1 + j; *dn = it + 1; }
   }
@@ -260,6 +260,7 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
     ca.X = fz->X; ca.S = fz->S; ca.Rd1 = fz->Rd1; ca.C = fz->C; ca.rec = fz->rec; ca.cl_out = fz->cl_out; ca.y_out = fz->y_out;
     ca.outS = fz->outS; ca.outX = fz->outX; ca.partials = fz->partials; ca.partials2 = fz->partials2;
     ca.sig = fz->sig; ca.inv_sig = fz->inv_sig; ca.tau_sig = fz->tau_sig; ca.isig = fz->isig; ca.bscale = fz->bscale;
+    ca.iter0 = fz->iter0;
     ca.pstride = fz->pstride; ca.mode = fz->mode; ca.iters = fz->iters > 1 ? fz->iters : 1; ca.first = first; ca.count = count;
     if (fz->iters > 1) {
       constexpr int WAVES = 4 * OCC > 16 ? 16 : 4 * OCC, WG_PER_CU = 4 * OCC / WAVES;
@@ -312,6 +313,8 @@ static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_
   static const int wpg = getenv("CUADMM_PSD_W32_WPG") ? atoi(getenv("CUADMM_PSD_W32_WPG")) : 1;
   static const int occ = getenv("CUADMM_PSD_W32_OCC") ? atoi(getenv("CUADMM_PSD_W32_OCC")) : 3;
   const int gen = psd_knobs().gen;
+  static const int cu_occ = getenv("CUADMM_CU_OCC") ? atoi(getenv("CUADMM_CU_OCC")) : 4;     // A/B: wavefronts per SIMD of the batched launches
+  if (fz && fz->iters > 1 && cu_occ == 3) return launch_sign_wave<2, 3>(a, first, count, st, fz, slot0);
   if (gen == 3 && (!a.dbg || fz)) return launch_sign_wave<2, 3>(a, first, count, st, fz, slot0);
   if ((gen == 4 && !a.dbg) || fz) return launch_sign_wave<2, 4>(a, first, count, st, fz, slot0);
   static const int pad = getenv("CUADMM_PSD_W32_PAD") ? atoi(getenv("CUADMM_PSD_W32_PAD")) : 0;   // occupancy experiments: unused dynamic LDS
@@ -394,7 +397,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     cls_begin[c] = (int)ids.size();
     std::vector<int> members;
     for (int k = 0; k < mat_num; ++k)
-      if (blk[k] > 0 && psd_class_of(blk[k]) == c && blk[k] < sign_min) members.push_back(k);
+      if (blk[k] > 0 && class_of(blk[k]) == c && blk[k] < sign_min) members.push_back(k);
     std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return blk[x] > blk[y]; });
     for (int k : members) {
       ids.push_back(k);
@@ -430,6 +433,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     fused_slots(slot_of);
     for (size_t q = 0; q < ids.size(); ++q) desc[q] = PsdDesc{off[ids[q]], blk[ids[q]], ids[q], slot_of[ids[q]], {0, 0, 0}};
     CUADMM_HIP_TRY(hipMalloc(&d_desc, sizeof(PsdDesc) * desc.size()));
+    CUADMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_desc_pin), sizeof(PsdDesc) * desc.size(), hipHostMallocDefault));   // reorder_by_steps_async
     { int rc_ = staged_h2d(d_desc, desc.data(), sizeof(PsdDesc) * desc.size()); if (rc_) return rc_; }
     h_desc = desc;
   }
@@ -540,6 +544,21 @@ bool PsdPlan::sort_by_steps_host(const int* steps_host, std::vector<std::pair<in
   return !ranges.empty();
 }
 
+bool PsdPlan::one_dominant_geometry() const {
+  double w[4] = {0, 0, 0, 0}, tot = 0;                     // NT = 1 .. 4
+  for (int c = 2; c <= 4; ++c) {
+    if ((c == 2 && !sign16) || (c == 4 && !wave4)) continue;
+    for (int q = 0; q < cls_count[c]; ++q) {
+      const int n = h_blk[h_ids[cls_begin[c] + q]];
+      const int nt = n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4));
+      const double x = (double)nt * nt * nt;               // the tile is what is paid for
+      w[nt - 1] += x; tot += x;
+    }
+  }
+  for (double x : w) if (x >= 0.9 * tot && tot > 0) return true;
+  return false;
+}
+
 int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
   std::vector<std::pair<int, int>> ranges;
   sort_by_steps_host(steps_host, ranges);
@@ -553,7 +572,6 @@ int PsdPlan::reorder_by_steps(const int* steps_host, hipStream_t st) {
 int PsdPlan::reorder_by_steps_async(const int* steps_host, hipStream_t st) {
   std::vector<std::pair<int, int>> ranges;
   if (!sort_by_steps_host(steps_host, ranges)) return CUADMM_OK;
-  if (!h_desc_pin) CUADMM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_desc_pin), sizeof(PsdDesc) * h_desc.size(), hipHostMallocDefault));
   std::copy(h_desc.begin(), h_desc.end(), h_desc_pin);
   for (auto& rg : ranges)
     CUADMM_HIP_TRY(hipMemcpyAsync(d_desc + rg.first, h_desc_pin + rg.first, sizeof(PsdDesc) * (size_t)rg.second, hipMemcpyHostToDevice, st));
@@ -577,7 +595,7 @@ int PsdPlan::build_rest_index() {
   long long off = 0;
   for (int k = 0; k < nblk; ++k) {
     const long long len = blk_svec_len(h_blk[k]);
-    const int c = h_blk[k] > 0 && h_blk[k] < sign_min ? psd_class_of(h_blk[k]) : -1;
+    const int c = h_blk[k] > 0 && h_blk[k] < sign_min ? class_of(h_blk[k]) : -1;
     if (!(c == 3 || (c == 4 && wave4) || (c == 2 && sign16)))
       for (long long i = off; i < off + len; ++i) rest.push_back((int)i);
     off += len;
@@ -591,7 +609,7 @@ int PsdPlan::build_rest_index() {
 }
 
 int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const SignFuse* fz) const {
-  if (d_hint && (++n_project & 15) == 0) {
+  if (d_hint && !(fz && fz->rec) && (++n_project & 15) == 0) {   // closed blocks age their hints themselves (psd_sign_closed.h)
     hipLaunchKernelGGL(hint_decay_kernel, dim3((nblk + 255) / 256), dim3(256), 0, st, d_hint, nblk);
     CUADMM_HIP_TRY(hipGetLastError());
   }

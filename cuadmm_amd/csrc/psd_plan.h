@@ -64,11 +64,21 @@ struct PsdPlan {
   long long n_rest = 0;
   bool fusable() const;
   int fused_blocks() const { return (sign16 ? cls_count[2] : 0) + cls_count[3] + (wave4 ? cls_count[4] : 0); }
+  // Several iterations per launch run one persistent workgroup per CU and tile geometry (psd_sign_closed_cu_kernel); workgroups
+  // of different geometries cannot share a CU's LDS, so their launches would run one after the other instead of side by side
+  // (measured on BASELINE configs[3], four geometries: 2.24 vs 1.74 ms per iteration): only when one geometry holds >= 90 % of
+  // the fused blocks' work
+  bool one_dominant_geometry() const;
   // 32 < n <= 64 on the one-wavefront kernels (throughput: 1.3x the one-workgroup kernels in bulk) only when there are enough
   // blocks to fill the chip; a handful of blocks (moment relaxations) is a LATENCY problem, and there six / ten wavefronts per
   // block win (measured crossover: ~1000 blocks at n = 45 and at n = 64; CUADMM_PSD_WAVE4_MIN moves it)
   bool wave4 = false;
   bool sign16 = true;          // 9 <= n <= 16 on the one-wavefront sign kernel too (CUADMM_PSD_N16=eig: register eigensolver)
+  // n <= 8 on the one-wavefront sign kernel as well (one 16 x 16 sub-tile; set before build).  Slower than the register
+  // eigensolver as a projection (sixteen 3 x 3 blocks share a wavefront there), but it lets a block-diagonal problem with tiny
+  // blocks run its WHOLE iteration in the closed-block kernels: no stand-alone vector kernels, several iterations per launch.
+  bool tiny_sign = false;
+  int class_of(int n) const { return (tiny_sign && sign16 && n <= 16) ? 2 : psd_class_of(n); }
   int build_rest_index();
   // Longest block first: a launch ends with blocks running alone on their SIMD, and a block that needs 19 steps started last
   // keeps the chip waiting.  The step count of a block barely moves from one ADMM iteration to the next, so the engine now and

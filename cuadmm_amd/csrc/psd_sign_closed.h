@@ -141,6 +141,7 @@ struct ClosedArgs {
   double sig, inv_sig, tau_sig, isig, bscale;
   long long pstride;
   int mode, iters, first, count;
+  int iter0;                                          // iterations run before this launch (the schedule hints age with it)
 };
 
 #define CUADMM_SWC_STAMP(k) \
@@ -153,7 +154,7 @@ struct ClosedArgs {
 // loop-invariant -- hoisted out of the loop it would stay live across the whole body; the lane id is made opaque instead.
 template <int NT, bool TASK_LOOP = false>
 __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n, double* S, int* steps_out, int* hint, long long* dbg,
-                                                     long long off, int slot, long long poff) {
+                                                     long long off, int slot, long long poff, int it_local = 0) {
   using Cfg = SignWaveT<NT>;
   constexpr int LD = Cfg::LD, NP = Cfg::NP, U = Cfg::U, NSLOT = Cfg::NSLOT;
   constexpr int NB = (NSLOT + U - 1) / U;                 // batches of the flat walk
@@ -262,7 +263,13 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   wave_fence();
   double f[4 * NT][NT];
   SignSched sched;
-  if (hint) { const int h = __builtin_amdgcn_readfirstlane(*hint); if (h > 0) sched.lift0 = h; }
+  if (hint) {
+    int h = __builtin_amdgcn_readfirstlane(*hint);
+    // the hint ages by one lift every 16th iteration, staggered over the blocks: a function of the iteration index alone, so one
+    // launch per iteration and several iterations per launch run the same schedules
+    if (h > 1 && (((unsigned)fz.iter0 + (unsigned)it_local + (unsigned)slot) & 15u) == 15u) --h;
+    if (h > 0) sched.lift0 = h;
+  }
   bool last = false;
   const long long c1 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   while (!last) {

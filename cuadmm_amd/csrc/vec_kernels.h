@@ -62,6 +62,7 @@ int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, con
                      const SpmvLongRows* long_rows = nullptr, const int* rowmap = nullptr);   // rowmap: compact row -> output slot
 
 int launch_scale(double* v, long long n, double s, hipStream_t st);
+int launch_copy(double* dst, const double* src, long long n, hipStream_t st);   // device to device, 16-byte aligned pointers
 // y = (L D L^T)^-1 (-A(S-C) + (b - A X) / sigma) on the device, one thread per tree of the elimination forest
 int launch_forest_solve(int ntrees, const int* tree_ptr, const int* tree_cols, const long long* Lp, const int* Li, const double* Lx,
                         const double* D, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st);

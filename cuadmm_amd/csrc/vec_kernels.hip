@@ -605,6 +605,24 @@ void SpmvLongRows::release() {
 __global__ void scale_kernel(double* v, long long n, double s) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) v[i] *= s;
 }
+// dst <- src (device to device), as a kernel on the caller's stream: the runtime's own device-to-device copy measured at 0.3 ms
+// for 42 MB on this driver (a copy-engine path); 16 bytes per lane, two in flight
+__global__ __launch_bounds__(kVecThreads) void copy_kernel(double* __restrict__ dst, const double* __restrict__ src, long long n) {
+  const long long n2 = n / 2, stride = (long long)gridDim.x * blockDim.x;
+  const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+  double2* __restrict__ d2 = reinterpret_cast<double2*>(dst);
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n2; i += 2 * stride) { const double2 a = s2[i], b = s2[i + stride]; d2[i] = a; d2[i + stride] = b; }
+  for (; i < n2; i += stride) d2[i] = s2[i];
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+int launch_copy(double* dst, const double* src, long long n, hipStream_t st) {
+  if (n <= 0) return CUADMM_OK;
+  hipLaunchKernelGGL(copy_kernel, dim3(grid_for(n / 2 + 1, kVecThreads, 256 * 8)), dim3(kVecThreads), 0, st, dst, src, n);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 int launch_scale(double* v, long long n, double s, hipStream_t st) {
   if (n <= 0) return CUADMM_OK;
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, kVecThreads)), dim3(kVecThreads), 0, st, v, n, s);
