@@ -4,8 +4,13 @@
     python bench.py --gpus 1 --steps 200 --warmup 20                       # the headline line (BASELINE configs[1])
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config c1            # PlanarHand_N=1 moment relaxation (BASELINE configs[0]; inputs rebuilt from the shipped .mat)
     python bench.py --config c3            # max-cut, one block n = 2000 (BASELINE configs[2])
     python bench.py --config c4            # 100 000 mixed moment-SOS blocks (BASELINE configs[3]; --scaling strong at N > 1)
+    python bench.py --config c5            # pendulum N = 80 trajectory SDP (BASELINE configs[4]); c1 / c5 shard by block index
+                                           # over the general path (all-reduce + replicated device-side solve) at N > 1
+    ... --c-sparse                         # SURVEY 8d variant of c2: C = A^T y0 + svec(I) (sparse C)
+    ... --projection-only                  # SURVEY 8d micro-benchmark: Xb ~ N(0,1)^L through the projection kernels alone
     ... --sharding allreduce               # force the general sharded path: RCCL all-reduce of [A X | sums | A(S-C)] (2m+2
                                            # doubles) before every replicated host y-solve, instead of owned constraints
 
@@ -93,6 +98,13 @@ def cpu_baseline(prob, threads, budget_s=20.0):
                       % (n_iters, threads, dt, n_proj, secs)}
 
 
+def _as_synth(p):
+    """cuadmm_amd.Problem -> the attribute names of synthetic.SyntheticProblem (what the rest of this file reads)"""
+    from cuadmm_amd.synthetic import SyntheticProblem
+    return SyntheticProblem(p.vec_len, p.con_num, p.blk_vals, p.At_csc_col_ptrs, p.At_csc_row_ids, p.At_csc_vals, p.b_indices, p.b_vals,
+                            p.C_indices, p.C_vals)
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows nproc = 256 under
     a 16-CPU quota; 256 busy threads there are 16 CPUs' worth of work)."""
@@ -134,7 +146,7 @@ def issued_mfma_flops(blk, steps):
     blk = np.asarray(blk, np.int64)
     steps = np.asarray(steps, np.float64)
     fl = np.zeros(blk.size)
-    m = (blk > 8) & (blk <= 16)
+    m = (blk <= 16) & (steps > 0)                            # n <= 8 only when they run the sign kernel (closed plans)
     fl[m] = (steps[m] * 8 + 4) * 2048.0
     m = (blk > 16) & (blk <= 32)
     fl[m] = (steps[m] * 48 + 24) * 2048.0
@@ -152,30 +164,77 @@ def issued_mfma_flops(blk, steps):
     return float(fl.sum())
 
 
+def projection_only(args, lib):
+    """SURVEY 8d micro-benchmark: Xb ~ N(0,1)^L through the projection kernels alone (cuadmm_op_psd_project: svec in, projected
+    svec out, 16 B per svec element), `steps` repetitions after `warmup`."""
+    import ctypes as C
+    from cuadmm_amd import synthetic
+    from cuadmm_amd._lib import check
+    from tests.helpers import Dev
+    blk = {"c2": np.full(args.blocks_per_gpu, BLOCK_N), "c3": np.array([2000]), "c4": synthetic.config_c4_blk(args.blocks_per_gpu)}.get(args.config)
+    if blk is None:
+        d = np.load(os.path.join(ROOT, "tests", "golden", "problems", {"c1": "PlanarHand_N=1_MOMENT", "c5": "pendulum_N=80"}[args.config] + ".npz"))
+        blk = d["blk"]
+    blk = np.ascontiguousarray(blk, np.int32)
+    L = int(np.sum(blk.astype(np.int64) * (blk + 1) // 2))
+    x = np.random.default_rng(20240601).standard_normal(L)
+    din, dout = Dev(x), Dev(shape=(L,), dtype=np.float64)
+    steps_dev = Dev(np.zeros(blk.size, np.int32))
+    plan = C.c_void_p()
+    check(lib.cuadmm_psd_plan_create(blk.ctypes.data_as(C.c_void_p), int(blk.size), 0, C.byref(plan)))
+    for _ in range(max(args.warmup, 1)):
+        check(lib.cuadmm_psd_plan_project(plan, din.ptr, dout.ptr, steps_dev.ptr, None))
+    check(lib.cuadmm_dev_sync())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        check(lib.cuadmm_psd_plan_project(plan, din.ptr, dout.ptr, steps_dev.ptr, None))
+    check(lib.cuadmm_dev_sync())
+    dt = (time.perf_counter() - t0) / args.steps
+    steps_blk = steps_dev.get()
+    nominal = (32.0 / 3.0) * float(np.sum(blk.astype(np.float64) ** 3))
+    issued = issued_mfma_flops(blk, steps_blk)
+    print(json.dumps({
+        "metric": "PSD projections/sec of the %s block mix (projection-only micro-benchmark, SURVEY 8d)" % args.config,
+        "value": 1.0 / dt, "unit": "projections/s (one projection of all %d blocks)" % blk.size, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Xb ~ N(0,1)^L, blocks of %s, svec in -> projected svec out (cuadmm_psd_plan_project on a plan built once)" % args.config,
+                   "blocks_total": int(blk.size), "vec_len": L},
+        "roofline": {"kernel": "projection kernels of the size classes present (unfused)", "bound": "mfma", "achieved": nominal / dt / 1e12, "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": nominal / dt / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": dt * 1e3,
+                     "mfma_issued_tflops": issued / dt / 1e12, "hbm_gbs": 16.0 * L / dt / 1e9, "algorithmic_bytes_per_launch": 16.0 * L,
+                     "newton_schulz_steps": {"mean": float(steps_blk[steps_blk > 0].mean()) if (steps_blk > 0).any() else 0.0},
+                     "blocks_per_s": blk.size / dt}}), flush=True)
+    lib.cuadmm_psd_plan_destroy(plan)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--c-sparse", action="store_true", help="c2 / c4 with the sparse C of SURVEY 8d (C = A^T y0 + svec(I))")
+    ap.add_argument("--projection-only", action="store_true", help="time the PSD projection of Xb ~ N(0,1)^L alone (cuadmm_op_psd_project)")
+    ap.add_argument("--time-to-tol", type=float, default=None, help="also run a fresh solve to this tolerance (untimed region) and report it")
     ap.add_argument("--blocks-per-gpu", type=int, default=None)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--sharding", choices=["owned", "allreduce"], default="owned")
     ap.add_argument("--mode", choices=["admm", "sgs"], default="admm")
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch")
     ap.add_argument("--batch", type=int, default=None, help="ADMM iterations per launch on closed blocks (engine option 'batch'; 0 = one launch per iteration)")
+    ap.add_argument("--option", action="append", help="engine option key=value (cuadmm_set_option), repeatable: A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"c2": 200, "c3": 50, "c4": 100}[args.config]
+        args.steps = {"c1": 100, "c2": 200, "c3": 50, "c4": 100, "c5": 200}[args.config]
     if args.warmup is None:
-        args.warmup = {"c2": 20, "c3": 5, "c4": 10}[args.config]
+        args.warmup = {"c1": 10, "c2": 20, "c3": 5, "c4": 10, "c5": 20}[args.config]
     if args.scaling is None:
         args.scaling = "weak" if args.config == "c2" else "strong"
     if args.blocks_per_gpu is None:
-        args.blocks_per_gpu = {"c2": BLOCKS_PER_GPU, "c3": 1, "c4": 100000}[args.config]
+        args.blocks_per_gpu = {"c1": 122, "c2": BLOCKS_PER_GPU, "c3": 1, "c4": 100000, "c5": 239}[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -184,8 +243,6 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
-    if args.sharding == "allreduce":
-        os.environ["CUADMM_NO_LOCAL_CONSTRAINTS"] = "1"     # engine.hip: keep every constraint on every rank
 
     # CUADMM_BENCH_FORCE_DIST=1 exercises the torch.distributed/RCCL hook with a single rank (transport check)
     force_dist = os.environ.get("CUADMM_BENCH_FORCE_DIST") == "1"
@@ -209,24 +266,45 @@ def main():
     if lib.cuadmm_device_count() < 1:
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
+    if args.projection_only:
+        return projection_only(args, lib)
+
     n_units = args.blocks_per_gpu * (world if args.scaling == "weak" else 1)
     if args.config == "c2":
-        prob = synthetic.config_c2(n_units, BLOCK_N)
-        workload = "BASELINE configs[1]: %d PSD blocks of %dx%d %s, m=5/blk, nnz=8/constraint, dense C" % (
-            args.blocks_per_gpu, BLOCK_N, BLOCK_N, "per GPU" if args.scaling == "weak" else "in total")
+        prob = synthetic.make_synthetic([BLOCK_N] * n_units, dense_C=not args.c_sparse)
+        workload = "BASELINE configs[1]: %d PSD blocks of %dx%d %s, m=5/blk, nnz=8/constraint, %s C" % (
+            args.blocks_per_gpu, BLOCK_N, BLOCK_N, "per GPU" if args.scaling == "weak" else "in total", "sparse" if args.c_sparse else "dense")
     elif args.config == "c4":
-        prob = synthetic.config_c4(n_units)
+        prob = synthetic.config_c4(n_units) if not args.c_sparse else synthetic.make_synthetic(synthetic.config_c4_blk(n_units), cons_per_block=3, dense_C=False)
         workload = "BASELINE configs[3]: %d moment-SOS blocks of sizes {3,6,10,15,28,45} %s, m=3/blk" % (
             args.blocks_per_gpu, "per GPU" if args.scaling == "weak" else "in total")
+    elif args.config in ("c1", "c5"):
+        # real data: inputs rebuilt from the reference's shipped .mat files (tests/golden/make_golden.py), committed as fixtures
+        name = {"c1": "PlanarHand_N=1_MOMENT", "c5": "pendulum_N=80"}[args.config]
+        d = np.load(os.path.join(ROOT, "tests", "golden", "problems", name + ".npz"))
+        prob = cuadmm_amd.Problem.from_coo(d["blk"], int(d["con_num"]), d["At_row"], d["At_col"], d["At_val"], d["b_idx"], d["b_val"], d["C_idx"], d["C_val"])
+        prob = _as_synth(prob)
+        args.scaling = "strong"
+        workload = {"c1": "BASELINE configs[0]: examples/SPOT PlanarHand_N=1_MOMENT (122 blocks, n <= 120, m = 66 008; moment relaxation: coupled "
+                          "constraints, GPU tail + device-side sweeps of the A A^T solve)",
+                    "c5": "BASELINE configs[4]: examples/pendulum N=80 (159 x 10 + 80 x 55, m = 112 028; the largest horizon the reference ships)"}[args.config]
     else:
         prob = synthetic.config_c3(2000)
         workload = "BASELINE configs[2]: max-cut relaxation, one PSD block n=2000 (N independent replicas at N GPUs)"
     workload += ", " + ("ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM")
     eng_world, eng_rank = (1, 0) if replicas else (world, rank)
+    engine_options = {}
+    if args.batch is not None:
+        engine_options["batch"] = args.batch
+    if args.sharding == "allreduce":
+        engine_options["local_constraints"] = 0             # keep every constraint on every rank (the general sharded path)
+    for kv in args.option or []:
+        k, v = kv.split("=")
+        engine_options[k] = float(v)
     use_comm = (world > 1 and not replicas) or force_dist
     solver = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, profile=2,
                                   force_comm=force_dist, psd_steps=True,
-                                  options={} if args.batch is None else {"batch": args.batch})
+                                  options=engine_options)
 
     keep = []
     if use_comm:
@@ -293,6 +371,28 @@ def main():
         sync()
         breakdown = {k: v["ms"] / nb for k, v in solver.profile().items() if v["launches"]}
 
+    time_to_tol = None
+    if args.time_to_tol is None and args.config in ("c1", "c5"):
+        args.time_to_tol = 1e-3
+    if args.time_to_tol:
+        # a fresh solve to the tolerance with the parameters of the reference's logs (untimed region of this benchmark)
+        s2 = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, force_comm=force_dist,
+                                  options=engine_options)
+        if use_comm:
+            s2.set_allreduce(keep[0]) if keep else None
+        s2.init_problem(cuadmm_amd.Problem(prob.vec_len, prob.con_num, prob.blk, prob.At_col_ptrs, prob.At_row_ids,
+                                           prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals))
+        cap = 30000
+        sync()
+        t0 = time.perf_counter()
+        s2.solve(cap, args.time_to_tol, 0, 50, 100, 0 if args.mode == "admm" else 11000, 1.05)
+        sync()
+        t1 = time.perf_counter() - t0
+        st2 = s2.state()
+        time_to_tol = {"tol": args.time_to_tol, "iterations": s2.info_iter_num, "seconds": t1, "reached": bool(max(st2["errRp"], st2["errRd"], st2["relgap"]) < args.time_to_tol),
+                       "final": {k: st2[k] for k in ("errRp", "errRd", "relgap", "pobj", "dobj")}, "iteration_cap": cap}
+        del s2
+
     if rank == 0:
         psd = prof["psd_project"]
         launches = max(psd["launches"], 1)
@@ -302,21 +402,35 @@ def main():
         # read Xb + write Xproj, 8 B each per svec element; blocks of the FUSED iteration (9 <= n <= 64, psd_fuse.h)
         # also carry the vector work of aty_xb / post: row pointer 4 + C 8 + X 8 read, Rd1 8 write | X 8 + Rd1 8 + C 8 read,
         # S 8 + X 8 write = 68 B per svec element, and Xb / Xproj never reach HBM
-        fused = os.environ.get("CUADMM_FUSE", "1") != "0"
-        fb = blk_local[(blk_local > 8) & (blk_local <= 64)].astype(np.int64)
+        plan = solver.counters()
+        fused = plan["fused"] > 0
+        closed = plan["closed_blocks"] > 0
+        fb = blk_local[((blk_local > 8) | closed) & (blk_local <= 64)].astype(np.int64)
         L_fused = int(np.sum(fb * (fb + 1) // 2)) if fused else 0
-        alg_bytes = 68.0 * L_fused + 16.0 * (L_local - L_fused)
+        # closed blocks (psd_sign_closed.h): X and C read, S and X written (32 B per svec element; Rd1, Xb, Xproj never reach HBM,
+        # the kernel re-reads X twice and C once through L2) + one 1.5 KB record per block; fused, not closed: 68 B; else 16 B
+        alg_bytes = (32.0 if closed else 68.0) * L_fused + 16.0 * (L_local - L_fused) + (1472.0 * fb.size if closed else 0.0)
         nominal_flops = (32.0 / 3.0) * float(np.sum(blk_local.astype(np.float64) ** 3))
         issued_flops = issued_mfma_flops(blk_local, steps_blk)
-        sign_blocks = blk_local > 8
-        kernel = {"c2": "psd_sign_wave_kernel<2, 4, fused> (X / A^T y / C -> adaptive matrix-sign projection -> S, X updates; one wavefront per block)",
+        sign_blocks = blk_local > (0 if closed else 8)
+        batched = plan["batch_launches"] > 0
+        kernel = {"c1": "psd_project phase: lg_gemm_sym_kernel (n = 66 ... 120, batched upper-triangle fp64-MFMA GEMMs) | psd_sign_lds_kernel (n = 55) | psd_sign_wave_kernel (n <= 28), concurrent streams",
+                  "c2": ("psd_sign_closed_cu_kernel<2, 16, 4> (several ADMM iterations of every block per launch: y-solve, A^T y, Xb, adaptive matrix-sign projection, S / X updates, "
+                         "A X, A (S - C), partial sums; one persistent workgroup per CU)" if batched else
+                         "psd_sign_closed_kernel<2, 4> (whole ADMM iteration of a block, one wavefront per block)" if closed else
+                         "psd_sign_wave_kernel<2, 4, fused> (X / A^T y / C -> adaptive matrix-sign projection -> S, X updates; one wavefront per block)"),
                   "c3": "lg_gemm_sym_kernel (adaptive matrix-sign projection of the n=2000 block as batched upper-triangle fp64-MFMA GEMMs)",
-                  "c4": "psd_project phase: psd_sign_wave_kernel<3, 2> (n=45) | <2, 4> (n=28) | <1, 8> (n=10, 15), fused | psd_small_reg_kernel (n<=6), concurrent streams"}[args.config]
-        kname = {"c2": "psd_sign_wave_kernel<2", "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_wave_kernel<3"}[args.config]
+                  "c4": "psd_project phase: psd_sign_closed_kernel<3, 2> (n=45) | <2, 4> (n=28) | <1, 8> (n <= 15), whole iteration per block, concurrent streams" if closed else
+                        "psd_project phase: psd_sign_wave_kernel<3, 2> (n=45) | <2, 4> (n=28) | <1, 8> (n=10, 15), fused | psd_small_reg_kernel (n<=6), concurrent streams",
+                  "c5": "psd_project phase: psd_sign_lds_kernel<64> (80 blocks of n = 55, one workgroup per block) | psd_sign_wave_kernel<1, 8> (159 blocks of n = 10)"}[args.config]
+        kname = {"c1": "lg_gemm_sym_kernel", "c2": "psd_sign_closed_cu_kernel<2" if batched else ("psd_sign_closed_kernel<2" if closed else "psd_sign_wave_kernel<2"),
+                 "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_closed_kernel<3" if closed else "psd_sign_wave_kernel<3", "c5": "psd_sign_lds_kernel"}[args.config]
         per_s = psd_ms * 1e-3
         shard_iters = (world if (args.scaling == "weak" or replicas) else 1) * args.steps
         out = {
-            "metric": {"c2": "ADMM iters/sec, 10k x 32-blk synthetic per GPU (+ PSD-proj TFLOP/s in roofline)",
+            "metric": {"c1": "ADMM iters/sec, PlanarHand_N=1 moment relaxation (+ PSD-proj TFLOP/s in roofline)",
+                       "c5": "ADMM iters/sec, pendulum N=80 trajectory SDP (+ PSD-proj TFLOP/s in roofline)",
+                       "c2": "ADMM iters/sec, 10k x 32-blk synthetic per GPU (+ PSD-proj TFLOP/s in roofline)",
                        "c3": "ADMM iters/sec, max-cut n=2000 single block (+ PSD-proj TFLOP/s in roofline)",
                        "c4": "ADMM iters/sec, 100k mixed moment-SOS blocks (+ PSD-proj TFLOP/s in roofline)"}[args.config],
             "value": shard_iters / dt,
@@ -325,7 +439,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if (args.scaling == "weak" or replicas) else "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if args.config in ("c2", "c3", "c4") else "reference example inputs (rebuilt from the shipped .mat, tests/golden/problems)",
             "config": {"workload": workload,
                        "blocks_total": int(np.asarray(prob.blk).size) * (world if replicas else 1), "vec_len": int(prob.vec_len), "con_num": int(prob.con_num),
                        "sharding": "single GPU" if world == 1 and not force_dist else (
@@ -361,7 +475,9 @@ def main():
                          "blocks_per_s": blk_local.size / per_s if per_s > 0 else 0.0},
             "final_state": {k: st[k] for k in ("errRp", "errRd", "relgap", "sig")},
         }
-        out["engine_plan"] = solver.counters()
+        out["engine_plan"] = plan
+        if args.time_to_tol:
+            out["time_to_tol"] = time_to_tol
         if breakdown is not None:
             out["breakdown_ms_per_iter"] = breakdown      # psd_project / aty_xb / post_proj / spmv_A / copies / comm / host / tail_solve
         if world == 1 and not args.no_cpu_baseline:

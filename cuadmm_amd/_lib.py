@@ -117,6 +117,9 @@ PROTOTYPES = {
     "cuadmm_op_max_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "cuadmm_op_mul_diag_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cuadmm_op_mul_trans_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cuadmm_psd_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cuadmm_psd_plan_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cuadmm_psd_plan_destroy": (None, [C.c_void_p]),
     "cuadmm_op_psd_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cuadmm_op_permute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cuadmm_op_get_normA": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

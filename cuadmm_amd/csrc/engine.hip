@@ -202,6 +202,7 @@ struct cuadmm_solver {
   // starts from (restored when the stopping test or the tau rule fires inside it).
   struct Batch {
     int max_iters = 64;
+    bool allow_mixed = false;      // option "batch_mixed": batches although several tile geometries share the work (tests)
     DevBuf<double> p1, p2, scal_d, ck_X, ck_S, ck_y, ck_out;
     DevBuf<int> ck_hint;
     long long ck_iters_done = 0;
@@ -217,9 +218,35 @@ struct cuadmm_solver {
   // if_first = false then simply continues, instead of unscaling and rescaling three vectors and recomputing A X, A (S - C)
   bool pending_unscale = false;
   int lazy_unscale = 1;
-  int opt_tiny_sign = getenv("CUADMM_TINY_SIGN") ? atoi(getenv("CUADMM_TINY_SIGN")) : 1;   // option "tiny_sign": 0 never, 1 closed candidates, 2 always
+  // Behavioural switches (cuadmm_set_option, before init).  The environment variables of round 1 / 2 only give the DEFAULTS, read
+  // once per solver in its constructor: two solvers in a process can choose differently, and tests reach every variant.
+  struct Switches {
+    int fuse = 1;                 // "fuse": the vector work of 9 <= n <= 64 blocks inside their projection kernels
+    int fuse_rows = 1;            // "fuse_rows": constraint rows local to one fused block evaluated there
+    int fuse_solve = -1;          // "fuse_solve": closed blocks solve for their own multipliers (-1: whenever possible)
+    int host_solve = 0;           // "host_solve": keep the y-solve on the host (no forest / lead / tail on the device)
+    int host_scalars = 0;         // "host_scalars": owned constraints: the four scalars through the host
+    int tail_k = -1;              // "tail_k": -1 cost model, 0 host-only factor, k > 0 forces the GPU tail size
+    int local_constraints = 1;    // "local_constraints": owned-constraints sharding when the problem allows it
+    int mapped_out = 1;           // "mapped_out": results through a mapped pinned buffer when no collective is needed
+    int lpt = 1;                  // "lpt": longest block first
+    int aty_post2 = 1;            // "aty_post2": the sGS second half in one pass
+    int debug_eig = 0;            // developer aid
+  } sw;
+  cuadmm_solver() {
+    auto env = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+    sw.fuse = env("CUADMM_FUSE", 1); sw.fuse_rows = env("CUADMM_FUSE_ROWS", 1); sw.fuse_solve = env("CUADMM_FUSE_SOLVE", -1);
+    sw.host_solve = env("CUADMM_HOST_SOLVE", 0); sw.tail_k = env("CUADMM_TAIL_K", -1);
+    sw.local_constraints = env("CUADMM_NO_LOCAL_CONSTRAINTS", 0) ? 0 : 1;
+    sw.mapped_out = env("CUADMM_NO_MAPPED_OUT", 0) ? 0 : 1;
+    sw.host_scalars = env("CUADMM_HOST_SCALARS", 0);
+    opt_hint = env("CUADMM_PSD_HINT", 1);
+    plan.opt = PsdOptions::from_env();
+  }
+  int opt_tiny_sign = 1;       // option "tiny_sign": 0 never, 1 closed candidates, 2 always
   bool closed_candidate = false;
-  int opt_hint = getenv("CUADMM_PSD_HINT") ? atoi(getenv("CUADMM_PSD_HINT")) : 1;   // option "psd_hint": 0 off, 1 one-wavefront kernels, 2 all
+  int duo_cpu_eig_on_gpu = 0;
+  int opt_hint = 1;            // option "psd_hint": 0 off, 1 one-wavefront kernels, 2 all
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -507,7 +534,7 @@ struct cuadmm_solver {
   // --- several iterations per launch ---------------------------------------------------------------------------------
   bool can_batch() const {
     return bt.max_iters >= 2 && fuse && closed.active && dev_solve && !lead.ready && plan.n_rest == 0 && eig_rank == 0 && !out_mapped &&
-           plan.fused_blocks() > 0 && plan.one_dominant_geometry();
+           plan.fused_blocks() > 0 && (bt.allow_mixed || plan.one_dominant_geometry());
   }
   int batch_alloc() {
     if (bt.p1.p) return CUADMM_OK;
@@ -518,7 +545,7 @@ struct cuadmm_solver {
         (rc = bt.ck_S.alloc(L)) || (rc = bt.ck_y.alloc(std::max(m, 1))) || (rc = bt.ck_out.alloc(2 * (size_t)m + 2)))
       return rc;
     void* dp = nullptr;
-    if (!getenv("CUADMM_NO_MAPPED_OUT") && hipHostGetDevicePointer(&dp, bt.h.p, 0) == hipSuccess && dp) bt.h_dev = static_cast<double*>(dp);
+    if (sw.mapped_out && hipHostGetDevicePointer(&dp, bt.h.p, 0) == hipSuccess && dp) bt.h_dev = static_cast<double*>(dp);
     else { hipError_t e = hipGetLastError(); (void)e; }
     return CUADMM_OK;
   }
@@ -583,179 +610,55 @@ static int check_device(int device) {
   return CUADMM_OK;
 }
 
-extern "C" {
-
-const char* cuadmm_last_error(void) { return get_error(); }
-const char* cuadmm_version(void) { return "cuadmm_amd 0.1 (gfx950)"; }
-int cuadmm_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-  return n;
-}
-
-int cuadmm_create(cuadmm_solver** out) {
-  if (!out) { set_error("create: null"); return CUADMM_ERR_INVALID; }
-  *out = new cuadmm_solver();
-  return CUADMM_OK;
-}
-void cuadmm_destroy(cuadmm_solver* s) { delete s; }
-
-int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
-  if (!s || !key) { set_error("set_option: null"); return CUADMM_ERR_INVALID; }
-  std::string k(key);
-  if (k == "device") s->device = (int)value;
-  else if (k == "verbose") s->verbose = (int)value;
-  else if (k == "rank") s->rank = (int)value;
-  else if (k == "world") s->world = (int)value;
-  else if (k == "profile") s->profile = (int)value;
-  else if (k == "force_comm") s->force_comm = (int)value;   // call the collective hook even when world == 1 (testing)
-  else if (k == "eig_rank") s->eig_rank = (int)value;
-  else if (k == "eig_rank_begin_iter") s->eig_rank_begin_iter = (int)value;
-  else if (k == "eig_rank_maxfeas") s->eig_rank_maxfeas = value;
-  else if (k == "psd_steps") s->psd_steps = (int)value;       // record the sign kernels' step count per block (cuadmm_get_psd_steps)
-  else if (k == "batch") s->bt.max_iters = std::max(0, std::min(256, (int)value));   // iterations per launch, closed blocks (0 / 1: off)
-  else if (k == "lazy_unscale") s->lazy_unscale = (int)value;
-  else if (k == "psd_hint") s->opt_hint = (int)value;
-  else if (k == "tiny_sign") s->opt_tiny_sign = (int)value;                               // n <= 8 on the sign kernel (before init)                                     // schedule warm start (before init)                            // 0: unscale X, y, S at the end of every solve
-  else if (k == "graph") {}
-  else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
-  return CUADMM_OK;
-}
-
-int cuadmm_set_allreduce(cuadmm_solver* s, cuadmm_allreduce_fn fn, void* user) {
-  if (!s) { set_error("set_allreduce: null"); return CUADMM_ERR_INVALID; }
-  s->allreduce = fn; s->allreduce_user = user;
-  return CUADMM_OK;
-}
-
-int cuadmm_rccl_unique_id(char out128[128]) {
-  if (!g_rccl.load()) { set_error("RCCL not loadable"); return CUADMM_ERR_COMM; }
-  NcclUid id;
-  if (g_rccl.GetUniqueId(&id)) { set_error("ncclGetUniqueId failed"); return CUADMM_ERR_COMM; }
-  std::memcpy(out128, id.internal, 128);
-  return CUADMM_OK;
-}
-
-int cuadmm_use_rccl(cuadmm_solver* s, const char unique_id128[128], int rank, int world) {
-  if (!s || !unique_id128) { set_error("use_rccl: null"); return CUADMM_ERR_INVALID; }
-  if (!g_rccl.load()) { set_error("RCCL not loadable"); return CUADMM_ERR_COMM; }
-  int rc = check_device(s->device);
-  if (rc) return rc;
-  NcclUid id;
-  std::memcpy(id.internal, unique_id128, 128);
-  if (g_rccl.CommInitRank(&s->rccl_comm, world, id, rank)) { set_error("ncclCommInitRank failed"); return CUADMM_ERR_COMM; }
-  s->rank = rank; s->world = world;
-  return CUADMM_OK;
-}
-
 // ------------------------------------------------------------------------------------------
-// SDPSolver::init
+// SDPSolver::init, in stages.  InitIn: the caller's arrays (solver.h:208-223); InitCtx: what one stage leaves for the next.
 // ------------------------------------------------------------------------------------------
-int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread_num, int vec_len, int con_num,
-                const int* At_cp, const int* At_ri, const double* At_vx, int At_nnz, const int* b_idx,
-                const double* b_vals, int b_nnz, const int* C_idx, const double* C_vals, int C_nnz,
-                const int* blk, int mat_num, const double* X0, const double* y0, const double* S0, double sig) {
-  (void)eig_stream_num_per_gpu; (void)cpu_eig_thread_num;
-  if (!s) { set_error("init: null solver"); return CUADMM_ERR_INVALID; }
-  if (s->initialised) { set_error("init: solver already initialised (one init per object, as in the reference)"); return CUADMM_ERR_INVALID; }
-  if (vec_len < 0 || con_num < 0 || At_nnz < 0 || b_nnz < 0 || C_nnz < 0 || mat_num < 0 || !At_cp || !blk ||
-      (At_nnz > 0 && (!At_ri || !At_vx)) || (b_nnz > 0 && (!b_idx || !b_vals)) || (C_nnz > 0 && (!C_idx || !C_vals))) {
-    set_error("init: invalid argument");
-    return CUADMM_ERR_INVALID;
-  }
-  if (s->world < 1 || s->rank < 0 || s->rank >= s->world) { set_error("init: bad rank/world %d/%d", s->rank, s->world); return CUADMM_ERR_INVALID; }
-  long long Lchk = 0;
-  for (int k = 0; k < mat_num; ++k) {
-    if (blk[k] == 0) { set_error("init: block %d has size 0", k); return CUADMM_ERR_INVALID; }
-    Lchk += blk_svec_len(blk[k]);                       // negative size = unconstrained block of -blk[k] variables
-  }
-  if (Lchk != vec_len) { set_error("init: vec_len %d does not match blk (sum n(n+1)/2 = %lld)", vec_len, Lchk); return CUADMM_ERR_INVALID; }
-  if (At_cp[0] != 0 || At_cp[con_num] != At_nnz) { set_error("init: At column pointers inconsistent with At_nnz"); return CUADMM_ERR_INVALID; }
-  for (int p = 0; p < At_nnz; ++p)
-    if (At_ri[p] < 0 || At_ri[p] >= vec_len) { set_error("init: At row index %d out of range at %d", At_ri[p], p); return CUADMM_ERR_INVALID; }
+namespace {
+struct InitIn {
+  int vec_len, con_num, At_nnz, b_nnz, C_nnz, mat_num;
+  const int *At_cp, *At_ri, *b_idx, *C_idx, *blk;
+  const double *At_vx, *b_vals, *C_vals, *X0, *y0, *S0;
+  double sig;
+};
+struct InitCtx {
+  std::vector<double> vals;      // A^T values with the columns normalised (get_normA)
+  std::vector<int> rp, rci;      // A^T in CSR over the svec rows: row pointers, constraint of every entry
+  std::vector<double> rv;
+};
+#define CUADMM_INIT_STAGE_PROLOGUE \
+  const int vec_len = in.vec_len, con_num = in.con_num, At_nnz = in.At_nnz, b_nnz = in.b_nnz, C_nnz = in.C_nnz, mat_num = in.mat_num; \
+  const int *At_cp = in.At_cp, *At_ri = in.At_ri, *b_idx = in.b_idx, *C_idx = in.C_idx, *blk = in.blk; \
+  const double *At_vx = in.At_vx, *b_vals = in.b_vals, *C_vals = in.C_vals, *X0 = in.X0, *y0 = in.y0, *S0 = in.S0; \
+  const double sig = in.sig; \
+  const int m = con_num; \
+  const long long Lf = vec_len, L = s->L; \
+  std::vector<double>&vals = c.vals, &rv = c.rv; \
+  std::vector<int>&rp = c.rp, &rci = c.rci; \
+  int rc = CUADMM_OK; \
+  (void)vec_len; (void)At_nnz; (void)b_nnz; (void)C_nnz; (void)mat_num; (void)At_cp; (void)At_ri; (void)b_idx; (void)C_idx; (void)blk; (void)At_vx; \
+  (void)b_vals; (void)C_vals; (void)X0; (void)y0; (void)S0; (void)sig; (void)m; (void)Lf; (void)L; (void)vals; (void)rv; (void)rp; (void)rci; \
+  (void)0;
 
-  if (s->world > 1) cuadmm_host_pool_hint(s->world);       // the ranks of a job share the node's CPUs (before the pool's first use)
-  if (s->world > 1 && !s->local_mode && !getenv("CUADMM_NO_LOCAL_CONSTRAINTS")) {
-    // does every constraint live inside one rank's block range?
-    std::vector<int> first;
-    partition_blocks(blk, mat_num, s->world, first);
-    std::vector<long long> svb((size_t)s->world + 1, 0);
-    {
-      long long off = 0;
-      int r = 0;
-      for (int k = 0; k <= mat_num; ++k) {
-        while (r <= s->world && first[r] == k) svb[r++] = off;
-        if (k < mat_num) off += blk_svec_len(blk[k]);
-      }
-    }
-    std::vector<int> owner(con_num, 0);
-    bool all_owned = true;
-    for (int j = 0; j < con_num && all_owned; ++j) {
-      if (At_cp[j] == At_cp[j + 1]) continue;                      // empty constraint: rank 0
-      const int r = (int)(std::upper_bound(svb.begin(), svb.end(), (long long)At_ri[At_cp[j]]) - svb.begin()) - 1;
-      for (int p = At_cp[j]; p < At_cp[j + 1]; ++p)
-        if (At_ri[p] < svb[r] || At_ri[p] >= svb[r + 1]) { all_owned = false; break; }
-      owner[j] = r;
-    }
-    if (all_owned) {
-      const int me = s->rank;
-      // global norms (solver.cu:169-191) from the full inputs every rank holds
-      double nb = 0, nc = 0, nb2 = 0;
-      for (int i = 0; i < b_nnz; ++i) {
-        if (b_idx[i] < 0 || b_idx[i] >= con_num) { set_error("init: b index %d out of range", b_idx[i]); return CUADMM_ERR_INVALID; }
-        nb += b_vals[i] * b_vals[i];
-        double cn = 0;
-        for (int p = At_cp[b_idx[i]]; p < At_cp[b_idx[i] + 1]; ++p) cn += At_vx[p] * At_vx[p];
-        const double v = b_vals[i] / std::max(1.0, std::sqrt(cn));
-        nb2 += v * v;
-      }
-      for (int i = 0; i < C_nnz; ++i) nc += C_vals[i] * C_vals[i];
-      std::vector<int> cons, g2l(con_num, -1);
-      for (int j = 0; j < con_num; ++j) if (owner[j] == me) { g2l[j] = (int)cons.size(); cons.push_back(j); }
-      const long long lo = svb[me], hi = svb[me + 1];
-      std::vector<int> lcp(cons.size() + 1, 0), lri, lbi, lCi;
-      std::vector<double> lvx, lbv, lCv, ly0;
-      for (size_t q = 0; q < cons.size(); ++q) {
-        for (int p = At_cp[cons[q]]; p < At_cp[cons[q] + 1]; ++p) { lri.push_back((int)(At_ri[p] - lo)); lvx.push_back(At_vx[p]); }
-        lcp[q + 1] = (int)lri.size();
-      }
-      for (int i = 0; i < b_nnz; ++i) if (g2l[b_idx[i]] >= 0) { lbi.push_back(g2l[b_idx[i]]); lbv.push_back(b_vals[i]); }
-      for (int i = 0; i < C_nnz; ++i) {
-        if (C_idx[i] < 0 || C_idx[i] >= vec_len) { set_error("init: C index %d out of range", C_idx[i]); return CUADMM_ERR_INVALID; }
-        if (C_idx[i] >= lo && C_idx[i] < hi) { lCi.push_back((int)(C_idx[i] - lo)); lCv.push_back(C_vals[i]); }
-      }
-      if (y0) { ly0.resize(cons.size()); for (size_t q = 0; q < cons.size(); ++q) ly0[q] = y0[cons[q]]; }
-      s->local_mode = true;
-      s->comm_world = s->world; s->comm_rank = s->rank;
-      s->m_full = con_num; s->cons_local = cons; s->sv_off = lo; s->blk_off = first[me];
-      s->L_caller = vec_len; s->nblk_caller = mat_num;
-      s->ov_nb = nb; s->ov_nc = nc; s->ov_nb2 = nb2;
-      s->world = 1; s->rank = 0;
-      if (s->comm_rank != 0) s->verbose = 0;      // one console table per job
-      int one = 0;
-      return cuadmm_init(s, eig_stream_num_per_gpu, cpu_eig_thread_num, (int)(hi - lo), (int)cons.size(), lcp.data(),
-                         lri.empty() ? &one : lri.data(), lvx.empty() ? nullptr : lvx.data(), (int)lri.size(),
-                         lbi.empty() ? nullptr : lbi.data(), lbv.empty() ? nullptr : lbv.data(), (int)lbi.size(),
-                         lCi.empty() ? nullptr : lCi.data(), lCv.empty() ? nullptr : lCv.data(), (int)lCi.size(),
-                         blk + first[me], first[me + 1] - first[me], X0 ? X0 + lo : nullptr, y0 ? ly0.data() : nullptr,
-                         S0 ? S0 + lo : nullptr, sig);
-    }
-  }
-
-  int rc = check_device(s->device);
-  if (rc) return rc;
+// stage: stream, events, global dimensions
+static int init_device(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
+  if ((rc = check_device(s->device))) return rc;
   s->t_init0 = wall_s();                                  // the reference's timer starts in init (solver.cu:41-44)
   CUADMM_HIP_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
   if (s->profile)
     for (int k = 0; k < K_NUM; ++k)
       for (int j = 0; j < 2; ++j) { CUADMM_HIP_TRY(hipEventCreate(&s->ev0[k][j])); CUADMM_HIP_TRY(hipEventCreate(&s->ev1[k][j])); }
 
-  const int m = con_num;
-  const long long Lf = vec_len;
   s->m = m; s->L_full = vec_len; s->nblk_full = mat_num; s->sig = sig;
 
+  return rc;
+}
+
+// stage: get_normA and A^T in CSR over the svec rows (what the factor and the device matrices are built from)
+static int init_normalise(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   // --- get_normA (sparse_matrix_norm.cu:11-31): norm_j = max(1,||col j||), column scaled in place
-  std::vector<double> vals(At_vx, At_vx + At_nnz);
+  vals.assign(At_vx, At_vx + At_nnz);
   s->normA.assign(m, 1.0);
   for (int j = 0; j < m; ++j) {
     double nrm = 0.0;
@@ -766,8 +669,8 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   }
 
   // --- At in CSR over the svec rows (== CSC of A), solver.cu:83-88
-  std::vector<int> rp((size_t)Lf + 1, 0), rci((size_t)At_nnz);
-  std::vector<double> rv((size_t)At_nnz);
+  rp.assign((size_t)Lf + 1, 0); rci.assign((size_t)At_nnz, 0);
+  rv.assign((size_t)At_nnz, 0.0);
   for (int p = 0; p < At_nnz; ++p) rp[(size_t)At_ri[p] + 1]++;
   for (long long i = 0; i < Lf; ++i) rp[i + 1] += rp[i];
   {
@@ -779,13 +682,19 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       }
   }
 
+  return rc;
+}
+
+// stage: A A^T + eps I: ordering, host factor, GPU tail of the Schur complement with its probe solve, permutation
+static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   // --- factor of A A^T + 1e-15 I (solver.cu:91-96, cholesky_cpu.h:62-141): ordering, symbolic analysis and the sparse
   // leading columns on the host; when the cost model finds a dense tail, its Schur complement is factored (dense
   // LDL^T) and inverted on the GPU and applied as two GEMVs per solve (tail_solve.hip).
   // CUADMM_TAIL_K: 0 = everything on the host, k > 0 forces the tail size (A/B measurements).
   {
     int max_k = 32768;
-    if (const char* e = getenv("CUADMM_TAIL_K")) max_k = -std::min(std::max(0, atoi(e)), m);
+    if (s->sw.tail_k >= 0) max_k = -std::min(s->sw.tail_k, m);
     double t0 = wall_s();
     if (max_k == 0) rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
     else rc = cuadmm_aat_create_split(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, max_k, &s->fac);
@@ -849,6 +758,12 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->perm_inv.assign(m, 0);
   for (int i = 0; i < m; ++i) s->perm_inv[s->perm[i]] = i;
 
+  return rc;
+}
+
+// stage: census, this rank's block range, the projection plan (closed-block candidate, schedule hints, step counts)
+static int init_plan(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   // --- census (analyze_blk.cu:63-99, matrix_sizes.cu:75-113)
   if (s->verbose) {
     std::vector<int> sizes, nums;
@@ -873,8 +788,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     if (k + 1 == s->blk_end) s->sv_end = off;
   }
   if (s->blk_begin == s->blk_end) { s->sv_begin = s->sv_end = (s->blk_begin == mat_num ? off : s->sv_begin); }
-  const long long L = s->sv_end - s->sv_begin;
-  s->L = L;
+  s->L = s->sv_end - s->sv_begin;
   s->blk_local.assign(blk + s->blk_begin, blk + s->blk_end);
   s->plan.eig_rank = s->eig_rank > 0 ? s->eig_rank : 0;
   {
@@ -922,6 +836,12 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   s->plan.sign.allow_graph = true;   // same buffers every iteration: replay the sign-path launch sequence from a hipGraph
   if (rc) return rc;
 
+  return rc;
+}
+
+// stage: A^T and A on the device with the permutation folded in; which blocks fuse, which constraint rows are local to one
+static int init_matrices(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   // --- device matrices with the permutation folded in
   {
     std::vector<int> lrp((size_t)L + 1, 0), lci;
@@ -948,10 +868,9 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     s->A_avg_nnz = m > 0 ? (double)aci.size() / m : 1.0;
     if ((rc = s->A_long.build(m, arp.data()))) return rc;
     // fused iteration: needs the one-wavefront-per-block sign kernels and no long rows of A^T (they are summed by their own kernel)
-    s->fuse = s->plan.fusable() && s->At_long.nlong == 0 && !getenv("CUADMM_DEBUG_EIG") &&
-              !(getenv("CUADMM_FUSE") && atoi(getenv("CUADMM_FUSE")) == 0);
+    s->fuse = s->plan.fusable() && s->At_long.nlong == 0 && !s->sw.debug_eig && s->sw.fuse != 0;
     s->lrows.active = false; s->lrows.nlocal = s->lrows.nrest = 0;
-    if (s->fuse && s->A_long.nlong == 0 && m > 0 && !(getenv("CUADMM_FUSE_ROWS") && atoi(getenv("CUADMM_FUSE_ROWS")) == 0)) {
+    if (s->fuse && s->A_long.nlong == 0 && m > 0 && s->sw.fuse_rows != 0) {
       // constraint rows local to one fused block -> that block's kernel (psd_fuse.h)
       std::vector<int> slot_of;
       s->plan.fused_slots(slot_of);                                    // block -> partial-sum slot, -1: not fused
@@ -1036,6 +955,12 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     s->A_v.n = av.size();
   }
 
+  return rc;
+}
+
+// stage: scaling (solver.cu:169-191), b / C / X / S / y in the solver's units, work vectors
+static int init_vectors(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   // --- scaling (solver.cu:169-191)
   double nb = 0, nc = 0;
   for (int i = 0; i < b_nnz; ++i) nb += b_vals[i] * b_vals[i];
@@ -1107,10 +1032,16 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
   if (s->fuse && s->verbose)
     printf(" fused iteration: %d blocks form Xb and apply the S / X updates inside their projection kernel (%lld of %lld svec entries outside); "
            "%d of %d constraint rows are local to one of them\n", s->plan.fused_blocks(), s->plan.n_rest, L, s->lrows.nlocal, m);
-  s->dev_scalars = s->local_mode && s->comm_world > 1 && !getenv("CUADMM_HOST_SCALARS");
+  return rc;
+}
+
+// stage: where the y-solve runs: device-side sweeps around the GPU tail, one thread per tree of a block-diagonal factor, or the host
+static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
+  s->dev_scalars = s->local_mode && s->comm_world > 1 && !s->sw.host_scalars;
   // device-side y-solve: whole factor on the host side of the split (no GPU tail) and a forest of many small trees
   s->dev_solve = false;
-  if (s->tail.k > 0 && !getenv("CUADMM_HOST_SOLVE")) {
+  if (s->tail.k > 0 && !s->sw.host_solve) {
     // split factor: leading sweeps on the device too when the leading elimination forest is shallow enough (cost model:
     // the deepest tree decides the kernel; host: 1.2 ns per leading nonzero for both sweeps + the PCIe hops of the tail)
     const int64_t* Lp; const int* Li; const double* Lx; const double* D;
@@ -1125,7 +1056,7 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       s->lead.release();
     }
   }
-  if (s->tail.k == 0 && m > 0 && !getenv("CUADMM_HOST_SOLVE")) {
+  if (s->tail.k == 0 && m > 0 && !s->sw.host_solve) {
     int ntrees = 0, maxc = 0;
     const int *tp = nullptr, *tc = nullptr;
     if (cuadmm_aat_forest(s->fac, &ntrees, &maxc, &tp, &tc) == CUADMM_OK && ntrees >= 256 && maxc <= 64) {
@@ -1143,14 +1074,19 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       if (s->verbose) printf(" y-solve on the device: %d independent trees of the elimination forest (<= %d columns each)\n", ntrees, maxc);
     }
   }
+  return rc;
+}
+
+// stage: closed blocks: per-block records for psd_sign_closed.h
+static int init_closed(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   s->closed.active = false;
   // Default: only when no block with rows is smaller than 17 -- the solve adds two dependent memory round trips to a block's
   // prologue: < 4 % of the lifetime of an n >= 17 block (C2: 0.307 -> 0.300 ms per iteration, the solve and statistics kernels
   // gone), but 15 % of an n <= 16 block's (C4 with its 67 000 tiny blocks: 1.89 -> 1.91).  CUADMM_FUSE_SOLVE=1 / 0 forces it.
   // (round 2 kept blocks with rows and n < 17 out: the solve added two dependent round trips to their prologue; with the block
   // records of psd_sign_closed.h it rides in the one trip the prologue makes anyway)
-  bool want_closed = true;
-  if (const char* e = getenv("CUADMM_FUSE_SOLVE")) want_closed = atoi(e) != 0;
+  const bool want_closed = s->sw.fuse_solve != 0;
   if (want_closed && s->fuse && s->lrows.active && s->lrows.nrest == 0 && s->dev_solve && !s->lead.ready && s->forest_trees > 0 && s->lrows.nlocal == m) {
     const auto& hd = s->lrows.h_desc;
     const auto& hrow = s->lrows.h_row;
@@ -1222,14 +1158,20 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
       }
     }
   }
+  return rc;
+}
+
+// stage: device copies of b / normA for the device-side scalars, mapped result buffers, initial residuals (solver.cu:195-228)
+static int init_finish(Solver* s, const InitIn& in, InitCtx& c) {
+  CUADMM_INIT_STAGE_PROLOGUE
   if (s->dev_scalars || s->dev_solve) {
     if ((rc = s->b_d.alloc(std::max(m, 1))) || (rc = s->normA_d.alloc(std::max(m, 1)))) return rc;
     if ((rc = s->b_d.upload(s->b_p.data(), (size_t)m)) || (rc = s->normA_d.upload(s->normA_p.data(), (size_t)m))) return rc;
     void* dp = nullptr;
-    if (!getenv("CUADMM_NO_MAPPED_OUT") && hipHostGetDevicePointer(&dp, s->h_scal.p, 0) == hipSuccess && dp) s->h_scal_dev = static_cast<double*>(dp);
+    if (s->sw.mapped_out && hipHostGetDevicePointer(&dp, s->h_scal.p, 0) == hipSuccess && dp) s->h_scal_dev = static_cast<double*>(dp);
     else { hipError_t e = hipGetLastError(); (void)e; }
   }
-  if (s->world <= 1 && !s->force_comm && !s->dev_scalars && !s->dev_solve && !getenv("CUADMM_NO_MAPPED_OUT")) {
+  if (s->world <= 1 && !s->force_comm && !s->dev_scalars && !s->dev_solve && s->sw.mapped_out) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, s->h_out.p, 0) == hipSuccess && dp) { s->out_w = static_cast<double*>(dp); s->out_mapped = true; }
     else { hipError_t e = hipGetLastError(); (void)e; }
@@ -1264,6 +1206,192 @@ int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread
     s->dobj = bty * s->objscale;
     s->relgap = std::fabs(s->pobj - s->dobj) / (1 + std::fabs(s->pobj) + std::fabs(s->dobj));
   }
+  return rc;
+}
+
+#undef CUADMM_INIT_STAGE_PROLOGUE
+}  // namespace
+
+extern "C" {
+
+const char* cuadmm_last_error(void) { return get_error(); }
+const char* cuadmm_version(void) { return "cuadmm_amd 0.1 (gfx950)"; }
+int cuadmm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int cuadmm_create(cuadmm_solver** out) {
+  if (!out) { set_error("create: null"); return CUADMM_ERR_INVALID; }
+  *out = new cuadmm_solver();
+  return CUADMM_OK;
+}
+void cuadmm_destroy(cuadmm_solver* s) { delete s; }
+
+int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
+  if (!s || !key) { set_error("set_option: null"); return CUADMM_ERR_INVALID; }
+  std::string k(key);
+  if (k == "device") s->device = (int)value;
+  else if (k == "verbose") s->verbose = (int)value;
+  else if (k == "rank") s->rank = (int)value;
+  else if (k == "world") s->world = (int)value;
+  else if (k == "profile") s->profile = (int)value;
+  else if (k == "force_comm") s->force_comm = (int)value;   // call the collective hook even when world == 1 (testing)
+  else if (k == "eig_rank") s->eig_rank = (int)value;
+  else if (k == "eig_rank_begin_iter") s->eig_rank_begin_iter = (int)value;
+  else if (k == "eig_rank_maxfeas") s->eig_rank_maxfeas = value;
+  else if (k == "psd_steps") s->psd_steps = (int)value;       // record the sign kernels' step count per block (cuadmm_get_psd_steps)
+  else if (k == "batch") s->bt.max_iters = std::max(0, std::min(256, (int)value));   // iterations per launch, closed blocks (0 / 1: off)
+  else if (k == "fuse") s->sw.fuse = (int)value;
+  else if (k == "fuse_rows") s->sw.fuse_rows = (int)value;
+  else if (k == "fuse_solve") s->sw.fuse_solve = (int)value;
+  else if (k == "host_solve") s->sw.host_solve = (int)value;
+  else if (k == "host_scalars") s->sw.host_scalars = (int)value;
+  else if (k == "tail_k") s->sw.tail_k = (int)value;
+  else if (k == "local_constraints") s->sw.local_constraints = (int)value;
+  else if (k == "mapped_out") s->sw.mapped_out = (int)value;
+  else if (k == "lpt") s->sw.lpt = (int)value;
+  else if (k == "aty_post2") s->sw.aty_post2 = (int)value;
+  else if (k == "debug_eig") s->sw.debug_eig = (int)value;
+  else if (s->plan.opt.set(k, value)) {}                      // "psd_*": the projection planner's switches (psd_options.h)
+  else if (k == "batch_mixed") s->bt.allow_mixed = value != 0;
+  else if (k == "lazy_unscale") s->lazy_unscale = (int)value;
+  else if (k == "psd_hint") s->opt_hint = (int)value;
+  else if (k == "duo_cpu_eig_on_gpu") s->duo_cpu_eig_on_gpu = (int)value;
+  else if (k == "tiny_sign") s->opt_tiny_sign = (int)value;                               // n <= 8 on the sign kernel (before init)                                     // schedule warm start (before init)                            // 0: unscale X, y, S at the end of every solve
+  else if (k == "graph") {}
+  else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
+  return CUADMM_OK;
+}
+
+int cuadmm_set_allreduce(cuadmm_solver* s, cuadmm_allreduce_fn fn, void* user) {
+  if (!s) { set_error("set_allreduce: null"); return CUADMM_ERR_INVALID; }
+  s->allreduce = fn; s->allreduce_user = user;
+  return CUADMM_OK;
+}
+
+int cuadmm_rccl_unique_id(char out128[128]) {
+  if (!g_rccl.load()) { set_error("RCCL not loadable"); return CUADMM_ERR_COMM; }
+  NcclUid id;
+  if (g_rccl.GetUniqueId(&id)) { set_error("ncclGetUniqueId failed"); return CUADMM_ERR_COMM; }
+  std::memcpy(out128, id.internal, 128);
+  return CUADMM_OK;
+}
+
+int cuadmm_use_rccl(cuadmm_solver* s, const char unique_id128[128], int rank, int world) {
+  if (!s || !unique_id128) { set_error("use_rccl: null"); return CUADMM_ERR_INVALID; }
+  if (!g_rccl.load()) { set_error("RCCL not loadable"); return CUADMM_ERR_COMM; }
+  int rc = check_device(s->device);
+  if (rc) return rc;
+  NcclUid id;
+  std::memcpy(id.internal, unique_id128, 128);
+  if (g_rccl.CommInitRank(&s->rccl_comm, world, id, rank)) { set_error("ncclCommInitRank failed"); return CUADMM_ERR_COMM; }
+  s->rank = rank; s->world = world;
+  return CUADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SDPSolver::init
+// ------------------------------------------------------------------------------------------
+int cuadmm_init(cuadmm_solver* s, int eig_stream_num_per_gpu, int cpu_eig_thread_num, int vec_len, int con_num,
+                const int* At_cp, const int* At_ri, const double* At_vx, int At_nnz, const int* b_idx,
+                const double* b_vals, int b_nnz, const int* C_idx, const double* C_vals, int C_nnz,
+                const int* blk, int mat_num, const double* X0, const double* y0, const double* S0, double sig) {
+  (void)eig_stream_num_per_gpu; (void)cpu_eig_thread_num;
+  if (!s) { set_error("init: null solver"); return CUADMM_ERR_INVALID; }
+  if (s->initialised) { set_error("init: solver already initialised (one init per object, as in the reference)"); return CUADMM_ERR_INVALID; }
+  if (vec_len < 0 || con_num < 0 || At_nnz < 0 || b_nnz < 0 || C_nnz < 0 || mat_num < 0 || !At_cp || !blk ||
+      (At_nnz > 0 && (!At_ri || !At_vx)) || (b_nnz > 0 && (!b_idx || !b_vals)) || (C_nnz > 0 && (!C_idx || !C_vals))) {
+    set_error("init: invalid argument");
+    return CUADMM_ERR_INVALID;
+  }
+  if (s->world < 1 || s->rank < 0 || s->rank >= s->world) { set_error("init: bad rank/world %d/%d", s->rank, s->world); return CUADMM_ERR_INVALID; }
+  long long Lchk = 0;
+  for (int k = 0; k < mat_num; ++k) {
+    if (blk[k] == 0) { set_error("init: block %d has size 0", k); return CUADMM_ERR_INVALID; }
+    Lchk += blk_svec_len(blk[k]);                       // negative size = unconstrained block of -blk[k] variables
+  }
+  if (Lchk != vec_len) { set_error("init: vec_len %d does not match blk (sum n(n+1)/2 = %lld)", vec_len, Lchk); return CUADMM_ERR_INVALID; }
+  if (At_cp[0] != 0 || At_cp[con_num] != At_nnz) { set_error("init: At column pointers inconsistent with At_nnz"); return CUADMM_ERR_INVALID; }
+  for (int p = 0; p < At_nnz; ++p)
+    if (At_ri[p] < 0 || At_ri[p] >= vec_len) { set_error("init: At row index %d out of range at %d", At_ri[p], p); return CUADMM_ERR_INVALID; }
+
+  if (s->world > 1) cuadmm_host_pool_hint(s->world);       // the ranks of a job share the node's CPUs (before the pool's first use)
+  if (s->world > 1 && !s->local_mode && s->sw.local_constraints) {
+    // does every constraint live inside one rank's block range?
+    std::vector<int> first;
+    partition_blocks(blk, mat_num, s->world, first);
+    std::vector<long long> svb((size_t)s->world + 1, 0);
+    {
+      long long off = 0;
+      int r = 0;
+      for (int k = 0; k <= mat_num; ++k) {
+        while (r <= s->world && first[r] == k) svb[r++] = off;
+        if (k < mat_num) off += blk_svec_len(blk[k]);
+      }
+    }
+    std::vector<int> owner(con_num, 0);
+    bool all_owned = true;
+    for (int j = 0; j < con_num && all_owned; ++j) {
+      if (At_cp[j] == At_cp[j + 1]) continue;                      // empty constraint: rank 0
+      const int r = (int)(std::upper_bound(svb.begin(), svb.end(), (long long)At_ri[At_cp[j]]) - svb.begin()) - 1;
+      for (int p = At_cp[j]; p < At_cp[j + 1]; ++p)
+        if (At_ri[p] < svb[r] || At_ri[p] >= svb[r + 1]) { all_owned = false; break; }
+      owner[j] = r;
+    }
+    if (all_owned) {
+      const int me = s->rank;
+      // global norms (solver.cu:169-191) from the full inputs every rank holds
+      double nb = 0, nc = 0, nb2 = 0;
+      for (int i = 0; i < b_nnz; ++i) {
+        if (b_idx[i] < 0 || b_idx[i] >= con_num) { set_error("init: b index %d out of range", b_idx[i]); return CUADMM_ERR_INVALID; }
+        nb += b_vals[i] * b_vals[i];
+        double cn = 0;
+        for (int p = At_cp[b_idx[i]]; p < At_cp[b_idx[i] + 1]; ++p) cn += At_vx[p] * At_vx[p];
+        const double v = b_vals[i] / std::max(1.0, std::sqrt(cn));
+        nb2 += v * v;
+      }
+      for (int i = 0; i < C_nnz; ++i) nc += C_vals[i] * C_vals[i];
+      std::vector<int> cons, g2l(con_num, -1);
+      for (int j = 0; j < con_num; ++j) if (owner[j] == me) { g2l[j] = (int)cons.size(); cons.push_back(j); }
+      const long long lo = svb[me], hi = svb[me + 1];
+      std::vector<int> lcp(cons.size() + 1, 0), lri, lbi, lCi;
+      std::vector<double> lvx, lbv, lCv, ly0;
+      for (size_t q = 0; q < cons.size(); ++q) {
+        for (int p = At_cp[cons[q]]; p < At_cp[cons[q] + 1]; ++p) { lri.push_back((int)(At_ri[p] - lo)); lvx.push_back(At_vx[p]); }
+        lcp[q + 1] = (int)lri.size();
+      }
+      for (int i = 0; i < b_nnz; ++i) if (g2l[b_idx[i]] >= 0) { lbi.push_back(g2l[b_idx[i]]); lbv.push_back(b_vals[i]); }
+      for (int i = 0; i < C_nnz; ++i) {
+        if (C_idx[i] < 0 || C_idx[i] >= vec_len) { set_error("init: C index %d out of range", C_idx[i]); return CUADMM_ERR_INVALID; }
+        if (C_idx[i] >= lo && C_idx[i] < hi) { lCi.push_back((int)(C_idx[i] - lo)); lCv.push_back(C_vals[i]); }
+      }
+      if (y0) { ly0.resize(cons.size()); for (size_t q = 0; q < cons.size(); ++q) ly0[q] = y0[cons[q]]; }
+      s->local_mode = true;
+      s->comm_world = s->world; s->comm_rank = s->rank;
+      s->m_full = con_num; s->cons_local = cons; s->sv_off = lo; s->blk_off = first[me];
+      s->L_caller = vec_len; s->nblk_caller = mat_num;
+      s->ov_nb = nb; s->ov_nc = nc; s->ov_nb2 = nb2;
+      s->world = 1; s->rank = 0;
+      if (s->comm_rank != 0) s->verbose = 0;      // one console table per job
+      int one = 0;
+      return cuadmm_init(s, eig_stream_num_per_gpu, cpu_eig_thread_num, (int)(hi - lo), (int)cons.size(), lcp.data(),
+                         lri.empty() ? &one : lri.data(), lvx.empty() ? nullptr : lvx.data(), (int)lri.size(),
+                         lbi.empty() ? nullptr : lbi.data(), lbv.empty() ? nullptr : lbv.data(), (int)lbi.size(),
+                         lCi.empty() ? nullptr : lCi.data(), lCv.empty() ? nullptr : lCv.data(), (int)lCi.size(),
+                         blk + first[me], first[me + 1] - first[me], X0 ? X0 + lo : nullptr, y0 ? ly0.data() : nullptr,
+                         S0 ? S0 + lo : nullptr, sig);
+    }
+  }
+
+  InitIn in{vec_len, con_num, At_nnz, b_nnz, C_nnz, mat_num, At_cp, At_ri, b_idx, C_idx, blk, At_vx, b_vals, C_vals, X0, y0, S0, sig};
+  InitCtx ctx;
+  int rc;
+  if ((rc = init_device(s, in, ctx)) || (rc = init_normalise(s, in, ctx)) || (rc = init_factor(s, in, ctx)) || (rc = init_plan(s, in, ctx)) ||
+      (rc = init_matrices(s, in, ctx)) || (rc = init_vectors(s, in, ctx)) || (rc = init_solve_plan(s, in, ctx)) || (rc = init_closed(s, in, ctx)) ||
+      (rc = init_finish(s, in, ctx)))
+    return rc;
   s->prim_win = 0; s->dual_win = 0; s->ratioconst = 1e0; s->sigmax = 1e3; s->sigmin = 1e-3;
   s->initialised = true;
   return CUADMM_OK;
@@ -1311,7 +1439,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     std::cout << " -------------------------------------------------------------------------------" << std::endl;
   }
 
-  static const bool lpt_enabled = !(getenv("CUADMM_PSD_LPT") && atoi(getenv("CUADMM_PSD_LPT")) == 0);
+  const bool lpt_enabled = s->sw.lpt != 0;
   long long& lpt_ev = s->lpt_next;             // counts iterations over all solve calls of this solver
   if (!lpt_enabled) lpt_ev = 0;
   for (int iter = 1; iter <= max_iter + 1; ++iter) {
@@ -1423,8 +1551,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if ((rc = s->launch_aty(true))) return rc;
       s->plan.rank_active = s->eig_rank > 0 && (iter >= s->eig_rank_begin_iter || s->maxfeas < s->eig_rank_maxfeas);   // duo_solver.cu:844
       if ((rc = s->launch_project())) return rc;
-      static const char* const debug_eig_dir = getenv("CUADMM_DEBUG_EIG");   // read once, not per iteration
-      if (debug_eig_dir) {   // developer aid: dump the projection input when a block hits the QL cap
+      const char* const debug_eig_dir = s->sw.debug_eig ? getenv("CUADMM_DEBUG_EIG") : nullptr;
+      if (debug_eig_dir) {   // developer aid (option debug_eig + CUADMM_DEBUG_EIG=<dir>): dump the projection input when a block hits the QL cap
         int f = s->plan.fail_count(s->st);
         if (f != s->eig_fail_total) {
           fprintf(stderr, "[cuadmm debug] iter %d: QL cap hits %d -> %d\n", iter, s->eig_fail_total, f);
@@ -1447,8 +1575,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if ((rc = s->fetch_out((size_t)m + 2, (size_t)m))) return rc;
       if ((rc = s->host_solve())) return rc;
       if ((rc = s->upload_y())) return rc;
-      static const bool aty_post2 = !getenv("CUADMM_NO_ATY_POST2");
-      if (s->At_long.nlong == 0 && aty_post2) {   // one pass, Rd1 not stored (vec_kernels.hip)
+      if (s->At_long.nlong == 0 && s->sw.aty_post2) {   // one pass, Rd1 not stored (vec_kernels.hip)
         s->prof_begin(K_POST);
         rc = launch_aty_post2(L, s->At_rp.p, s->At_ci.p, s->At_v.p, s->y_d.p, s->C.p, s->S.p, s->X.p, tau * s->sig, s->partials.p,
                               s->out_w + (size_t)m, s->st);
@@ -1588,8 +1715,15 @@ int cuadmm_duo_init(cuadmm_solver* s, int if_gpu_eig_mom, int device_num_request
                     int cpu_eig_thread_num, int vec_len, int con_num, const int* At_cp, const int* At_ri, const double* At_vx,
                     int At_nnz, const int* b_idx, const double* b_vals, int b_nnz, const int* C_idx, const double* C_vals,
                     int C_nnz, const int* blk, int mat_num, const double* X0, const double* y0, const double* S0, double sig) {
-  (void)if_gpu_eig_mom;     // false = the reference's host-LAPACK moment-matrix path: this engine has no CPU projection
   if (!s || !blk || mat_num <= 0) { set_error("duo_init: invalid argument"); return CUADMM_ERR_INVALID; }
+  // if_gpu_eig_mom = false asks for the reference's host-LAPACK moment-matrix path (duo_solver.cu:578-618,793-834).  This engine
+  // has no CPU projection (and no CPU fallback by design): say so instead of silently running the GPU kernels; the option
+  // "duo_cpu_eig_on_gpu" = 1 accepts the request and projects on the GPU (same iterates, to the projection's tolerance).
+  if (!if_gpu_eig_mom && !s->duo_cpu_eig_on_gpu) {
+    set_error("duo_init: if_gpu_eig_mom = false selects the reference's host LAPACK eigendecomposition; this engine projects on the GPU only "
+              "(set option duo_cpu_eig_on_gpu = 1 to run the GPU projection for such a call)");
+    return CUADMM_ERR_INVALID;
+  }
   // duo_solver.cu:487-577 spreads the moment matrices over device_num_requested GPUs from ONE process; here a GPU is a
   // rank (options "rank" / "world", one process per GPU), so the request must agree with the sharding in force
   if (device_num_requested > 1 && device_num_requested != s->world) {
@@ -1781,6 +1915,25 @@ int cuadmm_op_psd_project_ex(const double* Xb, double* Xproj, const int* blk_hos
   if (fails != 0) { set_error("psd_project: %d blocks hit the QL sweep cap", fails); return CUADMM_ERR_EIG; }
   return CUADMM_OK;
 }
+
+struct cuadmm_psd_plan { PsdPlan plan; };
+int cuadmm_psd_plan_create(const int* blk_host, int mat_num, int eig_rank, cuadmm_psd_plan** out) {
+  if (!blk_host || mat_num < 0 || eig_rank < 0 || !out) { set_error("psd_plan_create: bad arguments"); return CUADMM_ERR_INVALID; }
+  cuadmm_psd_plan* p = new cuadmm_psd_plan();
+  p->plan.eig_rank = eig_rank;
+  int rc = p->plan.build(blk_host, mat_num);
+  if (rc) { delete p; return rc; }
+  p->plan.overlap = true;
+  *out = p;
+  return CUADMM_OK;
+}
+int cuadmm_psd_plan_project(cuadmm_psd_plan* p, const double* Xb, double* Xproj, int* steps_dev, void* stream) {
+  if (!p || !Xb || !Xproj) { set_error("psd_plan_project: bad arguments"); return CUADMM_ERR_INVALID; }
+  p->plan.d_steps = steps_dev;
+  p->plan.sign.d_steps = steps_dev;
+  return p->plan.project(Xb, Xproj, (hipStream_t)stream);
+}
+void cuadmm_psd_plan_destroy(cuadmm_psd_plan* p) { delete p; }
 
 int cuadmm_dev_malloc(void** ptr, size_t bytes) { CUADMM_HIP_TRY(hipMalloc(ptr, bytes ? bytes : 8)); return CUADMM_OK; }
 int cuadmm_dev_free(void* ptr) { if (ptr) CUADMM_HIP_TRY(hipFree(ptr)); return CUADMM_OK; }

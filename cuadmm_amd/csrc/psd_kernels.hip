@@ -2,7 +2,7 @@
 //
 // Projection (MODE 0), one launch per size class:
 //   n <= 16              : psd_small_reg_kernel<4|8|16>: register-resident eigensolver, 16..4 blocks per wavefront
-//   17 <= n <= 32        : psd_sign_wave32_kernel: matrix-sign iteration on the fp64 matrix cores, one wavefront per block
+//   9 <= n <= 64         : psd_sign_wave_kernel / psd_sign_closed_kernel: matrix-sign iteration on the fp64 matrix cores, one wavefront per block
 //   33 <= n <= 64        : psd_sign_lds_kernel<48|64>: same iteration resident in LDS, one workgroup per block
 //   larger               : psd_large.hip (batched GEMM launches)
 // The sign kernels stop per block (sign_sched.h).  Explicit eigendecomposition (MODE 1, cuadmm_op_batch_eig):
@@ -149,30 +149,8 @@ __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(P
                         a.hint ? a.hint + id : nullptr);
 }
 
-// n <= 32 (projection only): one wavefront per block (psd_sign_lds.h, SignWave32); WPG wavefronts per workgroup.
-// Blocks stop at different steps, so small workgroups (a workgroup's LDS and wave slots are released when its last
-// wavefront ends) keep the SIMDs fed.
-#define CUADMM_SW32_KERNEL(NAME, OCC, DBG)                                                                                           \
-  template <int WPG>                                                                                                                \
-  __global__ __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(OCC, 4))) void NAME(PsdArgs a, int first, int count) { \
-    __shared__ double sw_smem[WPG * SignWave32::PER_WAVE];                                                                          \
-    const int w = (int)threadIdx.x >> 6;                                                                                            \
-    const int m = (int)blockIdx.x * WPG + w;                                                                                        \
-    if (m >= count) return;                                                                                                         \
-    const int id = a.ids ? a.ids[first + m] : first + m;                                                                            \
-    psd_sign_wave32_body<DBG>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sw_smem + w * SignWave32::PER_WAVE,          \
-                              a.steps ? a.steps + id : nullptr, a.hint ? a.hint + id : nullptr,                                    \
-                              a.dbg ? a.dbg + 10 * (long long)m : nullptr);                                                         \
-  }
-// two register budgets of the same kernel: 4 wavefronts per SIMD (<= 128 VGPRs, a few spills outside the iteration) and 3
-// (<= 168, no spills); CUADMM_PSD_W32_OCC=3|4 selects, the default is the measured winner
-CUADMM_SW32_KERNEL(psd_sign_wave32_kernel, 4, false)
-CUADMM_SW32_KERNEL(psd_sign_wave32_occ3_kernel, 3, false)
-CUADMM_SW32_KERNEL(psd_sign_wave32_dbg_kernel, 3, true)     // CUADMM_PSD_DEBUG: per-phase cycle stamps inside the step
-#undef CUADMM_SW32_KERNEL
-
-// one WAVEFRONT per block (psd_sign_wave.h): NT = 3 (n <= 48, two wavefronts per SIMD), NT = 4 (n <= 64, one); NT = 2 is the
-// successor of psd_sign_wave32_kernel (CUADMM_PSD_W32_GEN=3|4: waves per SIMD; 0 = the hand-unrolled kernel)
+// one WAVEFRONT per block (psd_sign_wave.h): NT = 1 (n <= 16, eight wavefronts per SIMD), NT = 2 (n <= 32, four -- or three: option
+// psd_w32_occ), NT = 3 (n <= 48, two), NT = 4 (n <= 64, one)
 template <int NT, int OCC, bool FUSED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_wave_kernel(PsdArgs a, SignFuse fz, int first, int count, int slot0) {
   extern __shared__ double swt_smem[];
@@ -250,9 +228,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
   }
 }
 
-// fz != nullptr: the fused variant (SignFuse, psd_sign_wave.h); slot0 = partial-sum slot of the first member of this launch
+// fz != nullptr: the fused variant (SignFuse, psd_sign_wave.h); the partial-sum slot of a member comes with its descriptor
 template <int NT, int OCC>
-static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t st, const SignFuse* fz = nullptr, int slot0 = 0) {
+static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t st, const SignFuse* fz = nullptr) {
   if (count <= 0) return CUADMM_OK;
   if (fz && fz->rec) {                                   // closed blocks: psd_sign_closed.h
     ClosedArgs ca{};
@@ -284,50 +262,18 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
       hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
     }
   }
-  else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count, slot0);
+  else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count, 0);
   else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count, 0);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
 
-// A/B switches of the projection kernels, read from the environment once
-struct PsdKnobs {
-  bool debug, sign32, sign16, mid_eig, mid_lds, w64;
-  int gen;   // n <= 32: 3 | 4 = psd_sign_wave_kernel<2> at that many wavefronts per SIMD, 0 = the hand-unrolled SignWave32 kernel
-  PsdKnobs() {
-    auto is = [](const char* name, const char* val) { const char* e = getenv(name); return e && std::string(e) == val; };
-    debug = getenv("CUADMM_PSD_DEBUG") != nullptr;
-    sign32 = !is("CUADMM_PSD_N32", "eig");
-    sign16 = !is("CUADMM_PSD_N16", "eig");
-    mid_eig = is("CUADMM_PSD_MID", "eig");
-    mid_lds = is("CUADMM_PSD_MID", "lds");
-    w64 = !(getenv("CUADMM_PSD_W64") && atoi(getenv("CUADMM_PSD_W64")) == 0);
-    gen = getenv("CUADMM_PSD_W32_GEN") ? atoi(getenv("CUADMM_PSD_W32_GEN")) : 4;
-    if (gen != 3 && gen != 4) gen = 0;
-  }
-};
-static const PsdKnobs& psd_knobs() { static const PsdKnobs k; return k; }
-
-static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_t st, const SignFuse* fz = nullptr, int slot0 = 0) {
+// 17 <= n <= 32: three or four wavefronts per SIMD (PsdOptions::w32_occ; the launches of several iterations: cu_occ)
+static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_t st, const PsdOptions& opt, const SignFuse* fz = nullptr) {
   if (count <= 0) return CUADMM_OK;
-  static const int wpg = getenv("CUADMM_PSD_W32_WPG") ? atoi(getenv("CUADMM_PSD_W32_WPG")) : 1;
-  static const int occ = getenv("CUADMM_PSD_W32_OCC") ? atoi(getenv("CUADMM_PSD_W32_OCC")) : 3;
-  const int gen = psd_knobs().gen;
-  static const int cu_occ = getenv("CUADMM_CU_OCC") ? atoi(getenv("CUADMM_CU_OCC")) : 4;     // A/B: wavefronts per SIMD of the batched launches
-  if (fz && fz->iters > 1 && cu_occ == 3) return launch_sign_wave<2, 3>(a, first, count, st, fz, slot0);
-  if (gen == 3 && (!a.dbg || fz)) return launch_sign_wave<2, 3>(a, first, count, st, fz, slot0);
-  if ((gen == 4 && !a.dbg) || fz) return launch_sign_wave<2, 4>(a, first, count, st, fz, slot0);
-  static const int pad = getenv("CUADMM_PSD_W32_PAD") ? atoi(getenv("CUADMM_PSD_W32_PAD")) : 0;   // occupancy experiments: unused dynamic LDS
-  if (a.dbg) {
-    hipLaunchKernelGGL(psd_sign_wave32_dbg_kernel<1>, dim3(count), dim3(64), pad, st, a, first, count);
-  } else if (occ == 3) {
-    if (wpg == 4) hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<4>, dim3((count + 3) / 4), dim3(256), 0, st, a, first, count);
-    else hipLaunchKernelGGL(psd_sign_wave32_occ3_kernel<1>, dim3(count), dim3(64), pad, st, a, first, count);
-  } else {
-    hipLaunchKernelGGL(psd_sign_wave32_kernel<1>, dim3(count), dim3(64), 0, st, a, first, count);
-  }
-  CUADMM_HIP_TRY(hipGetLastError());
-  return CUADMM_OK;
+  const int occ = (fz && fz->iters > 1) ? opt.cu_occ : opt.w32_occ;
+  if (occ == 3) return launch_sign_wave<2, 3>(a, first, count, st, fz);
+  return launch_sign_wave<2, 4>(a, first, count, st, fz);
 }
 
 template <int NP>
@@ -368,14 +314,15 @@ int PsdPlan::build(const int* blk, int mat_num) {
   release();
   nblk = mat_num;
   h_blk.assign(blk, blk + mat_num);
-  sign16 = psd_knobs().sign16 && psd_knobs().gen != 0;
+  sign16 = opt.n16_sign != 0;
+  sign.opt = opt;
   std::vector<long long> off((size_t)mat_num + 1, 0);
   std::vector<long long> free_off, free_len;   // unconstrained blocks (negative size): identity "projection"
   for (int k = 0; k < mat_num; ++k) {
     if (blk[k] == 0) { set_error("block %d has size 0", k); return CUADMM_ERR_INVALID; }
     if (blk[k] > kMaxBlockSize) { set_error("block %d has size %d > %d (largest supported this build)", k, blk[k], kMaxBlockSize); return CUADMM_ERR_INVALID; }
-    if (eig_rank > 0 && blk[k] > kMaxEigSize && !getenv("CUADMM_EIG_ALLOW_SLOW")) {
-      set_error("rank-limited projection: block %d has size %d > %d (explicit eigendecomposition of large blocks is too slow; CUADMM_EIG_ALLOW_SLOW=1 overrides)",
+    if (eig_rank > 0 && blk[k] > kMaxEigSize && !opt.eig_allow_slow) {
+      set_error("rank-limited projection: block %d has size %d > %d (explicit eigendecomposition of large blocks is too slow; option eig_allow_slow = 1 overrides)",
                 k, blk[k], kMaxEigSize);
       return CUADMM_ERR_INVALID;
     }
@@ -383,7 +330,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     if (blk[k] < 0) { free_off.push_back(off[k]); free_len.push_back(-(long long)blk[k]); }
   }
   vec_len = off[mat_num];
-  if (const char* e = getenv("CUADMM_PSD_SIGN_MIN")) sign_min = std::max(65, atoi(e));
+  sign_min = std::max(65, opt.sign_min);
   // a rank mask needs eigenvalues: with eig_rank set every block goes through the eigensolver kernels
   if (eig_rank > 0) sign_min = 0x7fffffff;
   std::vector<int> sign_members;
@@ -407,11 +354,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     }
     cls_count[c] = (int)ids.size() - cls_begin[c];
   }
-  {
-    const PsdKnobs& kn = psd_knobs();
-    const int wave4_min = getenv("CUADMM_PSD_WAVE4_MIN") ? atoi(getenv("CUADMM_PSD_WAVE4_MIN")) : 1024;   // read per plan: tests set it
-    wave4 = kn.w64 && !kn.mid_lds && !kn.mid_eig && kn.gen != 0 && cls_count[4] >= wave4_min;
-  }
+  wave4 = opt.mid == 0 && cls_count[4] >= opt.wave4_min;
   n_free = (int)free_off.size();
   if (n_free > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_free_off, sizeof(long long) * free_off.size()));
@@ -516,9 +459,7 @@ __global__ void hint_decay_kernel(int* hint, int n) {
 
 // Blocks of the one-wavefront-per-block sign kernels (classes 3 and 4) can take the iteration's vector work with them
 bool PsdPlan::fusable() const {
-  const PsdKnobs& k = psd_knobs();
-  return eig_rank == 0 && !k.debug && k.sign32 && k.gen != 0 && !k.mid_eig && fused_blocks() > 0 &&
-         vec_len < 0x7fffffffLL;
+  return eig_rank == 0 && !opt.debug && opt.n32_sign && opt.mid != 1 && fused_blocks() > 0 && vec_len < 0x7fffffffLL;
 }
 
 bool PsdPlan::sort_by_steps_host(const int* steps_host, std::vector<std::pair<int, int>>& ranges) {
@@ -613,9 +554,8 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     hipLaunchKernelGGL(hint_decay_kernel, dim3((nblk + 255) / 256), dim3(256), 0, st, d_hint, nblk);
     CUADMM_HIP_TRY(hipGetLastError());
   }
-  const PsdKnobs& knobs = psd_knobs();                                      // environment read once, not per projection
-  const bool psd_debug = knobs.debug;
-  static const bool no_overlap = (getenv("CUADMM_PSD_OVERLAP") && atoi(getenv("CUADMM_PSD_OVERLAP")) == 0) || psd_debug;
+  const bool psd_debug = opt.debug != 0;
+  const bool no_overlap = !opt.overlap || psd_debug;
   if (fz && !fusable()) { set_error("psd: fused projection requested on a plan that cannot fuse"); return CUADMM_ERR_INVALID; }
   int lanes = sign.empty() ? 0 : 1;
   for (int c = 0; c < kNumPsdClasses; ++c) lanes += cls_count[c] > 0;
@@ -629,9 +569,9 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
   }
   if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
   hipStream_t main_st = st;
-  // 16 < n <= 32: CUADMM_PSD_N32 = eig (register eigensolver, psd_small_reg.h) | sign (one wavefront per block, psd_sign_lds.h)
-  // Default sign: 0.805 ms vs 0.92 ms per 10 000 x 32 blocks (MI355X), and 0.16 ms vs 0.35 ms latency for a single block.
-  const bool sign32 = knobs.sign32;
+  // 16 < n <= 32: option psd_n32 = 0 -> register eigensolver (psd_small_reg.h), default the one-wavefront sign kernel
+  // (0.256 vs 0.92 ms per 10 000 x 32 blocks on MI355X, 0.05 vs 0.35 ms latency for a single block)
+  const bool sign32 = opt.n32_sign != 0;
   for (int c = 0; c < kNumPsdClasses; ++c) {
     if (cls_count[c] == 0) continue;
     if (fork) {   // the sign path keeps the main stream (it is the longest chain)
@@ -646,8 +586,8 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     a.hint = d_hint;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
-    if (psd_debug && eig_rank == 0 && knobs.gen != 0 && ((c == 2 && sign16) || c == 3 || (c == 4 && wave4)) && getenv("CUADMM_PSD_DEBUG_GEN")) {
-      // phase ticks of the generic one-wavefront kernels (CUADMM_PSD_DEBUG=1 CUADMM_PSD_DEBUG_GEN=1), unfused
+    if (psd_debug && eig_rank == 0 && !fz && ((c == 2 && sign16) || (c == 3 && sign32) || (c == 4 && wave4))) {
+      // phase ticks of the one-wavefront kernels (CUADMM_PSD_DEBUG=1 / option psd_debug), unfused
       std::vector<long long> h((size_t)cls_count[c] * 10, 0);
       long long* d = nullptr;
       CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
@@ -673,13 +613,13 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
       continue;
     }
-    if (c == 3 && fz && fz->iters > 1 && getenv("CUADMM_CU_DBG")) {   // developer aid: phase ticks of the batched launches at full occupancy
+    if (c == 3 && fz && fz->iters > 1 && opt.debug >= 2) {   // developer aid (psd_debug = 2): phase ticks of the batched launches at full occupancy
       std::vector<long long> h((size_t)cls_count[c] * 10, 0);
       long long* d = nullptr;
       CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
       CUADMM_HIP_TRY(hipMemset(d, 0, sizeof(long long) * h.size()));
       a.dbg = d;
-      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st, fz, 0);
+      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz);
       if (rc2) return rc2;
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
       CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
@@ -698,47 +638,28 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
       continue;
     }
-    if (c == 3 && psd_debug && sign32 && eig_rank == 0) {   // phase cycles of the one-wavefront-per-block sign kernel
-      std::vector<long long> h((size_t)cls_count[c] * 10);
-      long long* d = nullptr;
-      CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
-      a.dbg = d;
-      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st);
-      if (rc2) return rc2;
-      CUADMM_HIP_TRY(hipStreamSynchronize(st));
-      CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-      double ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 10; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
-      const double nw = cls_count[c], ns = std::max(ph[3], 1.0);
-      fprintf(stderr, "[psd debug] sign wave32: %d blocks: ticks/block prologue %.0f iteration %.0f (%.1f steps, %.0f per step) epilogue %.0f | per step: "
-                      "frags %.0f  Y=SS %.0f  transpose+stats %.0f  SY %.0f  reduce+decide %.0f  combine+store %.0f\n",
-              cls_count[c], ph[0] / nw, ph[1] / nw, ph[3] / nw, ph[1] / ns, ph[2] / nw, ph[4] / ns, ph[5] / ns, ph[6] / ns, ph[7] / ns, ph[8] / ns, ph[9] / ns);
-      { hipError_t e = hipFree(d); (void)e; }
-      if (fork) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
-      continue;
-    }
-    if (c == 3 && psd_debug) {
+    if (c == 3 && psd_debug && !sign32) {   // phase cycles of the register eigensolver
       CUADMM_HIP_TRY(hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)nwg));
       CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));
       a.dbg = dbg;
     }
     int rc;
-    if (c == 4 && !knobs.mid_eig && eig_rank == 0) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
-      // one wavefront per block (psd_sign_wave.h); CUADMM_PSD_MID=lds restores the one-workgroup-per-block kernels (A/B),
-      // CUADMM_PSD_MID=eig the register eigensolver.  Fused: partial-sum slots follow those of class 3.
+    if (c == 4 && opt.mid != 1 && eig_rank == 0) {   // members are sorted by size, largest first: [0, cls4_big) have n > 48
+      // one wavefront per block (psd_sign_wave.h) from psd_wave4_min blocks on, else one workgroup per block (latency); option
+      // psd_mid = 2 forces the one-workgroup kernels, 1 the register eigensolver
       if (wave4) {
-        rc = launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz, fused_blocks() - cls_count[4]);
-        if (!rc) rc = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz, fused_blocks() - cls_count[4] + cls4_big);
+        rc = launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz);
+        if (!rc) rc = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz);
       } else {
         rc = launch_sign_lds<64>(a, 0, cls4_big, st);
         if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st);
       }
     } else if (c == 3 && sign32 && eig_rank == 0) {
-      rc = launch_sign_wave32(a, 0, cls_count[c], st, fz, sign16 ? cls_count[2] : 0);
+      rc = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz);
     } else if (c == 2 && sign16 && eig_rank == 0 && !psd_debug) {
       // 9 <= n <= 16: the same iteration on ONE 16 x 16 sub-tile, eight wavefronts per SIMD (the register eigensolver needs
       // ~20 us of dependent rotations per block; here a block is 8 MFMAs per step)
-      rc = launch_sign_wave<1, 8>(a, 0, cls_count[c], st, fz, 0);
+      rc = launch_sign_wave<1, 8>(a, 0, cls_count[c], st, fz);
     } else {
       rc = launch_class<0>(c, a, cls_maxn[c], st);
     }
@@ -789,7 +710,7 @@ int PsdPlan::fail_count(hipStream_t st) const {
 int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream_t st) {
   if (n < 1 || count < 0) { set_error("batch_eig: bad n/count"); return CUADMM_ERR_INVALID; }
   if (n > kMaxBlockSize) { set_error("batch_eig: n=%d > %d", n, kMaxBlockSize); return CUADMM_ERR_INVALID; }
-  if (n > kMaxEigSize && !getenv("CUADMM_EIG_ALLOW_SLOW")) {
+  if (n > kMaxEigSize && !getenv("CUADMM_EIG_ALLOW_SLOW")) {   // op entry point without a handle: the environment is its only switch
     set_error("batch_eig: n=%d > %d: the explicit eigendecomposition of one large block runs on a single workgroup (76 s at n = 2000); "
               "set CUADMM_EIG_ALLOW_SLOW=1 to run it anyway", n, kMaxEigSize);
     return CUADMM_ERR_INVALID;

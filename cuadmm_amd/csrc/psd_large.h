@@ -4,10 +4,13 @@
 
 #include <vector>
 
+#include "psd_options.h"
+
 namespace cuadmm {
 
 struct SignPsd {
   struct Group { int N = 0, begin = 0, count = 0, pred = 0; };   // pred: steps the previous projection needed
+  PsdOptions opt;                            // the owner's switches (PsdPlan::build copies its own)
   std::vector<Group> groups;                 // same padded size N, bounded workspace
   int* d_ids = nullptr;                      // block ids, group after group
   int* d_steps = nullptr;                    // not owned; when set: Newton-Schulz steps taken per block

@@ -405,9 +405,8 @@ __global__ __launch_bounds__(256) void lg_diff_kernel(const double* __restrict__
 
 static int lg_pad(int n) { return (n + LG_TM - 1) / LG_TM * LG_TM; }
 
-static bool lg_small_tiles(bool mirror, int N, int count) {
-  // 32 x 32 tiles when the 64 x 64 tiling would leave the chip under-filled (CUADMM_LG_TILE=32|64 forces one)
-  static const int tile_force = getenv("CUADMM_LG_TILE") ? atoi(getenv("CUADMM_LG_TILE")) : 0;
+static bool lg_small_tiles(bool mirror, int N, int count, int tile_force = 0) {
+  // 32 x 32 tiles when the 64 x 64 tiling would leave the chip under-filled (option psd_lg_tile = 32 | 64 forces one)
   const int nb64 = N / 64;
   const long long tiles64 = (long long)(mirror ? nb64 * (nb64 + 1) / 2 : nb64 * nb64) * count;
   // measured: better up to N ~ 3000, and down to N = 128 (a moment relaxation's handful of 65 <= n <= 128 blocks: the launch
@@ -418,8 +417,8 @@ static bool lg_small_tiles(bool mirror, int N, int count) {
 
 template <int ROLE>
 static int lg_gemm_mirror(int N, int count, const double* A, const double* B, double alpha, double beta, const double* E, double* C,
-                          hipStream_t st, const SignArgs& sa, const double* B2) {
-  const bool small_tiles = lg_small_tiles(true, N, count);
+                          hipStream_t st, const SignArgs& sa, const double* B2, int tile_force = 0) {
+  const bool small_tiles = lg_small_tiles(true, N, count, tile_force);
   const int nb = small_tiles ? N / 32 : N / 64;
   if (count == 1 && nb >= 16) {
     const int sb = (nb + 7) / 8;                               // 8x8-tile super-blocks per direction
@@ -467,7 +466,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   release();
   if (members.empty()) return CUADMM_OK;
   size_t ws_cap = (size_t)8 << 30;   // bytes of workspace (4 matrices per member); 288 GB of HBM make this generous
-  if (const char* e = getenv("CUADMM_PSD_SIGN_WS_MB")) ws_cap = (size_t)std::max(1, atoi(e)) << 20;
+  ws_cap = (size_t)std::max(1, opt.sign_ws_mb) << 20;
   std::map<int, std::vector<int>> by_pad;
   for (int k : members) by_pad[lg_pad(blk[k])].push_back(k);
   std::vector<int> ids;
@@ -483,9 +482,9 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
       int nmax = 0;
       for (int k : kv.second) nmax = std::max(nmax, blk[k]);
       const int cnt = (int)std::min<size_t>((size_t)chunk, kv.second.size());
-      static const bool pad32 = !(getenv("CUADMM_LG_PAD32") && atoi(getenv("CUADMM_LG_PAD32")) == 0);
-      if (pad32 && nmax <= N - 32 && lg_small_tiles(true, N, cnt) && lg_small_tiles(true, N - 32, cnt) &&
-          lg_small_tiles(true, N - 32, (int)(kv.second.size() % (size_t)chunk ? kv.second.size() % (size_t)chunk : cnt)))
+      const int tf = opt.lg_tile;
+      if (opt.lg_pad32 && nmax <= N - 32 && lg_small_tiles(true, N, cnt, tf) && lg_small_tiles(true, N - 32, cnt, tf) &&
+          lg_small_tiles(true, N - 32, (int)(kv.second.size() % (size_t)chunk ? kv.second.size() % (size_t)chunk : cnt), tf))
         N -= 32;
     }
     for (size_t b = 0; b < kv.second.size(); b += (size_t)chunk) {
@@ -536,7 +535,7 @@ void SignPsd::release() {
 // the cost is the device-side drain/flush between dependent kernels, not host launch overhead.  Kept behind
 // CUADMM_PSD_GRAPH=1 for re-measurement on other ROCm versions.
 int SignPsd::project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
-  static const bool use_graph = getenv("CUADMM_PSD_GRAPH") && atoi(getenv("CUADMM_PSD_GRAPH")) == 1 && !getenv("CUADMM_PSD_DEBUG");
+  const bool use_graph = opt.graph == 1 && !opt.debug;
   if (!use_graph || !allow_graph || st == nullptr || groups.empty()) return project_launch(in, out, boff, bn, d_fail, st);
   if (graph_exec && (g_in != in || g_out != out || g_boff != boff || g_bn != bn || g_fail != d_fail)) {
     hipError_t e = hipGraphExecDestroy(graph_exec); (void)e;
@@ -559,10 +558,10 @@ int SignPsd::project(const double* in, double* out, const long long* boff, const
 }
 
 int SignPsd::project_launch(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
-  static const int debug = getenv("CUADMM_PSD_DEBUG") ? std::max(1, atoi(getenv("CUADMM_PSD_DEBUG"))) : 0;
-  static const int max_steps = getenv("CUADMM_PSD_SIGN_MAXSTEPS") ? std::max(1, atoi(getenv("CUADMM_PSD_SIGN_MAXSTEPS"))) : SignSched::kCap;
-  static const int decide_force = !getenv("CUADMM_LG_DECIDE") ? 0 : (std::string(getenv("CUADMM_LG_DECIDE")) == "kernel" ? 2 : 1);
-  static const bool sync_ok = !(getenv("CUADMM_PSD_SIGN_SYNC") && atoi(getenv("CUADMM_PSD_SIGN_SYNC")) == 0);
+  const int debug = opt.debug;
+  const int max_steps = opt.sign_maxsteps > 0 ? opt.sign_maxsteps : SignSched::kCap;
+  const int decide_force = opt.lg_decide;
+  const bool sync_ok = opt.sign_sync != 0;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (st) { hipError_t e = hipStreamIsCapturing(st, &cap); (void)e; }
   const bool poll = sync_ok && cap == hipStreamCaptureStatusNone;
@@ -593,8 +592,8 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     double* t = T;
     int rc;
     // The decision of a step sums the tiles' slots: inside every workgroup of the S Y product when they are few, as a launch
-    // of its own when that would cost more than a launch (CUADMM_LG_DECIDE=inline|kernel forces one).
-    const int nbt = lg_small_tiles(true, N, cnt) ? N / 32 : N / 64, ntiles = nbt * (nbt + 1) / 2;
+    // of its own when that would cost more than a launch (option psd_lg_decide = 1 | 2 forces one).
+    const int nbt = lg_small_tiles(true, N, cnt, opt.lg_tile) ? N / 32 : N / 64, ntiles = nbt * (nbt + 1) / 2;
     const bool decide_kernel = decide_force ? decide_force == 2 : ntiles > 300;
     // Steps are enqueued in chunks; between chunks the host polls "members not finished" (8 bytes, one stream
     // synchronisation of ~20 us) instead of enqueueing the worst case kCap: a launch for a finished group costs ~5 us,
@@ -607,12 +606,12 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
       for (int it = 0; it < chunk && enq < max_steps; ++it, ++enq) {
         // Y = S*S ; [decision] ; T = 1.5 mu S - 0.5 mu^3 S*Y ; finished members return at once
         sa.step = enq;
-        if ((rc = lg_gemm_mirror<1>(N, cnt, s, s, 1.0, 0.0, nullptr, Y, st, sa, nullptr))) return rc;
+        if ((rc = lg_gemm_mirror<1>(N, cnt, s, s, 1.0, 0.0, nullptr, Y, st, sa, nullptr, opt.lg_tile))) return rc;
         if (decide_kernel) {
           hipLaunchKernelGGL(lg_decide_kernel, dim3(cnt), dim3(256), 0, st, sa, ntiles);
-          if ((rc = lg_gemm_mirror<4>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr))) return rc;
+          if ((rc = lg_gemm_mirror<4>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr, opt.lg_tile))) return rc;
         } else {
-          if ((rc = lg_gemm_mirror<2>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr))) return rc;
+          if ((rc = lg_gemm_mirror<2>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr, opt.lg_tile))) return rc;
         }
         std::swap(s, t);
       }
@@ -624,7 +623,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     }
     // P = 0.5 * (X0 + X0 * S_final); S_final is in S after an even number of steps, in T after an odd one
     sa.step = enq;
-    if ((rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T))) return rc;
+    if ((rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T, opt.lg_tile))) return rc;
     hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
     if (d_steps) hipLaunchKernelGGL(lg_steps_out_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, d_steps);
     CUADMM_HIP_TRY(hipGetLastError());

@@ -7,6 +7,7 @@
 
 #include "psd_fuse.h"
 #include "psd_large.h"
+#include "psd_options.h"
 
 namespace cuadmm {
 
@@ -25,6 +26,7 @@ struct PsdDesc {
 };
 
 struct PsdPlan {
+  PsdOptions opt = PsdOptions::from_env();   // set before build()
   int nblk = 0;
   long long vec_len = 0;
   double sum_n3 = 0;
@@ -40,7 +42,7 @@ struct PsdPlan {
   long long* d_wsoff = nullptr;
   // blocks with n >= sign_min (default 65: everything beyond the register kernels) take the GEMM-only matrix-sign
   // path (psd_large.hip); the workgroup eigensolver kernels (classes 5, 6) then only serve cuadmm_op_batch_eig.
-  // CUADMM_PSD_SIGN_MIN=<n> moves the boundary (A/B measurements).
+  // Option psd_sign_min moves the boundary (A/B measurements).
   int sign_min = 65;
   // f4: unconstrained blocks (negative size in blk) are copied through; eig_rank > 0 (set before build)
   // keeps only the eig_rank largest eigenvalues of every PSD block while rank_active (reference: dense_scalar.cu:51-57,
@@ -71,9 +73,9 @@ struct PsdPlan {
   bool one_dominant_geometry() const;
   // 32 < n <= 64 on the one-wavefront kernels (throughput: 1.3x the one-workgroup kernels in bulk) only when there are enough
   // blocks to fill the chip; a handful of blocks (moment relaxations) is a LATENCY problem, and there six / ten wavefronts per
-  // block win (measured crossover: ~1000 blocks at n = 45 and at n = 64; CUADMM_PSD_WAVE4_MIN moves it)
+  // block win (measured crossover: ~1000 blocks at n = 45 and at n = 64; option psd_wave4_min moves it)
   bool wave4 = false;
-  bool sign16 = true;          // 9 <= n <= 16 on the one-wavefront sign kernel too (CUADMM_PSD_N16=eig: register eigensolver)
+  bool sign16 = true;          // 9 <= n <= 16 on the one-wavefront sign kernel too (option psd_n16 = 0: register eigensolver)
   // n <= 8 on the one-wavefront sign kernel as well (one 16 x 16 sub-tile; set before build).  Slower than the register
   // eigensolver as a projection (sixteen 3 x 3 blocks share a wavefront there), but it lets a block-diagonal problem with tiny
   // blocks run its WHOLE iteration in the closed-block kernels: no stand-alone vector kernels, several iterations per launch.

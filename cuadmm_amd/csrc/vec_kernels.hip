@@ -60,20 +60,37 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
 // Rows with more than `skip_above` entries (> 0) are left to aty_xb_long_kernel: a moment relaxation has svec slots --
 // the (1,1) entry of the moment matrix -- that appear in thousands of constraints (PushT_N=10: one row with 2720 of
 // the 46 388 nonzeros made this kernel take 0.39 ms of a 0.89 ms iteration).
+// FOUR rows per thread and pass (rows i, i + stride, ...: every access still coalesced across the wavefront): the row pointers, C
+// and X of all four are in flight before the first data-dependent nonzero loop starts.  With one row per thread the kernel was
+// bound by memory-level parallelism, not bandwidth: 3.3 TB/s at BASELINE configs[3] size (41 % of 8 TB/s).
 template <bool WRITE_XB>
 __global__ __launch_bounds__(kVecThreads) void aty_xb_kernel(long long L, const int* __restrict__ rp,
                                                              const int* __restrict__ ci, const double* __restrict__ av,
                                                              const double* __restrict__ y, const double* __restrict__ C,
                                                              const double* __restrict__ X, double sig,
                                                              double* __restrict__ Rd1, double* __restrict__ Xb, int skip_above) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
-    const int p0 = rp[i], p1 = rp[i + 1];
-    if (skip_above > 0 && p1 - p0 > skip_above) continue;
-    double t = 0.0;
-    for (int p = p0; p < p1; ++p) t += av[p] * y[ci[p]];
-    const double r = t - C[i];
-    Rd1[i] = r;
-    if (WRITE_XB) Xb[i] = X[i] + r * sig;
+  constexpr int R = 4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < L; i0 += R * stride) {
+    int p0[R], p1[R];
+    double c[R], x[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * stride;
+      const long long ii = i < L ? i : i0;                   // out of range: the thread's first row again (masked below)
+      p0[k] = rp[ii]; p1[k] = rp[ii + 1]; c[k] = C[ii];
+      x[k] = WRITE_XB ? X[ii] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * stride;
+      if (i >= L || (skip_above > 0 && p1[k] - p0[k] > skip_above)) continue;
+      double t = 0.0;
+      for (int p = p0[k]; p < p1[k]; ++p) t += av[p] * y[ci[p]];
+      const double r = t - c[k];
+      Rd1[i] = r;
+      if (WRITE_XB) Xb[i] = x[k] + r * sig;
+    }
   }
 }
 
@@ -453,7 +470,7 @@ __global__ void spmv_finish_kernel(int nlong, const int* __restrict__ long_row, 
 
 int launch_aty_xb(bool write_xb, long long L, const int* rp, const int* ci, const double* av, const double* y,
                   const double* C, const double* X, double sig, double* Rd1, double* Xb, hipStream_t st, const AtyLongRows* lr) {
-  const int grid = grid_for(L, kVecThreads, 256 * 16);
+  const int grid = grid_for((L + 3) / 4, kVecThreads, 256 * 16);
   const int skip = (lr && lr->nlong > 0) ? lr->cap : 0;
   if (write_xb)
     hipLaunchKernelGGL(aty_xb_kernel<true>, dim3(grid), dim3(kVecThreads), 0, st, L, rp, ci, av, y, C, X, sig, Rd1, Xb, skip);

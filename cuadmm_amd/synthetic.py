@@ -96,13 +96,16 @@ def config_c2(n_blocks=10000, n=32, seed=20240601):
     return make_synthetic([n] * n_blocks, seed=seed)
 
 
-def config_c4(n_blocks=100000, seed=20240601):
-    """BASELINE config 4: sizes {3,6,10,15,28,45} in equal shares, shuffled with the seed, 3 constraints/block."""
+def config_c4_blk(n_blocks=100000, seed=20240601):
     sizes = np.array([3, 6, 10, 15, 28, 45])
     blk = np.repeat(sizes, n_blocks // 6 + 1)[:n_blocks]
     rng = np.random.Generator(np.random.PCG64(seed + 1))
-    blk = blk[rng.permutation(blk.size)]
-    return make_synthetic(blk, cons_per_block=3, seed=seed)
+    return blk[rng.permutation(blk.size)]
+
+
+def config_c4(n_blocks=100000, seed=20240601):
+    """BASELINE config 4: sizes {3,6,10,15,28,45} in equal shares, shuffled with the seed, 3 constraints/block."""
+    return make_synthetic(config_c4_blk(n_blocks, seed), cons_per_block=3, seed=seed)
 
 
 def config_c3(n=2000, degree=8, seed=20240601):

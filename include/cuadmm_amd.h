@@ -322,6 +322,12 @@ int cuadmm_op_mul_trans_batch(double* P, const double* T, const double* V, int n
  * blk[mat_num] sizes in blk.txt order; Xproj may alias Xb.  eig_fail (device int, may be
  * NULL) is incremented per block whose QL iteration hit its cap. */
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream);
+/* The same projection through a plan that is built once (block descriptors, size classes, workspaces on the device) and reused:
+ * what the solver does every iteration; cuadmm_op_psd_project builds and drops a plan per call. */
+typedef struct cuadmm_psd_plan cuadmm_psd_plan;
+int cuadmm_psd_plan_create(const int* blk_host, int mat_num, int eig_rank, cuadmm_psd_plan** out);
+int cuadmm_psd_plan_project(cuadmm_psd_plan* plan, const double* Xb, double* Xproj, int* steps_dev /* may be NULL */, void* stream);
+void cuadmm_psd_plan_destroy(cuadmm_psd_plan* plan);
 /* General form: blk[k] < 0 is an UNCONSTRAINED block of -blk[k] variables (blk.txt type 'u', reference README.md:55-64),
  * copied through; eig_rank > 0 keeps only the eig_rank largest eigenvalues of every PSD block: V diag(max(W,0) * mask) V^T with
  * the mask of get_eig_rank_mask.cu:13-37 (dense_scalar.cu:51-57) -- computed through the eigensolver kernels. */

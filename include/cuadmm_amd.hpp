@@ -7,11 +7,39 @@
 #pragma once
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "cuadmm_amd.h"
 
 namespace cuadmm_amd {
+
+// Problem (include/cuadmm/problem.h:12-41; Problem::from_txt, src/problem.cu:11-83): the TXT directory of cuadmm_exe with the
+// reference's member names -- blk_vals as (type, size) pairs, At in CSC over the constraints, sparse b and C; X / y / S stay
+// empty (cold start: their data() is what main.cu hands to init).
+class Problem {
+ public:
+  int vec_len = 0, con_num = 0, mat_num = 0, At_nnz = 0, b_nnz = 0, C_nnz = 0;
+  std::vector<std::tuple<char, int>> blk_vals;
+  std::vector<int> At_csc_col_ptrs, At_csc_row_ids, b_indices, C_indices;
+  std::vector<double> At_csc_vals, b_vals, C_vals, X_vals, y_vals, S_vals;
+
+  void from_txt(const std::string& prefix) {
+    cuadmm_problem* p = nullptr;
+    if (cuadmm_problem_from_txt(prefix.c_str(), &p) != CUADMM_OK) throw std::runtime_error(cuadmm_last_error());
+    cuadmm_problem_view v;
+    if (cuadmm_problem_view_get(p, &v) != CUADMM_OK) { cuadmm_problem_free(p); throw std::runtime_error(cuadmm_last_error()); }
+    vec_len = v.vec_len; con_num = v.con_num; mat_num = v.mat_num; At_nnz = v.At_nnz; b_nnz = v.b_nnz; C_nnz = v.C_nnz;
+    At_csc_col_ptrs.assign(v.At_csc_col_ptrs, v.At_csc_col_ptrs + v.con_num + 1);
+    At_csc_row_ids.assign(v.At_csc_row_ids, v.At_csc_row_ids + v.At_nnz);
+    At_csc_vals.assign(v.At_csc_vals, v.At_csc_vals + v.At_nnz);
+    b_indices.assign(v.b_indices, v.b_indices + v.b_nnz); b_vals.assign(v.b_vals, v.b_vals + v.b_nnz);
+    C_indices.assign(v.C_indices, v.C_indices + v.C_nnz); C_vals.assign(v.C_vals, v.C_vals + v.C_nnz);
+    blk_vals.clear();
+    for (int k = 0; k < v.mat_num; ++k) blk_vals.emplace_back(v.blk_vals[k] < 0 ? 'u' : 's', v.blk_vals[k] < 0 ? -v.blk_vals[k] : v.blk_vals[k]);
+    cuadmm_problem_free(p);
+  }
+};
 
 class SDPSolver {
  public:

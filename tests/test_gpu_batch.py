@@ -25,8 +25,8 @@ def _amd(p):
     return cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
 
 
-def _run(p, batch, calls, stop_tol=0.0, stage2=100, lazy=1):
-    s = cuadmm_amd.SDPSolver(verbose=False, options={"batch": batch, "lazy_unscale": lazy})
+def _run(p, batch, calls, stop_tol=0.0, stage2=100, lazy=1, extra=None):
+    s = cuadmm_amd.SDPSolver(verbose=False, options=dict({"batch": batch, "batch_mixed": 1, "lazy_unscale": lazy}, **(extra or {})))
     s.init_problem(_amd(p))
     first = True
     for k in calls:
@@ -36,18 +36,17 @@ def _run(p, batch, calls, stop_tol=0.0, stage2=100, lazy=1):
 
 
 @pytest.mark.parametrize("blk,env", [
-    (None, {}),                                                                         # 17 <= n <= 32: psd_sign_wave_cu_kernel<2, 16, 4>
-    ([32] * 200 + [12] * 150 + [16] * 50, {"CUADMM_FUSE_SOLVE": "1"}),                  # + n <= 16: <1, 16, 8>, two workgroups per CU
-    ([40] * 40 + [56] * 30 + [64] * 10 + [24] * 50, {"CUADMM_PSD_WAVE4_MIN": "1"}),     # + n <= 48: <3, 8, 2>, n <= 64: <4, 4, 1>
-    ([12] * 300, {"CUADMM_FUSE_SOLVE": "1"}),                                           # fewer blocks than workgroups (2 x 256)
+    (None, {}),                                                                         # 17 <= n <= 32: psd_sign_closed_cu_kernel<2, 16, 4>
+    ([32] * 200 + [12] * 150 + [5] * 50 + [1] * 7, {}),                                 # + n <= 16 (tiny blocks too): <1, 16, 8>, two workgroups per CU
+    ([40] * 40 + [56] * 30 + [64] * 10 + [24] * 50, {"psd_wave4_min": 1}),              # + n <= 48: <3, 8, 2>, n <= 64: <4, 4, 1>
+    (None, {"psd_cu_occ": 3, "psd_w32_occ": 3}),                                        # three wavefronts per SIMD
+    ([12] * 300, {}),                                                                   # fewer blocks than workgroups (2 x 256)
 ])
-def test_batched_launches_leave_the_same_bits_as_one_launch_per_iteration(blk, env, monkeypatch):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def test_batched_launches_leave_the_same_bits_as_one_launch_per_iteration(blk, env):
     p = _problem(blk=blk)
-    a = _run(p, 0, [45])
-    b = _run(p, 16, [45])
-    c = _run(p, 64, [45])
+    a = _run(p, 0, [45], extra=env)
+    b = _run(p, 16, [45], extra=env)
+    c = _run(p, 64, [45], extra=env)
     assert a.counters()["closed_blocks"] == 1 and a.counters()["batch_launches"] == 0
     assert b.counters()["batch_launches"] >= 3 and b.counters()["batch_iters"] == 44      # iteration 1 may change sigma: alone
     assert c.counters()["batch_launches"] == 1

@@ -74,15 +74,11 @@ def test_c5_pendulum_first_log_rows(ref_logs):
 
 def test_gpu_tail_of_the_aat_solve_matches_host_only_solve(monkeypatch):
     """pendulum N=80: the cost model moves the dense trailing triangle of L to the GPU (tail_solve.hip); the iterates
-    must agree with the host-only solve (CUADMM_TAIL_K=0) far below the stopping tolerance."""
+    must agree with the host-only solve (option tail_k = 0) far below the stopping tolerance."""
     p = load_npz_problem("pendulum_N=80")
     runs = {}
     for mode in ("gpu_tail", "host_only"):
-        if mode == "host_only":
-            monkeypatch.setenv("CUADMM_TAIL_K", "0")
-        else:
-            monkeypatch.delenv("CUADMM_TAIL_K", raising=False)
-        s = cuadmm_amd.SDPSolver(verbose=False, profile=1)
+        s = cuadmm_amd.SDPSolver(verbose=False, profile=1, options={"tail_k": 0} if mode == "host_only" else None)
         s.init_problem(problem_to_amd(p))
         s.solve(60, 1e-3, 0, 50, 100, 11000, 1.05)
         runs[mode] = (s.X, s.y, s.S, s.profile())

@@ -42,11 +42,9 @@ def _coupled_problem(blk, n_couple, seed=5):
 
 
 def _run(prob, iters, sw, monkeypatch, fuse, stop_tol=0.0, rows=True, solve=True):
-    monkeypatch.setenv("CUADMM_FUSE_SOLVE", "1" if solve else "0")
-    monkeypatch.setenv("CUADMM_PSD_WAVE4_MIN", "1")        # the one-wavefront kernels for 32 < n <= 64 whatever the block count
-    monkeypatch.setenv("CUADMM_FUSE", "1" if fuse else "0")
-    monkeypatch.setenv("CUADMM_FUSE_ROWS", "1" if rows else "0")
-    s = cuadmm_amd.SDPSolver(verbose=False)
+    # every switch through the ABI (cuadmm_set_option); psd_wave4_min = 1: the one-wavefront kernels for 32 < n <= 64 whatever the count
+    s = cuadmm_amd.SDPSolver(verbose=False, options={"fuse_solve": 1 if solve else 0, "psd_wave4_min": 1, "fuse": 1 if fuse else 0,
+                                                     "fuse_rows": 1 if rows else 0})
     s.init_problem(prob)
     s.solve(iters, stop_tol, 0, 50, 100, sw, 1.05)
     return s

@@ -47,12 +47,9 @@ class HostAllReduce:
 def test_two_shards_match_single_engine(sw, iters, mode, monkeypatch):
     """Every constraint of the synthetic problem touches one block, hence one rank: by default each rank then keeps only
     its own constraints and the ranks exchange four scalars per iteration ("owned constraints"); with
-    CUADMM_NO_LOCAL_CONSTRAINTS=1 the general path runs (A*X all-reduced, solve replicated).  Both must agree with the
+    option local_constraints = 0 the general path runs (A*X all-reduced, solve replicated).  Both must agree with the
     single engine."""
-    if mode == "replicated_solve":
-        monkeypatch.setenv("CUADMM_NO_LOCAL_CONSTRAINTS", "1")
-    else:
-        monkeypatch.delenv("CUADMM_NO_LOCAL_CONSTRAINTS", raising=False)
+    opts = {"local_constraints": 0} if mode == "replicated_solve" else None
     blk = [32] * 40 + [7] * 30 + [15] * 21 + [40, 3, 3, 28]
     rng = np.random.default_rng(2)
     blk = list(np.array(blk)[rng.permutation(len(blk))])
@@ -63,7 +60,7 @@ def test_two_shards_match_single_engine(sw, iters, mode, monkeypatch):
 
     world = 2
     ar = HostAllReduce(world)
-    solvers = [cuadmm_amd.SDPSolver(verbose=False, rank=r, world=world) for r in range(world)]
+    solvers = [cuadmm_amd.SDPSolver(verbose=False, rank=r, world=world, options=opts) for r in range(world)]
     errs = []
 
     def run(r):

@@ -38,7 +38,7 @@ def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path
     constraints, the replicated y-solve with the GPU tail and the device-side leading sweeps on every rank -- against the
     committed oracle trajectory (tests/golden/oracle_traj_moment.json), same tolerance as the one-rank test."""
     import json
-    from tests.test_gpu_moment_parity import TOL, SIX, FLOOR
+    from tests.test_gpu_moment_parity import TOL, SIX, rel_dev
     with open(os.path.join(ROOT, "tests", "golden", "oracle_traj_moment.json")) as f:
         rec = json.load(f)[name + "/switch=11000"]
     out = tmp_path / "res.npz"
@@ -52,6 +52,6 @@ def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path
     th = TOL[name + "/switch=11000"][0]
     for nm in SIX:
         ref = np.array([float(x) for x in rec[nm]])
-        dev = np.max(np.abs(d[nm][:ref.size] - ref) / (FLOOR[nm] + np.abs(ref)))
+        dev = rel_dev(d[nm][:ref.size], ref, nm)
         assert dev <= th, (nm, dev)
     assert np.array_equal(d["sig"][:60], np.array([float(x) for x in rec["sig"]]))

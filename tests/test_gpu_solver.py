@@ -162,6 +162,15 @@ def test_duo_solver_front(problem_dirs):
     o = orc.OracleSolver().init_problem(p)
     info = o.solve(20, 0.0, 0, 50, 100, 11000, 1.05)
     _cmp("duo:pobj", s.info_arr("pobj"), np.array(info.pobj), rtol=1e-8, atol=1e-11)
+    # the reference's host-LAPACK mode is refused loudly (no CPU projection here) unless the caller opts into the GPU kernels
+    with pytest.raises(cuadmm_amd.CuadmmError, match="if_gpu_eig_mom"):
+        cuadmm_amd.SDPSolver(verbose=False).duo_init(False, 1, 15, 30, a.vec_len, a.con_num, a.At_csc_col_ptrs, a.At_csc_row_ids, a.At_csc_vals,
+                                                     a.At_nnz, a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
+    s3 = cuadmm_amd.SDPSolver(verbose=False, options={"duo_cpu_eig_on_gpu": 1})
+    s3.duo_init(False, 1, 15, 30, a.vec_len, a.con_num, a.At_csc_col_ptrs, a.At_csc_row_ids, a.At_csc_vals, a.At_nnz,
+                a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
+    s3.solve(20, 0.0, 0, 50, 100, 11000, 1.05)
+    assert np.array_equal(s3.info_arr("pobj"), s.info_arr("pobj"))
     q = orc.load_problem_txt(problem_dirs["rose13"])            # a single size -> rejected like the reference's assert
     b = problem_to_amd(q)
     with pytest.raises(cuadmm_amd.CuadmmError):
@@ -174,17 +183,13 @@ def test_device_side_y_solve_matches_the_host_solve(monkeypatch):
     """Block-diagonal A A^T (every constraint touches one block): the elimination forest of the factor is one small tree per
     block and the y-solve runs on the device, one thread per tree (forest_solve_kernel), with y, A X, A(S-C) and b resident
     in HBM.  Inside a tree it is the serial host algorithm with unfused multiply-subtract, so the whole trajectory must be
-    identical to roundoff to the host solve (CUADMM_HOST_SOLVE=1) -- sGS phase, the switch and the ADMM phase included."""
+    identical to roundoff to the host solve (option host_solve = 1) -- sGS phase, the switch and the ADMM phase included."""
     from cuadmm_amd.synthetic import make_synthetic
     p = make_synthetic([32] * 300 + [6] * 100 + [45] * 40, cons_per_block=4, seed=13)
     prob = cuadmm_amd.Problem(p.vec_len, p.con_num, p.blk, p.At_col_ptrs, p.At_row_ids, p.At_vals, p.b_idx, p.b_vals, p.C_idx, p.C_vals)
     runs = {}
     for mode in ("device", "host"):
-        if mode == "host":
-            monkeypatch.setenv("CUADMM_HOST_SOLVE", "1")
-        else:
-            monkeypatch.delenv("CUADMM_HOST_SOLVE", raising=False)
-        s = cuadmm_amd.SDPSolver(verbose=False, profile=1)
+        s = cuadmm_amd.SDPSolver(verbose=False, profile=1, options={"host_solve": 1} if mode == "host" else None)
         s.init_problem(prob)
         s.solve(40, 0.0, 0, 10, 10, 15, 1.05)
         s.solve(10, 0.0, 0, 10, 10, 0, 1.05, if_first=False)            # warm restart path

@@ -4,6 +4,6 @@
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 3000 python -m pytest tests -q -m gpu -x -s > gpurun_out/gpu_tests_full.log 2>&1
+timeout 3000 python -m pytest tests -q -m gpu -s > gpurun_out/gpu_tests_full.log 2>&1
 echo "rc=$?" >> gpurun_out/gpu_tests_full.log
-grep -E "head|late|passed|failed|rc=" gpurun_out/gpu_tests_full.log | tail -30
+grep -E "passed|failed|rc=|^FAILED|^ERROR" gpurun_out/gpu_tests_full.log | tail -30
