@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "device_util.h"
+#include "eig_large.h"
 #include "psd_device.h"
 #include "psd_plan.h"
 #include "psd_small_reg.h"
@@ -188,8 +189,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
   extern __shared__ double swt_smem[];
   constexpr int TILE = SignWaveT<NT>::NP * SignWaveT<NT>::LD;
   int* ctl = reinterpret_cast<int*>(swt_smem + (size_t)WAVES * TILE);      // [0]: next task; [1 + j]: iterations completed on member j
+  // members g, g + G, g + 2 G, ... : the class is sorted longest block first, so a STRIDED share gives every workgroup the same mix
+  // of long and short blocks (contiguous shares left the first workgroups with ~20 % more Newton-Schulz steps than the last)
   const int g = (int)blockIdx.x, G = (int)gridDim.x;
-  const int j0 = (int)((long long)a.count * g / G), nb = (int)((long long)a.count * (g + 1) / G) - j0;
+  const int nb = (a.count - g + G - 1) / G;
   for (int i = (int)threadIdx.x; i < nb + 1; i += 64 * WAVES) ctl[i] = 0;
   __syncthreads();
   const int ntask = nb * a.iters;
@@ -215,14 +218,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
 #else
     const ClosedArgs al = a;
 #endif
-    const PsdDesc d = al.desc[al.first + j0 + j];
+    const PsdDesc d = al.desc[al.first + g + j * G];
     int toff = ((int)threadIdx.x >> 6) * TILE;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(toff));                     // not hoisted out of the task loop (it would stay live across the body)
 #endif
     double* tile = swt_smem + toff;
     psd_sign_closed_body<NT, true>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
-                             al.dbg ? al.dbg + 10 * (long long)(j0 + j) : nullptr, d.off, d.slot, (long long)it * al.pstride, it);
+                             al.dbg ? al.dbg + 10 * (long long)(g + j * G) : nullptr, d.off, d.slot, (long long)it * al.pstride, it);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane_id() == 0) { volatile int* dn = ctl + 1 + j; *dn = it + 1; }
   }
@@ -709,11 +712,14 @@ int PsdPlan::fail_count(hipStream_t st) const {
 // `count` dense n x n matrices: eigenvectors in place + ascending eigenvalues
 int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream_t st) {
   if (n < 1 || count < 0) { set_error("batch_eig: bad n/count"); return CUADMM_ERR_INVALID; }
-  if (n > kMaxBlockSize) { set_error("batch_eig: n=%d > %d", n, kMaxBlockSize); return CUADMM_ERR_INVALID; }
-  if (n > kMaxEigSize && !getenv("CUADMM_EIG_ALLOW_SLOW")) {   // op entry point without a handle: the environment is its only switch
-    set_error("batch_eig: n=%d > %d: the explicit eigendecomposition of one large block runs on a single workgroup (76 s at n = 2000); "
-              "set CUADMM_EIG_ALLOW_SLOW=1 to run it anyway", n, kMaxEigSize);
-    return CUADMM_ERR_INVALID;
+  if (n > kEigLargeMax) { set_error("batch_eig: n=%d > %d", n, kEigLargeMax); return CUADMM_ERR_INVALID; }
+  if (n >= kEigLargeMin) {
+    // one matrix at a time on the whole chip (eig_large.hip): tridiagonalisation, bisection, inverse iteration, Cholesky-QR
+    for (int i = 0; i < count; ++i) {
+      int rc = eig_large(mat + (size_t)i * n * n, W + (size_t)i * n, info ? info + i : nullptr, n, st);
+      if (rc) return rc;
+    }
+    return CUADMM_OK;
   }
   if (count == 0) return CUADMM_OK;
   const int c = psd_class_of(n);

@@ -19,4 +19,11 @@ struct TailSolve {
   ~TailSolve() { release(); }
 };
 
+// dense building blocks (row-major K x K device matrices, K a multiple of 64; asynchronous on `st`), shared with eig_large.hip
+int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, long long sA, const double* B, long long ldb,
+            long long sB, double* C, long long ldc, long long sC, int batch, hipStream_t st);      // C = alpha A B (batched by strides)
+int ts_transpose(const double* src, double* dst, int K, hipStream_t st);
+int ts_ldlt_factor(double* dS, int K, double* dd, double* Yp, int* dflag, hipStream_t st);         // in place, lower triangle
+int ts_unit_lower_inverse(const double* dL, double* W, double* dT, int K, hipStream_t st);         // W = inv(L), dT: scratch
+
 }  // namespace cuadmm

@@ -291,7 +291,7 @@ __global__ void ts_dinv_kernel(const double* __restrict__ d, double* __restrict_
   if (i < K) dinv[i] = 1.0 / d[i];
 }
 
-static int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, long long sA, const double* B, long long ldb,
+int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, long long sA, const double* B, long long ldb,
                    long long sB, double* C, long long ldc, long long sC, int batch, hipStream_t st) {
   if (batch <= 0 || M <= 0 || N <= 0) return CUADMM_OK;
   hipLaunchKernelGGL(ts_gemm_nn_kernel, dim3((M / TS_TM) * (N / TS_TM), batch), dim3(256), 0, st, M, N, Kd, alpha, A, lda, sA, B, ldb, sB,
@@ -321,11 +321,10 @@ int TailSolve::alloc(int k_) {
   return CUADMM_OK;
 }
 
-// W = inv(dL) by recursive doubling (dL: K x K unit lower triangular on the device, strict upper part never read;
-// Wt doubles as the scratch matrix of the products), then Wt = W^T
-int TailSolve::invert(const double* dL, hipStream_t st) {
+// W = inv(dL) by recursive doubling (dL: K x K unit lower triangular on the device, row-major, strict upper part never read;
+// dT: K x K scratch of the products).  Asynchronous on `st`.
+int ts_unit_lower_inverse(const double* dL, double* W, double* dT, int K, hipStream_t st) {
   const long long ld = K;
-  double* dT = Wt;
   CUADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * (size_t)K * K, st));
   hipLaunchKernelGGL(ts_diag_inverse_kernel, dim3(K / 64), dim3(64), 0, st, dL, W, ld);
   CUADMM_HIP_TRY(hipGetLastError());
@@ -346,9 +345,37 @@ int TailSolve::invert(const double* dL, hipStream_t st) {
       if (!rc) rc = ts_gemm((int)h2, (int)h, (int)h2, -1.0, W + o + h * (ld + 1), ld, 0, dT + o + h * ld, ld, 0, W + o + h * ld, ld, 0, 1, st);
     }
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(ts_transpose_kernel, dim3(K / 32, K / 32), dim3(256), 0, st, W, Wt, ld);
+  return rc;
+}
+
+int ts_transpose(const double* src, double* dst, int K, hipStream_t st) {
+  hipLaunchKernelGGL(ts_transpose_kernel, dim3(K / 32, K / 32), dim3(256), 0, st, src, dst, (long long)K);
   CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// in-place dense LDL^T of a K x K symmetric matrix (row-major, lower triangle referenced and overwritten by the unit factor; dd: the
+// pivots; Yp: K x 64 scratch; dflag: counts zero / non-finite pivots).  Asynchronous on `st`.
+int ts_ldlt_factor(double* dS, int K, double* dd, double* Yp, int* dflag, hipStream_t st) {
+  const long long ld = K;
+  const int nbk = K / 64;
+  for (int b = 0; b < nbk; ++b) {
+    const int b0 = b * 64, T = nbk - b - 1;
+    hipLaunchKernelGGL(ts_ldlt_diag_kernel, dim3(1), dim3(64), 0, st, dS, ld, b0, dd, dflag);
+    if (T > 0) {
+      hipLaunchKernelGGL(ts_ldlt_panel_kernel, dim3(T), dim3(64), 0, st, dS, ld, b0, dd, Yp);
+      hipLaunchKernelGGL(ts_ldlt_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, st, dS, ld, b0, Yp);
+    }
+  }
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// W = inv(dL), then Wt = W^T (Wt doubles as the scratch matrix of the products)
+int TailSolve::invert(const double* dL, hipStream_t st) {
+  int rc = ts_unit_lower_inverse(dL, W, Wt, K, st);
+  if (rc) return rc;
+  if ((rc = ts_transpose(W, Wt, K, st))) return rc;
   CUADMM_HIP_TRY(hipStreamSynchronize(st));
   return CUADMM_OK;
 }
@@ -411,15 +438,7 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   }
   if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return e == hipErrorOutOfMemory ? CUADMM_ERR_INVALID : CUADMM_ERR_NO_DEVICE; }
   hipLaunchKernelGGL(ts_scatter_csr_kernel, dim3(K), dim3(256), 0, st, drp, dci, dval, k, dS, ld);
-  const int nbk = K / 64;
-  for (int b = 0; b < nbk; ++b) {
-    const int b0 = b * 64, T = nbk - b - 1;
-    hipLaunchKernelGGL(ts_ldlt_diag_kernel, dim3(1), dim3(64), 0, st, dS, ld, b0, dd, dflag);
-    if (T > 0) {
-      hipLaunchKernelGGL(ts_ldlt_panel_kernel, dim3(T), dim3(64), 0, st, dS, ld, b0, dd, Yp);
-      hipLaunchKernelGGL(ts_ldlt_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, st, dS, ld, b0, Yp);
-    }
-  }
+  if ((rc = ts_ldlt_factor(dS, K, dd, Yp, dflag, st))) { cleanup(); release(); return rc; }
   hipLaunchKernelGGL(ts_dinv_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dd, dinv, K);
   int hflag = 0;
   e = hipGetLastError();

@@ -299,7 +299,9 @@ int cuadmm_op_matrices_to_vector(double* Xb, const double* large_mat, const doub
                                  int vec_len, void* stream);
 /* batch_eig_cusolver / single_eig_cusolver (include/cuadmm/cusolver.h:76-95,154-171):
  * `count` contiguous n x n column-major symmetric matrices, overwritten by eigenvectors
- * (column-major, column k <-> W[k]); W ascending; info[i] = 0 or 1 (iteration cap hit). */
+ * (column-major, column k <-> W[k]); W ascending; info[i] = 0 or 1 (iteration cap hit / orthonormalisation not converged).
+ * n <= 128: one wavefront / workgroup per matrix; 129 <= n <= 8192: one matrix at a time on the whole chip (csrc/eig_large.hip:
+ * tridiagonalisation, bisection, inverse iteration, Cholesky-QR; n = 2000 in 0.06 s); larger n: CUADMM_ERR_INVALID. */
 int cuadmm_op_batch_eig(double* mat, double* W, int* info, int n, int count, void* stream);
 /* The DGEMM of the large-block rebuild (the reference calls cublasDgemm on large_mat, src/solver.cu:630-644).
  * C = alpha * A * B + beta * E for n x n row-major SYMMETRIC A and B (device pointers, n a multiple of 64,
