@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -443,36 +444,55 @@ int el_allow_lds(KernT kern, size_t bytes) {
   return CUADMM_OK;
 }
 
-struct ElBuf {
-  std::vector<void*> p;
-  template <typename T>
-  int get(T** out, size_t count) {
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, sizeof(T) * std::max<size_t>(count, 1));
-    if (e != hipSuccess) { set_error("eig_large: workspace allocation failed (%s)", hipGetErrorString(e)); return CUADMM_ERR_NO_DEVICE; }
-    p.push_back(q);
-    *out = static_cast<T*>(q);
-    return CUADMM_OK;
+// ---- projection of one block through the eigendecomposition -------------------------------------------------------------------
+// svec (column-major upper triangle, off-diagonal scaled by sqrt 2) -> dense column-major symmetric
+__global__ __launch_bounds__(EL_NT) void el_unpack_svec_kernel(const double* __restrict__ sv, int n, double* __restrict__ A) {
+  const int c = (int)blockIdx.x;
+  const double* col = sv + (long long)c * (c + 1) / 2;
+  for (int r = (int)threadIdx.x; r <= c; r += EL_NT) {
+    const double v = r == c ? col[r] : col[r] * 0.70710678118654752440;
+    A[(size_t)c * n + r] = v;
+    A[(size_t)r * n + c] = v;
   }
-  ~ElBuf() { for (void* q : p) { hipError_t e = hipFree(q); (void)e; } }
-};
+}
+// out = svec(sum_{k >= k0} max(W_k, 0) v_k v_k^T): one workgroup per column c of the upper triangle, the eigenvalues ascending
+__global__ __launch_bounds__(EL_NT) void el_rebuild_kernel(const double* __restrict__ V, const double* __restrict__ W, int n, int k0,
+                                                           double* __restrict__ sv) {
+  extern __shared__ double el_sm[];
+  double* vc = el_sm;                    // lambda_k^+ V[c, k], k = k0 .. n-1
+  const int c = (int)blockIdx.x;
+  int kpos = k0;
+  // ascending eigenvalues: the positive ones are a suffix; its start is found by every thread (n reads of a cached array at most)
+  while (kpos < n && !(W[kpos] > 0.0)) ++kpos;
+  for (int k = kpos + (int)threadIdx.x; k < n; k += EL_NT) vc[k - kpos] = W[k] * V[(size_t)k * n + c];
+  __syncthreads();
+  double* col = sv + (long long)c * (c + 1) / 2;
+  for (int r = (int)threadIdx.x; r <= c; r += EL_NT) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = kpos;
+    for (; k + 1 < n; k += 2) { acc0 += V[(size_t)k * n + r] * vc[k - kpos]; acc1 += V[(size_t)(k + 1) * n + r] * vc[k + 1 - kpos]; }
+    if (k < n) acc0 += V[(size_t)k * n + r] * vc[k - kpos];
+    const double v = acc0 + acc1;
+    col[r] = r == c ? v : v * 1.41421356237309504880;
+  }
+}
+__global__ void el_flag_fail_kernel(const int* __restrict__ info, int* __restrict__ fail) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *info != 0) atomicAdd(fail, 1);
+}
 
 }  // namespace
 
-int eig_large(double* mat, double* W, int* info, int n, hipStream_t st) {
+int eig_large(double* mat, double* W, int* info, int n, hipStream_t st, EigLargeWs* ws) {
   if (n < 2 || n > kEigLargeMax) { set_error("eig_large: n = %d outside [2, %d]", n, kEigLargeMax); return CUADMM_ERR_INVALID; }
   const int K = (n + 63) / 64 * 64;
   const size_t KK = (size_t)K * K;
-  ElBuf buf;
-  int rc;
-  double *H, *tau, *dvec, *evec, *P, *lamp, *scal, *work, *Z, *M, *Mt, *G, *Winv, *Wtmp, *dd, *Yp, *err;
-  int* dflag;
-  if ((rc = buf.get(&H, (size_t)n * n)) || (rc = buf.get(&tau, n)) || (rc = buf.get(&dvec, n)) || (rc = buf.get(&evec, n)) ||
-      (rc = buf.get(&P, n)) || (rc = buf.get(&lamp, n)) || (rc = buf.get(&scal, 4)) || (rc = buf.get(&work, 5 * (size_t)n * K)) ||
-      (rc = buf.get(&Z, KK)) || (rc = buf.get(&M, KK)) || (rc = buf.get(&Mt, KK)) || (rc = buf.get(&G, KK)) || (rc = buf.get(&Winv, KK)) ||
-      (rc = buf.get(&Wtmp, KK)) || (rc = buf.get(&dd, K)) || (rc = buf.get(&Yp, (size_t)K * 64)) || (rc = buf.get(&err, (size_t)K + 2)) ||
-      (rc = buf.get(&dflag, 1)))
-    return rc;
+  EigLargeWs local;
+  if (!ws) ws = &local;
+  int rc = ws->ensure(n);
+  if (rc) return rc;
+  double *H = ws->H, *tau = ws->tau, *dvec = ws->dvec, *evec = ws->evec, *P = ws->P, *lamp = ws->lamp, *scal = ws->scal, *work = ws->work,
+         *Z = ws->Z, *M = ws->M, *Mt = ws->Mt, *G = ws->G, *Winv = ws->Winv, *Wtmp = ws->Wtmp, *dd = ws->dd, *Yp = ws->Yp, *err = ws->err;
+  int* dflag = ws->dflag;
   const long long ld = n;
 
   // ---- 1. tridiagonalisation (in place: `mat` is destroyed, the eigenvectors replace it at the end)
@@ -558,6 +578,52 @@ int eig_large(double* mat, double* W, int* info, int n, hipStream_t st) {
     if ((rc = staged_h2d(info, &v, sizeof(int), st))) return rc;
   }
   CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  return CUADMM_OK;
+}
+
+int EigLargeWs::ensure(int n) {
+  if (n <= cap) return CUADMM_OK;
+  release();
+  const size_t K = ((size_t)n + 63) / 64 * 64, KK = K * K;
+  auto get = [&](auto** out, size_t count) -> int {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, sizeof(**out) * std::max<size_t>(count, 1));
+    if (e != hipSuccess) { set_error("eig_large: workspace allocation failed (%s)", hipGetErrorString(e)); return CUADMM_ERR_NO_DEVICE; }
+    bufs.push_back(q);
+    *out = static_cast<std::remove_reference_t<decltype(**out)>*>(q);
+    return CUADMM_OK;
+  };
+  int rc;
+  if ((rc = get(&H, (size_t)n * n)) || (rc = get(&tau, n)) || (rc = get(&dvec, n)) || (rc = get(&evec, n)) || (rc = get(&P, n)) ||
+      (rc = get(&lamp, n)) || (rc = get(&scal, 4)) || (rc = get(&work, 5 * (size_t)n * K)) || (rc = get(&Z, KK)) || (rc = get(&M, KK)) ||
+      (rc = get(&Mt, KK)) || (rc = get(&G, KK)) || (rc = get(&Winv, KK)) || (rc = get(&Wtmp, KK)) || (rc = get(&dd, K)) ||
+      (rc = get(&Yp, K * 64)) || (rc = get(&err, K + 2)) || (rc = get(&dflag, 1)) || (rc = get(&dense, (size_t)n * n)) || (rc = get(&Wd, n))) {
+    release();
+    return rc;
+  }
+  cap = n;
+  return CUADMM_OK;
+}
+
+void EigLargeWs::release() {
+  for (void* q : bufs) { hipError_t e = hipFree(q); (void)e; }
+  bufs.clear();
+  cap = 0;
+}
+
+int eig_large_project(const double* svec_in, double* svec_out, int n, int eig_rank, int* fail, hipStream_t st, EigLargeWs* ws) {
+  if (!ws) { set_error("eig_large_project: no workspace"); return CUADMM_ERR_INVALID; }
+  int rc = ws->ensure(n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(el_unpack_svec_kernel, dim3(n), dim3(EL_NT), 0, st, svec_in, n, ws->dense);
+  CUADMM_HIP_TRY(hipGetLastError());
+  if ((rc = eig_large(ws->dense, ws->Wd, ws->dflag, n, st, ws))) return rc;
+  if (fail) hipLaunchKernelGGL(el_flag_fail_kernel, dim3(1), dim3(64), 0, st, ws->dflag, fail);
+  const int k0 = eig_rank > 0 ? std::max(0, n - eig_rank) : 0;
+  const size_t lds = sizeof(double) * (size_t)n;
+  if ((rc = el_allow_lds(el_rebuild_kernel, lds))) return rc;
+  hipLaunchKernelGGL(el_rebuild_kernel, dim3(n), dim3(EL_NT), lds, st, ws->dense, ws->Wd, n, k0, svec_out);
+  CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
 

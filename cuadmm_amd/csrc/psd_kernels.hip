@@ -7,8 +7,8 @@
 //   larger               : psd_large.hip (batched GEMM launches)
 // The sign kernels stop per block (sign_sched.h).  Explicit eigendecomposition (MODE 1, cuadmm_op_batch_eig):
 //   n <= 64              : psd_small_reg_kernel<NMAX>
-//   65 <= n <= ~136      : psd_wg_kernel<NT,false>: one workgroup per block, matrix in LDS
-//   larger               : psd_wg_kernel<NT,true>: one workgroup per block, matrix in an HBM workspace
+//   65 <= n <= ~136      : psd_wg_kernel<NT>: one workgroup per block, matrix in LDS (op entry: n <= 128)
+//   larger               : eig_large.hip: one matrix at a time on the whole chip (also the rank-limited projection of such blocks)
 // MODE 0: svec in -> projected svec out (the fused replacement of solver.cu:534-647)
 // MODE 1: dense column-major symmetric in -> eigenvectors (column-major) + ascending eigenvalues
 //         (the contract of the reference's cuSOLVER wrappers, cusolver.h:76-95,154-171)
@@ -41,8 +41,6 @@ struct PsdArgs {
   const int* bn;           // size per block (MODE 0)
   int count;               // members in this launch
   int n_uniform;           // MODE 1
-  double* workspace;       // GLOBAL variant
-  const long long* ws_off; // GLOBAL variant: workspace offset per member
   long long* dbg;          // developer aid: per-workgroup phase timestamps (CUADMM_PSD_DEBUG)
   int* steps;              // developer aid: Newton-Schulz steps taken per block (sign kernels; may be null)
   int* hint;               // per block, in/out: lift steps the previous projection needed (schedule warm start; may be null)
@@ -68,7 +66,7 @@ __global__ __launch_bounds__(64) void psd_small_reg_kernel(PsdArgs a) {
   }
 }
 
-template <int NT, int MODE, bool GLOBAL_M>
+template <int NT, int MODE>
 __global__ __launch_bounds__(NT) void psd_wg_kernel(PsdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   using Gp = WgGroup<NT>;
@@ -77,15 +75,8 @@ __global__ __launch_bounds__(NT) void psd_wg_kernel(PsdArgs a) {
   const int bi = a.ids ? a.ids[slot] : slot;
   const int n = (MODE == 0) ? a.bn[bi] : a.n_uniform;
   const int ld = n | 1;
-  double* M;
-  double* vecs;
-  if (GLOBAL_M) {
-    M = a.workspace + a.ws_off[slot];
-    vecs = dsm;
-  } else {
-    M = dsm;
-    vecs = dsm + (size_t)n * ld;
-  }
+  double* M = dsm;
+  double* vecs = dsm + (size_t)n * ld;
   double* dsh = vecs;
   double* esh = dsh + n;
   double* tau = esh + n;
@@ -294,10 +285,10 @@ static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t s
   return CUADMM_OK;
 }
 
-static size_t wg_lds_bytes(int n, int nt, bool global_m) {
+static size_t wg_lds_bytes(int n, int nt) {
   const int ld = n | 1;
   const int nw = nt / 64;   // a single wavefront runs QL directly on the shared d/e
-  size_t doubles = (global_m ? 0 : (size_t)n * ld) + 5 * (size_t)n + 8 + (nw > 1 ? 2 * (size_t)n * nw : 0);
+  size_t doubles = (size_t)n * ld + 5 * (size_t)n + 8 + (nw > 1 ? 2 * (size_t)n * nw : 0);
   return doubles * sizeof(double);
 }
 
@@ -309,7 +300,7 @@ int psd_class_of(int n) {
   if (n <= 16) return 2;
   if (n <= 32) return 3;
   if (n <= 64) return 4;
-  if (wg_lds_bytes(n, wg_threads_lds(n), false) <= kMaxLdsBytes) return 5;
+  if (wg_lds_bytes(n, wg_threads_lds(n)) <= kMaxLdsBytes) return 5;
   return 6;
 }
 
@@ -324,11 +315,6 @@ int PsdPlan::build(const int* blk, int mat_num) {
   for (int k = 0; k < mat_num; ++k) {
     if (blk[k] == 0) { set_error("block %d has size 0", k); return CUADMM_ERR_INVALID; }
     if (blk[k] > kMaxBlockSize) { set_error("block %d has size %d > %d (largest supported this build)", k, blk[k], kMaxBlockSize); return CUADMM_ERR_INVALID; }
-    if (eig_rank > 0 && blk[k] > kMaxEigSize && !opt.eig_allow_slow) {
-      set_error("rank-limited projection: block %d has size %d > %d (explicit eigendecomposition of large blocks is too slow; option eig_allow_slow = 1 overrides)",
-                k, blk[k], kMaxEigSize);
-      return CUADMM_ERR_INVALID;
-    }
     off[k + 1] = off[k] + blk_svec_len(blk[k]);
     if (blk[k] < 0) { free_off.push_back(off[k]); free_len.push_back(-(long long)blk[k]); }
   }
@@ -341,8 +327,6 @@ int PsdPlan::build(const int* blk, int mat_num) {
     if (blk[k] >= sign_min) sign_members.push_back(k);
   std::vector<int> ids;
   cls4_big = 0;
-  std::vector<long long> wsoff;
-  long long ws_total = 0;
   for (int c = 0; c < kNumPsdClasses; ++c) {
     cls_begin[c] = (int)ids.size();
     std::vector<int> members;
@@ -351,7 +335,6 @@ int PsdPlan::build(const int* blk, int mat_num) {
     std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return blk[x] > blk[y]; });
     for (int k : members) {
       ids.push_back(k);
-      if (c == 6) { wsoff.push_back(ws_total); ws_total += (long long)blk[k] * (blk[k] | 1); }
       if (c >= 4) cls_maxn[c] = std::max(cls_maxn[c], blk[k]);
       if (c == 4 && blk[k] > 48) ++cls4_big;
     }
@@ -388,11 +371,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
     if (rc) return rc;
   }
   CUADMM_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
-  if (ws_total > 0) {
-    CUADMM_HIP_TRY(hipMalloc(&d_ws, sizeof(double) * (size_t)ws_total));
-    CUADMM_HIP_TRY(hipMalloc(&d_wsoff, sizeof(long long) * wsoff.size()));
-    { int rc_ = staged_h2d(d_wsoff, wsoff.data(), sizeof(long long) * wsoff.size()); if (rc_) return rc_; }
-  }
+  h_off = off;
   // nominal flops 10.67 n^3 per block, GEMM-shaped part 2 n^3
   sum_n3 = 0;
   for (int k = 0; k < mat_num; ++k) if (blk[k] > 0) sum_n3 += (double)blk[k] * blk[k] * blk[k];
@@ -400,11 +379,12 @@ int PsdPlan::build(const int* blk, int mat_num) {
 }
 
 void PsdPlan::release() {
-  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_ws, (void*)d_wsoff, (void*)d_free_off, (void*)d_free_len, (void*)d_rest, (void*)d_desc})
+  for (void* p : {(void*)d_off, (void*)d_n, (void*)d_ids, (void*)d_fail, (void*)d_free_off, (void*)d_free_len, (void*)d_rest, (void*)d_desc})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   d_rest = nullptr; n_rest = 0; d_desc = nullptr;
   if (h_desc_pin) { hipError_t e = hipHostFree(h_desc_pin); (void)e; h_desc_pin = nullptr; }
-  d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr; d_ws = nullptr; d_wsoff = nullptr;
+  d_off = nullptr; d_n = nullptr; d_ids = nullptr; d_fail = nullptr;
+  big_ws.release();
   d_free_off = d_free_len = nullptr; n_free = 0;
   sign.release();
   if (ev_fork) {
@@ -415,11 +395,11 @@ void PsdPlan::release() {
   for (int c = 0; c < kNumPsdClasses; ++c) { cls_begin[c] = cls_count[c] = 0; cls_maxn[c] = 0; }
 }
 
-template <int NT, int MODE, bool GLOBAL_M>
+template <int NT, int MODE>
 static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
-  const size_t lds = wg_lds_bytes(maxn, NT, GLOBAL_M);
+  const size_t lds = wg_lds_bytes(maxn, NT);
   if (lds > kMaxLdsBytes) { set_error("psd: block of size %d needs %zu bytes of LDS", maxn, lds); return CUADMM_ERR_INVALID; }
-  auto kern = psd_wg_kernel<NT, MODE, GLOBAL_M>;
+  auto kern = psd_wg_kernel<NT, MODE>;
   if (lds > 48 * 1024)
     CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(a.count), dim3(NT), lds, st, a);
@@ -438,13 +418,10 @@ static int launch_class(int c, PsdArgs a, int maxn, hipStream_t st) {
     case 3: hipLaunchKernelGGL((psd_small_reg_kernel<32, MODE>), dim3((a.count + 1) / 2), dim3(64), 0, st, a); break;
     case 4: hipLaunchKernelGGL((psd_small_reg_kernel<64, MODE>), dim3(a.count), dim3(64), 0, st, a); break;
     case 5:
-      if (maxn <= 64) return launch_wg<64, MODE, false>(a, maxn, st);
-      if (maxn <= 128) return launch_wg<128, MODE, false>(a, maxn, st);
-      return launch_wg<256, MODE, false>(a, maxn, st);
-    case 6:
-      if (wg_lds_bytes(maxn, 256, true) <= kMaxLdsBytes) return launch_wg<256, MODE, true>(a, maxn, st);
-      return launch_wg<64, MODE, true>(a, maxn, st);
-    default: break;
+      if (maxn <= 64) return launch_wg<64, MODE>(a, maxn, st);
+      if (maxn <= 128) return launch_wg<128, MODE>(a, maxn, st);
+      return launch_wg<256, MODE>(a, maxn, st);
+    default: break;      // class 6 (blocks beyond the LDS of one workgroup): eig_large.hip, from the callers
   }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
@@ -584,7 +561,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     PsdArgs a{};
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
     a.ids = d_ids + cls_begin[c]; a.boff = d_off; a.bn = d_n; a.desc = d_desc + cls_begin[c];
-    a.count = cls_count[c]; a.n_uniform = 0; a.workspace = d_ws; a.ws_off = d_wsoff; a.steps = d_steps;
+    a.count = cls_count[c]; a.n_uniform = 0; a.steps = d_steps;
     a.eig_rank = (eig_rank > 0 && rank_active) ? eig_rank : 0;
     a.hint = d_hint;
     long long* dbg = nullptr;
@@ -663,6 +640,14 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       // 9 <= n <= 16: the same iteration on ONE 16 x 16 sub-tile, eight wavefronts per SIMD (the register eigensolver needs
       // ~20 us of dependent rotations per block; here a block is 8 MFMAs per step)
       rc = launch_sign_wave<1, 8>(a, 0, cls_count[c], st, fz);
+    } else if (c == 6) {
+      // blocks beyond one workgroup's LDS that need EIGENVALUES (the rank-limited projection; everything else of this size takes
+      // the matrix-sign path): one block at a time on the whole chip (eig_large.hip)
+      rc = CUADMM_OK;
+      for (int q = 0; q < cls_count[c] && !rc; ++q) {
+        const int k = h_ids[cls_begin[c] + q];
+        rc = eig_large_project(Xb + h_off[k], Xproj + h_off[k], h_blk[k], a.eig_rank, d_fail, st, &big_ws);
+      }
     } else {
       rc = launch_class<0>(c, a, cls_maxn[c], st);
     }
@@ -726,23 +711,7 @@ int psd_batch_eig(double* mat, double* W, int* info, int n, int count, hipStream
   PsdArgs a{};
   a.in = mat; a.out = mat; a.Wout = W; a.info = info; a.ids = nullptr; a.boff = nullptr; a.bn = nullptr;
   a.count = count; a.n_uniform = n;
-  double* ws = nullptr;
-  long long* wsoff = nullptr;
-  if (c == 6) {
-    std::vector<long long> off((size_t)count);
-    for (int i = 0; i < count; ++i) off[i] = (long long)i * n * (n | 1);
-    CUADMM_HIP_TRY(hipMalloc(&ws, sizeof(double) * (size_t)count * n * (n | 1)));
-    CUADMM_HIP_TRY(hipMalloc(&wsoff, sizeof(long long) * (size_t)count));
-    { int rc_ = staged_h2d(wsoff, off.data(), sizeof(long long) * (size_t)count); if (rc_) return rc_; }
-    a.workspace = ws; a.ws_off = wsoff;
-  }
   int rc = launch_class<1>(c, a, n, st);
-  if (c == 6) {
-    hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess && rc == CUADMM_OK) { set_error("batch_eig: %s", hipGetErrorString(e)); rc = CUADMM_ERR_NO_DEVICE; }
-    e = hipFree(ws); (void)e;
-    e = hipFree(wsoff); (void)e;
-  }
   return rc;
 }
 

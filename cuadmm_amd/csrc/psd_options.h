@@ -17,7 +17,6 @@ struct PsdOptions {
   int cu_occ = 4;          // psd_cu_occ: the same for the launches that run several iterations (psd_sign_closed_cu_kernel)
   int sign_min = 65;       // psd_sign_min: blocks from this size on take the batched-GEMM matrix-sign path
   int overlap = 1;         // psd_overlap: size classes on their own streams
-  int eig_allow_slow = 0;  // eig_allow_slow: explicit eigendecomposition above kMaxEigSize (one workgroup, minutes at n = 2000)
   // batched-GEMM path (psd_large.hip)
   int lg_tile = 0;         // psd_lg_tile: 0 = by size, 32 | 64 forces the tile
   int lg_pad32 = 1;        // psd_lg_pad32: groups on 32 x 32 tiles pad to a multiple of 32
@@ -34,7 +33,7 @@ struct PsdOptions {
     struct { const char* name; int* field; } tab[] = {
         {"CUADMM_PSD_DEBUG", &o.debug},           {"CUADMM_PSD_WAVE4_MIN", &o.wave4_min}, {"CUADMM_PSD_SIGN_MIN", &o.sign_min},
         {"CUADMM_PSD_W32_OCC", &o.w32_occ},       {"CUADMM_PSD_CU_OCC", &o.cu_occ},       {"CUADMM_PSD_OVERLAP", &o.overlap},
-        {"CUADMM_EIG_ALLOW_SLOW", &o.eig_allow_slow}, {"CUADMM_PSD_N16", &o.n16_sign},    {"CUADMM_PSD_N32", &o.n32_sign},
+        {"CUADMM_PSD_N16", &o.n16_sign},    {"CUADMM_PSD_N32", &o.n32_sign},
         {"CUADMM_PSD_MID", &o.mid}};
     for (auto& t : tab)
       if (const char* e = getenv(t.name)) {
@@ -57,7 +56,6 @@ struct PsdOptions {
     else if (k == "psd_cu_occ") cu_occ = v == 3 ? 3 : 4;
     else if (k == "psd_sign_min") sign_min = v < 65 ? 65 : v;
     else if (k == "psd_overlap") overlap = v;
-    else if (k == "eig_allow_slow") eig_allow_slow = v;
     else if (k == "psd_lg_tile") lg_tile = v;
     else if (k == "psd_lg_pad32") lg_pad32 = v;
     else if (k == "psd_lg_decide") lg_decide = v;

@@ -5,6 +5,8 @@
 #include "device_util.h"
 #include <vector>
 
+#include "eig_large.h"
+
 #include "psd_fuse.h"
 #include "psd_large.h"
 #include "psd_options.h"
@@ -38,8 +40,8 @@ struct PsdPlan {
   int* d_hint = nullptr;       // not owned; per block: lift steps the previous projection needed (sign_sched.h warm start)
   mutable unsigned n_project = 0;
   int* d_steps = nullptr;      // not owned; when set, the sign kernels record their Newton-Schulz step count per block
-  double* d_ws = nullptr;      // HBM workspace of the large-block path
-  long long* d_wsoff = nullptr;
+  mutable EigLargeWs big_ws;   // rank-limited projection of blocks beyond one workgroup's LDS (eig_large.hip)
+  std::vector<long long> h_off;   // host copy of the svec offsets
   // blocks with n >= sign_min (default 65: everything beyond the register kernels) take the GEMM-only matrix-sign
   // path (psd_large.hip); the workgroup eigensolver kernels (classes 5, 6) then only serve cuadmm_op_batch_eig.
   // Option psd_sign_min moves the boundary (A/B measurements).

@@ -101,15 +101,28 @@ def test_oracle_admm_with_a_free_block_keeps_its_dual_slack_zero():
 def test_gpu_projection_free_blocks_and_rank_mask(eig_rank):
     from tests.helpers import psd_project_gpu
     rng = np.random.default_rng(3)
-    blk = np.array([5, -4, 20, 32, -1, 50, 64, 3, 100, 16, 8, -9, 130], np.int32)
+    blk = np.array([5, -4, 20, 32, -1, 50, 64, 3, 100, 16, 8, -9, 130, 150, 260], np.int32)   # 150, 260: the whole-chip eigensolver (eig_large.hip)
     L = int(orc.blk_svec_len(blk).sum())
     x = rng.standard_normal(L)
     ref = orc.psd_project_svec(orc.BlockIndex(blk), x, eig_rank=eig_rank)
     got = psd_project_gpu(x, blk, eig_rank=eig_rank)
-    assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(x)) * 130
+    assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(x)) * 260
     off = orc.svec_block_offsets(blk)
     for k in np.nonzero(blk < 0)[0]:
         assert np.array_equal(got[off[k]:off[k + 1]], x[off[k]:off[k + 1]])
+
+
+@pytest.mark.gpu
+def test_gpu_rank_limited_projection_of_a_block_beyond_the_old_fence():
+    """n = 1500 with a rank mask: refused in round 2 (one workgroup would have needed ~30 s); now one eigendecomposition on the
+    whole chip per projection (csrc/eig_large.hip: eig_large_project)."""
+    from tests.helpers import psd_project_gpu
+    rng = np.random.default_rng(11)
+    blk = np.array([1500, 7], np.int32)
+    x = rng.standard_normal(int(orc.blk_svec_len(blk).sum()))
+    ref = orc.psd_project_svec(orc.BlockIndex(blk), x, eig_rank=4)
+    got = psd_project_gpu(x, blk, eig_rank=4)
+    assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(x)) * 1500
 
 
 @pytest.mark.gpu
