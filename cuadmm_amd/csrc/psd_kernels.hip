@@ -372,6 +372,7 @@ int PsdPlan::build(const int* blk, int mat_num) {
   }
   CUADMM_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
   h_off = off;
+  dominant_geometry = compute_dominant_geometry();
   // nominal flops 10.67 n^3 per block, GEMM-shaped part 2 n^3
   sum_n3 = 0;
   for (int k = 0; k < mat_num; ++k) if (blk[k] > 0) sum_n3 += (double)blk[k] * blk[k] * blk[k];
@@ -465,7 +466,7 @@ bool PsdPlan::sort_by_steps_host(const int* steps_host, std::vector<std::pair<in
   return !ranges.empty();
 }
 
-bool PsdPlan::one_dominant_geometry() const {
+bool PsdPlan::compute_dominant_geometry() const {
   double w[4] = {0, 0, 0, 0}, tot = 0;                     // NT = 1 .. 4
   for (int c = 2; c <= 4; ++c) {
     if ((c == 2 && !sign16) || (c == 4 && !wave4)) continue;

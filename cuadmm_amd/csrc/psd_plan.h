@@ -72,7 +72,9 @@ struct PsdPlan {
   // of different geometries cannot share a CU's LDS, so their launches would run one after the other instead of side by side
   // (measured on BASELINE configs[3], four geometries: 2.24 vs 1.74 ms per iteration): only when one geometry holds >= 90 % of
   // the fused blocks' work
-  bool one_dominant_geometry() const;
+  bool one_dominant_geometry() const { return dominant_geometry; }   // computed once by build(): the engine asks every iteration
+  bool dominant_geometry = false;
+  bool compute_dominant_geometry() const;
   // 32 < n <= 64 on the one-wavefront kernels (throughput: 1.3x the one-workgroup kernels in bulk) only when there are enough
   // blocks to fill the chip; a handful of blocks (moment relaxations) is a LATENCY problem, and there six / ten wavefronts per
   // block win (measured crossover: ~1000 blocks at n = 45 and at n = 64; option psd_wave4_min moves it)
