@@ -79,6 +79,7 @@ struct SignArgs {
   int* hint;                // per block (all blocks of the plan), in/out: schedule warm start; may be null
   const int* ids;           // member -> block id
   int count, step;
+  unsigned* bar;            // per member: barrier counter of the one-launch variant (lg_sign_cluster_kernel); may be null
 };
 
 // Sums the statistics' slots in a fixed order (all 256 threads), runs the schedule's decision for step sa.step on thread 0
@@ -139,17 +140,20 @@ __global__ __launch_bounds__(256) void lg_decide_kernel(SignArgs sa, int ntiles)
 //         slots ||S - S Y||_F^2;   ROLE 4: the same with mu read from the state (lg_decide_kernel ran in between);
 // ROLE 3: the final product: B = the buffer that holds the last iterate (Bb after an even number of steps, B2b after
 //         an odd one).
+template <bool MIRROR, int TM, int BK>
+struct LgGemmCfg {
+  static constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
+  static constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * BK * LDS ? TM * (TM + 1) : 2 * BK * LDS) : 2 * BK * LDS;
+};
+// The body of one output tile: workgroup (tile_x of grid_x, member).  smem: LgGemmCfg::SMEM doubles, red: 16 doubles.
 template <bool MIRROR, int TM, int BK, int ROLE>
-__global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
-                                                          double alpha, double beta, const double* __restrict__ Eb,
-                                                          double* __restrict__ Cb, int sb, SignArgs sg, const double* __restrict__ B2b) {
+__device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
+                                                 double alpha, double beta, const double* __restrict__ Eb,
+                                                 double* __restrict__ Cb, int sb, const SignArgs& sg, const double* __restrict__ B2b,
+                                                 const int member, const int tile_x, const int grid_x, double* smem, double* red) {
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
-  constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * BK * LDS ? TM * (TM + 1) : 2 * BK * LDS) : 2 * BK * LDS;
-  __shared__ double smem[SMEM];
-  __shared__ double red[16];
-  const int member = (int)blockIdx.y;
   if (ROLE == 1 || ROLE == 2 || ROLE == 4) {
     if (sg.done[member].done_at <= sg.step) return;   // uniform over the workgroup: before any barrier
   }
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
   double* As = smem;
   double* Bs = smem + BK * LDS;
   double* Ct = smem;                // TM x (TM+1) transposed output tile (MIRROR), after the k loop
-  const size_t mat = (size_t)blockIdx.y * (size_t)N * (size_t)N;
+  const size_t mat = (size_t)member * (size_t)N * (size_t)N;
   const double* A = Ab + mat;
   const double* B = Bb + mat;
   const double* E = Eb ? Eb + mat : nullptr;
@@ -171,20 +175,20 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
       // XCD-aware order for one big matrix: workgroup i runs on XCD i % 8 (round-robin dispatch); give every XCD a
       // contiguous range of the tile sequence, and let the sequence walk 8x8-tile super-blocks of the upper triangle,
       // so that the ~128 tiles resident on an XCD share ~16 row/column strips in its private L2.
-      const int per_xcd = (int)gridDim.x / 8;
-      const int L = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+      const int per_xcd = grid_x / 8;
+      const int L = (tile_x % 8) * per_xcd + tile_x / 8;
       int sbx, sby;
       tri_decode(L / 64, sbx, sby);
       by = sby * 8 + (L % 64) / 8;
       bx = sbx * 8 + (L % 64) % 8;
       if (sbx >= sb || bx < by || bx >= N / TM) return;   // whole workgroup leaves before any barrier
     } else {
-      tri_decode((int)blockIdx.x, bx, by);   // bx >= by
+      tri_decode(tile_x, bx, by);   // bx >= by
     }
   } else {
     const int nb = N / TM;
-    by = (int)blockIdx.x / nb;
-    bx = (int)blockIdx.x % nb;
+    by = tile_x / nb;
+    bx = tile_x % nb;
   }
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wy = wave >> 1, wx = wave & 1;
@@ -313,6 +317,81 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
       }
     }
   }
+}
+
+template <bool MIRROR, int TM, int BK, int ROLE>
+__global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
+                                                          double alpha, double beta, const double* __restrict__ Eb,
+                                                          double* __restrict__ Cb, int sb, SignArgs sg, const double* __restrict__ B2b) {
+  __shared__ double smem[LgGemmCfg<MIRROR, TM, BK>::SMEM];
+  __shared__ double red[16];
+  lg_gemm_sym_body<MIRROR, TM, BK, ROLE>(N, Ab, Bb, alpha, beta, Eb, Cb, sb, sg, B2b, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, smem, red);
+}
+
+// ---- a handful of mid-size blocks: the WHOLE sign iteration in one launch --------------------------------------------------
+// A moment relaxation has a few blocks of 65 <= n <= 128 (PlanarHand_N=1: nine).  Their products are a few workgroups deep, so
+// the ~95 dependent launches of a projection cost their launch latency (5.6 / 11.8 us each: 0.8 ms), not their flops.  Here one
+// persistent workgroup per (member, output tile) runs every step: Y = S S, [barrier], T = 1.5 mu S - 0.5 mu^3 S Y, [barrier], ...
+// and the final product.  The barrier is per MEMBER (its nb (nb + 1) / 2 workgroups): a monotone counter in global memory, an
+// agent-scope release before the increment and an acquire after the wait (the workgroups of a member may sit on different
+// XCDs, whose L2s are not coherent with each other).  Same tile bodies, same slots, same state machine as the launches: the
+// results are bit-identical.  What bounds it: a phase is ~5 dependent trips to the device's coherence point (operands, stores
+// complete, arrive, poll, the slots) of ~1.2 us each -- PlanarHand_N=1: 17.5 -> 15 us per step, projection 1.07 -> 0.80 ms.
+// Measured and NOT faster (round 3): both operand panels resident in LDS with every load of a phase issued at once and the
+// decision overlapped (0.84 ms); relaxed agent-scope atomic loads / stores for everything exchanged instead of the bulk
+// release / acquire, the state carried per workgroup (0.80 ms) -- the trips, not the L2 maintenance, are the cost.  The grid must be co-resident (the host only takes this path for <= kClusterMaxWgs workgroups);
+// a workgroup that waits longer than ~2 s gives up and raises the failure counter instead of hanging the device.
+constexpr int kClusterMaxWgs = 224;
+struct ClusterArgs {
+  double *S, *T, *Y, *X0;
+  unsigned* bar;            // per member, zeroed by lg_state_init_kernel
+  int* fail;
+  int N, max_steps;
+};
+__device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target) {
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int good = 1;
+    long long spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1ll << 24)) { good = 0; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+template <int TM, int BK>
+__global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterArgs ca, SignArgs sg) {
+  __shared__ double smem[LgGemmCfg<true, TM, BK>::SMEM];
+  __shared__ double red[16];
+  const int member = (int)blockIdx.y, tile = (int)blockIdx.x;
+  const int N = ca.N;
+  const int nbt = N / TM;
+  const unsigned ntiles = (unsigned)(nbt * (nbt + 1) / 2);
+  unsigned* bar = ca.bar + member;
+  double* s = ca.S;
+  double* t = ca.T;
+  unsigned phase = 0;
+  int step = 0;
+  for (; step < ca.max_steps; ++step) {
+    sg.step = step;
+    // done_at is written by this member's writer workgroup during the second product of the step before: ordered by the barrier
+    if (__hip_atomic_load(&sg.done[member].done_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) break;
+    lg_gemm_sym_body<true, TM, BK, 1>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, nullptr, member, tile, (int)gridDim.x, smem, red);
+    if (!lg_member_barrier(bar, ntiles * ++phase)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+    lg_gemm_sym_body<true, TM, BK, 2>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, nullptr, member, tile, (int)gridDim.x, smem, red);
+    if (!lg_member_barrier(bar, ntiles * ++phase)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+    double* u = s; s = t; t = u;
+  }
+  // P = 0.5 (X0 + X0 S_final); `s` holds the last iterate
+  sg.step = step;
+  lg_gemm_sym_body<true, TM, BK, 0>(N, ca.X0, s, 0.5, 0.5, ca.X0, ca.Y, 0, sg, nullptr, member, tile, (int)gridDim.x, smem, red);
 }
 
 // Group descriptors: member m of the group is block ids[m]; n = bn[id], svec offset boff[id].
@@ -452,6 +531,7 @@ __global__ void lg_state_init_kernel(SignArgs sa, const int* __restrict__ ids, c
   sa.st[m] = s;
   sa.done[m].done_at = 0x7fffffff;
   sa.done[m].steps = 0;
+  if (sa.bar) sa.bar[m] = 0u;
 }
 __global__ void lg_steps_out_kernel(SignArgs sa, const int* __restrict__ ids, int* __restrict__ steps) {
   const int m = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -510,6 +590,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   CUADMM_HIP_TRY(hipMalloc(&d_state, sizeof(SignDevState) * 2 * (size_t)max_count));
   CUADMM_HIP_TRY(hipMalloc(&d_done, sizeof(SignDone) * (size_t)max_count));
   CUADMM_HIP_TRY(hipMalloc(&d_group, sizeof(int) * 2));
+  CUADMM_HIP_TRY(hipMalloc(&d_bar, sizeof(unsigned) * (size_t)max_count));
   CUADMM_HIP_TRY(hipHostMalloc(&h_group, sizeof(int) * 2, hipHostMallocDefault));
   size_t max_part = 0;
   for (const Group& g : groups) max_part = std::max(max_part, (size_t)g.count * 2 * (size_t)(g.N / 32) * (size_t)(g.N / 32 + 1) / 2);
@@ -520,11 +601,11 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
 
 void SignPsd::release() {
   if (graph_exec) { hipError_t e = hipGraphExecDestroy(graph_exec); (void)e; graph_exec = nullptr; }
-  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done})
+  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   if (d_group) { hipError_t e = hipFree(d_group); (void)e; d_group = nullptr; }
   if (h_group) { hipError_t e = hipHostFree(h_group); (void)e; h_group = nullptr; }
-  d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr;
+  d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr; d_bar = nullptr;
   X0 = S = Y = T = colsum = scale = nullptr;
   groups.clear();
 }
@@ -587,6 +668,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     sa.ids = ids;
     sa.count = cnt;
     sa.step = 0;
+    sa.bar = d_bar;
     hipLaunchKernelGGL(lg_state_init_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, bn);
     double* s = S;
     double* t = T;
@@ -602,6 +684,14 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     // with CUADMM_PSD_SIGN_SYNC=0) the whole cap is enqueued and nothing synchronises.
     int enq = 0;
     int chunk = poll ? std::min(max_steps, g.pred > 0 ? g.pred + 2 : 24) : max_steps;
+    // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
+    const bool cluster = opt.lg_cluster != 0 && !decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)ntiles * cnt <= kClusterMaxWgs;
+    if (cluster) {
+      ClusterArgs ca{S, T, Y, X0, d_bar, d_fail, N, max_steps};
+      hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(ntiles, cnt), dim3(256), 0, st, ca, sa);
+      CUADMM_HIP_TRY(hipGetLastError());
+      enq = max_steps;
+    }
     while (enq < max_steps) {
       for (int it = 0; it < chunk && enq < max_steps; ++it, ++enq) {
         // Y = S*S ; [decision] ; T = 1.5 mu S - 0.5 mu^3 S*Y ; finished members return at once
@@ -623,7 +713,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     }
     // P = 0.5 * (X0 + X0 * S_final); S_final is in S after an even number of steps, in T after an odd one
     sa.step = enq;
-    if ((rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T, opt.lg_tile))) return rc;
+    if (!cluster && (rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T, opt.lg_tile))) return rc;
     hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
     if (d_steps) hipLaunchKernelGGL(lg_steps_out_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, d_steps);
     CUADMM_HIP_TRY(hipGetLastError());

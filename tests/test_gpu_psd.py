@@ -288,6 +288,31 @@ def test_project_sign_path_batched_groups_and_zero_block():
     assert np.all(got[int(bidx.off[zero_k]):int(bidx.off[zero_k + 1])] == 0.0)
 
 
+@pytest.mark.parametrize("blk", [[66, 66, 66, 91, 91, 91, 120, 120, 120], [128], [65, 200, 100, 224], [300, 300]])
+def test_project_sign_path_one_launch_variant_is_bit_identical(blk, monkeypatch):
+    """A handful of mid-size blocks (PlanarHand_N=1's nine of 66 / 91 / 120 first) run their whole sign iteration in ONE launch
+    with per-member barriers (lg_sign_cluster_kernel) instead of ~95 dependent launches: same tile bodies, same slots, same state
+    machine -- the projection must not differ by one bit, on easy spectra and on moment-like ones (rank deficient, ~40 steps)."""
+    blk = np.array(blk, dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    rng = np.random.default_rng(int(blk.sum()))
+    mats = []
+    for k, n in enumerate(blk):
+        if k % 2 == 0:
+            mats.append(_spectrum_matrix(int(n), "randn", rng))
+        else:                                                   # moment-matrix-like: rank 3 plus noise at 1e-12
+            U = rng.standard_normal((int(n), 3)); G = rng.standard_normal((int(n), int(n)))
+            mats.append(U @ U.T + 1e-12 * (G + G.T))
+    x = np.concatenate([orc.BlockIndex([m.shape[0]]).pack([m[None]]) for m in mats])
+    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "1")
+    one = psd_project_gpu(x, blk)
+    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "0")
+    many = psd_project_gpu(x, blk)
+    assert np.array_equal(one, many)
+    ref = orc.psd_project_svec(bidx, x)
+    assert np.max(np.abs(one - ref)) <= 2e-12 * max(np.linalg.norm(m, 2) for m in mats) * np.sqrt(2)
+
+
 def test_project_sign_path_full_size_properties():
     """BASELINE config 3 size (one block of n = 2000): oracle parity, idempotence, Moreau decomposition, complementarity."""
     n = 2000
