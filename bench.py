@@ -253,11 +253,18 @@ def main():
         # import torch BEFORE loading the engine so that both share one HIP runtime (same soname, first one wins)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # CUADMM_BENCH_BACKEND=gloo (tests only): the same script with N ranks SHARING the GPUs that exist (rank r on device
+        # r mod count) and a host-staged all-reduce -- what tests/test_gpu_bench_ranks.py runs on a one-GPU box
+        backend = os.environ.get("CUADMM_BENCH_BACKEND", "nccl")
+        if backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import cuadmm_amd
     from cuadmm_amd import synthetic
@@ -321,6 +328,13 @@ def main():
                     self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (count,), "typestr": "<f8", "version": 2}
             cache = {}
 
+            def allreduce_host(ptr, count, stream):     # gloo: through the host (tests)
+                cuadmm_amd._lib.check(lib.cuadmm_dev_sync())
+                h = np.empty(count)
+                cuadmm_amd._lib.check(lib.cuadmm_memcpy_d2h(h.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), count * 8))
+                dist.all_reduce(torch.from_numpy(h))
+                cuadmm_amd._lib.check(lib.cuadmm_memcpy_h2d(ctypes.c_void_p(ptr), h.ctypes.data_as(ctypes.c_void_p), count * 8))
+
             def allreduce(ptr, count, stream):
                 key = (ptr, count)
                 if key not in cache:
@@ -328,6 +342,8 @@ def main():
                 ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", local_rank))
                 with torch.cuda.stream(ext):
                     dist.all_reduce(cache[key], op=dist.ReduceOp.SUM)
+            if dist.get_backend() == "gloo":
+                allreduce = allreduce_host
             solver.set_allreduce(allreduce)
             keep.append(allreduce)
 
@@ -351,7 +367,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert solver.info_iter_num == args.steps
