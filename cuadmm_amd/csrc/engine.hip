@@ -231,6 +231,8 @@ struct cuadmm_solver {
     int mapped_out = 1;           // "mapped_out": results through a mapped pinned buffer when no collective is needed
     int lpt = 1;                  // "lpt": longest block first
     int aty_post2 = 1;            // "aty_post2": the sGS second half in one pass
+    int lead_stream = 0;          // "lead_stream": the leading sweeps on the streaming kernels only (no LDS-resident trees; A/B, tests)
+    int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
     int debug_eig = 0;            // developer aid
   } sw;
   cuadmm_solver() {
@@ -1046,6 +1048,8 @@ static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
     // the deepest tree decides the kernel; host: 1.2 ns per leading nonzero for both sweeps + the PCIe hops of the tail)
     const int64_t* Lp; const int* Li; const double* Lx; const double* D;
     if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
+    s->lead.stream_only = s->sw.lead_stream != 0;
+    s->lead.debug = s->sw.lead_debug != 0;
     if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D))) return rc;
     const double host_us = 1.2e-3 * (double)Lp[m - s->tail.k] + 150.0;
     if (s->lead.ready && s->lead.est_us < 0.7 * host_us) {
@@ -1253,6 +1257,8 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "mapped_out") s->sw.mapped_out = (int)value;
   else if (k == "lpt") s->sw.lpt = (int)value;
   else if (k == "aty_post2") s->sw.aty_post2 = (int)value;
+  else if (k == "lead_stream") s->sw.lead_stream = (int)value;
+  else if (k == "lead_debug") s->sw.lead_debug = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;
   else if (s->plan.opt.set(k, value)) {}                      // "psd_*": the projection planner's switches (psd_options.h)
   else if (k == "batch_mixed") s->bt.allow_mixed = value != 0;

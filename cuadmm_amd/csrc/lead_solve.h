@@ -30,6 +30,15 @@ struct LeadSolve {
   int* lvl_ptr_f = nullptr; int* lvl_ptr_b = nullptr;      // offsets into lvl_off_* per tree (ntrees + 1)
   int* lvl_off_f = nullptr; int* lvl_off_b = nullptr;      // level boundaries in nodes_* (levels + 1 entries per tree)
   int* lvl_g_f = nullptr; int* lvl_g_b = nullptr;          // lanes per row of each level (power of two, from its mean row length)
+  // trees by the LDS they need with their stream resident: <= 16 KB | up to one workgroup's LDS | streaming kernels
+  void *desc_small_f = nullptr, *desc_small_b = nullptr, *desc_big_f = nullptr, *desc_big_b = nullptr;   // LeadTreeDesc per tree and sweep
+  int* trees_stream = nullptr;
+  int n_small = 0, n_big = 0, n_stream = 0;
+  size_t lds_small = 0, lds_big = 0;
+  hipStream_t aux = nullptr;    // the big trees' launches run beside the small trees' (fork / join events on the caller's stream)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool debug = false;           // option lead_debug: forest statistics on stderr at build
+  bool stream_only = false;     // option lead_stream = 1: every tree on the streaming kernels (A/B, tests)
   bool ready = false;
   double est_us = 0;            // cost model used to decide (per solve)
 

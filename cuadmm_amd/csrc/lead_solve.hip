@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <numeric>
 #include <vector>
 
@@ -17,6 +18,7 @@
 #include "lead_solve.h"
 #include "psd_device.h"
 #include "tail_solve.h"
+#include "wave_reduce.h"
 
 namespace cuadmm {
 
@@ -35,7 +37,7 @@ __device__ __forceinline__ double lead_rhs(const double* __restrict__ ax, const 
 
 // sum over a group of G lanes (G a power of two <= 64, groups aligned)
 __device__ __forceinline__ double group_sum(double s, int G) {
-  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
   return s;
 }
 
@@ -50,12 +52,12 @@ __global__ __launch_bounds__(64) void lead_forward_kernel(const int* __restrict_
                                                           const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
                                                           const double* __restrict__ v, const double* __restrict__ ax, const double* __restrict__ asmc,
                                                           const double* __restrict__ b, double isig, double* __restrict__ x, int max_nodes,
-                                                          int max_levels) {
+                                                          int max_levels, const int* __restrict__ tree_ids) {
   extern __shared__ double lead_smem[];
   double* xs = lead_smem;
   int* s_off = reinterpret_cast<int*>(xs + max_nodes);
   int* s_g = s_off + max_levels + 1;
-  const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
+  const int t = tree_ids[blockIdx.x], lane = (int)threadIdx.x;
   const int l0 = lvl_ptr[t], nlev = lvl_ptr[t + 1] - 1 - l0;
   for (int l = lane; l <= nlev; l += 64) s_off[l] = lvl_off[l0 + l];
   for (int l = lane; l < nlev; l += 64) s_g[l] = lvl_g[l0 + l];
@@ -115,12 +117,12 @@ __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long*
 __global__ __launch_bounds__(64) void lead_backward_kernel(const int* __restrict__ lvl_ptr, const int* __restrict__ lvl_off, const int* __restrict__ lvl_g,
                                                            const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
                                                            const double* __restrict__ v, const double* __restrict__ D, const double* __restrict__ w,
-                                                           double* __restrict__ x, int max_nodes, int max_levels) {
+                                                           double* __restrict__ x, int max_nodes, int max_levels, const int* __restrict__ tree_ids) {
   extern __shared__ double lead_smem[];
   double* xs = lead_smem;
   int* s_off = reinterpret_cast<int*>(xs + max_nodes);
   int* s_g = s_off + max_levels + 1;
-  const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
+  const int t = tree_ids[blockIdx.x], lane = (int)threadIdx.x;
   const int l0 = lvl_ptr[t], nlev = lvl_ptr[t + 1] - 1 - l0;
   for (int l = lane; l <= nlev; l += 64) s_off[l] = lvl_off[l0 + l];
   for (int l = lane; l < nlev; l += 64) s_g[l] = lvl_g[l0 + l];
@@ -146,15 +148,91 @@ __global__ __launch_bounds__(64) void lead_backward_kernel(const int* __restrict
   }
 }
 
+// The same sweeps with the tree's WHOLE index / value stream resident in LDS.  The streaming kernels above pay two dependent
+// global-memory round trips per level (row pointers, then entries: ~2.5 us on the loaded chip), and the deepest tree decides:
+// 61 levels = 158 / 198 us per sweep on pendulum N = 80 -- 45 % of its iteration.  A tree's stream is ONE contiguous chunk
+// (slots are in processing order, trees contiguous: on average 105 entries, 3 914 at most), so the wavefront copies it in
+// two coalesced passes -- row offsets, node ids, level table; then the entries and the gathered right-hand sides -- and every
+// level after that touches LDS only.  Same gather order, same group sums: bit-identical to the streaming kernels.
+// LDS: xs[cnt] | rhs[cnt] | sv[nnz] doubles, then sptr[cnt + 1] | sci[nnz] | snode[cnt] | s_off[nlev + 1] | s_g[nlev] ints.
+// sum over aligned groups of 2^lg lanes on the DPP crossbar (quad_perm, row_half_mirror, row_mirror: no LDS traffic) up to 16
+// lanes, ds_bpermute beyond; the same association order as group_sum (xor butterfly from offset 1 up)
+__device__ __forceinline__ double group_sum_dpp(double s, int lg) {
+  if (lg >= 1) s += sw_dpp<0xB1>(s);       // quad_perm [1,0,3,2]                                   = xor 1
+  if (lg >= 2) s += sw_dpp<0x4E>(s);       // quad_perm [2,3,0,1]                                   = xor 2
+  if (lg >= 3) s += sw_dpp<0x141>(s);      // row_half_mirror (quads are uniform by now)            = xor 4
+  if (lg >= 4) s += sw_dpp<0x140>(s);      // row_mirror (halves of a row are uniform by now)       = xor 8
+  if (lg >= 5) s += __shfl_xor(s, 16, 64);
+  if (lg >= 6) s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+struct LeadTreeDesc { int l0, nlev, first, cnt, nnz, pad; long long q0; };     // per tree and sweep: everything the kernel start needs in one load
+
+// NW wavefronts per tree: one for the many small trees; four for the few big ones (rows of a level are independent: the
+// wavefronts take them in turn and meet at a workgroup barrier per level; the copy-in runs four times as wide)
+template <bool BACKWARD, int NW>
+__global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeDesc* __restrict__ desc, const int* __restrict__ lvl_off,
+                                                            const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
+                                                            const int* __restrict__ ci, const double* __restrict__ v,
+                                                            const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
+                                                            const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
+  extern __shared__ double lead_smem[];
+  constexpr int NT = 64 * NW;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const LeadTreeDesc d = desc[blockIdx.x];
+  const int l0 = d.l0, nlev = d.nlev, first = d.first, cnt = d.cnt, nnz = d.nnz;
+  const long long q0 = d.q0;
+  double* xs = lead_smem;
+  double* rhs = xs + cnt;
+  double* sv = rhs + cnt;
+  int* sptr = reinterpret_cast<int*>(sv + nnz);
+  int* sci = sptr + cnt + 1;
+  int* snode = sci + nnz;
+  int* s_off = snode + cnt;
+  int* s_g = s_off + nlev + 1;
+  for (int l = tid; l <= nlev; l += NT) s_off[l] = lvl_off[l0 + l] - first;
+  for (int l = tid; l < nlev; l += NT) { const int G = lvl_g[l0 + l]; s_g[l] = 31 - __clz(G); }      // log2 of the lanes per row
+  for (int i = tid; i <= cnt; i += NT) sptr[i] = (int)(ptr[first + i] - q0);
+  for (int i = tid; i < cnt; i += NT) {
+    const int nd = nodes[first + i];
+    snode[i] = nd;
+    rhs[i] = BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs(ax, asmc, b, isig, nd);
+  }
+  for (int q = tid; q < nnz; q += NT) { sv[q] = v[q0 + q]; sci[q] = ci[q0 + q]; }
+  if (NW > 1) __syncthreads(); else wave_fence();
+  int beg = s_off[0];
+  for (int l = 0; l < nlev; ++l) {
+    const int lg = s_g[l], G = 1 << lg, sub = lane & (G - 1), grp = lane >> lg, ngrp = 64 >> lg;
+    const int end = s_off[l + 1];
+    for (int base = beg + wave * ngrp; base < end; base += NW * ngrp) {       // uniform trip count inside a wavefront: the reductions need every lane
+      const int idx = base + grp;
+      double s = 0.0;
+      if (idx < end)
+        for (int q = sptr[idx] + sub; q < sptr[idx + 1]; q += G) s += sv[q] * xs[sci[q]];
+      s = group_sum_dpp(s, lg);
+      if (idx < end && sub == 0) {
+        const double xi = rhs[idx] - s;
+        xs[idx] = xi;
+        x[snode[idx]] = xi;
+      }
+    }
+    beg = end;
+    if (NW > 1) __syncthreads(); else wave_fence();        // the next level reads xs written by this one
+  }
+}
+
 }  // namespace
 
 void LeadSolve::release() {
   for (void* p : {(void*)rp21, (void*)ci21, (void*)v21, (void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)tptr,
                   (void*)tri, (void*)tv_, (void*)D1, (void*)wvec, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f, (void*)lvl_ptr_b, (void*)lvl_off_f,
-                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b})
+                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b, (void*)desc_big_f, (void*)desc_big_b, (void*)trees_stream})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   rp21 = fptr = bptr = tptr = nullptr; ci21 = fci = bci = tri = nullptr; v21 = fv_ = bv_ = tv_ = D1 = wvec = nullptr;
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
+  if (aux) { hipError_t e = hipStreamDestroy(aux); (void)e; e = hipEventDestroy(ev_fork); (void)e; e = hipEventDestroy(ev_join); (void)e; aux = nullptr; ev_fork = ev_join = nullptr; }
+  desc_small_f = desc_small_b = desc_big_f = desc_big_b = nullptr; trees_stream = nullptr; n_small = n_big = n_stream = 0;
   ready = false;
 }
 
@@ -283,11 +361,55 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
       if (Li[p] >= n1) { tr[(size_t)q] = Li[p] - n1; tv[(size_t)q] = Lx[p]; ++q; }
     tp[(size_t)j + 1] = q;
   }
+  if (debug) {
+    long long mx_f = 0, mx_b = 0;
+    std::vector<int> cnt((size_t)ntrees, 0);
+    for (int j = 0; j < n1; ++j) cnt[tree_of[j]]++;
+    int acc = 0;
+    for (int t = 0; t < ntrees; ++t) { mx_f = std::max(mx_f, fp[(size_t)acc + cnt[t]] - fp[acc]); mx_b = std::max(mx_b, bp[(size_t)acc + cnt[t]] - bp[acc]); acc += cnt[t]; }
+    fprintf(stderr, "[lead debug] n1 %d k %d trees %d max_nodes %d max_levels %d nnz11 %lld (fwd) %lld (bwd) max per tree %lld / %lld nnz21 %lld\n", n1, k, ntrees,
+            max_nodes, max_levels, (long long)fp[n1], (long long)bp[n1], mx_f, mx_b, (long long)r21[k]);
+  }
   // cost model: per level two dependent global-memory latencies (~2 us) in the deepest tree, per sweep, plus the streaming part
   est_us = 2.0 * 2.0 * max_levels + 40.0 + (double)nnz * 2e-4;
   if (max_nodes > 6144 || max_levels > 2048) { est_us = 1e30; return CUADMM_OK; }     // LDS budget of one wavefront's tree
   lds_bytes = sizeof(double) * (size_t)max_nodes + sizeof(int) * (2 * (size_t)max_levels + 2);
+  // classes by the LDS a tree needs with its stream resident (the larger of the two sweeps): small trees share a CU in numbers,
+  // the few big ones get a launch of their own, anything beyond one workgroup's LDS keeps the streaming kernels
+  std::vector<int> t_stream;
+  std::vector<LeadTreeDesc> dsf, dsb, dbf, dbb;        // small / big trees, forward / backward sweep
+  lds_small = lds_big = 0;
+  {
+    int acc = 0;
+    std::vector<int> cnt((size_t)ntrees, 0);
+    for (int j = 0; j < n1; ++j) cnt[tree_of[j]]++;
+    for (int t = 0; t < ntrees; ++t) {
+      const long long nzf = fp[(size_t)acc + cnt[t]] - fp[acc], nzb = bp[(size_t)acc + cnt[t]] - bp[acc];
+      const int nlf = lpf[(size_t)t + 1] - lpf[t] - 1, nlb = lpb[(size_t)t + 1] - lpb[t] - 1;
+      const long long nz = std::max(nzf, nzb);
+      const int nlev_t = std::max(nlf, nlb);
+      const size_t need = sizeof(double) * (2 * (size_t)cnt[t] + (size_t)nz) + sizeof(int) * (2 * (size_t)cnt[t] + 1 + (size_t)nz + 2 * (size_t)nlev_t + 2) + 16;
+      const LeadTreeDesc df{lpf[t], nlf, acc, cnt[t], (int)nzf, 0, fp[acc]}, db{lpb[t], nlb, acc, cnt[t], (int)nzb, 0, bp[acc]};
+      if (stream_only || need > kMaxLdsBytes - 1024) t_stream.push_back(t);
+      else if (need <= 16 * 1024) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
+      else { dbf.push_back(df); dbb.push_back(db); lds_big = std::max(lds_big, need); }
+      acc += cnt[t];
+    }
+  }
+  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size();
+  if (debug) fprintf(stderr, "[lead debug] resident trees: %d small (%zu B), %d big (%zu B), %d streaming\n", n_small, lds_small, n_big, lds_big, n_stream);
   int rc;
+  {
+    LeadTreeDesc *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;
+    if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(trees_stream, t_stream))) return rc;
+    desc_small_f = a0; desc_small_b = a1; desc_big_f = a2; desc_big_b = a3;
+  }
+  if (lds_big > 48 * 1024) {
+    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_sweep_lds_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_sweep_lds_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+  }
+  // cost model of the resident variant: two bulk round trips, then ~0.15 us of LDS work per level
+  if (n_stream == 0) est_us = 2.0 * (6.0 + 0.15 * max_levels) * (n_big > 0 ? 2.0 : 1.0) + 40.0 + (double)nnz * 2e-4;
   if ((rc = to_device(rp21, r21)) || (rc = to_device(ci21, c21)) || (rc = to_device(v21, w21)) ||
       (rc = to_device(fptr, fp)) || (rc = to_device(fci, fc)) || (rc = to_device(fv_, fv)) ||
       (rc = to_device(bptr, bp)) || (rc = to_device(bci, bc)) || (rc = to_device(bv_, bv)) ||
@@ -301,21 +423,43 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
     CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
+  if (n_big > 0 && n_small > 0) {
+    CUADMM_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
   ready = true;
   return CUADMM_OK;
 }
 
 int LeadSolve::solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const {
   if (!ready) { set_error("lead_solve: not built"); return CUADMM_ERR_INVALID; }
-  hipLaunchKernelGGL(lead_forward_kernel, dim3(ntrees), dim3(64), lds_bytes, st, lvl_ptr_f, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, y,
-                     max_nodes, max_levels);
+  // the few big trees (four wavefronts each) run beside the many small ones on a second stream
+  const bool side = n_big > 0 && n_small > 0 && aux != nullptr;
+  hipStream_t sb = side ? aux : st;
+  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_fork, st)); CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0)); }
+  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_f), lvl_off_f, lvl_g_f,
+                                    nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
+  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_join, aux));
+  if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_f), lvl_off_f,
+                                      lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
+  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+  if (n_stream > 0) hipLaunchKernelGGL(lead_forward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_f, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b,
+                                       isig, y, max_nodes, max_levels, trees_stream);
   hipLaunchKernelGGL(lead_tail_rhs_kernel, dim3((k * 8 + 255) / 256), dim3(256), 0, st, k, n1, rp21, ci21, v21, ax, asmc, b, isig, y, tail.vin);
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
   hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
-  hipLaunchKernelGGL(lead_backward_kernel, dim3(ntrees), dim3(64), lds_bytes, st, lvl_ptr_b, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_, D1, wvec, y,
-                     max_nodes, max_levels);
+  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_fork, st)); CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0)); }
+  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_b), lvl_off_b, lvl_g_b,
+                                    nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
+  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_join, aux));
+  if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_b), lvl_off_b,
+                                      lvl_g_b, nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
+  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+  if (n_stream > 0) hipLaunchKernelGGL(lead_backward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_b, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_, D1, wvec, y,
+                                       max_nodes, max_levels, trees_stream);
   CUADMM_HIP_TRY(hipGetLastError());
   CUADMM_HIP_TRY(hipMemcpyAsync(y + n1, tail.vin, sizeof(double) * (size_t)k, hipMemcpyDeviceToDevice, st));
   return CUADMM_OK;

@@ -111,3 +111,20 @@ def test_moment_relaxation_trajectory_matches_the_oracle(key, tmp_path):
 def test_pusht30_with_the_factor_on_the_host_is_exact(tmp_path):
     """the same input without the GPU tail: 1e-8 on every quantity (what POBJ_HEAD_TOL above is measured against)"""
     run_and_compare("PushT_N=30_MOMENT/switch=11000", tmp_path, {"tail_k": 0}, None)
+
+
+@pytest.mark.parametrize("name", ["pendulum_N=80", "PlanarHand_N=1_MOMENT"])
+def test_resident_and_streaming_leading_sweeps_agree_bit_for_bit(name, tmp_path):
+    """lead_solve.hip: the sweeps with a tree's whole stream resident in LDS (small trees: one wavefront; big trees: four, on a
+    side stream) and the streaming kernels of round 2 (option lead_stream = 1) gather in the same order with the same group
+    sums -- identical iterates, bit for bit."""
+    p = load_problem(name, tmp_path)
+    out = []
+    for opt in ({}, {"lead_stream": 1}):
+        s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
+        s.init_problem(problem_to_amd(p))
+        s.solve(40, 0.0, 0, 50, 100, 20, 1.05)
+        assert s.counters()["dev_solve"] == 1
+        out.append((s.info_arr("pobj").copy(), s.info_arr("errRp").copy(), s.y.copy(), s.X.copy()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
