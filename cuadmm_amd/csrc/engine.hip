@@ -232,6 +232,7 @@ struct cuadmm_solver {
     int lpt = 1;                  // "lpt": longest block first
     int aty_post2 = 1;            // "aty_post2": the sGS second half in one pass
     int lead_stream = 0;          // "lead_stream": the leading sweeps on the streaming kernels only (no LDS-resident trees; A/B, tests)
+    int tail_one_pass = 1;        // "tail_one_pass": the GPU tail applied in one pass over inv(L22) (0: two triangular GEMVs)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
     int debug_eig = 0;            // developer aid
   } sw;
@@ -706,6 +707,7 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
     if (tk > 0) {
       const int64_t* srp; const int* sci; const double* sv;
       rc = cuadmm_aat_tail_schur(s->fac, &srp, &sci, &sv);
+      s->tail.one_pass = s->sw.tail_one_pass != 0;
       if (!rc) rc = s->tail.build_from_schur(reinterpret_cast<const long long*>(srp), sci, sv, tk, s->st);
       // The tail is applied as an explicit inverse built without pivoting (tail_solve.hip); with (nearly) dependent
       // constraints the pivots approach the regularisation 1e-15 and inv(L22) could lose accuracy silently.  Probe it with
@@ -1259,6 +1261,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "aty_post2") s->sw.aty_post2 = (int)value;
   else if (k == "lead_stream") s->sw.lead_stream = (int)value;
   else if (k == "lead_debug") s->sw.lead_debug = (int)value;
+  else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;
   else if (s->plan.opt.set(k, value)) {}                      // "psd_*": the projection planner's switches (psd_options.h)
   else if (k == "batch_mixed") s->bt.allow_mixed = value != 0;

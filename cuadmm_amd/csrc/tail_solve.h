@@ -8,6 +8,10 @@ struct TailSolve {
   int k = 0, K = 0;            // tail size, padded to a multiple of 64
   double *W = nullptr, *Wt = nullptr, *dinv = nullptr, *vin = nullptr, *vmid = nullptr;   // device
   double* h_vec = nullptr;     // pinned staging vector
+  double* xpart = nullptr;     // one-pass variant: n_wg partial result vectors
+  int n_wg = 0;
+  bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
+  int apply(hipStream_t st);   // vin <- W^T diag(dinv) W vin
   double build_s = 0, factor_s = 0;
   int build(const double* L22, const double* D2, int k, hipStream_t st);                                        // host factor
   int build_from_schur(const long long* row_ptr, const int* col, const double* val, int k, hipStream_t st);    // GPU factor

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "device_util.h"
 #include "tail_solve.h"
+#include "wave_reduce.h"
 
 namespace cuadmm {
 
@@ -151,6 +152,79 @@ __global__ __launch_bounds__(256) void ts_tri_gemv_kernel(const double* __restri
   if (lane == 0) out[i] = scale ? s * scale[i] : s;
 }
 
+
+// x = W^T diag(dinv) W z in ONE pass over W.  The two triangular GEMVs above read W and then W^T: 8 K^2 bytes per solve, and they
+// are what bounds the y-solve of a moment relaxation (PlanarHand_N=1, K = 17 152: 215 + 194 us at 5.5 - 6 TB/s).  Row i of W
+// serves both products -- u_i = W_i z, then x += (dinv_i u_i) W_i^T -- so a workgroup that keeps the row in REGISTERS between
+// the two uses needs it from memory once: 1024 threads, thread t holds columns t, t + 1024, ... (NC of them) of the current
+// row(s) and of its partial x; z sits in LDS; one block reduction per row group (double-buffered: one barrier).  Workgroup g
+// takes rows K-1-g, K-1-g-G, ... (long rows first, interleaved: equal shares of the triangle); the G partial vectors are summed
+// in workgroup order by ts_onepass_reduce_kernel.  Deterministic; half the HBM traffic.
+template <int NC, int RB>
+__global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
+                                                          const double* __restrict__ dinv, double* __restrict__ P) {
+  extern __shared__ double ts_zs[];          // z, K doubles (zero beyond K up to 1024 NC)
+  __shared__ double red[2][RB][16];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[c] : 0.0;
+  double xa[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) xa[c] = 0.0;
+  __syncthreads();
+  // column of (thread, c): every wavefront owns a contiguous segment of 64 NC columns, slot c of it is one coalesced 512-byte access
+  // at a compile-time offset from the segment's base (one address register pair per 8 slots instead of one per slot)
+  const int col0 = wave * (64 * NC) + lane;
+  const double* zs = ts_zs + col0;
+  const int G = (int)gridDim.x, g = (int)blockIdx.x;
+  int it = 0;
+  for (int r0 = g * RB; r0 < K; r0 += G * RB, ++it) {
+    double w[RB][NC], part[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int i = K - 1 - (r0 + q);            // < 0: no such row (all-zero contribution)
+      const double* row = W + (size_t)(i < 0 ? 0 : i) * ld + col0;
+      const int lim = i - col0;                  // slot c is inside the triangle iff 64 c <= lim
+#pragma unroll
+      for (int c = 0; c < NC; ++c) w[q][c] = 64 * c <= lim ? row[64 * c] : 0.0;     // entries above the diagonal are exact zeros and are not read
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      part[q] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) part[q] += w[q][c] * zs[64 * c];
+      part[q] = wave_sum(part[q]);
+      if (lane == 0) red[it & 1][q][wave] = part[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int i = K - 1 - (r0 + q);
+      const double* rr = red[it & 1][q];
+      const double u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
+                       (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
+      const double vq = i >= 0 ? u * dinv[i] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) xa[c] += vq * w[q][c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)g * K + col] = xa[c]; }
+}
+__global__ __launch_bounds__(64) void ts_onepass_reduce_kernel(const double* __restrict__ P, int K, int G, double* __restrict__ x) {
+  const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (col >= K) return;
+  double s = 0.0;
+  int g = 0;
+  for (; g + 8 <= G; g += 8) {                                  // eight loads in flight; workgroup order: fixed
+    double p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = P[(size_t)(g + q) * K + col];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += p[q];
+  }
+  for (; g < G; ++g) s += P[(size_t)g * K + col];
+  x[col] = s;
+}
 
 // ------------------------------------------------------------------------------------------
 // Dense LDL^T (no pivoting, as the host factor) of the Schur complement, right-looking, 64-wide block columns:
@@ -301,9 +375,9 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 }
 
 void TailSolve::release() {
-  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart}) if (p) { hipError_t e = hipFree(p); (void)e; }
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
-  W = Wt = dinv = vin = vmid = h_vec = nullptr;
+  W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
   k = K = 0;
 }
 
@@ -317,6 +391,14 @@ int TailSolve::alloc(int k_) {
   CUADMM_HIP_TRY(hipMalloc(&dinv, sizeof(double) * (size_t)K));
   CUADMM_HIP_TRY(hipMalloc(&vin, sizeof(double) * (size_t)K));
   CUADMM_HIP_TRY(hipMalloc(&vmid, sizeof(double) * (size_t)K));
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CUADMM_HIP_TRY(hipGetDevice(&dev));
+    CUADMM_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    n_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  CUADMM_HIP_TRY(hipMalloc(&xpart, sizeof(double) * (size_t)K * (size_t)n_wg));
   CUADMM_HIP_TRY(hipHostMalloc(&h_vec, sizeof(double) * (size_t)K, hipHostMallocDefault));
   return CUADMM_OK;
 }
@@ -460,9 +542,7 @@ int TailSolve::solve(double* z2, hipStream_t st) {
   std::copy(z2, z2 + k, h_vec);
   std::fill(h_vec + k, h_vec + K, 0.0);
   CUADMM_HIP_TRY(hipMemcpyAsync(vin, h_vec, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
-  hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
-  CUADMM_HIP_TRY(hipGetLastError());
+  { int rc_ = apply(st); if (rc_) return rc_; }
   CUADMM_HIP_TRY(hipMemcpyAsync(h_vec, vin, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, st));
   CUADMM_HIP_TRY(hipStreamSynchronize(st));
   std::copy(h_vec, h_vec + k, z2);
@@ -472,8 +552,38 @@ int TailSolve::solve(double* z2, hipStream_t st) {
 // the same on a right-hand side that is already in `vin` (written by lead_tail_rhs_kernel): nothing crosses PCIe
 int TailSolve::solve_device(hipStream_t st) {
   if (!W) { set_error("tail_solve: not built"); return CUADMM_ERR_INVALID; }
-  hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
-  hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
+  return apply(st);
+}
+
+// vin <- W^T diag(dinv) W vin
+int TailSolve::apply(hipStream_t st) {
+  const int nc = (K + 1023) / 1024;
+  const size_t lds = sizeof(double) * 1024 * (size_t)(nc + (nc & 1));
+  if (one_pass && xpart && lds <= kMaxLdsBytes - 1024 && nc <= 20) {
+    auto launch = [&](auto kern) -> int {
+      if (lds > 48 * 1024) CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, (long long)K, K, vin, dinv, xpart);
+      return CUADMM_OK;
+    };
+    int rc;
+    switch ((nc + 1) / 2) {           // NC = the even number >= nc; two rows in flight while the registers allow it
+      case 1: rc = launch(ts_onepass_kernel<2, 2>); break;
+      case 2: rc = launch(ts_onepass_kernel<4, 2>); break;
+      case 3: rc = launch(ts_onepass_kernel<6, 2>); break;
+      case 4: rc = launch(ts_onepass_kernel<8, 2>); break;
+      case 5: rc = launch(ts_onepass_kernel<10, 2>); break;
+      case 6: rc = launch(ts_onepass_kernel<12, 2>); break;
+      case 7: rc = launch(ts_onepass_kernel<14, 2>); break;
+      case 8: rc = launch(ts_onepass_kernel<16, 1>); break;
+      case 9: rc = launch(ts_onepass_kernel<18, 1>); break;
+      default: rc = launch(ts_onepass_kernel<20, 1>); break;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, n_wg, vin);
+  } else {
+    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
+    hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
+  }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
