@@ -1570,7 +1570,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         if (f != s->eig_fail_total) {
           fprintf(stderr, "[cuadmm debug] iter %d: QL cap hits %d -> %d\n", iter, s->eig_fail_total, f);
           std::vector<double> h((size_t)L);
-          if (hipMemcpy(h.data(), s->Xb.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost) == hipSuccess) {
+          if (staged_d2h(h.data(), s->Xb.p, sizeof(double) * (size_t)L, s->st) == CUADMM_OK) {
             char fn[256];
             snprintf(fn, sizeof fn, "%s/xb_fail_iter%d.bin", debug_eig_dir, iter);
             if (FILE* fp = fopen(fn, "wb")) { fwrite(h.data(), sizeof(double), (size_t)L, fp); fclose(fp); }

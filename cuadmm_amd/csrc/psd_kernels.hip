@@ -583,7 +583,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       }
       if (rc2) return rc2;
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
-      CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      { int rc_ = staged_d2h(h.data(), d, sizeof(long long) * h.size(), st); if (rc_) return rc_; }
       double ph[7] = {0, 0, 0, 0, 0, 0, 0};
       for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 7; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
       const double nw = cls_count[c];
@@ -603,7 +603,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       int rc2 = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz);
       if (rc2) return rc2;
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
-      CUADMM_HIP_TRY(hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      { int rc_ = staged_d2h(h.data(), d, sizeof(long long) * h.size(), st); if (rc_) return rc_; }
       double ph[10] = {0};
       for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 10; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
       const double nw = cls_count[c];
@@ -656,7 +656,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     if (dbg) {
       std::vector<long long> h((size_t)nwg * 8);
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
-      CUADMM_HIP_TRY(hipMemcpy(h.data(), dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      { int rc_ = staged_d2h(h.data(), dbg, sizeof(long long) * h.size(), st); if (rc_) return rc_; }
       double ph[6] = {0, 0, 0, 0, 0, 0}, its = 0, slots = 0;
       long long tmin = h[0], tmax = 0;
       for (int w = 0; w < nwg; ++w) {
@@ -690,8 +690,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
 int PsdPlan::fail_count(hipStream_t st) const {
   int h = 0;
   if (!d_fail) return 0;
-  if (hipMemcpyAsync(&h, d_fail, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  if (staged_d2h(&h, d_fail, sizeof(int), st)) return -1;      // never a runtime copy into pageable memory (staging.hip)
   return h;
 }
 

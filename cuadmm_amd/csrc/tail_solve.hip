@@ -524,8 +524,7 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   hipLaunchKernelGGL(ts_dinv_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dd, dinv, K);
   int hflag = 0;
   e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess && staged_d2h(&hflag, dflag, sizeof(int), st)) e = hipErrorUnknown;      // staged: never a runtime copy into pageable memory
   factor_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return CUADMM_ERR_NO_DEVICE; }
   if (hflag) { set_error("Factorization fails! (%d zero or non-finite pivots in the dense tail of A*A^T)", hflag); cleanup(); release(); return CUADMM_ERR_FACTOR; }
