@@ -132,12 +132,12 @@ __global__ __launch_bounds__(256) void copy_ranges_kernel(const double* __restri
 // planner
 // ---------------------------------------------------------------------------------------
 // 32 < n <= 64 (projection only): matrix-sign iteration resident in LDS, one workgroup per block (psd_sign_lds.h)
-template <int NP>
+template <int NP, bool TRIPLE>
 __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(PsdArgs a, int first) {
   extern __shared__ double sign_smem[];
   const int m = first + (int)blockIdx.x;
   const int id = a.ids ? a.ids[m] : m;
-  psd_sign_lds_body<NP>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, a.steps ? a.steps + id : nullptr,
+  psd_sign_lds_body<NP, TRIPLE>(a.in + a.boff[id], a.out + a.boff[id], a.bn[id], a.info, sign_smem, a.steps ? a.steps + id : nullptr,
                         a.hint ? a.hint + id : nullptr);
 }
 
@@ -270,11 +270,10 @@ static int launch_sign_wave32(const PsdArgs& a, int first, int count, hipStream_
   return launch_sign_wave<2, 4>(a, first, count, st, fz);
 }
 
-template <int NP>
-static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t st) {
-  if (count <= 0) return CUADMM_OK;
-  const size_t lds = sizeof(double) * 2 * NP * SignLdsCfg<NP>::LD;
-  auto kern = psd_sign_lds_kernel<NP>;
+template <int NP, bool TRIPLE>
+static int launch_sign_lds_t(const PsdArgs& a, int first, int count, hipStream_t st) {
+  const size_t lds = sizeof(double) * (TRIPLE ? 3 : 2) * NP * SignLdsCfg<NP>::LD;
+  auto kern = psd_sign_lds_kernel<NP, TRIPLE>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -283,6 +282,13 @@ static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t s
   hipLaunchKernelGGL(kern, dim3(count), dim3(SignLdsCfg<NP>::THREADS), lds, st, a, first);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
+}
+// triple = the variant with a third matrix in LDS (one barrier and the statistics less on most steps): when the class leaves at
+// most one workgroup per CU anyway (a moment relaxation's handful of blocks), so the extra LDS costs no occupancy
+template <int NP>
+static int launch_sign_lds(const PsdArgs& a, int first, int count, hipStream_t st, bool triple) {
+  if (count <= 0) return CUADMM_OK;
+  return triple ? launch_sign_lds_t<NP, true>(a, first, count, st) : launch_sign_lds_t<NP, false>(a, first, count, st);
 }
 
 static size_t wg_lds_bytes(int n, int nt) {
@@ -632,8 +638,9 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
         rc = launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz);
         if (!rc) rc = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz);
       } else {
-        rc = launch_sign_lds<64>(a, 0, cls4_big, st);
-        if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st);
+        const bool triple = opt.lds_triple != 0 && cls_count[c] <= 256;
+        rc = launch_sign_lds<64>(a, 0, cls4_big, st, triple);
+        if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st, triple);
       }
     } else if (c == 3 && sign32 && eig_rank == 0) {
       rc = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz);

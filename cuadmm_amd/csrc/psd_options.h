@@ -15,6 +15,7 @@ struct PsdOptions {
   int wave4_min = 1024;    // psd_wave4_min: blocks of a 33 <= n <= 64 class from which one wavefront per block wins over one workgroup
   int w32_occ = 4;         // psd_w32_occ: wavefronts per SIMD of the n <= 32 one-wavefront kernels (3 | 4)
   int cu_occ = 4;          // psd_cu_occ: the same for the launches that run several iterations (psd_sign_closed_cu_kernel)
+  int lds_triple = 1;      // psd_lds_triple: one-workgroup kernels of 33 <= n <= 64 with a third LDS matrix when the class has <= 256 blocks
   int sign_min = 65;       // psd_sign_min: blocks from this size on take the batched-GEMM matrix-sign path
   int overlap = 1;         // psd_overlap: size classes on their own streams
   // batched-GEMM path (psd_large.hip)
@@ -35,7 +36,7 @@ struct PsdOptions {
         {"CUADMM_PSD_DEBUG", &o.debug},           {"CUADMM_PSD_WAVE4_MIN", &o.wave4_min}, {"CUADMM_PSD_SIGN_MIN", &o.sign_min},
         {"CUADMM_PSD_W32_OCC", &o.w32_occ},       {"CUADMM_PSD_CU_OCC", &o.cu_occ},       {"CUADMM_PSD_OVERLAP", &o.overlap},
         {"CUADMM_PSD_N16", &o.n16_sign},    {"CUADMM_PSD_N32", &o.n32_sign},
-        {"CUADMM_PSD_MID", &o.mid},             {"CUADMM_PSD_LG_CLUSTER", &o.lg_cluster}};
+        {"CUADMM_PSD_MID", &o.mid},             {"CUADMM_PSD_LG_CLUSTER", &o.lg_cluster}, {"CUADMM_PSD_LDS_TRIPLE", &o.lds_triple}};
     for (auto& t : tab)
       if (const char* e = getenv(t.name)) {
         // historical spellings: N16 / N32 = "eig" (register eigensolver), MID = "eig" | "lds"
@@ -55,6 +56,7 @@ struct PsdOptions {
     else if (k == "psd_wave4_min") wave4_min = v;
     else if (k == "psd_w32_occ") w32_occ = v == 3 ? 3 : 4;
     else if (k == "psd_cu_occ") cu_occ = v == 3 ? 3 : 4;
+    else if (k == "psd_lds_triple") lds_triple = v;
     else if (k == "psd_sign_min") sign_min = v < 65 ? 65 : v;
     else if (k == "psd_overlap") overlap = v;
     else if (k == "psd_lg_tile") lg_tile = v;

@@ -95,7 +95,11 @@ __device__ __forceinline__ void sl_unpack(const double* __restrict__ src, int n,
 // Per-block adaptive schedule (sign_sched.h): every wavefront reduces the statistics of its own sub-tile (off-diagonal
 // sub-tiles count twice), the workgroup sums the NU partials in a fixed order after the barrier that the products need
 // anyway (+1 barrier per step between S Y and the combine), and every thread runs the same (uniform) state machine.
-template <int NP>
+// TRIPLE: a third matrix in LDS (the next iterate is stored beside the current one: no barrier between the last read of S and the
+// store of T) and the statistics -- three wave reductions, their exchange and its barrier -- only on the steps whose decision reads
+// them (SignSched::needs_stats: same decisions, same iterates bit for bit).  Two barriers per lift / probe step instead of three;
+// a moment relaxation's blocks spend 35 of ~41 steps there.  Taken when the class has at most one workgroup per CU anyway.
+template <int NP, bool TRIPLE>
 __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail,
                                                   double* smem, int* steps_out, int* hint) {
   using Cfg = SignLdsCfg<NP>;
@@ -107,6 +111,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   // fp64 matrix-core peak on the n = 45 blocks of C4).
   double* S = smem;
   double* Y = S + NP * LD;
+  double* S2 = TRIPLE ? Y + NP * LD : S;
   __shared__ double red[64];
   __shared__ double stat[3 * 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,40 +132,50 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   for (int c = 0; c < NP; ++c) { const double v = red[c]; nrm = (v > nrm || !(v == v)) ? v : nrm; }
   const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);
   for (int e = tid; e < NP * LD; e += Cfg::THREADS) S[e] *= scale;
+  if (TRIPLE) for (int e = tid; e < NP * LD; e += Cfg::THREADS) S2[e] = 0.0;       // the padding of the second copy
   __syncthreads();
   SignSched sched;
   if (hint && *hint > 0) sched.lift0 = *hint;
   bool last = false;
   while (!last) {
+    const bool stats = !TRIPLE || sched.needs_stats();
     const sl_v4f64 y = sl_mma<NP>(S, S, ti, tj, lane);                               // Y = S*S
     sl_store<NP>(Y, y, ti, tj, lane);
     double pa = 0.0, pb = 0.0;
+    if (stats) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (ti == tj && kk + 4 * r == r16) pa += y[r];
-      pb += y[r] * y[r];
+      for (int r = 0; r < 4; ++r) {
+        if (ti == tj && kk + 4 * r == r16) pa += y[r];
+        pb += y[r] * y[r];
+      }
+      pa = wave_sum(pa);
+      pb = wave_sum(pb) * wgt;
     }
-    pa = wave_sum(pa);
-    pb = wave_sum(pb) * wgt;
     __syncthreads();
     const sl_v4f64 z = sl_mma<NP>(S, Y, ti, tj, lane);                               // S*Y
     const sl_v4f64 e = sl_tile<NP>(S, ti, tj, lane);
-    double pg = 0.0;
+    double mu;
+    if (stats) {
+      double pg = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const double d = e[r] - z[r]; pg += d * d; }
-    pg = wave_sum(pg) * wgt;
-    if (lane == 0) { stat[wave] = pa; stat[16 + wave] = pb; stat[32 + wave] = pg; }
-    __syncthreads();                                                                 // statistics visible; all reads of S done
-    double ta = 0.0, tb = 0.0, tg = 0.0;
+      for (int r = 0; r < 4; ++r) { const double d = e[r] - z[r]; pg += d * d; }
+      pg = wave_sum(pg) * wgt;
+      if (lane == 0) { stat[wave] = pa; stat[16 + wave] = pb; stat[32 + wave] = pg; }
+      __syncthreads();                                                               // statistics visible; all reads of S done
+      double ta = 0.0, tb = 0.0, tg = 0.0;
 #pragma unroll
-    for (int w = 0; w < Cfg::NU; ++w) { ta += stat[w]; tb += stat[16 + w]; tg += stat[32 + w]; }
-    const double mu = sched.decide<false>(n, ta, tb, tg, last);
+      for (int w = 0; w < Cfg::NU; ++w) { ta += stat[w]; tb += stat[16 + w]; tg += stat[32 + w]; }
+      mu = sched.decide<false>(n, ta, tb, tg, last);
+    } else {
+      mu = sched.decide<false>(n, 0.0, 0.0, 0.0, last);                              // the scale of this step was fixed in advance
+    }
     const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
     sl_v4f64 t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = alpha * z[r] + beta * e[r];                   // T = 1.5 mu S - 0.5 mu^3 S*Y
-    sl_store<NP>(S, t, ti, tj, lane);                                                // in place: the sub-tile and its mirror image
+    sl_store<NP>(S2, t, ti, tj, lane);                                               // the sub-tile and its mirror image (TRIPLE: beside S, else in place)
     __syncthreads();
+    if (TRIPLE) { double* u = S; S = S2; S2 = u; }
   }
   if (steps_out && tid == 0) *steps_out = sched.steps;
   if (hint && tid == 0) *hint = sched.lifts;

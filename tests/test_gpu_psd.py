@@ -313,6 +313,25 @@ def test_project_sign_path_one_launch_variant_is_bit_identical(blk, monkeypatch)
     assert np.max(np.abs(one - ref)) <= 2e-12 * max(np.linalg.norm(m, 2) for m in mats) * np.sqrt(2)
 
 
+def test_project_one_workgroup_kernels_third_lds_matrix_is_bit_identical(monkeypatch):
+    """33 <= n <= 64 with few blocks of a class (a moment relaxation: pendulum N = 80 has 80 of n = 55): the one-workgroup kernel
+    with the next iterate stored beside the current one and the statistics only where the schedule reads them
+    (psd_sign_lds_body<NP, TRIPLE>) against the two-matrix variant -- same decisions, same iterates, not one bit of difference."""
+    rng = np.random.default_rng(5)
+    blk = np.array([55] * 40 + [45] * 30 + [64, 33, 48, 49], np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = rng.standard_normal(int(bidx.off[-1]))
+    for k in range(0, blk.size, 3):                             # moment-matrix-like: rank 3 plus noise at 1e-12 (~40 steps)
+        n = int(blk[k]); U = rng.standard_normal((n, 3)); G = rng.standard_normal((n, n))
+        x[int(bidx.off[k]):int(bidx.off[k + 1])] = orc.BlockIndex([n]).pack([(U @ U.T + 1e-12 * (G + G.T))[None]])
+    monkeypatch.setenv("CUADMM_PSD_LDS_TRIPLE", "1")
+    a = psd_project_gpu(x, blk)
+    monkeypatch.setenv("CUADMM_PSD_LDS_TRIPLE", "0")
+    b = psd_project_gpu(x, blk)
+    assert np.array_equal(a, b)
+    assert np.max(np.abs(a - orc.psd_project_svec(bidx, x))) <= 1e-12 * 64
+
+
 def test_project_sign_path_full_size_properties():
     """BASELINE config 3 size (one block of n = 2000): oracle parity, idempotence, Moreau decomposition, complementarity."""
     n = 2000
