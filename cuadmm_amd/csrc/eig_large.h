@@ -19,6 +19,9 @@ struct EigLargeWs {
   int* dflag = nullptr;
   int ensure(int n);
   void release();
+  EigLargeWs() = default;
+  EigLargeWs(const EigLargeWs&) = delete;              // owns device memory
+  EigLargeWs& operator=(const EigLargeWs&) = delete;
   ~EigLargeWs() { release(); }
 };
 
