@@ -23,6 +23,7 @@ struct SignPsd {
   int* d_group = nullptr;                    // [members not finished, largest step count] of the group in flight
   int* h_group = nullptr;                    // pinned host copy (polled between chunks of steps)
   unsigned* d_bar = nullptr;                 // per member: barrier counter of the one-launch variant
+  int* d_xcc = nullptr;                      // [member][tile]: XCD of every workgroup of the one-launch variant (run-time check)
   int build(const int* blk, const std::vector<int>& members);
   void release();
   int project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);

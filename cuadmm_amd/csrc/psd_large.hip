@@ -345,53 +345,83 @@ constexpr int kClusterMaxWgs = 224;
 struct ClusterArgs {
   double *S, *T, *Y, *X0;
   unsigned* bar;            // per member, zeroed by lg_state_init_kernel
+  int* xcc;                 // [member][tile]: the XCD every workgroup found itself on
   int* fail;
-  int N, max_steps;
+  int N, max_steps, count, force_agent;
+  int spread;               // 1: workgroups in plain order (member = w / ntiles) -- a member too large for one XCD's CUs
 };
-__device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target) {
+// local: every workgroup of the member sits on the SAME XCD (checked at run time, below).  Then their common L2 is the coherence
+// point: a workgroup signals once its own stores have completed (s_waitcnt vmcnt(0): the per-CU L1 writes through) and a waiter
+// only drops its CU's L1 (buffer_inv sc0) -- no write-back of the XCD's L2, no L2 invalidate, and the operands of the next phase
+// are L2 hits.  Otherwise: agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1), correct across XCDs.
+__device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target, bool local) {
+  if (local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int ok;
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int good = 1;
     long long spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(2);
       if (++spins > (1ll << 24)) { good = 0; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (local) asm volatile("buffer_inv sc0" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     ok = good;
   }
   __syncthreads();
   return ok != 0;
 }
+// 1-D grid: workgroup w runs on XCD w % 8 (round-robin dispatch: tools/ubench/xcc_probe.hip), so member m = (w % 8) + 8 j takes the
+// workgroups w = (m % 8) + 8 (j ntiles + tile): all of a member's workgroups on one XCD.  Nothing RELIES on that: every workgroup
+// publishes the XCD it really runs on (HW_REG_XCC_ID), and after a first (agent-scope) barrier each checks that its member's are equal
+// -- only then the light barrier is used.
 template <int TM, int BK>
 __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterArgs ca, SignArgs sg) {
   __shared__ double smem[LgGemmCfg<true, TM, BK>::SMEM];
   __shared__ double red[16];
-  const int member = (int)blockIdx.y, tile = (int)blockIdx.x;
+  __shared__ int s_local;
   const int N = ca.N;
   const int nbt = N / TM;
   const unsigned ntiles = (unsigned)(nbt * (nbt + 1) / 2);
+  const int w = (int)blockIdx.x, slot = w >> 3;
+  const int member = ca.spread ? w / (int)ntiles : (w & 7) + 8 * (slot / (int)ntiles);
+  const int tile = ca.spread ? w % (int)ntiles : slot % (int)ntiles;
+  if (member >= ca.count) return;               // the whole workgroup, before any barrier
   unsigned* bar = ca.bar + member;
+  unsigned phase = 0;
+  {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) __hip_atomic_store(ca.xcc + (size_t)member * ntiles + tile, x & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!lg_member_barrier(bar, ntiles * ++phase, false)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+    if (threadIdx.x == 0) {
+      int same = ca.force_agent ? 0 : 1;
+      for (unsigned q = 0; q < ntiles; ++q)
+        same &= __hip_atomic_load(ca.xcc + (size_t)member * ntiles + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (x & 15);
+      s_local = same;
+    }
+    __syncthreads();
+  }
+  const bool local = s_local != 0;
   double* s = ca.S;
   double* t = ca.T;
-  unsigned phase = 0;
   int step = 0;
   for (; step < ca.max_steps; ++step) {
     sg.step = step;
     // done_at is written by this member's writer workgroup during the second product of the step before: ordered by the barrier
     if (__hip_atomic_load(&sg.done[member].done_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) break;
-    lg_gemm_sym_body<true, TM, BK, 1>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, nullptr, member, tile, (int)gridDim.x, smem, red);
-    if (!lg_member_barrier(bar, ntiles * ++phase)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
-    lg_gemm_sym_body<true, TM, BK, 2>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, nullptr, member, tile, (int)gridDim.x, smem, red);
-    if (!lg_member_barrier(bar, ntiles * ++phase)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+    lg_gemm_sym_body<true, TM, BK, 1>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
+    if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+    lg_gemm_sym_body<true, TM, BK, 2>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
+    if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
     double* u = s; s = t; t = u;
   }
   // P = 0.5 (X0 + X0 S_final); `s` holds the last iterate
   sg.step = step;
-  lg_gemm_sym_body<true, TM, BK, 0>(N, ca.X0, s, 0.5, 0.5, ca.X0, ca.Y, 0, sg, nullptr, member, tile, (int)gridDim.x, smem, red);
+  lg_gemm_sym_body<true, TM, BK, 0>(N, ca.X0, s, 0.5, 0.5, ca.X0, ca.Y, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
 }
 
 // Group descriptors: member m of the group is block ids[m]; n = bn[id], svec offset boff[id].
@@ -591,6 +621,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   CUADMM_HIP_TRY(hipMalloc(&d_done, sizeof(SignDone) * (size_t)max_count));
   CUADMM_HIP_TRY(hipMalloc(&d_group, sizeof(int) * 2));
   CUADMM_HIP_TRY(hipMalloc(&d_bar, sizeof(unsigned) * (size_t)max_count));
+  CUADMM_HIP_TRY(hipMalloc(&d_xcc, sizeof(int) * (size_t)(kClusterMaxWgs + 64)));
   CUADMM_HIP_TRY(hipHostMalloc(&h_group, sizeof(int) * 2, hipHostMallocDefault));
   size_t max_part = 0;
   for (const Group& g : groups) max_part = std::max(max_part, (size_t)g.count * 2 * (size_t)(g.N / 32) * (size_t)(g.N / 32 + 1) / 2);
@@ -601,11 +632,11 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
 
 void SignPsd::release() {
   if (graph_exec) { hipError_t e = hipGraphExecDestroy(graph_exec); (void)e; graph_exec = nullptr; }
-  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar})
+  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar, (void*)d_xcc})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   if (d_group) { hipError_t e = hipFree(d_group); (void)e; d_group = nullptr; }
   if (h_group) { hipError_t e = hipHostFree(h_group); (void)e; h_group = nullptr; }
-  d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr; d_bar = nullptr;
+  d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr; d_bar = nullptr; d_xcc = nullptr;
   X0 = S = Y = T = colsum = scale = nullptr;
   groups.clear();
 }
@@ -687,8 +718,11 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
     const bool cluster = opt.lg_cluster != 0 && !decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)ntiles * cnt <= kClusterMaxWgs;
     if (cluster) {
-      ClusterArgs ca{S, T, Y, X0, d_bar, d_fail, N, max_steps};
-      hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(ntiles, cnt), dim3(256), 0, st, ca, sa);
+      // one XCD has 32 CUs x 4 workgroups of this kernel: a member's workgroups go to ONE XCD only while everything mapped there stays
+      // co-resident with room to spare; else plain order over the whole chip (agent-scope barriers)
+      const int spread = ((cnt + 7) / 8) * ntiles > 96 ? 1 : 0;
+      ClusterArgs ca{S, T, Y, X0, d_bar, d_xcc, d_fail, N, max_steps, cnt, opt.lg_cluster == 2 ? 1 : 0, spread};   // psd_lg_cluster = 2: agent-scope barriers always (A/B, tests)
+      hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(spread ? cnt * ntiles : 8 * ((cnt + 7) / 8) * ntiles), dim3(256), 0, st, ca, sa);
       CUADMM_HIP_TRY(hipGetLastError());
       enq = max_steps;
     }

@@ -304,11 +304,13 @@ def test_project_sign_path_one_launch_variant_is_bit_identical(blk, monkeypatch)
             U = rng.standard_normal((int(n), 3)); G = rng.standard_normal((int(n), int(n)))
             mats.append(U @ U.T + 1e-12 * (G + G.T))
     x = np.concatenate([orc.BlockIndex([m.shape[0]]).pack([m[None]]) for m in mats])
-    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "1")
+    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "1")          # members on one XCD each: barriers through the shared L2 (checked at run time)
     one = psd_project_gpu(x, blk)
+    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "2")          # the same launch with agent-scope release / acquire barriers
+    one_agent = psd_project_gpu(x, blk)
     monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "0")
     many = psd_project_gpu(x, blk)
-    assert np.array_equal(one, many)
+    assert np.array_equal(one, many) and np.array_equal(one_agent, many)
     ref = orc.psd_project_svec(bidx, x)
     assert np.max(np.abs(one - ref)) <= 2e-12 * max(np.linalg.norm(m, 2) for m in mats) * np.sqrt(2)
 
