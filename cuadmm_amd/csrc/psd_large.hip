@@ -377,7 +377,8 @@ __device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target
 // 1-D grid: workgroup w runs on XCD w % 8 (round-robin dispatch: tools/ubench/xcc_probe.hip), so member m = (w % 8) + 8 j takes the
 // workgroups w = (m % 8) + 8 (j ntiles + tile): all of a member's workgroups on one XCD.  Nothing RELIES on that: every workgroup
 // publishes the XCD it really runs on (HW_REG_XCC_ID), and after a first (agent-scope) barrier each checks that its member's are equal
-// -- only then the light barrier is used.
+// -- only then the light barrier is used.  (Measured and rejected: workgroup-scope read-modify-writes on the counter, hoping they
+// would be served by the shared L2 -- they are not coherent between CUs: the waiters time out.)
 template <int TM, int BK>
 __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterArgs ca, SignArgs sg) {
   __shared__ double smem[LgGemmCfg<true, TM, BK>::SMEM];
