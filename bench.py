@@ -133,7 +133,9 @@ def pmc_traffic(kernel_substr, config):
                     continue
                 for k, v in d.items():
                     if kernel_substr in k:
-                        best = v.get("hbm_bytes_per_launch")
+                        # a kernel that runs several iterations per launch is recorded per ITERATION too (the profiled run's launches
+                        # need not be as long as this run's): scaled to this run's launch length by the caller
+                        best = (v.get("hbm_bytes_per_launch"), v.get("hbm_bytes_per_iteration"))
     return best
 
 
@@ -455,6 +457,9 @@ def main():
         kname = {"c1": "lg_gemm_sym_kernel", "c2": "psd_sign_closed_cu_kernel<2" if batched else ("psd_sign_closed_kernel<2" if closed else "psd_sign_wave_kernel<2"),
                  "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_closed_kernel<3" if closed else "psd_sign_wave_kernel<3", "c5": "psd_sign_lds_kernel"}[args.config]
         per_s = psd_ms * 1e-3
+        traffic = pmc_traffic(kname, args.config)
+        if traffic is not None:
+            traffic = traffic[1] * iters_per_launch if (batched and traffic[1]) else traffic[0]
         shard_iters = (world if (args.scaling == "weak" or replicas) else 1) * args.steps
         out = {
             "metric": {"c1": "ADMM iters/sec, PlanarHand_N=1 moment relaxation (+ PSD-proj TFLOP/s in roofline)",
@@ -485,7 +490,7 @@ def main():
                          "achieved": nominal_flops / per_s / 1e12 if per_s > 0 else 0.0,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (nominal_flops / per_s / 1e12 / FP64_PEAK_TFLOPS) if per_s > 0 else 0.0,
-                         "traffic": pmc_traffic(kname, args.config), "avg_launch_ms": psd_ms * iters_per_launch,
+                         "traffic": traffic, "avg_launch_ms": psd_ms * iters_per_launch,
                          "launches": int(launches), "iterations_per_launch": iters_per_launch, "ms_per_iteration": psd_ms,
                          # what the matrix cores deliver when EVERY SIMD runs nothing but independent v_mfma_f64_16x16x4_f64
                          # (tools/ubench/mfma_sustained.hip, profiles/r02_mfma_sustained.log): the achievable ceiling
@@ -499,8 +504,9 @@ def main():
                                                  "note": "per-block adaptive schedule (csrc/sign_sched.h); round 1 ran a fixed 44"},
                          "hbm_gbs": alg_bytes / per_s / 1e9 if per_s > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes * iters_per_launch,
                          "note": "fp64 matrix-core bound (DESIGN.md section 4); traffic = FETCH_SIZE*2 + WRITE_SIZE from the "
-                                 "committed rocprofv3 PMC passes (profiles/); algorithmic bytes 68 B per svec element of a fused block "
-                                 "(the launch also does the aty_xb / post vector work), 16 B elsewhere",
+                                 "committed rocprofv3 PMC passes (profiles/), for launches of several iterations the profile's bytes "
+                                 "per iteration x this run's iterations per launch; algorithmic bytes 32 B per svec element of a closed "
+                                 "block (X, C read; S, X written) + its 1.5 KB record, 68 B of a fused block, 16 B elsewhere",
                          "blocks_per_s": blk_local.size / per_s if per_s > 0 else 0.0},
             "final_state": {k: st[k] for k in ("errRp", "errRd", "relgap", "sig")},
         }

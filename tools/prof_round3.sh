@@ -13,11 +13,11 @@ prof () {   # tag, command...
   timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$G/prof_${tag}_fetch" -- "$@" > "$G/${tag}_fetch.log" 2>&1
   timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$G/prof_${tag}_write" -- "$@" > "$G/${tag}_write.log" 2>&1
   timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$G/prof_${tag}_sq" -- "$@" > "$G/${tag}_sq.log" 2>&1
+  grep '^{' "$G/${tag}_fetch.log" > "$G/r03_${tag}_bench_under_rocprof.json" || true
   python3 "$R/tools/summarize_prof.py" "r03_${tag}" "$(dirname "$(find "$G/prof_${tag}" -name "*kernel_stats.csv" | head -1)")" \
       "$(dirname "$(find "$G/prof_${tag}_fetch" -name "*counter_collection.csv" | head -1)")" \
       "$(dirname "$(find "$G/prof_${tag}_write" -name "*counter_collection.csv" | head -1)")" \
-      "$(dirname "$(find "$G/prof_${tag}_sq" -name "*counter_collection.csv" | head -1)")" > "$G/${tag}_summary.log" 2>&1
-  grep '^{' "$G/${tag}_trace.log" > "$G/r03_${tag}_bench_under_rocprof.json" || true
+      "$(dirname "$(find "$G/prof_${tag}_sq" -name "*counter_collection.csv" | head -1)")" "$G/r03_${tag}_bench_under_rocprof.json" > "$G/${tag}_summary.log" 2>&1
   rm -rf "$G/prof_${tag}" "$G/prof_${tag}_fetch" "$G/prof_${tag}_write" "$G/prof_${tag}_sq"
 }
 CFG="${*:-c2 c2_20 c4 c1 c5 c3}"

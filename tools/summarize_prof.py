@@ -41,6 +41,20 @@ for k in sorted(set(fetch) | set(write)):
     wr = write.get(k, (0.0, 0))[0] * 1024.0
     summary[k] = {"FETCH_SIZE_bytes_raw": fr, "fetch_bytes_corrected_x2": 2.0 * fr, "WRITE_SIZE_bytes": wr,
                   "hbm_bytes_per_launch": 2.0 * fr + wr, "launches_sampled": fetch.get(k, (0, 0))[1]}
+# kernels that run SEVERAL ADMM iterations per launch: bytes per iteration from the engine's own counters in the bench line of the
+# profiled run (argv[6]: its JSON; engine_plan.batch_iters / batch_launches), so that a reader can compare with another run's launches
+bench = None
+if len(sys.argv) > 6 and os.path.exists(sys.argv[6]):
+    try:
+        bench = json.load(open(sys.argv[6]))
+    except Exception:
+        bench = None
+if bench and bench.get("engine_plan", {}).get("batch_launches", 0) > 0:
+    ipl = bench["engine_plan"]["batch_iters"] / bench["engine_plan"]["batch_launches"]
+    for k, v in summary.items():
+        if "closed_cu_kernel" in k:
+            v["iterations_per_launch_in_profile"] = ipl
+            v["hbm_bytes_per_iteration"] = v["hbm_bytes_per_launch"] / ipl
 with open(os.path.join(out, "%s_pmc_hbm_traffic.json" % tag), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1)[:3000])
