@@ -191,16 +191,59 @@ __global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeD
   int* snode = sci + nnz;
   int* s_off = snode + cnt;
   int* s_g = s_off + nlev + 1;
-  for (int l = tid; l <= nlev; l += NT) s_off[l] = lvl_off[l0 + l] - first;
-  for (int l = tid; l < nlev; l += NT) { const int G = lvl_g[l0 + l]; s_g[l] = 31 - __clz(G); }      // log2 of the lanes per row
-  for (int i = tid; i <= cnt; i += NT) sptr[i] = (int)(ptr[first + i] - q0);
-  for (int i = tid; i < cnt; i += NT) {
+  // Copy-in in TWO memory round trips.  Written as plain loops (load, store to LDS, next element) every iteration waits for its
+  // own load: five loops of up to five iterations each cost ~35 us on a big tree -- most of the kernel.  So: every load that is
+  // addressed from the descriptor alone is issued first (U elements per thread and array), then the gathers that need the node
+  // ids, then the stores; what does not fit U elements per thread follows in plain loops.
+  constexpr int U = 8, UV = 16;
+  {
+    int r_off[U], r_g[U], r_ptr[U], r_nd[U], r_c[UV];
+    double r_v[UV], r_rhs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid + u * NT;
+      r_off[u] = i <= nlev ? lvl_off[l0 + i] : 0;
+      r_g[u] = i < nlev ? lvl_g[l0 + i] : 1;
+      r_ptr[u] = i <= cnt ? (int)(ptr[first + i] - q0) : 0;
+      r_nd[u] = i < cnt ? nodes[first + i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int q = tid + u * NT;
+      r_v[u] = q < nnz ? v[q0 + q] : 0.0;
+      r_c[u] = q < nnz ? ci[q0 + q] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid + u * NT, nd = r_nd[u];
+      r_rhs[u] = i < cnt ? (BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs(ax, asmc, b, isig, nd)) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid + u * NT;
+      if (i <= nlev) s_off[i] = r_off[u] - first;
+      if (i < nlev) s_g[i] = 31 - __clz(r_g[u]);             // log2 of the lanes per row
+      if (i <= cnt) sptr[i] = r_ptr[u];
+      if (i < cnt) { snode[i] = r_nd[u]; rhs[i] = r_rhs[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int q = tid + u * NT;
+      if (q < nnz) { sv[q] = r_v[u]; sci[q] = r_c[u]; }
+    }
+  }
+  for (int l = tid + U * NT; l <= nlev; l += NT) s_off[l] = lvl_off[l0 + l] - first;
+  for (int l = tid + U * NT; l < nlev; l += NT) { const int G = lvl_g[l0 + l]; s_g[l] = 31 - __clz(G); }
+  for (int i = tid + U * NT; i <= cnt; i += NT) sptr[i] = (int)(ptr[first + i] - q0);
+  for (int i = tid + U * NT; i < cnt; i += NT) {
     const int nd = nodes[first + i];
     snode[i] = nd;
     rhs[i] = BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs(ax, asmc, b, isig, nd);
   }
-  for (int q = tid; q < nnz; q += NT) { sv[q] = v[q0 + q]; sci[q] = ci[q0 + q]; }
+  for (int q = tid + UV * NT; q < nnz; q += NT) { sv[q] = v[q0 + q]; sci[q] = ci[q0 + q]; }
   if (NW > 1) __syncthreads(); else wave_fence();
+  // (Measured and rejected: fetching the level table, the row bounds and the first entry of every row one level ahead -- the level
+  // time of 1 180 ticks on a big tree is not the chain of LDS reads; it did not move.)
   int beg = s_off[0];
   for (int l = 0; l < nlev; ++l) {
     const int lg = s_g[l], G = 1 << lg, sub = lane & (G - 1), grp = lane >> lg, ngrp = 64 >> lg;
@@ -211,15 +254,13 @@ __global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeD
       if (idx < end)
         for (int q = sptr[idx] + sub; q < sptr[idx + 1]; q += G) s += sv[q] * xs[sci[q]];
       s = group_sum_dpp(s, lg);
-      if (idx < end && sub == 0) {
-        const double xi = rhs[idx] - s;
-        xs[idx] = xi;
-        x[snode[idx]] = xi;
-      }
+      if (idx < end && sub == 0) xs[idx] = rhs[idx] - s;
     }
     beg = end;
     if (NW > 1) __syncthreads(); else wave_fence();        // the next level reads xs written by this one
   }
+  // the solution leaves in one pass at the end
+  for (int i = tid; i < cnt; i += NT) x[snode[i]] = xs[i];
 }
 
 }  // namespace
