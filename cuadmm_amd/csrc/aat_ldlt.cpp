@@ -284,7 +284,12 @@ HostPool& host_pool() {
 
 // Cost model of the dense-tail split: host 1.2 ns per nonzero of the leading columns (both sweeps, measured),
 // GPU 60 us + k^2 * 8 B at 4 TB/s.  Returns 0 when the split does not pay for its PCIe round trip.
-int plan_tail(const int64_t* Lp, int m, int max_k) {
+// With the elimination tree (parent) the choice is refined for the DEVICE-side solve the engine runs when the leading forest is
+// shallow (lead_solve.hip): both sweeps cost ~0.65 us per level of the deepest leading tree (plus a side stream while big trees
+// exist), the tail one pass over k^2 / 2 doubles (two GEMVs beyond 20 480 columns) -- a somewhat larger tail that halves the depth
+// wins (pendulum N = 80: k 9 728 -> 12 032, depth 61 -> 28, y-solve 0.26 -> 0.20 ms).  The height of the forest restricted to the
+// first n1 columns is a prefix maximum of the node heights (a parent always has the larger index): one pass for every k.
+int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) {
   const double host_ns = 1.2, total = host_ns * (double)Lp[m];
   double best = total;
   int best_k = 0;
@@ -293,7 +298,29 @@ int plan_tail(const int64_t* Lp, int m, int max_k) {
     if (cost < best) { best = cost; best_k = k; }
   }
   if (best_k == 0 || best > 0.7 * total || total < 300e3) return 0;
-  return best_k;
+  if (!parent) return best_k;
+  std::vector<int> h((size_t)m, 1), hmax((size_t)m + 1, 0);      // hmax[n1] = height of the forest over columns < n1
+  for (int j = 0; j < m; ++j) {
+    hmax[(size_t)j + 1] = std::max(hmax[j], h[j]);
+    const int p = parent[j];
+    if (p >= 0 && h[p] < h[j] + 1) h[p] = h[j] + 1;
+  }
+  auto dev_us = [&](int k) {
+    const double ht = (double)hmax[(size_t)(m - k)];
+    const double tail = k <= 20480 ? (double)k * k * 4.0 / 4.6e6 + 15.0 : (double)k * k * 8.0 / 5.5e6;
+    return 2.0 * (8.0 + 0.65 * ht) + (ht > 40.0 ? 25.0 : 0.0) + tail;
+  };
+  // only where the device-side solve is plausible at all (the engine's own test: shallow forest); deep forests keep the host optimum
+  if (hmax[(size_t)(m - best_k)] > 256) return best_k;
+  int k_dev = best_k;
+  double c_dev = dev_us(best_k);
+  // only LARGER tails are considered: towards smaller ones the leading trees grow long rows, which the per-level figure does not
+  // see (PlanarHand_N=1 at k = 12 544 instead of 17 152: trees of 25 000 entries, sweeps three times slower)
+  for (int k = best_k + 256; k <= std::min(std::min(m, max_k), 2 * best_k); k += 256) {
+    const double c = dev_us(k);
+    if (c < 0.93 * c_dev) { c_dev = c; k_dev = k; }               // a clear gain only: the model is good to ~10 %
+  }
+  return k_dev;
 }
 
 int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* Ax, double eps, int split_max_k, cuadmm_aat** out);
@@ -415,7 +442,7 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
   for (int k = 0; k < m; ++k) f->Lp[k + 1] = f->Lp[k] + Lnz[k];
   f->analyze_s = now_s() - t0;
   t0 = now_s();
-  const int tail_k = split_max_k > 0 ? plan_tail(f->Lp.data(), m, split_max_k) : std::min(m, -split_max_k);
+  const int tail_k = split_max_k > 0 ? plan_tail(f->Lp.data(), m, split_max_k, parent.data()) : std::min(m, -split_max_k);
   const int n1 = m - tail_k;                     // rows / columns >= n1 belong to the unfactored tail
   f->tail_k = tail_k;
   try {
