@@ -8,6 +8,7 @@ namespace cuadmm {
 struct AtyLongRows {
   int cap = 128;
   int nlong = 0;
+  int max_short = 0;     // longest row below the cap (chooses the lanes-per-row variant of aty_xb)
   int* rows = nullptr;   // device
   int build(long long L, const int* rp_host);
   void release();
