@@ -513,6 +513,96 @@ __global__ __launch_bounds__(256) void lg_diff_kernel(const double* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// The one-launch variant's prologue in ONE launch (one workgroup of 1024 threads per member) instead of six (zero fill, unpack,
+// column sums, scale, scaled copy, state init: ~7 us each with their launch gaps -- a tenth of a PlanarHand projection): the svec is
+// gathered straight into the dense X0 (every element written: no zero fill), the column sums of |X0| are formed in the association
+// of lg_colsum_kernel / lg_scale_kernel (LG_CS_ROWS row chunks summed in chunk order: the same bits), S = X0 / ||X0||_1, and thread 0
+// writes the member's fresh schedule state.  For the small N of that variant only (the matrix is walked by one workgroup).
+__global__ __launch_bounds__(1024) void lg_prep_kernel(const double* __restrict__ src, const int* __restrict__ ids, const long long* __restrict__ boff,
+                                                       const int* __restrict__ bn, int N, double* __restrict__ X0b, double* __restrict__ Sb, SignArgs sa) {
+  __shared__ double red[1024];
+  const int m = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const int id = ids[m], n = bn[id];
+  const double* sv = src + boff[id];
+  double* X0 = X0b + (size_t)m * N * N;
+  double* S = Sb + (size_t)m * N * N;
+  for (int idx = tid; idx < N * N; idx += 1024) {
+    const int r = idx / N, c = idx - r * N;
+    double v = 0.0;
+    if (r < n && c < n) {
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      v = sv[(long long)hi * (hi + 1) / 2 + lo];
+      if (lo != hi) v *= kSqrt2Inv;
+    }
+    X0[idx] = v;
+  }
+  __syncthreads();
+  // column sums (lg_colsum_kernel: chunk z covers rows [z rows, (z + 1) rows), rows = ceil(N / LG_CS_ROWS); lg_scale_kernel: chunks in
+  // order).  All 1024 threads: thread t forms the chunk sums z = t / N, t / N + 1024 / N, ... of column t % N into LDS; then one thread per
+  // column adds its LG_CS_ROWS chunk sums in chunk order.
+  extern __shared__ double lgp_cs[];           // LG_CS_ROWS x N
+  const int rows = (N + LG_CS_ROWS - 1) / LG_CS_ROWS;
+  if (tid < (1024 / N) * N) {
+    const int c = tid % N;
+    for (int z = tid / N; z < LG_CS_ROWS; z += 1024 / N) {
+      const int r0 = z * rows, r1 = r0 + rows < N ? r0 + rows : N;
+      double s = 0.0;
+      for (int r = r0; r < r1; ++r) s += fabs(X0[(size_t)r * N + c]);
+      lgp_cs[z * N + c] = s;
+    }
+  }
+  __syncthreads();
+  double mx = 0.0;
+  for (int c = tid; c < N; c += 1024) {
+    double v = 0.0;
+    for (int z = 0; z < LG_CS_ROWS; ++z) v += lgp_cs[z * N + c];
+    mx = (v > mx || !(v == v)) ? v : mx;   // NaN propagates (flagged by the pack kernel)
+  }
+  red[tid] = mx;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if (tid < k) { const double v = red[tid + k]; if (v > red[tid] || !(v == v)) red[tid] = v; }
+    __syncthreads();
+  }
+  const double scale = red[0] > 0.0 ? 1.0 / red[0] : (red[0] == 0.0 ? 0.0 : red[0]);
+  for (int idx = tid; idx < N * N; idx += 1024) S[idx] = X0[idx] * scale;
+  if (tid == 0) {
+    if (m == 0) { sa.group[0] = sa.count; sa.group[1] = 0; }
+    SignDevState st;
+    st.sched = SignSched();
+    if (sa.hint && sa.hint[id] > 0) st.sched.lift0 = sa.hint[id];
+    st.mu = 1.0;
+    st.n = n;
+    sa.st[m] = st;
+    sa.done[m].done_at = 0x7fffffff;
+    sa.done[m].steps = 0;
+    if (sa.bar) sa.bar[m] = 0u;
+  }
+}
+// lg_pack_kernel + lg_steps_out_kernel in one launch (the one-launch variant's epilogue)
+__global__ void lg_pack_steps_kernel(const double* __restrict__ src, const int* __restrict__ ids, const long long* __restrict__ boff,
+                                     const int* __restrict__ bn, int N, double* __restrict__ dst, int* __restrict__ fail, SignArgs sa,
+                                     int* __restrict__ steps) {
+  const int id = ids[blockIdx.y];
+  const int n = bn[id];
+  const int len = n * (n + 1) / 2;
+  const double* s = src + (size_t)blockIdx.y * N * N;
+  double* d = dst + boff[id];
+  bool bad = false;
+  for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < len; e += (int)(gridDim.x * blockDim.x)) {
+    int i, j;
+    tri_decode(e, i, j);
+    const double v = s[(size_t)j * N + i];
+    bad |= !(fabs(v) <= 1.7976931348623157e308);
+    d[e] = (i == j) ? v : v * kSqrt2;
+  }
+  if (bad && fail) atomicAdd(fail, 1);
+  if (steps && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int m = (int)blockIdx.y;
+    steps[id] = sa.done[m].done_at <= sa.step ? sa.done[m].steps : sa.step;
+  }
+}
+
 static int lg_pad(int n) { return (n + LG_TM - 1) / LG_TM * LG_TM; }
 
 static bool lg_small_tiles(bool mirror, int N, int count, int tile_force = 0) {
@@ -684,12 +774,12 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     const int* ids = d_ids + g.begin;
     const unsigned gx = (unsigned)std::min<size_t>((per / 2 + 255) / 256, 1024);
     const auto t0 = std::chrono::steady_clock::now();
-    CUADMM_HIP_TRY(hipMemsetAsync(X0, 0, sizeof(double) * per * (size_t)cnt, st));
-    hipLaunchKernelGGL(lg_unpack_kernel, dim3(gx, cnt), dim3(256), 0, st, in, ids, boff, bn, N, X0);
-    hipLaunchKernelGGL(lg_colsum_kernel, dim3((N + 255) / 256, cnt, LG_CS_ROWS), dim3(256), 0, st, X0, N, colsum);
-    hipLaunchKernelGGL(lg_scale_kernel, dim3(cnt), dim3(256), 0, st, colsum, N, scale);
-    hipLaunchKernelGGL(lg_scaled_copy_kernel, dim3(gx, cnt), dim3(256), 0, st, X0, S, per, scale);
-    CUADMM_HIP_TRY(hipGetLastError());
+    // The decision of a step sums the tiles' slots: inside every workgroup of the S Y product when they are few, as a launch
+    // of its own when that would cost more than a launch (option psd_lg_decide = 1 | 2 forces one).
+    const int nbt = lg_small_tiles(true, N, cnt, opt.lg_tile) ? N / 32 : N / 64, ntiles = nbt * (nbt + 1) / 2;
+    const bool decide_kernel = decide_force ? decide_force == 2 : ntiles > 300;
+    // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
+    const bool cluster = opt.lg_cluster != 0 && !decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)ntiles * cnt <= kClusterMaxWgs;
     SignArgs sa{};
     sa.st = static_cast<SignDevState*>(d_state);
     sa.done = static_cast<SignDone*>(d_done);
@@ -701,14 +791,22 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     sa.count = cnt;
     sa.step = 0;
     sa.bar = d_bar;
-    hipLaunchKernelGGL(lg_state_init_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, bn);
+    if (cluster && N <= 512) {
+      const size_t lds_prep = sizeof(double) * LG_CS_ROWS * (size_t)N;
+      if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lg_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+      hipLaunchKernelGGL(lg_prep_kernel, dim3(cnt), dim3(1024), lds_prep, st, in, ids, boff, bn, N, X0, S, sa);
+    } else {
+      CUADMM_HIP_TRY(hipMemsetAsync(X0, 0, sizeof(double) * per * (size_t)cnt, st));
+      hipLaunchKernelGGL(lg_unpack_kernel, dim3(gx, cnt), dim3(256), 0, st, in, ids, boff, bn, N, X0);
+      hipLaunchKernelGGL(lg_colsum_kernel, dim3((N + 255) / 256, cnt, LG_CS_ROWS), dim3(256), 0, st, X0, N, colsum);
+      hipLaunchKernelGGL(lg_scale_kernel, dim3(cnt), dim3(256), 0, st, colsum, N, scale);
+      hipLaunchKernelGGL(lg_scaled_copy_kernel, dim3(gx, cnt), dim3(256), 0, st, X0, S, per, scale);
+      hipLaunchKernelGGL(lg_state_init_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, bn);
+    }
+    CUADMM_HIP_TRY(hipGetLastError());
     double* s = S;
     double* t = T;
     int rc;
-    // The decision of a step sums the tiles' slots: inside every workgroup of the S Y product when they are few, as a launch
-    // of its own when that would cost more than a launch (option psd_lg_decide = 1 | 2 forces one).
-    const int nbt = lg_small_tiles(true, N, cnt, opt.lg_tile) ? N / 32 : N / 64, ntiles = nbt * (nbt + 1) / 2;
-    const bool decide_kernel = decide_force ? decide_force == 2 : ntiles > 300;
     // Steps are enqueued in chunks; between chunks the host polls "members not finished" (8 bytes, one stream
     // synchronisation of ~20 us) instead of enqueueing the worst case kCap: a launch for a finished group costs ~5 us,
     // i.e. 0.5 ms per projection when the blocks stop after 16 of 64 steps.  The first chunk is the previous projection's
@@ -716,8 +814,6 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     // with CUADMM_PSD_SIGN_SYNC=0) the whole cap is enqueued and nothing synchronises.
     int enq = 0;
     int chunk = poll ? std::min(max_steps, g.pred > 0 ? g.pred + 2 : 24) : max_steps;
-    // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
-    const bool cluster = opt.lg_cluster != 0 && !decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)ntiles * cnt <= kClusterMaxWgs;
     if (cluster) {
       // one XCD has 32 CUs x 4 workgroups of this kernel: a member's workgroups go to ONE XCD only while everything mapped there stays
       // co-resident with room to spare; else plain order over the whole chip (agent-scope barriers)
@@ -749,8 +845,12 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     // P = 0.5 * (X0 + X0 * S_final); S_final is in S after an even number of steps, in T after an odd one
     sa.step = enq;
     if (!cluster && (rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T, opt.lg_tile))) return rc;
-    hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
-    if (d_steps) hipLaunchKernelGGL(lg_steps_out_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, d_steps);
+    if (cluster) {
+      hipLaunchKernelGGL(lg_pack_steps_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail, sa, d_steps);
+    } else {
+      hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
+      if (d_steps) hipLaunchKernelGGL(lg_steps_out_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, d_steps);
+    }
     CUADMM_HIP_TRY(hipGetLastError());
     if (debug) {
       CUADMM_HIP_TRY(hipStreamSynchronize(st));

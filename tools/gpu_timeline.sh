@@ -1,0 +1,20 @@
+#!/bin/bash
+# kernel timeline of one iteration of a bench configuration: bash tools/gpu_timeline.sh <bench args...>
+: "${GRAFT_REPO_ROOT:?}"
+set -u
+R="$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_tl" -- python3 "$R/bench.py" "$@" --no-cpu-baseline --no-breakdown > "$R/gpurun_out/tl_trace.log" 2>&1
+python3 - "$(find "$R/gpurun_out/prof_tl" -name '*kernel_trace.csv' | head -1)" <<'P'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+# find the 40th cluster / closed kernel and print the window around it
+idx=[i for i,r in enumerate(rows) if "cluster" in r["Kernel_Name"] or "sign_lds" in r["Kernel_Name"]]
+if not idx: idx=[len(rows)//2]
+c=idx[min(40,len(idx)-1)]
+t0=int(rows[max(0,c-25)]["Start_Timestamp"])
+for r in rows[max(0,c-25):c+30]:
+    print("%9.1f %8.1f  q%-3s %s" % ((int(r["Start_Timestamp"])-t0)/1e3, (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3, r.get("Queue_Id","?"), r["Kernel_Name"][:90]))
+P
+rm -rf "$R/gpurun_out/prof_tl"
