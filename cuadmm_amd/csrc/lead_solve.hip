@@ -478,13 +478,15 @@ int LeadSolve::solve(const double* ax, const double* asmc, const double* b, doub
   // the few big trees (four wavefronts each) run beside the many small ones on a second stream
   const bool side = n_big > 0 && n_small > 0 && aux != nullptr;
   hipStream_t sb = side ? aux : st;
-  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_fork, st)); CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0)); }
-  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_f), lvl_off_f, lvl_g_f,
-                                    nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
-  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_join, aux));
+  // the many small trees first, on the caller's stream (nothing to wait for: the first kernel of an iteration starts as soon as it is
+  // submitted); the few big ones beside them behind the fork event
+  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
   if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_f), lvl_off_f,
                                       lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
-  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0));
+  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_f), lvl_off_f, lvl_g_f,
+                                    nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
+  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_join, aux)); CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0)); }
   if (n_stream > 0) hipLaunchKernelGGL(lead_forward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_f, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b,
                                        isig, y, max_nodes, max_levels, trees_stream);
   hipLaunchKernelGGL(lead_tail_rhs_kernel, dim3((k * 8 + 255) / 256), dim3(256), 0, st, k, n1, rp21, ci21, v21, ax, asmc, b, isig, y, tail.vin);
@@ -492,13 +494,13 @@ int LeadSolve::solve(const double* ax, const double* asmc, const double* b, doub
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
   hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
-  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_fork, st)); CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0)); }
-  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_b), lvl_off_b, lvl_g_b,
-                                    nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_join, aux));
+  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
   if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_b), lvl_off_b,
                                       lvl_g_b, nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0));
+  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_b), lvl_off_b, lvl_g_b,
+                                    nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
+  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_join, aux)); CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0)); }
   if (n_stream > 0) hipLaunchKernelGGL(lead_backward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_b, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_, D1, wvec, y,
                                        max_nodes, max_levels, trees_stream);
   CUADMM_HIP_TRY(hipGetLastError());

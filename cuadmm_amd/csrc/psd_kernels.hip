@@ -563,15 +563,21 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
   bool side_forked = false;
   int last_class = -1;
   for (int c = 0; c < kNumPsdClasses; ++c) if (cls_count[c] > 0) last_class = c;
+  // without a sign path the class of the LARGEST blocks (the longest chain: pendulum N = 80's 80 blocks of n = 55) stays on the caller's
+  // stream: it starts right behind the kernel before it instead of behind a fork event, and the join waits for the short classes only
+  const int main_class = (fork && sign.empty()) ? last_class : -1;
   for (int c = 0; c < kNumPsdClasses; ++c) {
     if (cls_count[c] == 0) continue;
     if (fork) {   // the sign path keeps the main stream (it is the longest chain)
       // beside a sign path (hundreds of microseconds) the small classes (tens each) share ONE side stream, one after the other: one
       // fork and one join instead of one per class (each costs ~10 us of idle queue), and none of them can land on the hardware queue
       // of the main stream (streams are multiplexed onto four queues: the n = 28 class of PlanarHand_N=1 ran in FRONT of the sign path)
-      st = one_side ? aux[0] : aux[c];
-      if (!one_side || !side_forked) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_fork, 0));
-      side_forked = true;
+      if (c == main_class) st = main_st;
+      else {
+        st = one_side ? aux[0] : aux[c];
+        if (!one_side || !side_forked) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_fork, 0));
+        side_forked = true;
+      }
     }
     PsdArgs a{};
     a.in = Xb; a.out = Xproj; a.Wout = nullptr; a.info = d_fail;
@@ -605,7 +611,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
                       "iteration %.0f (%.1f steps, %.0f per step) epilogue %.0f\n",
               c, cls_count[c], ph[0] / nw, ph[4] / nw, ph[5] / nw, ph[6] / nw, ph[1] / nw, ph[3] / nw, ph[1] / std::max(ph[3], 1.0), ph[2] / nw);
       { hipError_t e = hipFree(d); (void)e; }
-      if (fork && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
+      if (fork && c != main_class && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
       continue;
     }
     if (c == 3 && fz && fz->iters > 1 && opt.debug >= 2) {   // developer aid (psd_debug = 2): phase ticks of the batched launches at full occupancy
@@ -630,7 +636,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
               ph[0] + ph[1] + ph[2]);
       (void)it0;
       { hipError_t e = hipFree(d); (void)e; }
-      if (fork && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
+      if (fork && c != main_class && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
       continue;
     }
     if (c == 3 && psd_debug && !sign32) {   // phase cycles of the register eigensolver
@@ -685,7 +691,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       (void)slots; (void)tmin; (void)tmax;
       { hipError_t e = hipFree(dbg); (void)e; }
     }
-    if (fork && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
+    if (fork && c != main_class && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
   }
   st = main_st;
   if (n_free > 0 && Xb != Xproj) {   // unconstrained blocks: Xproj = Xb on their svec ranges
@@ -698,7 +704,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
   }
   if (fork)
     for (int c = 0; c < kNumPsdClasses; ++c)
-      if (cls_count[c] > 0 && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_done[c], 0));
+      if (cls_count[c] > 0 && c != main_class && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_done[c], 0));
   return CUADMM_OK;
 }
 
