@@ -194,6 +194,7 @@ struct cuadmm_solver {
     bool out_dirty = true;         // a stand-alone kernel rewrote [A X | A (S - C)] by row: refresh the per-block copy first
     long long iters_done = 0;      // fused closed iterations launched so far (ages the schedule hints deterministically)
   } closed;
+  DevBuf<double> quad_seg;         // segment sums of launch_reduce_quads (more than 16 384 fused blocks)
   bool stats_fused = false;        // this iteration's four scalars were formed by launch_reduce_quads
   int fused_nparts = 0;
   // Several iterations per launch (SignFuse::iters; closed blocks, ADMM phase): option "batch" = most iterations per launch
@@ -529,7 +530,8 @@ struct cuadmm_solver {
                           out_w + (size_t)m, st, stats_fused ? &nparts : nullptr);
     if (!rc && stats_fused) {   // all four scalars of the stopping test in one launch (rp_stats is not needed this iteration)
       double* dst = (!dev_scalars && h_scal_dev) ? h_scal_dev : scal_d.p;
-      rc = launch_reduce_quads(partials.p, nparts, closed.partials2.p, plan.fused_blocks(), dst, out_w + (size_t)m, st);
+      if (!quad_seg.p && reduce_quads_segments(nparts, plan.fused_blocks()) > 1 && (rc = quad_seg.alloc(4 * (size_t)reduce_quads_segments(nparts, plan.fused_blocks()) + 4))) return rc;
+      rc = launch_reduce_quads(partials.p, nparts, closed.partials2.p, plan.fused_blocks(), dst, out_w + (size_t)m, quad_seg.p, st);
     }
     prof_end(K_POST, (mode == 0 ? 48.0 : 32.0) * (double)plan.n_rest);
     return rc;

@@ -566,7 +566,9 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
   // without a sign path the class of the LARGEST blocks (the longest chain: pendulum N = 80's 80 blocks of n = 55) stays on the caller's
   // stream: it starts right behind the kernel before it instead of behind a fork event, and the join waits for the short classes only
   const int main_class = (fork && sign.empty()) ? last_class : -1;
-  for (int c = 0; c < kNumPsdClasses; ++c) {
+  for (int cc = 0; cc < kNumPsdClasses; ++cc) {
+    // the class that stays on the caller's stream (the longest chain) is launched FIRST, the others in ascending order
+    const int c = main_class < 0 ? cc : (cc == 0 ? main_class : (cc <= main_class ? cc - 1 : cc));
     if (cls_count[c] == 0) continue;
     if (fork) {   // the sign path keeps the main stream (it is the longest chain)
       // beside a sign path (hundreds of microseconds) the small classes (tens each) share ONE side stream, one after the other: one

@@ -38,7 +38,8 @@ int launch_aty_xb_idx(long long nidx, const int* idx, const int* rp, const int* 
 int launch_post_rest(int mode, long long nidx, const int* idx, int nfused, const double* Xproj, const double* Rd1, const double* C, double* X,
                      double* S, double inv_sig, double tau_sig, double* partials, double* sums_out, hipStream_t st, int* nparts_out = nullptr);
 // all four scalars of the stopping test from the per-block partial pairs of a fused iteration with closed blocks
-int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, hipStream_t st);
+int reduce_quads_segments(int n1, int n2);
+int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, double* seg_scratch, hipStream_t st);
 // per-block copy of the closed blocks' rows of [A X | A (S - C)] from the by-row vectors (psd_sign_closed.h)
 struct ClosedRec;
 int launch_closed_gather_out(const ClosedRec* rec, int nslots, const double* ax, const double* as, double* cl_out, hipStream_t st);

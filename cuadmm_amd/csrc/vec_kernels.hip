@@ -272,22 +272,42 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pairs_kernel(const doub
 // Fused iteration with closed blocks (psd_fuse.h): the projection kernels left BOTH partial pairs per block -- (sum Rd^2,
 // <C, X>) in p1 (followed by the pairs of the stand-alone post step) and (||Rp org||^2, b^T y) in p2 -- and this one
 // workgroup forms all four scalars of the stopping test: out4 = [||Rp||^2, b.y, sum Rd^2, <C,X>], sums_out = out4[2..3].
+// The sums are formed per SEGMENT of kQuadSeg consecutive pairs (one workgroup per segment: thread t adds pairs t, t + 1024, ... of
+// its segment into two alternating accumulators, then the workgroup's tree) and the segment sums are added in segment order.  Up to
+// kQuadSeg pairs (BASELINE configs[1]: 10 000 blocks) that is the single-workgroup reduction of round 2, bit for bit; beyond (configs[3]:
+// 100 000 blocks, 57 us through one CU) the segments run on as many workgroups.  Every variant -- one launch per iteration, several
+// iterations per launch -- uses this association: the same bits.
+constexpr int kQuadSeg = 16384;
+__device__ __forceinline__ void quad_segment_sum(const double2* __restrict__ q, int n, int seg, double& a, double& b) {
+  const int beg = seg * kQuadSeg, end = n < beg + kQuadSeg ? n : beg + kQuadSeg;
+  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+  int i = beg + (int)threadIdx.x;
+  for (; i + kReduceThreads < end; i += 2 * kReduceThreads) { const double2 u = q[i], v = q[i + kReduceThreads]; a0 += u.x; b0 += u.y; a1 += v.x; b1 += v.y; }
+  for (; i < end; i += kReduceThreads) { const double2 u = q[i]; a0 += u.x; b0 += u.y; }
+  a = a0 + a1; b = b0 + b1;
+  block_sum2<kReduceThreads>(a, b);      // valid in thread 0
+  __syncthreads();
+}
 __global__ __launch_bounds__(kReduceThreads) void reduce_quads_kernel(const double* __restrict__ p1, int n1, const double* __restrict__ p2, int n2,
-                                                                     double* __restrict__ out4, double* __restrict__ sums_out) {
+                                                                     double* __restrict__ out4, double* __restrict__ sums_out, double* __restrict__ seg_out) {
   const double2* __restrict__ q1 = reinterpret_cast<const double2*>(p1);
   const double2* __restrict__ q2 = reinterpret_cast<const double2*>(p2);
-  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, c0 = 0.0, d0 = 0.0, c1 = 0.0, d1 = 0.0;
-  int i = threadIdx.x;
-  for (; i + kReduceThreads < n1; i += 2 * kReduceThreads) { const double2 u = q1[i], v = q1[i + kReduceThreads]; a0 += u.x; b0 += u.y; a1 += v.x; b1 += v.y; }
-  for (; i < n1; i += kReduceThreads) { const double2 u = q1[i]; a0 += u.x; b0 += u.y; }
-  i = threadIdx.x;
-  for (; i + kReduceThreads < n2; i += 2 * kReduceThreads) { const double2 u = q2[i], v = q2[i + kReduceThreads]; c0 += u.x; d0 += u.y; c1 += v.x; d1 += v.y; }
-  for (; i < n2; i += kReduceThreads) { const double2 u = q2[i]; c0 += u.x; d0 += u.y; }
-  double a = a0 + a1, b = b0 + b1, c = c0 + c1, d = d0 + d1;
-  block_sum2<kReduceThreads>(a, b);
-  __syncthreads();
-  block_sum2<kReduceThreads>(c, d);
-  if (threadIdx.x == 0) { out4[0] = c; out4[1] = d; out4[2] = a; out4[3] = b; sums_out[0] = a; sums_out[1] = b; }
+  const int sg = (int)blockIdx.x;
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+  if (sg * kQuadSeg < n1 || sg == 0) quad_segment_sum(q1, n1, sg, a, b);
+  if (sg * kQuadSeg < n2 || sg == 0) quad_segment_sum(q2, n2, sg, c, d);
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) { out4[0] = c; out4[1] = d; out4[2] = a; out4[3] = b; sums_out[0] = a; sums_out[1] = b; }
+    else { double* o = seg_out + 4 * (size_t)sg; o[0] = c; o[1] = d; o[2] = a; o[3] = b; }
+  }
+}
+__global__ void reduce_quads_final_kernel(const double* __restrict__ seg_out, int nseg, double* __restrict__ out4, double* __restrict__ sums_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double v[4] = {seg_out[0], seg_out[1], seg_out[2], seg_out[3]};
+  for (int s = 1; s < nseg; ++s)
+    for (int k = 0; k < 4; ++k) v[k] += seg_out[4 * (size_t)s + k];
+  for (int k = 0; k < 4; ++k) out4[k] = v[k];
+  sums_out[0] = v[2]; sums_out[1] = v[3];
 }
 
 // Several iterations per launch (SignFuse::iters): workgroup k forms the four scalars of iteration k from that iteration's partial
@@ -297,17 +317,14 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_quads_batch_kernel(cons
                                                                            long long stride, double* __restrict__ out4) {
   const double2* __restrict__ q1 = reinterpret_cast<const double2*>(p1 + (long long)blockIdx.x * stride);
   const double2* __restrict__ q2 = reinterpret_cast<const double2*>(p2 + (long long)blockIdx.x * stride);
-  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, c0 = 0.0, d0 = 0.0, c1 = 0.0, d1 = 0.0;
-  int i = threadIdx.x;
-  for (; i + kReduceThreads < n; i += 2 * kReduceThreads) { const double2 u = q1[i], v = q1[i + kReduceThreads]; a0 += u.x; b0 += u.y; a1 += v.x; b1 += v.y; }
-  for (; i < n; i += kReduceThreads) { const double2 u = q1[i]; a0 += u.x; b0 += u.y; }
-  i = threadIdx.x;
-  for (; i + kReduceThreads < n; i += 2 * kReduceThreads) { const double2 u = q2[i], v = q2[i + kReduceThreads]; c0 += u.x; d0 += u.y; c1 += v.x; d1 += v.y; }
-  for (; i < n; i += kReduceThreads) { const double2 u = q2[i]; c0 += u.x; d0 += u.y; }
-  double a = a0 + a1, b = b0 + b1, c = c0 + c1, d = d0 + d1;
-  block_sum2<kReduceThreads>(a, b);
-  __syncthreads();
-  block_sum2<kReduceThreads>(c, d);
+  const int nseg = n > 0 ? (n + kQuadSeg - 1) / kQuadSeg : 1;
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+  for (int sg = 0; sg < nseg; ++sg) {
+    double sa, sb, sc, sd;
+    quad_segment_sum(q1, n, sg, sa, sb);
+    quad_segment_sum(q2, n, sg, sc, sd);
+    if (sg == 0) { a = sa; b = sb; c = sc; d = sd; } else { a += sa; b += sb; c += sc; d += sd; }
+  }
   if (threadIdx.x == 0) { double* o = out4 + 4 * (size_t)blockIdx.x; o[0] = c; o[1] = d; o[2] = a; o[3] = b; }
 }
 
@@ -336,8 +353,16 @@ int launch_closed_gather_out(const ClosedRec* rec, int nslots, const double* ax,
   return CUADMM_OK;
 }
 
-int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_quads_kernel, dim3(1), dim3(kReduceThreads), 0, st, p1, n1, p2, n2, out4, sums_out);
+int reduce_quads_segments(int n1, int n2) {
+  const int nmax = n1 > n2 ? n1 : n2;
+  return nmax > 0 ? (nmax + kQuadSeg - 1) / kQuadSeg : 1;
+}
+// seg_scratch: 4 doubles per segment (reduce_quads_segments), only touched when there is more than one segment
+int launch_reduce_quads(const double* p1, int n1, const double* p2, int n2, double* out4, double* sums_out, double* seg_scratch, hipStream_t st) {
+  const int nseg = reduce_quads_segments(n1, n2);
+  if (nseg > 1 && !seg_scratch) { set_error("reduce_quads: no scratch for %d segments", nseg); return CUADMM_ERR_INVALID; }
+  hipLaunchKernelGGL(reduce_quads_kernel, dim3(nseg), dim3(kReduceThreads), 0, st, p1, n1, p2, n2, out4, sums_out, seg_scratch);
+  if (nseg > 1) hipLaunchKernelGGL(reduce_quads_final_kernel, dim3(1), dim3(64), 0, st, seg_scratch, nseg, out4, sums_out);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
