@@ -22,5 +22,13 @@ int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t after = nul
 int staged_h2d_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, hipStream_t after = nullptr);
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB LDS per CU / per workgroup
+// Lifts a kernel's cap on dynamic LDS to everything its static LDS leaves.  The attribute is per kernel and process-wide, so callers
+// never set "what this launch needs": a later, smaller request would lower it under another object's larger launches.
+inline hipError_t allow_max_dynamic_lds(const void* kern) {
+  hipFuncAttributes fa;
+  hipError_t e = hipFuncGetAttributes(&fa, kern);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxLdsBytes - fa.sharedSizeBytes));
+}
 constexpr int kMaxBlockSize = 4000;           // largest block the projection plans accept
 }  // namespace cuadmm

@@ -440,7 +440,8 @@ __global__ __launch_bounds__(EL_NT) void el_backtransform_kernel(const double* _
 
 template <typename KernT>
 int el_allow_lds(KernT kern, size_t bytes) {
-  if (bytes > 48 * 1024) CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  // per kernel and process-wide: always the hardware maximum (a later, smaller call must not lower it under a concurrent larger one)
+  if (bytes > 48 * 1024) CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
   return CUADMM_OK;
 }
 

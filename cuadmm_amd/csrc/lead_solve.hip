@@ -445,9 +445,10 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
     if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(trees_stream, t_stream))) return rc;
     desc_small_f = a0; desc_small_b = a1; desc_big_f = a2; desc_big_b = a3;
   }
+  // the attribute is per kernel and process-wide: always the hardware maximum, so that a second solver with smaller trees cannot lower it
   if (lds_big > 48 * 1024) {
-    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_sweep_lds_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_sweep_lds_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_sweep_lds_kernel<false, 4>)));
+    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_sweep_lds_kernel<true, 4>)));
   }
   // cost model of the resident variant: two bulk round trips, then ~0.15 us of LDS work per level
   if (n_stream == 0) est_us = 2.0 * (6.0 + 0.15 * max_levels) * (n_big > 0 ? 2.0 : 1.0) + 40.0 + (double)nnz * 2e-4;
@@ -461,8 +462,8 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
     return rc;
   CUADMM_HIP_TRY(hipMalloc(&wvec, sizeof(double) * (size_t)n1));
   if (lds_bytes > 48 * 1024) {
-    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lead_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_forward_kernel)));
+    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_backward_kernel)));
   }
   if (n_big > 0 && n_small > 0) {
     CUADMM_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));

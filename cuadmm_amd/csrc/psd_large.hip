@@ -793,7 +793,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     sa.bar = d_bar;
     if (cluster && N <= 512) {
       const size_t lds_prep = sizeof(double) * LG_CS_ROWS * (size_t)N;
-      if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lg_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+      if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lg_prep_kernel)));
       hipLaunchKernelGGL(lg_prep_kernel, dim3(cnt), dim3(1024), lds_prep, st, in, ids, boff, bn, N, X0, S, sa);
     } else {
       CUADMM_HIP_TRY(hipMemsetAsync(X0, 0, sizeof(double) * per * (size_t)cnt, st));

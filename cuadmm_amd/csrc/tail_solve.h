@@ -10,6 +10,7 @@ struct TailSolve {
   double* h_vec = nullptr;     // pinned staging vector
   double* xpart = nullptr;     // one-pass variant: n_wg partial result vectors
   int n_wg = 0;
+  bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   int apply(hipStream_t st);   // vin <- W^T diag(dinv) W vin
   double build_s = 0, factor_s = 0;

@@ -378,6 +378,7 @@ void TailSolve::release() {
   for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart}) if (p) { hipError_t e = hipFree(p); (void)e; }
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
+  attr_set = false;
   k = K = 0;
 }
 
@@ -560,7 +561,10 @@ int TailSolve::apply(hipStream_t st) {
   const size_t lds = sizeof(double) * 1024 * (size_t)(nc + (nc & 1));
   if (one_pass && xpart && lds <= kMaxLdsBytes - 1024 && nc <= 20) {
     auto launch = [&](auto kern) -> int {
-      if (lds > 48 * 1024) CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (lds > 48 * 1024 && !attr_set) {      // once per object: K, and with it the instantiation, never changes
+        CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));   // process-wide per kernel: the maximum
+        attr_set = true;
+      }
       hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, (long long)K, K, vin, dinv, xpart);
       return CUADMM_OK;
     };

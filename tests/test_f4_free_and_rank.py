@@ -126,6 +126,21 @@ def test_gpu_rank_limited_projection_of_a_block_beyond_the_old_fence():
 
 
 @pytest.mark.gpu
+def test_gpu_one_workgroup_kernels_small_plan_then_large_plan():
+    """The cap on a kernel's dynamic LDS is per kernel and process-wide (hipFuncAttributeMaxDynamicSharedMemorySize): it is lifted
+    once to everything the kernel's static LDS leaves (device_util.h: allow_max_dynamic_lds), never set to "what this plan needs" --
+    a plan of small blocks followed (or accompanied) by one of large blocks on the same kernel must both launch."""
+    from tests.helpers import psd_project_gpu
+    rng = np.random.default_rng(12)
+    for n in (70, 128, 66, 120):                                         # each call builds and drops a plan of its own
+        blk = np.array([n], np.int32)
+        x = rng.standard_normal(int(orc.blk_svec_len(blk).sum()))
+        ref = orc.psd_project_svec(orc.BlockIndex(blk), x, eig_rank=5)
+        got = psd_project_gpu(x, blk, eig_rank=5)
+        assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(x)) * n
+
+
+@pytest.mark.gpu
 def test_gpu_solver_with_a_free_block_matches_the_oracle():
     p = _problem_with_free_block()
     s = cuadmm_amd.SDPSolver(verbose=False)
