@@ -155,6 +155,16 @@ def test_cli_matches_engine_and_reference_format(problem_dirs, ref_logs):
     # unreadable directory -> exit(1) like the reference (io.cu:30-33)
     r2 = subprocess.run([exe, "/nonexistent/"], capture_output=True, text=True)
     assert r2.returncode == 1
+    # --json=<file> (not in the reference): the run's figures beside the console table, only when asked for
+    import json, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        side = os.path.join(tmp, "run.json")
+        r3 = subprocess.run([exe, d, "--max_iter=60", "--switch_admm=5000", "--quiet", "--json=" + side], capture_output=True, text=True, timeout=300)
+        assert r3.returncode == 0, r3.stderr
+        j = json.load(open(side))
+        assert j["iterations"] == 60 and j["vec_len"] == p.vec_len and j["con_num"] == p.con_num
+        assert abs(j["pobj"] - o.info.pobj[59]) <= 1e-8 * (1 + abs(o.info.pobj[59]))
+        assert j["iters_per_s"] > 0 and j["phases"]["psd_project"]["launches"] >= 60 and j["psd_project_nominal_tflops"] > 0
 
 
 @pytest.mark.parametrize("n", [64, 192, 1024])
