@@ -74,7 +74,12 @@ PLATO_MAT = {
     "bqp-r1-40-1": ("plato/MATLAB/bqp-r1-40-1.mat", "plato/TXT/bqp-r1-40-1"),
     "swissroll": ("plato/MATLAB/swissroll.mat", "plato/TXT/swissroll"),
     "chs_5000": ("plato/MATLAB/chs_5000.mat", "plato/TXT/chs5000"),
+    # SeDuMi (At, b, c, K) with 14 blocks of 56 / 126 / 252; no cuADMM log is shipped, only MOSEK's and ADMM+'s: the fixture carries
+    # MOSEK's optimum (benchmarks/taha1a/MOSEK.log).  The TXT directory's b.txt has the OPPOSITE sign of the .mat's b (its At.txt is
+    # missing: it was written from a copy with A and b both negated -- the same feasible set); the .mat is what is converted.
+    "taha1a": ("plato/MATLAB/taha1a.mat", "plato/TXT/taha1a"),
 }
+MOSEK_OPT = {"taha1a": ("benchmarks/taha1a/MOSEK.log", -1.0000000103e+00, -1.0000000154e+00)}   # primal, dual objective of the log's summary
 COMMON = dict(sig=1.0, stop_tol=1e-3, sig_update_threshold=0, sig_update_stage_1=50,
               sig_update_stage_2=100, sigscale=1.05)
 
@@ -206,7 +211,7 @@ def main():
     for name, (matrel, txtrel) in PLATO_MAT.items():
         d = sio.loadmat(os.path.join(EX, matrel))
         blk = np.array([n for _, n in orc.read_blk(os.path.join(EX, txtrel, "blk.txt"))], dtype=np.int32)
-        if "At" not in d:      # SeDuMi (A, b, c, K): through the converter (cuadmm_amd/convert.py = examples/sedumi_to_txt.m)
+        if "At" not in d or "K" in d:      # SeDuMi (A | At, b, c, K): through the converter (cuadmm_amd/convert.py = examples/sedumi_to_txt.m)
             from cuadmm_amd import convert
             import scipy.sparse as sp
             q = convert.problem_from_sedumi_mat(os.path.join(EX, matrel))
@@ -214,11 +219,18 @@ def main():
             At = sp.csc_matrix((q.At_csc_vals, q.At_csc_row_ids, q.At_csc_col_ptrs), shape=(q.vec_len, q.con_num)).tocoo()
             bi_txt, bv_txt = orc.read_sparse_vector(os.path.join(EX, txtrel, "b.txt"))
             ci_txt, cv_txt = orc.read_sparse_vector(os.path.join(EX, txtrel, "C.txt"))
-            assert np.array_equal(q.b_indices, bi_txt) and np.allclose(q.b_vals, bv_txt, rtol=0, atol=1e-12)
+            b_sign = -1.0 if name == "taha1a" else 1.0          # see PLATO_MAT
+            assert np.array_equal(q.b_indices, bi_txt) and np.allclose(q.b_vals, b_sign * bv_txt, rtol=0, atol=1e-12)
             assert np.array_equal(q.C_indices, ci_txt) and np.allclose(q.C_vals, cv_txt, rtol=0, atol=1e-12)
+            extra = {}
+            if name in MOSEK_OPT:
+                logrel, pw, dw = MOSEK_OPT[name]
+                txt = open(os.path.join(EX, logrel)).read()
+                assert ("Primal.  obj: %.10e" % pw) in txt and ("Dual.    obj: %.10e" % dw) in txt
+                extra = dict(mosek_pobj=pw, mosek_dobj=dw)
             np.savez_compressed(os.path.join(out_prob, name + ".npz"), blk=blk, con_num=int(q.con_num),
                                 At_row=At.row.astype(np.int32), At_col=At.col.astype(np.int32), At_val=At.data,
-                                C_idx=ci_txt, C_val=cv_txt, b_idx=bi_txt, b_val=bv_txt)
+                                C_idx=ci_txt, C_val=cv_txt, b_idx=bi_txt, b_val=b_sign * bv_txt, **extra)
             continue
         At, Cm = d["At"].tocoo(), d["C"].tocoo()
         bm = np.asarray(d["b"].todense() if hasattr(d["b"], "todense") else d["b"]).ravel()

@@ -77,6 +77,35 @@ def test_runs_to_the_reference_stopping_iteration(key, rel, ref_logs, problem_di
         assert abs(s.state()[name] - w) <= 2 * tol * (1 + abs(w)), (name, s.state()[name], w)
 
 
+def test_taha1a_against_the_oracle_and_mosek():
+    """examples/plato/MATLAB/taha1a.mat (SeDuMi; 14 blocks of 56 / 126 / 252, m = 3002) through the converter.  The reference ships
+    no cuADMM log for it, only MOSEK's (examples/benchmarks/taha1a/MOSEK.log: optimum -1.0000000103 / -1.0000000154, kept in the
+    fixture): an INDEPENDENT solver's answer.  The trajectory is pinned to the oracle's (1e-8 relative over the solve to 1e-3: blocks
+    on the one-wavefront, the one-launch cluster and the batched-GEMM projection paths at once), the optimum of a solve to 1e-4 to
+    MOSEK's within twice the stopping tolerance."""
+    import os
+    from tests.conftest import GOLDEN
+    p = load_npz_problem("taha1a")
+    d = np.load(os.path.join(GOLDEN, "problems", "taha1a.npz"))
+    o = orc.OracleSolver().init_problem(p)
+    o.solve(3000, 1e-3, 0, 50, 100, 11000, 1.05)
+    s, _, _ = _solve(p, 3000, 1e-3, 11000)
+    n = len(o.info.pobj)
+    assert s.info_iter_num == n                                               # 137 iterations
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+        got, ref = np.asarray(s.info_arr(nm))[:n], np.asarray(getattr(o.info, nm))
+        err = np.abs(got - ref) / (1e-3 + np.abs(ref))
+        assert np.max(err) <= 1e-8, (nm, float(np.max(err)), int(np.argmax(err)))
+    tol = 1e-4
+    s, t_init, t_solve = _solve(p, 20000, tol, 11000)
+    it = s.info_iter_num
+    print("\n[longrun] %-30s oracle     656 it | here %6d it  init %.2f s  solve %.2f s (%.3f ms/it)  pobj %.9f dobj %.9f (MOSEK %.10f / %.10f)"
+          % ("taha1a/sGS tol 1e-4", it, t_init, t_solve, t_solve / max(it, 1) * 1e3, s.state()["pobj"], s.state()["dobj"], float(d["mosek_pobj"]), float(d["mosek_dobj"])))
+    assert abs(it - 656) <= 7                                                 # the oracle's stopping iteration, 1 %
+    for name, w in (("pobj", float(d["mosek_pobj"])), ("dobj", float(d["mosek_dobj"]))):
+        assert abs(s.state()[name] - w) <= 2 * tol * (1 + abs(w)), (name, s.state()[name], w)
+
+
 def test_pendulum_n80_hundred_thousand_iterations(ref_logs):
     """examples/pendulum/N=80_licols.log runs its full 100 000 iterations (stop_tol 1e-6 is never reached); the last printed
     row is compared.  Two fp64 implementations of a 100 000-step nonlinear iteration agree to the digits that the

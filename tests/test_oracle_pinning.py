@@ -193,6 +193,19 @@ def test_oracle_reproduces_pendulum_log(ref_logs):
     _check_log(lg, p, 100)
 
 
+def test_oracle_reaches_the_optimum_of_an_independent_solver():
+    """taha1a (SeDuMi .mat through cuadmm_amd/convert.py; the reference ships MOSEK's log for it, no cuADMM log): the oracle's solve to
+    1e-3 lands on MOSEK's optimum (examples/benchmarks/taha1a/MOSEK.log, -1.0000000103 / -1.0000000154) within twice what the gap test allows."""
+    p = load_npz_problem("taha1a")
+    d = np.load(os.path.join(GOLDEN, "problems", "taha1a.npz"))
+    o = orc.OracleSolver().init_problem(p)
+    o.solve(3000, 1e-3, 0, 50, 100, 11000, 1.05)
+    assert len(o.info.pobj) == 137
+    assert max(o.info.errRp[-1], o.info.errRd[-1], o.info.relgap[-1]) < 1e-3
+    bound = 2 * 1e-3 * (1 + abs(o.info.pobj[-1]) + abs(o.info.dobj[-1]))      # relgap < tol bounds |p - d| by tol (1 + |p| + |d|)
+    assert abs(o.info.pobj[-1] - float(d["mosek_pobj"])) <= bound and abs(o.info.dobj[-1] - float(d["mosek_dobj"])) <= bound
+
+
 def test_synthetic_generator_is_feasible():
     from cuadmm_amd.synthetic import make_synthetic
     p = make_synthetic([32] * 20, seed=7)
