@@ -8,8 +8,14 @@
 
 namespace cuadmm {
 
+struct ClusterMulti;
+
 struct SignPsd {
-  struct Group { int N = 0, begin = 0, count = 0, pred = 0; };   // pred: steps the previous projection needed
+  // pred: steps the previous projection needed.  merged: the group runs its whole sign iteration in ONE launch shared with the other
+  // merged groups (lg_sign_cluster_kernel over several padded sizes), so it has a workspace of its own (ws_off: elements into X0 / S /
+  // Y / T; mem_off: members into d_state / d_done / d_bar; part_off: into each half of d_part; slot: which [2] of d_group and which table
+  // of d_xcc); the others run on the caller's stream one after the other in the shared region (all offsets 0)
+  struct Group { int N = 0, begin = 0, count = 0, pred = 0, mem_off = 0, slot = 0; bool merged = false; size_t ws_off = 0, part_off = 0; };
   PsdOptions opt;                            // the owner's switches (PsdPlan::build copies its own)
   std::vector<Group> groups;                 // same padded size N, bounded workspace
   int* d_ids = nullptr;                      // block ids, group after group
@@ -25,6 +31,9 @@ struct SignPsd {
   unsigned* d_bar = nullptr;                 // per member: barrier counter of the one-launch variant
   int* d_xcc = nullptr;                      // [member][tile]: XCD of every workgroup of the one-launch variant (run-time check)
   int build(const int* blk, const std::vector<int>& members);
+  int launch_group(Group& g, const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st, bool poll);
+  void cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max_steps) const;     // appends g to a one-launch set
+  int cluster_run(ClusterMulti& cm, bool prologue, const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);
   void release();
   int project(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);
   int project_launch(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st);

@@ -350,6 +350,16 @@ struct ClusterArgs {
   int N, max_steps, count, force_agent;
   int spread;               // 1: workgroups in plain order (member = w / ntiles) -- a member too large for one XCD's CUs
 };
+// Several groups (different padded sizes N) in one launch: workgroup and member ranges per group.  A relaxation with blocks of 126 and
+// of 252 (taha1a) would otherwise run its two one-launch groups one after the other, each a few workgroups deep and bound by its barriers.
+constexpr int kClusterMaxGroups = 4;
+struct ClusterMulti {
+  int n;
+  int wg_begin[kClusterMaxGroups + 1];      // multiples of 8 (workgroup w runs on XCD w % 8)
+  int mem_begin[kClusterMaxGroups + 1];     // the prologue / epilogue launches run one workgroup (row) per member over all groups
+  ClusterArgs ca[kClusterMaxGroups];
+  SignArgs sg[kClusterMaxGroups];
+};
 // local: every workgroup of the member sits on the SAME XCD (checked at run time, below).  Then their common L2 is the coherence
 // point: a workgroup signals once its own stores have completed (s_waitcnt vmcnt(0): the per-CU L1 writes through) and a waiter
 // only drops its CU's L1 (buffer_inv sc0) -- no write-back of the XCD's L2, no L2 invalidate, and the operands of the next phase
@@ -380,14 +390,18 @@ __device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target
 // -- only then the light barrier is used.  (Measured and rejected: workgroup-scope read-modify-writes on the counter, hoping they
 // would be served by the shared L2 -- they are not coherent between CUs: the waiters time out.)
 template <int TM, int BK>
-__global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterArgs ca, SignArgs sg) {
+__global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
   __shared__ double smem[LgGemmCfg<true, TM, BK>::SMEM];
   __shared__ double red[16];
   __shared__ int s_local;
+  int gi = 0;
+  while (gi + 1 < cm.n && (int)blockIdx.x >= cm.wg_begin[gi + 1]) ++gi;     // uniform: scalar loads from the kernel arguments
+  const ClusterArgs ca = cm.ca[gi];      // by value: scalar registers, not a reload per use
+  SignArgs sg = cm.sg[gi];
   const int N = ca.N;
   const int nbt = N / TM;
   const unsigned ntiles = (unsigned)(nbt * (nbt + 1) / 2);
-  const int w = (int)blockIdx.x, slot = w >> 3;
+  const int w = (int)blockIdx.x - cm.wg_begin[gi], slot = w >> 3;
   const int member = ca.spread ? w / (int)ntiles : (w & 7) + 8 * (slot / (int)ntiles);
   const int tile = ca.spread ? w % (int)ntiles : slot % (int)ntiles;
   if (member >= ca.count) return;               // the whole workgroup, before any barrier
@@ -518,11 +532,17 @@ __global__ __launch_bounds__(256) void lg_diff_kernel(const double* __restrict__
 // gathered straight into the dense X0 (every element written: no zero fill), the column sums of |X0| are formed in the association
 // of lg_colsum_kernel / lg_scale_kernel (LG_CS_ROWS row chunks summed in chunk order: the same bits), S = X0 / ||X0||_1, and thread 0
 // writes the member's fresh schedule state.  For the small N of that variant only (the matrix is walked by one workgroup).
-__global__ __launch_bounds__(1024) void lg_prep_kernel(const double* __restrict__ src, const int* __restrict__ ids, const long long* __restrict__ boff,
-                                                       const int* __restrict__ bn, int N, double* __restrict__ X0b, double* __restrict__ Sb, SignArgs sa) {
+__global__ __launch_bounds__(1024) void lg_prep_kernel(const double* __restrict__ src, const long long* __restrict__ boff,
+                                                       const int* __restrict__ bn, ClusterMulti cm) {
   __shared__ double red[1024];
-  const int m = (int)blockIdx.x, tid = (int)threadIdx.x;
-  const int id = ids[m], n = bn[id];
+  int gi = 0;
+  while (gi + 1 < cm.n && (int)blockIdx.x >= cm.mem_begin[gi + 1]) ++gi;
+  const SignArgs& sa = cm.sg[gi];
+  const int N = cm.ca[gi].N;
+  double* __restrict__ X0b = cm.ca[gi].X0;
+  double* __restrict__ Sb = cm.ca[gi].S;
+  const int m = (int)blockIdx.x - cm.mem_begin[gi], tid = (int)threadIdx.x;
+  const int id = sa.ids[m], n = bn[id];
   const double* sv = src + boff[id];
   double* X0 = X0b + (size_t)m * N * N;
   double* S = Sb + (size_t)m * N * N;
@@ -580,13 +600,17 @@ __global__ __launch_bounds__(1024) void lg_prep_kernel(const double* __restrict_
   }
 }
 // lg_pack_kernel + lg_steps_out_kernel in one launch (the one-launch variant's epilogue)
-__global__ void lg_pack_steps_kernel(const double* __restrict__ src, const int* __restrict__ ids, const long long* __restrict__ boff,
-                                     const int* __restrict__ bn, int N, double* __restrict__ dst, int* __restrict__ fail, SignArgs sa,
-                                     int* __restrict__ steps) {
-  const int id = ids[blockIdx.y];
+__global__ void lg_pack_steps_kernel(const long long* __restrict__ boff, const int* __restrict__ bn, double* __restrict__ dst,
+                                     int* __restrict__ fail, int* __restrict__ steps, ClusterMulti cm) {
+  int gi = 0;
+  while (gi + 1 < cm.n && (int)blockIdx.y >= cm.mem_begin[gi + 1]) ++gi;
+  const SignArgs& sa = cm.sg[gi];             // sa.step = the steps enqueued (set by the host before this launch)
+  const int N = cm.ca[gi].N;
+  const int m = (int)blockIdx.y - cm.mem_begin[gi];
+  const int id = sa.ids[m];
   const int n = bn[id];
   const int len = n * (n + 1) / 2;
-  const double* s = src + (size_t)blockIdx.y * N * N;
+  const double* s = cm.ca[gi].Y + (size_t)m * N * N;
   double* d = dst + boff[id];
   bool bad = false;
   for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < len; e += (int)(gridDim.x * blockDim.x)) {
@@ -597,10 +621,7 @@ __global__ void lg_pack_steps_kernel(const double* __restrict__ src, const int* 
     d[e] = (i == j) ? v : v * kSqrt2;
   }
   if (bad && fail) atomicAdd(fail, 1);
-  if (steps && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int m = (int)blockIdx.y;
-    steps[id] = sa.done[m].done_at <= sa.step ? sa.done[m].steps : sa.step;
-  }
+  if (steps && blockIdx.x == 0 && threadIdx.x == 0) steps[id] = sa.done[m].done_at <= sa.step ? sa.done[m].steps : sa.step;
 }
 
 static int lg_pad(int n) { return (n + LG_TM - 1) / LG_TM * LG_TM; }
@@ -614,6 +635,8 @@ static bool lg_small_tiles(bool mirror, int N, int count, int tile_force = 0) {
   // 1.41 -> 1.02 ms)
   return tile_force ? tile_force == 32 : (mirror && N >= 128 && tiles64 < 1300);
 }
+// how a group's sign iteration is enqueued: tiles per member, decision as a launch of its own, everything in one launch
+struct LgPath { int ntiles; bool decide_kernel, cluster; int cluster_wgs, spread; };
 
 template <int ROLE>
 static int lg_gemm_mirror(int N, int count, const double* A, const double* B, double alpha, double beta, const double* E, double* C,
@@ -632,6 +655,7 @@ static int lg_gemm_mirror(int N, int count, const double* A, const double* B, do
   return CUADMM_OK;
 }
 
+static LgPath lg_path(const PsdOptions& opt, int N, int cnt);
 int large_gemm_sym(int N, const double* A, const double* B, double alpha, double beta, const double* E, double* C, hipStream_t st) {
   hipLaunchKernelGGL((lg_gemm_sym_kernel<false, 64, 16, 0>), dim3((N / 64) * (N / 64), 1), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0,
                      SignArgs{}, (const double*)nullptr);
@@ -700,24 +724,59 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
       groups.push_back(g);
     }
   }
+  // One-launch groups of DIFFERENT padded sizes (a relaxation with blocks of 126 and of 252: taha1a) share ONE launch
+  // (ClusterMulti), each with a workspace of its own, while all of them together stay within the co-residency bound of such a
+  // launch.  Everything else runs one group after the other in the shared region.  (First attempt: side streams.  A plain side
+  // stream landed on the caller's hardware queue -- no overlap at all; a high-priority one overlapped, and every small kernel of the
+  // caller's stream took 40 us instead of 5.)
+  auto part_of = [](const Group& g) { return (size_t)g.count * 2 * (size_t)(g.N / 32) * (size_t)(g.N / 32 + 1) / 2; };
+  size_t max_part = 0, side_elems = 0, side_part = 0;
+  int side_members = 0, n_merged = 0, wgs = 0;
+  for (Group& g : groups) {
+    const LgPath p = lg_path(opt, g.N, g.count);
+    if (opt.lg_merge != 0 && !opt.debug && p.cluster && g.N <= 512 && n_merged < kClusterMaxGroups &&
+        wgs + g.count * p.ntiles <= kClusterMaxWgs) {   // the workgroups that stay (the grid's others leave at once)
+      wgs += g.count * p.ntiles;
+      g.merged = true;
+      g.slot = 1 + n_merged++;
+    }
+  }
+  if (n_merged < 2)                             // nothing to merge: the plain path
+    for (Group& g : groups) { g.merged = false; g.slot = 0; }
+  if (n_merged < 2) n_merged = 0;
+  max_elems = 0; max_count = 0;                 // the shared region: the groups of the caller's stream only
+  for (const Group& g : groups)
+    if (!g.merged) {
+      max_elems = std::max(max_elems, (size_t)g.count * g.N * g.N);
+      max_count = std::max(max_count, g.count);
+      max_part = std::max(max_part, part_of(g));
+    }
+  for (Group& g : groups)
+    if (g.merged) {                             // behind the shared region
+      g.ws_off = max_elems + side_elems;
+      g.mem_off = max_count + side_members;
+      g.part_off = max_part + side_part;
+      side_elems += (size_t)g.count * g.N * g.N;
+      side_members += g.count;
+      side_part += part_of(g);
+    }
+  const size_t elems = std::max<size_t>(max_elems + side_elems, 1), members_cap = std::max<size_t>((size_t)max_count + (size_t)side_members, 1);
   CUADMM_HIP_TRY(hipMalloc(&d_ids, sizeof(int) * ids.size()));
   { int rc_ = staged_h2d(d_ids, ids.data(), sizeof(int) * ids.size()); if (rc_) return rc_; }
-  CUADMM_HIP_TRY(hipMalloc(&X0, sizeof(double) * max_elems));
-  CUADMM_HIP_TRY(hipMalloc(&S, sizeof(double) * max_elems));
-  CUADMM_HIP_TRY(hipMalloc(&Y, sizeof(double) * max_elems));
-  CUADMM_HIP_TRY(hipMalloc(&T, sizeof(double) * max_elems));
-  CUADMM_HIP_TRY(hipMalloc(&colsum, sizeof(double) * max_cols));
-  CUADMM_HIP_TRY(hipMalloc(&scale, sizeof(double) * (size_t)max_count));
-  CUADMM_HIP_TRY(hipMalloc(&d_state, sizeof(SignDevState) * 2 * (size_t)max_count));
-  CUADMM_HIP_TRY(hipMalloc(&d_done, sizeof(SignDone) * (size_t)max_count));
-  CUADMM_HIP_TRY(hipMalloc(&d_group, sizeof(int) * 2));
-  CUADMM_HIP_TRY(hipMalloc(&d_bar, sizeof(unsigned) * (size_t)max_count));
-  CUADMM_HIP_TRY(hipMalloc(&d_xcc, sizeof(int) * (size_t)(kClusterMaxWgs + 64)));
+  CUADMM_HIP_TRY(hipMalloc(&X0, sizeof(double) * elems));
+  CUADMM_HIP_TRY(hipMalloc(&S, sizeof(double) * elems));
+  CUADMM_HIP_TRY(hipMalloc(&Y, sizeof(double) * elems));
+  CUADMM_HIP_TRY(hipMalloc(&T, sizeof(double) * elems));
+  CUADMM_HIP_TRY(hipMalloc(&colsum, sizeof(double) * std::max<size_t>(max_cols, 1)));
+  CUADMM_HIP_TRY(hipMalloc(&scale, sizeof(double) * std::max<size_t>(members_cap, 1)));
+  CUADMM_HIP_TRY(hipMalloc(&d_state, sizeof(SignDevState) * 2 * members_cap));
+  CUADMM_HIP_TRY(hipMalloc(&d_done, sizeof(SignDone) * members_cap));
+  CUADMM_HIP_TRY(hipMalloc(&d_group, sizeof(int) * 2 * (size_t)(1 + n_merged)));
+  CUADMM_HIP_TRY(hipMalloc(&d_bar, sizeof(unsigned) * members_cap));
+  CUADMM_HIP_TRY(hipMalloc(&d_xcc, sizeof(int) * (size_t)(kClusterMaxWgs + 64) * (size_t)(1 + n_merged)));
   CUADMM_HIP_TRY(hipHostMalloc(&h_group, sizeof(int) * 2, hipHostMallocDefault));
-  size_t max_part = 0;
-  for (const Group& g : groups) max_part = std::max(max_part, (size_t)g.count * 2 * (size_t)(g.N / 32) * (size_t)(g.N / 32 + 1) / 2);
-  CUADMM_HIP_TRY(hipMalloc(&d_part, sizeof(double) * 2 * max_part));   // p1 | p2 (two parities)
-  part_half = max_part;
+  part_half = max_part + side_part;
+  CUADMM_HIP_TRY(hipMalloc(&d_part, sizeof(double) * 2 * std::max<size_t>(part_half, 1)));   // p1 | p2 (two parities)
   return CUADMM_OK;
 }
 
@@ -760,42 +819,113 @@ int SignPsd::project(const double* in, double* out, const long long* boff, const
   return CUADMM_OK;
 }
 
+static LgPath lg_path(const PsdOptions& opt, int N, int cnt) {
+  LgPath p{};
+  // The decision of a step sums the tiles' slots: inside every workgroup of the S Y product when they are few, as a launch
+  // of its own when that would cost more than a launch (option psd_lg_decide = 1 | 2 forces one).
+  const int nbt = lg_small_tiles(true, N, cnt, opt.lg_tile) ? N / 32 : N / 64;
+  p.ntiles = nbt * (nbt + 1) / 2;
+  p.decide_kernel = opt.lg_decide ? opt.lg_decide == 2 : p.ntiles > 300;
+  // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
+  p.cluster = opt.lg_cluster != 0 && !p.decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)p.ntiles * cnt <= kClusterMaxWgs;
+  // one XCD has 32 CUs x 4 workgroups of this kernel: a member's workgroups go to ONE XCD only while everything mapped there stays
+  // co-resident with room to spare; else plain order over the whole chip (agent-scope barriers)
+  p.spread = ((cnt + 7) / 8) * p.ntiles > 96 ? 1 : 0;
+  p.cluster_wgs = p.spread ? cnt * p.ntiles : 8 * ((cnt + 7) / 8) * p.ntiles;
+  return p;
+}
+
 int SignPsd::project_launch(const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
-  const int debug = opt.debug;
-  const int max_steps = opt.sign_maxsteps > 0 ? opt.sign_maxsteps : SignSched::kCap;
-  const int decide_force = opt.lg_decide;
   const bool sync_ok = opt.sign_sync != 0;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (st) { hipError_t e = hipStreamIsCapturing(st, &cap); (void)e; }
   const bool poll = sync_ok && cap == hipStreamCaptureStatusNone;
-  for (Group& g : groups) {
+  const int max_steps = opt.sign_maxsteps > 0 ? opt.sign_maxsteps : SignSched::kCap;
+  int rc;
+  // the merged one-launch groups: three launches for all of them (prologue, sign iteration, epilogue); then the rest, group by group
+  ClusterMulti cm{};
+  for (const Group& g : groups)
+    if (g.merged) cluster_add(cm, g, d_fail, max_steps);
+  if (cm.n > 0 && (rc = cluster_run(cm, true, in, out, boff, bn, d_fail, st))) return rc;
+  for (Group& g : groups)
+    if (!g.merged && (rc = launch_group(g, in, out, boff, bn, d_fail, st, poll))) return rc;
+  return CUADMM_OK;
+}
+
+// the group's share of the workspace and of the schedule's state as arguments of the one-launch kernels
+void SignPsd::cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max_steps) const {
+  const int i = cm.n++;
+  const LgPath path = lg_path(opt, g.N, g.count);
+  SignArgs& sa = cm.sg[i];
+  sa = SignArgs{};
+  sa.st = static_cast<SignDevState*>(d_state) + 2 * (size_t)g.mem_off;
+  sa.done = static_cast<SignDone*>(d_done) + g.mem_off;
+  sa.p1 = d_part + g.part_off;
+  sa.p2 = d_part + part_half + g.part_off;
+  sa.group = d_group + 2 * g.slot;
+  sa.hint = d_hint;
+  sa.ids = d_ids + g.begin;
+  sa.count = g.count;
+  sa.step = 0;
+  sa.bar = d_bar + g.mem_off;
+  // psd_lg_cluster = 2: agent-scope barriers always (A/B, tests)
+  cm.ca[i] = ClusterArgs{S + g.ws_off, T + g.ws_off, Y + g.ws_off, X0 + g.ws_off, d_bar + g.mem_off,
+                         d_xcc + (size_t)(kClusterMaxWgs + 64) * (size_t)g.slot, d_fail, g.N, max_steps, g.count, opt.lg_cluster == 2 ? 1 : 0, path.spread};
+  cm.wg_begin[i + 1] = cm.wg_begin[i] + (path.cluster_wgs + 7) / 8 * 8;
+  cm.mem_begin[i + 1] = cm.mem_begin[i] + g.count;
+}
+
+// prologue (optional: the caller has filled X0, S and the state itself), every step and the final product, epilogue: three launches
+int SignPsd::cluster_run(ClusterMulti& cm, bool prologue, const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
+  int maxN = 0;
+  for (int i = 0; i < cm.n; ++i) maxN = std::max(maxN, cm.ca[i].N);
+  if (prologue) {
+    const size_t lds_prep = sizeof(double) * LG_CS_ROWS * (size_t)maxN;
+    if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lg_prep_kernel)));
+    hipLaunchKernelGGL(lg_prep_kernel, dim3(cm.mem_begin[cm.n]), dim3(1024), lds_prep, st, in, boff, bn, cm);
+  }
+  hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(cm.wg_begin[cm.n]), dim3(256), 0, st, cm);
+  for (int i = 0; i < cm.n; ++i) cm.sg[i].step = cm.ca[i].max_steps;          // the steps enqueued
+  const unsigned gx = (unsigned)std::min<size_t>(((size_t)maxN * maxN / 2 + 255) / 256, 1024);
+  hipLaunchKernelGGL(lg_pack_steps_kernel, dim3(gx, cm.mem_begin[cm.n]), dim3(256), 0, st, boff, bn, out, d_fail, d_steps, cm);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+int SignPsd::launch_group(Group& g, const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st, bool poll) {
+  const int debug = opt.debug;
+  const int max_steps = opt.sign_maxsteps > 0 ? opt.sign_maxsteps : SignSched::kCap;
+  {
     const int N = g.N, cnt = g.count;
     const size_t per = (size_t)N * N;
     const int* ids = d_ids + g.begin;
     const unsigned gx = (unsigned)std::min<size_t>((per / 2 + 255) / 256, 1024);
     const auto t0 = std::chrono::steady_clock::now();
-    // The decision of a step sums the tiles' slots: inside every workgroup of the S Y product when they are few, as a launch
-    // of its own when that would cost more than a launch (option psd_lg_decide = 1 | 2 forces one).
-    const int nbt = lg_small_tiles(true, N, cnt, opt.lg_tile) ? N / 32 : N / 64, ntiles = nbt * (nbt + 1) / 2;
-    const bool decide_kernel = decide_force ? decide_force == 2 : ntiles > 300;
-    // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
-    const bool cluster = opt.lg_cluster != 0 && !decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)ntiles * cnt <= kClusterMaxWgs;
+    const LgPath path = lg_path(opt, N, cnt);
+    const int ntiles = path.ntiles;
+    const bool decide_kernel = path.decide_kernel, cluster = path.cluster;
+    // this group's share of the workspace (psd_large.h: Group)
+    double* const X0 = this->X0 + g.ws_off;
+    double* const S = this->S + g.ws_off;
+    double* const Y = this->Y + g.ws_off;
+    double* const T = this->T + g.ws_off;
+    double* const scale = this->scale + g.mem_off;
+    int* const d_group = this->d_group + 2 * g.slot;
+    unsigned* const d_bar = this->d_bar + g.mem_off;
     SignArgs sa{};
-    sa.st = static_cast<SignDevState*>(d_state);
-    sa.done = static_cast<SignDone*>(d_done);
-    sa.p1 = d_part;
-    sa.p2 = d_part + part_half;
+    sa.st = static_cast<SignDevState*>(d_state) + 2 * (size_t)g.mem_off;
+    sa.done = static_cast<SignDone*>(d_done) + g.mem_off;
+    sa.p1 = d_part + g.part_off;
+    sa.p2 = d_part + part_half + g.part_off;
     sa.group = d_group;
     sa.hint = d_hint;
     sa.ids = ids;
     sa.count = cnt;
     sa.step = 0;
     sa.bar = d_bar;
-    if (cluster && N <= 512) {
-      const size_t lds_prep = sizeof(double) * LG_CS_ROWS * (size_t)N;
-      if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lg_prep_kernel)));
-      hipLaunchKernelGGL(lg_prep_kernel, dim3(cnt), dim3(1024), lds_prep, st, in, ids, boff, bn, N, X0, S, sa);
-    } else {
+    ClusterMulti cm{};
+    if (cluster) cluster_add(cm, g, d_fail, max_steps);
+    if (!(cluster && N <= 512)) {              // else: the one-launch variant's own prologue (cluster_run)
       CUADMM_HIP_TRY(hipMemsetAsync(X0, 0, sizeof(double) * per * (size_t)cnt, st));
       hipLaunchKernelGGL(lg_unpack_kernel, dim3(gx, cnt), dim3(256), 0, st, in, ids, boff, bn, N, X0);
       hipLaunchKernelGGL(lg_colsum_kernel, dim3((N + 255) / 256, cnt, LG_CS_ROWS), dim3(256), 0, st, X0, N, colsum);
@@ -815,12 +945,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     int enq = 0;
     int chunk = poll ? std::min(max_steps, g.pred > 0 ? g.pred + 2 : 24) : max_steps;
     if (cluster) {
-      // one XCD has 32 CUs x 4 workgroups of this kernel: a member's workgroups go to ONE XCD only while everything mapped there stays
-      // co-resident with room to spare; else plain order over the whole chip (agent-scope barriers)
-      const int spread = ((cnt + 7) / 8) * ntiles > 96 ? 1 : 0;
-      ClusterArgs ca{S, T, Y, X0, d_bar, d_xcc, d_fail, N, max_steps, cnt, opt.lg_cluster == 2 ? 1 : 0, spread};   // psd_lg_cluster = 2: agent-scope barriers always (A/B, tests)
-      hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(spread ? cnt * ntiles : 8 * ((cnt + 7) / 8) * ntiles), dim3(256), 0, st, ca, sa);
-      CUADMM_HIP_TRY(hipGetLastError());
+      if ((rc = cluster_run(cm, N <= 512, in, out, boff, bn, d_fail, st))) return rc;
       enq = max_steps;
     }
     while (enq < max_steps) {
@@ -845,9 +970,7 @@ int SignPsd::project_launch(const double* in, double* out, const long long* boff
     // P = 0.5 * (X0 + X0 * S_final); S_final is in S after an even number of steps, in T after an odd one
     sa.step = enq;
     if (!cluster && (rc = lg_gemm_mirror<3>(N, cnt, X0, S, 0.5, 0.5, X0, Y, st, sa, T, opt.lg_tile))) return rc;
-    if (cluster) {
-      hipLaunchKernelGGL(lg_pack_steps_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail, sa, d_steps);
-    } else {
+    if (!cluster) {
       hipLaunchKernelGGL(lg_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, Y, ids, boff, bn, N, out, d_fail);
       if (d_steps) hipLaunchKernelGGL(lg_steps_out_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, sa, ids, d_steps);
     }

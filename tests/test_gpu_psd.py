@@ -315,6 +315,25 @@ def test_project_sign_path_one_launch_variant_is_bit_identical(blk, monkeypatch)
     assert np.max(np.abs(one - ref)) <= 2e-12 * max(np.linalg.norm(m, 2) for m in mats) * np.sqrt(2)
 
 
+@pytest.mark.parametrize("blk", [[252, 56, 56, 56] + [126] * 10, [66, 130, 300, 91, 140], [100, 200, 330, 450]])
+def test_project_sign_path_groups_in_one_launch_are_bit_identical(blk, monkeypatch):
+    """One-launch groups of different padded sizes (taha1a: ten blocks of 126 and one of 252) share ONE launch, each with a workspace of
+    its own, instead of running one after the other in a shared one (psd_lg_merge): the same tile bodies on the same data -- not one
+    bit may differ."""
+    blk = np.array(blk, dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    x = _rand_svec(blk, int(blk.sum()))
+    monkeypatch.setenv("CUADMM_PSD_LG_MERGE", "1")
+    beside = psd_project_gpu(x, blk)
+    beside2 = psd_project_gpu(-x, blk)
+    monkeypatch.setenv("CUADMM_PSD_LG_MERGE", "0")
+    serial = psd_project_gpu(x, blk)
+    serial2 = psd_project_gpu(-x, blk)
+    assert np.array_equal(beside, serial) and np.array_equal(beside2, serial2)
+    ref = orc.psd_project_svec(bidx, x)
+    assert np.max(np.abs(beside - ref)) <= 2e-12 * 70
+
+
 def test_project_one_workgroup_kernels_third_lds_matrix_is_bit_identical(monkeypatch):
     """33 <= n <= 64 with few blocks of a class (a moment relaxation: pendulum N = 80 has 80 of n = 55): the one-workgroup kernel
     with the next iterate stored beside the current one and the statistics only where the schedule reads them
