@@ -291,6 +291,13 @@ HostPool& host_pool() {
 // first n1 columns is a prefix maximum of the node heights (a parent always has the larger index): one pass for every k.
 int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) {
   const double host_ns = 1.2, total = host_ns * (double)Lp[m];
+  // Small systems: whatever its nonzeros, a host solve is two PCIe hops and a stream synchronisation (~150 us: taha1a, m = 3 002,
+  // 0.13 ms per solve).  The WHOLE factor as a dense tail on the device is one pass over 8 m^2 bytes of explicit inverse behind a
+  // right-hand side that never leaves HBM (lead_solve.hip with no leading columns): taha1a 1.12 -> 0.8 ms per sGS iteration.
+  if (parent && m >= 512 && m <= 4096 && max_k >= m) {
+    const double dev_ns = 40e3 + (double)m * m * 8.0 / 4000.0;
+    if (total + 150e3 > 1.5 * dev_ns) return m;
+  }
   double best = total;
   int best_k = 0;
   for (int k = 256; k <= std::min(m, max_k); k += 256) {

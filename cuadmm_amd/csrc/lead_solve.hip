@@ -280,7 +280,16 @@ void LeadSolve::release() {
 int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D) {
   release();
   m = m_; k = k_; n1 = m - k;
-  if (n1 <= 0 || k <= 0) return CUADMM_OK;
+  if (k <= 0 || n1 < 0) return CUADMM_OK;
+  if (n1 == 0) {
+    // the whole factor is the dense tail: rhs -> tail -> y, nothing to sweep (the tail-rhs kernel walks empty rows of L21)
+    std::vector<long long> zero((size_t)k + 1, 0);
+    CUADMM_HIP_TRY(hipMalloc(&rp21, sizeof(long long) * zero.size()));
+    { int rc_ = staged_h2d(rp21, zero.data(), sizeof(long long) * zero.size()); if (rc_) return rc_; }
+    est_us = 20.0;
+    ready = true;
+    return CUADMM_OK;
+  }
   const long long nnz = (long long)Lp[n1];
   // CSR of L11 and of L21 by counting sort over the leading columns (rows ascending inside a column => columns ascending inside a row)
   std::vector<long long> r11((size_t)n1 + 1, 0), r21((size_t)k + 1, 0);
@@ -494,7 +503,7 @@ int LeadSolve::solve(const double* ax, const double* asmc, const double* b, doub
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
-  hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
+  if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
   if (side) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
   if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_b), lvl_off_b,
                                       lvl_g_b, nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
