@@ -291,12 +291,14 @@ HostPool& host_pool() {
 // first n1 columns is a prefix maximum of the node heights (a parent always has the larger index): one pass for every k.
 int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) {
   const double host_ns = 1.2, total = host_ns * (double)Lp[m];
-  // Small systems: whatever its nonzeros, a host solve is two PCIe hops and a stream synchronisation (~150 us: taha1a, m = 3 002,
-  // 0.13 ms per solve).  The WHOLE factor as a dense tail on the device is one pass over 8 m^2 bytes of explicit inverse behind a
-  // right-hand side that never leaves HBM (lead_solve.hip with no leading columns): taha1a 1.12 -> 0.8 ms per sGS iteration.
+  // Small systems: a host solve is its nonzeros plus two PCIe hops and a stream synchronisation (~35 us); the WHOLE factor as a dense
+  // tail on the device is one pass over 8 m^2 bytes of explicit inverse behind a right-hand side that never leaves HBM (lead_solve.hip
+  // with no leading columns, ~40 us of launches).  Measured per sGS iteration, host -> device: taha1a (m = 3 002, 159 k nonzeros) 1.12 ->
+  // 0.86 ms, swissroll (3 380, 101 k) 3.59 -> 3.42, biggs (1 819, 42 k) 0.50 -> 0.48; rose13 (2 379, DIAGONAL A A^T) must stay where it
+  // is (forest solve on the device: 0.36 ms against 0.43 through a dense tail) -- and does by this model.
   if (parent && m >= 512 && m <= 4096 && max_k >= m) {
     const double dev_ns = 40e3 + (double)m * m * 8.0 / 4000.0;
-    if (total + 150e3 > 1.5 * dev_ns) return m;
+    if (total + 35e3 > 1.5 * dev_ns) return m;
   }
   double best = total;
   int best_k = 0;
