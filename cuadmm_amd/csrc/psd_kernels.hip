@@ -144,7 +144,7 @@ __global__ __launch_bounds__(SignLdsCfg<NP>::THREADS) void psd_sign_lds_kernel(P
 // one WAVEFRONT per block (psd_sign_wave.h): NT = 1 (n <= 16, eight wavefronts per SIMD), NT = 2 (n <= 32, four -- or three: option
 // psd_w32_occ), NT = 3 (n <= 48, two), NT = 4 (n <= 64, one)
 template <int NT, int OCC, bool FUSED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_wave_kernel(PsdArgs a, SignFuse fz, int first, int count, int slot0) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_wave_kernel(PsdArgs a, SignFuse fz, int first, int count) {
   extern __shared__ double swt_smem[];
   const int m = (int)blockIdx.x;
   if (m >= count) return;
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
     const ClosedArgs al = *reinterpret_cast<__attribute__((address_space(4))) const ClosedArgs*>(ka);
 #else
     const ClosedArgs al = a;
+    (void)ka;
 #endif
     const PsdDesc d = al.desc[al.first + g + j * G];
     int toff = ((int)threadIdx.x >> 6) * TILE;
@@ -256,8 +257,8 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
       hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
     }
   }
-  else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count, 0);
-  else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count, 0);
+  else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count);
+  else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }

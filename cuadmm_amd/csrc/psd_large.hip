@@ -53,7 +53,6 @@
 namespace cuadmm {
 
 typedef double lg_v4f64 __attribute__((ext_vector_type(4)));
-constexpr int LG_BK = 16;
 constexpr int LG_TM = 64;   // measured on MI355X: 64x64 tiles (4 workgroups per CU) beat 128x128 at every N (48 vs 41 TFLOP/s at 2048)
 
 // C = alpha * A*B + beta * E over a batch (blockIdx.y = matrix, stride N*N).  A (and, when MIRROR, the product) symmetric.
