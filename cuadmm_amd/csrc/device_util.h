@@ -30,5 +30,20 @@ inline hipError_t allow_max_dynamic_lds(const void* kern) {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxLdsBytes - fa.sharedSizeBytes));
 }
+// The same once per kernel AND DEVICE (a function's attributes belong to the device's copy of it; a process may hold solvers on
+// several devices): `static LdsCapOnce once;` beside the launch, `once(kern)` before it.
+struct LdsCapOnce {
+  bool done[64] = {};
+  hipError_t operator()(const void* kern) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return allow_max_dynamic_lds(kern);
+    if (done[dev]) return hipSuccess;
+    e = allow_max_dynamic_lds(kern);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+  }
+};
 constexpr int kMaxBlockSize = 4000;           // largest block the projection plans accept
 }  // namespace cuadmm

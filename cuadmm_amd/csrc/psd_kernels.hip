@@ -250,8 +250,8 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
       const size_t lds = WAVES * SignWaveT<NT>::LDS_BYTES + sizeof(int) * (nb_max + 2);
       if (lds > kMaxLdsBytes) { set_error("psd: %d blocks per workgroup do not fit the batched launch", (int)nb_max); return CUADMM_ERR_INVALID; }
       auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC>;
-      static bool attr_set = false;
-      if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
+      static LdsCapOnce once;
+      CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
     } else {
       hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
@@ -275,11 +275,8 @@ template <int NP, bool TRIPLE>
 static int launch_sign_lds_t(const PsdArgs& a, int first, int count, hipStream_t st) {
   const size_t lds = sizeof(double) * (TRIPLE ? 3 : 2) * NP * SignLdsCfg<NP>::LD;
   auto kern = psd_sign_lds_kernel<NP, TRIPLE>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    CUADMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static LdsCapOnce once;
+  if (lds > 48 * 1024) CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
   hipLaunchKernelGGL(kern, dim3(count), dim3(SignLdsCfg<NP>::THREADS), lds, st, a, first);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
@@ -408,11 +405,8 @@ static int launch_wg(const PsdArgs& a, int maxn, hipStream_t st) {
   const size_t lds = wg_lds_bytes(maxn, NT);
   if (lds > kMaxLdsBytes) { set_error("psd: block of size %d needs %zu bytes of LDS", maxn, lds); return CUADMM_ERR_INVALID; }
   auto kern = psd_wg_kernel<NT, MODE>;
-  static bool attr_set = false;     // per kernel and process-wide: the hardware maximum, once (plans with smaller blocks must not lower it)
-  if (!attr_set && lds > 48 * 1024) {
-    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));
-    attr_set = true;
-  }
+  static LdsCapOnce once;            // the hardware maximum, once per device (plans with smaller blocks must not lower it)
+  if (lds > 48 * 1024) CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
   hipLaunchKernelGGL(kern, dim3(a.count), dim3(NT), lds, st, a);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;

@@ -880,7 +880,8 @@ int SignPsd::cluster_run(ClusterMulti& cm, bool prologue, const double* in, doub
   for (int i = 0; i < cm.n; ++i) maxN = std::max(maxN, cm.ca[i].N);
   if (prologue) {
     const size_t lds_prep = sizeof(double) * LG_CS_ROWS * (size_t)maxN;
-    if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lg_prep_kernel)));
+    static LdsCapOnce once;                      // the cap is lifted to the kernel's maximum, once per device
+    if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(lg_prep_kernel)));
     hipLaunchKernelGGL(lg_prep_kernel, dim3(cm.mem_begin[cm.n]), dim3(1024), lds_prep, st, in, boff, bn, cm);
   }
   hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(cm.wg_begin[cm.n]), dim3(256), 0, st, cm);
