@@ -250,6 +250,23 @@ def test_aat_tail_plan_picks_the_dense_triangle():
     lib.cuadmm_aat_free(h)
 
 
+@pytest.mark.parametrize("name,whole", [("taha1a", True), ("swissroll", True), ("rose13", False), ("truss5", False)])
+def test_aat_small_systems_take_the_whole_factor_as_the_dense_tail(name, whole, problem_dirs):
+    """plan_tail for 512 <= m <= 4096 (csrc/aat_ldlt.cpp): a host solve is its nonzeros + ~35 us of PCIe hops and synchronisation,
+    the whole factor as a dense tail on the device ~40 us of launches + one pass over 8 m^2 bytes.  taha1a (m = 3 002, 159 k nonzeros in
+    L) and swissroll (3 380, 101 k) go to the device entirely; rose13's A A^T is DIAGONAL (2 379 nonzeros: the device-side forest solve
+    serves it) and truss5 (m = 208) is below the range: both keep the one-piece factor."""
+    from tests.conftest import load_npz_problem
+    p = orc.load_problem_txt(problem_dirs[name]) if name in problem_dirs else load_npz_problem(name)
+    At = sp.csc_matrix((p.At_vals, p.At_row_ids, p.At_col_ptrs), shape=(p.vec_len, p.con_num))
+    A = At.T.tocsc(); A.sort_indices()
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    hs = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(p.con_num, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(hs)))
+    assert lib.cuadmm_aat_tail_k(hs) == (p.con_num if whole else 0)
+    lib.cuadmm_aat_free(hs)
+
+
 @pytest.mark.parametrize("name,frac", [("rose13", 0.3), ("truss5", 0.5), ("hinf12", 1.0), ("ros_2000", 0.1)])
 def test_aat_split_factor_schur_complement(name, frac, problem_dirs):
     """cuadmm_aat_create_split leaves the last k columns unfactored and hands over the dense Schur complement:
