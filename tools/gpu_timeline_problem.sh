@@ -9,7 +9,7 @@ python3 - "$(find "$R/gpurun_out/prof_tl" -name '*kernel_trace.csv' | head -1)" 
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-idx=[i for i,r in enumerate(rows) if "cluster" in r["Kernel_Name"]]
+idx=[i for i,r in enumerate(rows) if "cluster" in r["Kernel_Name"] or "lg_gemm" in r["Kernel_Name"]]
 c=idx[min(60,len(idx)-1)] if idx else len(rows)//2
 t0=int(rows[max(0,c-12)]["Start_Timestamp"])
 for r in rows[max(0,c-12):c+24]:
