@@ -360,9 +360,14 @@ struct ClusterMulti {
   SignArgs sg[kClusterMaxGroups];
 };
 // local: every workgroup of the member sits on the SAME XCD (checked at run time, below).  Then their common L2 is the coherence
-// point: a workgroup signals once its own stores have completed (s_waitcnt vmcnt(0): the per-CU L1 writes through) and a waiter
-// only drops its CU's L1 (buffer_inv sc0) -- no write-back of the XCD's L2, no L2 invalidate, and the operands of the next phase
-// are L2 hits.  Otherwise: agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1), correct across XCDs.
+// point on the PRODUCER side: a workgroup signals once its own stores have completed (s_waitcnt vmcnt(0): the per-CU L1 writes
+// through) -- no write-back of the XCD's L2 (buffer_wbl2), which is what the agent-scope release costs.  The waiter's side is the
+// agent-scope invalidate, buffer_inv sc1.  (The first version issued buffer_inv sc0 -- workgroup scope -- to drop "only the CU's
+// L1": outside threadgroup-split mode that does not invalidate the L1 at all.  A phase streams far more than an L1 through the CU,
+// so stale operand lines were almost always evicted by then -- the bit-identity tests passed for a week -- until two groups in one
+// launch (ClusterMulti) changed the footprint: 1 solve in 3 left the per-group launches' bits after 5 ... 50 iterations, and a
+// two-rank taha1a run left the oracle's trajectory at 1e-2.  tools/dbg/merge_engine_check.py is the reproducer.)
+// Otherwise: agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1), correct across XCDs.
 __device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target, bool local) {
   if (local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -376,7 +381,7 @@ __device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1ll << 24)) { good = 0; break; }
     }
-    if (local) asm volatile("buffer_inv sc0" ::: "memory");
+    if (local) asm volatile("buffer_inv sc1" ::: "memory");
     else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     ok = good;
   }

@@ -19,7 +19,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 lib = cuadmm_amd.load()
 coupled = sys.argv[2] == "coupled"
-moment = sys.argv[2] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT")
+moment = sys.argv[2] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a")
 rng = np.random.default_rng(2)
 blk = list(np.array([32] * 20 + [7] * 15 + [15] * 11 + [40, 3, 28])[rng.permutation(49)])
 p = make_synthetic(blk, cons_per_block=3, seed=11)

@@ -34,6 +34,9 @@ RUNS = {
     "PushT_N=10_MOMENT/switch=0": ("PushT_N=10_MOMENT", 0, 60, 500),
     "PushT_N=10_MOMENT/switch=11000": ("PushT_N=10_MOMENT", 11000, 60, 500),
     "PushT_N=30_MOMENT/switch=11000": ("PushT_N=30_MOMENT", 11000, 60, 200),
+    # 14 blocks of 56 / 126 / 252, m = 3 002: the merged one-launch sign-path groups and the whole factor as the dense GPU tail
+    "taha1a/switch=0": ("taha1a", 0, 60, 400),
+    "taha1a/switch=11000": ("taha1a", 11000, 60, 400),
 }
 
 

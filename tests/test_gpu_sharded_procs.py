@@ -32,7 +32,7 @@ def test_two_processes_one_gpu(kind, port, tmp_path):
     assert np.max(np.abs(d["y"] - d["yref"])) <= 1e-8 * (1 + np.max(np.abs(d["yref"])))
 
 
-@pytest.mark.parametrize("name,port", [("pendulum_N=80", 29643), ("PlanarHand_N=1_MOMENT", 29644)])
+@pytest.mark.parametrize("name,port", [("pendulum_N=80", 29643), ("PlanarHand_N=1_MOMENT", 29644), ("taha1a", 29645)])
 def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path):
     """BASELINE configs[4] (pendulum N = 80) and configs[0] (PlanarHand) on TWO ranks: blocks sharded by index, coupled
     constraints, the replicated y-solve with the GPU tail and the device-side leading sweeps on every rank -- against the
