@@ -411,9 +411,11 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
   if (member >= ca.count) return;               // the whole workgroup, before any barrier
   unsigned* bar = ca.bar + member;
   unsigned phase = 0;
+  int xcc0;                                     // the XCD this workgroup started on
   {
     int x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    xcc0 = x & 15;
     if (threadIdx.x == 0) __hip_atomic_store(ca.xcc + (size_t)member * ntiles + tile, x & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!lg_member_barrier(bar, ntiles * ++phase, false)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
     if (threadIdx.x == 0) {
@@ -436,6 +438,13 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
     if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
     lg_gemm_sym_body<true, TM, BK, 2>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
     if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+    if (local) {
+      // the light barrier stands on "same XCD", established once at the start: a workgroup that finds itself elsewhere (a preempted
+      // queue restored on other hardware) raises the failure counter -- an error, not a silently stale operand
+      int x;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+      if ((x & 15) != xcc0 && threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1);
+    }
     double* u = s; s = t; t = u;
   }
   // P = 0.5 (X0 + X0 S_final); `s` holds the last iterate

@@ -334,6 +334,28 @@ def test_project_sign_path_groups_in_one_launch_are_bit_identical(blk, monkeypat
     assert np.max(np.abs(beside - ref)) <= 2e-12 * 70
 
 
+@pytest.mark.parametrize("blk", [[252, 56, 56, 56, 126], [200, 100], [252, 126]])
+def test_engine_solves_with_merged_one_launch_groups_leave_the_per_group_bits(blk):
+    """The regression test of the one-launch kernel's barrier (csrc/psd_large.hip: lg_member_barrier).  Its XCD-local variant once
+    issued a workgroup-scope invalidate that does not drop the L1; stale operand lines were almost always evicted in time, so the
+    op-level bit-identity tests passed -- but INSIDE THE ENGINE (the same plan and buffers projection after projection) two groups
+    in one launch left the per-group launches' bits in one solve of three.  80 sGS iterations, six solves, must be identical."""
+    import cuadmm_amd
+    from cuadmm_amd import synthetic
+    prob = synthetic.make_synthetic(blk, cons_per_block=5, dense_C=True)
+
+    def run(merge):
+        s = cuadmm_amd.SDPSolver(verbose=False, options={"psd_lg_merge": merge})
+        s.init_problem(cuadmm_amd.Problem(prob.vec_len, prob.con_num, prob.blk, prob.At_col_ptrs, prob.At_row_ids, prob.At_vals,
+                                          prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals))
+        s.solve(80, 0.0, 0, 50, 100, 11000, 1.05)
+        return np.array(s.info_arr("pobj")), np.array(s.info_arr("errRd"))
+    ref = run(0)
+    for _ in range(6):
+        got = run(1)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
 def test_project_one_workgroup_kernels_third_lds_matrix_is_bit_identical(monkeypatch):
     """33 <= n <= 64 with few blocks of a class (a moment relaxation: pendulum N = 80 has 80 of n = 55): the one-workgroup kernel
     with the next iterate stored beside the current one and the statistics only where the schedule reads them
