@@ -1115,6 +1115,7 @@ static int init_closed(Solver* s, const InitIn& in, InitCtx& c) {
       s->plan.fused_slots(slot_of);
       std::vector<ClosedRec> recs((size_t)std::max(s->plan.fused_blocks(), 1));
       std::memset(recs.data(), 0, sizeof(ClosedRec) * recs.size());
+      for (auto& R : recs) for (int a = 0; a < kClosedMaxRows; ++a) R.D[a] = 1.0;     // rows >= nk: the kernel's sweeps run unmasked
       for (size_t k = 0; k < nb && ok; ++k) {
         if (slot_of[k] < 0) continue;
         ClosedRec& R = recs[(size_t)slot_of[k]];
@@ -1141,8 +1142,10 @@ static int init_closed(Solver* s, const InitIn& in, InitCtx& c) {
           const int k0 = hd[k].x, nk = R.nk, z0 = hd[k].z;
           int maxmult = 0;
           for (int a = 0; a <= nk; ++a) R.nzp[a] = (unsigned char)(lnz[k0 + a] - z0);
+          for (int a = 0; a < nk; ++a) R.maxlen = std::max(R.maxlen, (int)R.nzp[a + 1] - (int)R.nzp[a]);
+          const int n_blk = std::abs(s->blk_local[k]);
           for (int q = 0; q < R.nnz; ++q) {
-            R.e[q] = (unsigned short)le[z0 + q];
+            R.nzt[q] = psd_closed_tab_entry(n_blk, le[z0 + q]);
             R.v[q] = lval[z0 + q];
             int rowpos = 0;
             while (rowpos + 1 <= nk && (int)R.nzp[rowpos + 1] <= q) ++rowpos;
@@ -1160,6 +1163,12 @@ static int init_closed(Solver* s, const InitIn& in, InitCtx& c) {
             (rc = s->closed.partials2.alloc(2 * (size_t)s->plan.fused_blocks() + 2)))
           return rc;
         CUADMM_HIP_TRY(hipMemset(s->closed.cl_out.p, 0, sizeof(double) * 16 * recs.size()));
+        {   // the records' headers travel with the block descriptors (one dependent load less in every kernel that reads them)
+          std::vector<int> aux(nb, 0);
+          for (size_t k = 0; k < nb; ++k)
+            if (slot_of[k] >= 0) { const ClosedRec& R = recs[(size_t)slot_of[k]]; aux[k] = closed_hdr_pack(R.nk, R.nnz, R.nrounds, R.maxlen); }
+          if ((rc = s->plan.set_desc_aux(aux))) return rc;
+        }
         s->closed.active = true;
         s->closed.out_dirty = true;
         if (s->verbose) printf(" closed blocks: each block solves for its own multipliers (<= %d rows) inside the projection kernel\n", kClosedMaxRows);

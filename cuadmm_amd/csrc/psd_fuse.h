@@ -49,6 +49,7 @@ struct SignFuse {
   const struct ClosedRec* rec;
   double* cl_out;
   int iter0;                                          // closed blocks: iterations run before this launch (ages the schedule hints)
+  int full;                                           // every block of the launch fills its tile (n = 16 NT): set per launch by PsdPlan::project
 };
 struct LcDesc { int x, y, z, w; };
 constexpr int kFuseRowsMax = 64;
@@ -59,14 +60,22 @@ constexpr int kClosedMaxRows = 8;
 // in the factor's order); rk = row position | round << 3, where `round` counts the earlier nonzeros on the same svec slot:
 // round k is applied after round k - 1, which reproduces the summation order of the CSR gather.
 struct alignas(64) ClosedRec {
-  int nk, nnz, nrounds, pad0;                 // local rows, their nonzeros, largest multiplicity of an svec slot
+  int nk, nnz, nrounds, maxlen;               // local rows, their nonzeros, largest multiplicity of an svec slot, longest row
   unsigned char nzp[16];                      // nonzeros of row k: nzp[k] .. nzp[k + 1]
   int rows[kClosedMaxRows];                   // constraint index (the factor's order) of local row k
-  unsigned short e[kFuseRowsMax];             // svec offset inside the block
+  unsigned nzt[kFuseRowsMax];                 // the nonzero's svec slot as the entry of the block's tile table (SwcTab<NT>: byte
+                                              // offsets of the element and of its Rd1 slot in the LDS tile; psd_closed_tab_entry)
   unsigned char rk[kFuseRowsMax];
   double v[kFuseRowsMax];
   double L[kClosedMaxRows * kClosedMaxRows];  // unit lower factor of the block's diagonal block of A A^T, row-major
   double D[kClosedMaxRows], b[kClosedMaxRows], normA[kClosedMaxRows];
 };
+
+// the record's header, packed into PsdDesc::pad[0] (PsdPlan::set_desc_aux): the kernels know it with the descriptor
+constexpr int closed_hdr_pack(int nk, int nnz, int nrounds, int maxlen) { return nk | (nnz << 4) | (nrounds << 11) | (maxlen << 18); }
+__host__ __device__ constexpr int closed_hdr_nk(int h) { return h & 15; }
+__host__ __device__ constexpr int closed_hdr_nnz(int h) { return (h >> 4) & 127; }
+__host__ __device__ constexpr int closed_hdr_nrounds(int h) { return (h >> 11) & 127; }
+__host__ __device__ constexpr int closed_hdr_maxlen(int h) { return (h >> 18) & 127; }
 
 }  // namespace cuadmm

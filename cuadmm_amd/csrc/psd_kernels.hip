@@ -156,13 +156,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 }
 
 // closed blocks (psd_sign_closed.h): the whole iteration of the block, one launch per iteration
-template <int NT, int OCC>
+template <int NT, int OCC, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_closed_kernel(ClosedArgs a) {
   extern __shared__ double swt_smem[];
   const int m = (int)blockIdx.x;
   if (m >= a.count) return;
   const PsdDesc d = a.desc[a.first + m];
-  psd_sign_closed_body<NT>(a, d.n, swt_smem, a.steps ? a.steps + d.id : nullptr, a.hint ? a.hint + d.id : nullptr, nullptr, d.off, d.slot, 0);
+  psd_sign_closed_body<NT, false, FULL>(a, d.n, swt_smem, a.steps ? a.steps + d.id : nullptr, a.hint ? a.hint + d.id : nullptr, nullptr, d.off, d.slot, 0, d.pad[0]);
 }
 
 // SEVERAL ADMM ITERATIONS PER LAUNCH (ClosedArgs::iters; closed blocks): one PERSISTENT WORKGROUP PER CU (WAVES = the CU's
@@ -175,7 +175,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 // Why: with one wavefront per block and one launch per iteration, 10 000 blocks on 4 096 wavefront slots are 2.44 rounds -- the
 // last one at 44 % occupancy -- plus a launch ramp, a tail and a host round trip every iteration; handing out (member,
 // iteration) pairs dynamically inside a CU keeps every SIMD at its four wavefronts until the last task of the batch.
-template <int NT, int WAVES, int OCC>
+// ints of the task counter + the members' flags, rounded so that the descriptor cache behind them is 16-byte aligned
+__host__ __device__ constexpr int closed_cu_ctl_ints(int nb_max) { return (nb_max + 2 + 3) & ~3; }
+static_assert(sizeof(PsdDesc) == 32, "the LDS descriptor cache copies a descriptor as two 16-byte words");
+
+template <int NT, int WAVES, int OCC, bool FULL>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_closed_cu_kernel(ClosedArgs a) {
   extern __shared__ double swt_smem[];
   constexpr int TILE = SignWaveT<NT>::NP * SignWaveT<NT>::LD;
@@ -185,24 +189,35 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
   const int g = (int)blockIdx.x, G = (int)gridDim.x;
   const int nb = (a.count - g + G - 1) / G;
   for (int i = (int)threadIdx.x; i < nb + 1; i += 64 * WAVES) ctl[i] = 0;
+  // The descriptors of the workgroup's members, copied to LDS once (a task's descriptor does not depend on its iteration): the
+  // first of a task's dependent memory round trips -- a global load of 3-6 k ticks on the loaded chip -- becomes an LDS read.
+  sl_v4i32* dcache = reinterpret_cast<sl_v4i32*>(ctl + closed_cu_ctl_ints((a.count + G - 1) / G));
+  if (a.dcache)
+    for (int i = (int)threadIdx.x; i < nb; i += 64 * WAVES) {
+      const sl_v4i32* src = reinterpret_cast<const sl_v4i32*>(a.desc + a.first + g + i * G);
+      dcache[2 * i] = src[0];
+      dcache[2 * i + 1] = src[1];
+    }
   __syncthreads();
   const int ntask = nb * a.iters;
+  const long long clk0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0, rt0 = a.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   // The kernel arguments are re-read from the kernarg segment for every task (scalar loads, cached): held in SGPRs across the
   // task loop they would be spilled at this kernel's register budget.
   using KArgC = __attribute__((address_space(4))) const char;
   KArgC* ka = (KArgC*)__builtin_amdgcn_kernarg_segment_ptr();
 #pragma unroll 1
   for (;;) {
+    const long long tk0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     int t = 0;
     if (lane_id() == 0) t = atomicAdd(&ctl[0], 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= ntask) break;
     const int it = t / nb, j = t - it * nb;
-    if (it > 0) {
-      volatile int* dn = ctl + 1 + j;
-      while (*dn < it) __builtin_amdgcn_s_sleep(8);
+    if (it > 0) {   // plain LDS atomics: a volatile access would become a FLAT one (system scope, a vmcnt(0) round trip each)
+      while (__hip_atomic_load(ctl + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const long long tk1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(ka));                       // opaque: nothing loaded through it is kept across tasks
     const ClosedArgs al = *reinterpret_cast<__attribute__((address_space(4))) const ClosedArgs*>(ka);
@@ -210,16 +225,34 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
     const ClosedArgs al = a;
     (void)ka;
 #endif
-    const PsdDesc d = al.desc[al.first + g + j * G];
+    PsdDesc d;
+    if (al.dcache) {
+      const sl_v4i32 q0 = dcache[2 * j], q1 = dcache[2 * j + 1];
+      d.off = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(q0[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(q0[0]));
+      d.n = __builtin_amdgcn_readfirstlane(q0[2]); d.id = __builtin_amdgcn_readfirstlane(q0[3]); d.slot = __builtin_amdgcn_readfirstlane(q1[0]);
+      d.pad[0] = __builtin_amdgcn_readfirstlane(q1[1]);
+    } else {
+      d = al.desc[al.first + g + j * G];
+    }
     int toff = ((int)threadIdx.x >> 6) * TILE;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(toff));                     // not hoisted out of the task loop (it would stay live across the body)
 #endif
     double* tile = swt_smem + toff;
-    psd_sign_closed_body<NT, true>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
-                             al.dbg ? al.dbg + 10 * (long long)(g + j * G) : nullptr, d.off, d.slot, (long long)it * al.pstride, it);
+    const long long tk2 = al.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    psd_sign_closed_body<NT, true, FULL>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
+                             al.dbg ? al.dbg + 16 * (long long)(g + j * G) : nullptr, d.off, d.slot, (long long)it * al.pstride, d.pad[0], it);
+    const long long tk3 = al.dbg ? (long long)__builtin_readcyclecounter() : 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane_id() == 0) { volatile int* dn = ctl + 1 + j; *dn = it + 1; }
+    if (lane_id() == 0) __hip_atomic_store(ctl + 1 + j, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (al.dbg && lane_id() == 0) {   // developer aid (psd_debug = 2): what a task spends outside its body
+      long long* q = al.dbg + 16 * (long long)(g + j * G);
+      q[10] = tk1 - tk0; q[11] = tk2 - tk1; q[12] = tk3 - tk2; q[13] = (long long)__builtin_readcyclecounter() - tk3;
+    }
+  }
+  if (a.dbg && threadIdx.x == 0) {   // the shader clock over the launch: s_memtime ticks per 100 MHz real-time tick
+    long long* q = a.dbg + 16 * (long long)g;
+    q[14] = (long long)__builtin_readcyclecounter() - clk0; q[15] = (long long)__builtin_amdgcn_s_memrealtime() - rt0;
   }
 }
 
@@ -237,24 +270,36 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
     ca.pstride = fz->pstride; ca.mode = fz->mode; ca.iters = fz->iters > 1 ? fz->iters : 1; ca.first = first; ca.count = count;
     if (fz->iters > 1) {
       constexpr int WAVES = 4 * OCC > 16 ? 16 : 4 * OCC, WG_PER_CU = 4 * OCC / WAVES;
-      static int n_cu = 0;
+      static int n_cu_of[64] = {0};                    // per DEVICE (two solvers of a process may sit on different GPUs)
+      int dev = 0;
+      CUADMM_HIP_TRY(hipGetDevice(&dev));
+      int& n_cu = n_cu_of[dev & 63];
       if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        CUADMM_HIP_TRY(hipGetDevice(&dev));
-        CUADMM_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int v = 0;
+        CUADMM_HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
       }
       const int grid = std::min(count, n_cu * WG_PER_CU);
       const size_t nb_max = ((size_t)count + grid - 1) / grid;
-      const size_t lds = WAVES * SignWaveT<NT>::LDS_BYTES + sizeof(int) * (nb_max + 2);
+      size_t lds = WAVES * SignWaveT<NT>::LDS_BYTES + sizeof(int) * (size_t)closed_cu_ctl_ints((int)nb_max);
+      ca.dcache = lds + sizeof(PsdDesc) * nb_max <= kMaxLdsBytes;     // the members' descriptors in LDS when they fit
+      if (ca.dcache) lds += sizeof(PsdDesc) * nb_max;
       if (lds > kMaxLdsBytes) { set_error("psd: %d blocks per workgroup do not fit the batched launch", (int)nb_max); return CUADMM_ERR_INVALID; }
-      auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC>;
-      static LdsCapOnce once;
-      CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
+      if (fz->full) {
+        auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC, true>;
+        static LdsCapOnce once;
+        CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
+      } else {
+        auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC, false>;
+        static LdsCapOnce once;
+        CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
+      }
+    } else if (fz->full) {
+      hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
     } else {
-      hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
+      hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
     }
   }
   else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count);
@@ -345,6 +390,15 @@ int PsdPlan::build(const int* blk, int mat_num) {
     cls_count[c] = (int)ids.size() - cls_begin[c];
   }
   wave4 = opt.mid == 0 && cls_count[4] >= opt.wave4_min;
+  // ranges whose members all fill their tile exactly (n = 16 NT): the closed-block kernels then know every slot of the svec walks
+  // at compile time (psd_sign_closed.h, FULL)
+  {
+    auto all_eq = [&](int begin, int count, int n) { for (int q = begin; q < begin + count; ++q) if (blk[ids[(size_t)q]] != n) return false; return count > 0; };
+    range_full[0] = all_eq(cls_begin[2], cls_count[2], 16);
+    range_full[1] = all_eq(cls_begin[3], cls_count[3], 32);
+    range_full[2] = all_eq(cls_begin[4] + cls4_big, cls_count[4] - cls4_big, 48);
+    range_full[3] = all_eq(cls_begin[4], cls4_big, 64);
+  }
   n_free = (int)free_off.size();
   if (n_free > 0) {
     CUADMM_HIP_TRY(hipMalloc(&d_free_off, sizeof(long long) * free_off.size()));
@@ -444,7 +498,7 @@ __global__ void hint_decay_kernel(int* hint, int n) {
 
 // Blocks of the one-wavefront-per-block sign kernels (classes 3 and 4) can take the iteration's vector work with them
 bool PsdPlan::fusable() const {
-  return eig_rank == 0 && !opt.debug && opt.n32_sign && opt.mid != 1 && fused_blocks() > 0 && vec_len < 0x7fffffffLL;
+  return eig_rank == 0 && opt.debug != 1 && opt.n32_sign && opt.mid != 1 && fused_blocks() > 0 && vec_len < 0x7fffffffLL;
 }
 
 bool PsdPlan::sort_by_steps_host(const int* steps_host, std::vector<std::pair<int, int>>& ranges) {
@@ -587,7 +641,7 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     a.hint = d_hint;
     long long* dbg = nullptr;
     const int nwg = (cls_count[c] + 1) / 2 + 4;
-    if (psd_debug && eig_rank == 0 && !fz && ((c == 2 && sign16) || (c == 3 && sign32) || (c == 4 && wave4))) {
+    if (opt.debug == 1 && eig_rank == 0 && !fz && ((c == 2 && sign16) || (c == 3 && sign32) || (c == 4 && wave4))) {
       // phase ticks of the one-wavefront kernels (CUADMM_PSD_DEBUG=1 / option psd_debug), unfused
       std::vector<long long> h((size_t)cls_count[c] * 10, 0);
       long long* d = nullptr;
@@ -615,31 +669,40 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       continue;
     }
     if (c == 3 && fz && fz->iters > 1 && opt.debug >= 2) {   // developer aid (psd_debug = 2): phase ticks of the batched launches at full occupancy
-      std::vector<long long> h((size_t)cls_count[c] * 10, 0);
+      std::vector<long long> h((size_t)cls_count[c] * 16, 0);
       long long* d = nullptr;
       CUADMM_HIP_TRY(hipMalloc(&d, sizeof(long long) * h.size()));
       CUADMM_HIP_TRY(hipMemset(d, 0, sizeof(long long) * h.size()));
       a.dbg = d;
-      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz);
+      SignFuse f2 = *fz;
+      f2.full = range_full[1];
+      int rc2 = launch_sign_wave32(a, 0, cls_count[c], st, opt, &f2);
       if (rc2) return rc2;
       CUADMM_HIP_TRY(hipStreamSynchronize(st));
       { int rc_ = staged_d2h(h.data(), d, sizeof(long long) * h.size(), st); if (rc_) return rc_; }
-      double ph[10] = {0};
-      for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 10; ++q) ph[q] += (double)h[(size_t)w * 10 + q];
+      double ph[16] = {0};
+      for (int w = 0; w < cls_count[c]; ++w) for (int q = 0; q < 16; ++q) ph[q] += (double)h[(size_t)w * 16 + q];
       const double nw = cls_count[c];
       for (double& x : ph) x /= nw;
       // stamps 4..9 are offsets from the start of the task; ph[0..2] are the phase lengths
       const double it0 = ph[0], ep0 = ph[0] + ph[1];
       fprintf(stderr, "[cu debug] %d blocks x %d iterations: ticks/task prologue %.0f [solve done %.0f, loads back %.0f, gather done %.0f] iteration %.0f (%.2f steps, %.0f per step) "
-                      "epilogue %.0f [Xb rebuilt +%.0f, P stored +%.0f, walk done +%.0f] total %.0f\n",
+                      "epilogue %.0f [Xb rebuilt +%.0f, P stored +%.0f, walk done +%.0f] total %.0f | outside the body: claim + flag wait %.0f, arguments + descriptor %.0f, "
+                      "body call %.0f, release + flag %.0f\n",
               cls_count[c], fz->iters, ph[0], ph[4], ph[5], ph[6], ph[1], ph[3], ph[1] / std::max(ph[3], 1.0), ph[2], ph[7] - ep0, ph[8] - ep0, ph[9] - ep0,
-              ph[0] + ph[1] + ph[2]);
+              ph[0] + ph[1] + ph[2], ph[10], ph[11], ph[12], ph[13]);
+      {
+        double ck = 0, rt = 0;
+        const int ng = std::min(cls_count[c], 256);
+        for (int w = 0; w < ng; ++w) { ck += (double)h[(size_t)w * 16 + 14]; rt += (double)h[(size_t)w * 16 + 15]; }
+        fprintf(stderr, "[cu debug] launch: %.3f ms, s_memtime runs at %.3f GHz\n", rt / ng * 1e-5, ck / std::max(rt, 1.0) * 0.1);
+      }
       (void)it0;
       { hipError_t e = hipFree(d); (void)e; }
       if (fork && c != main_class && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipEventRecord(ev_done[c], st));
       continue;
     }
-    if (c == 3 && psd_debug && !sign32) {   // phase cycles of the register eigensolver
+    if (c == 3 && opt.debug == 1 && !sign32) {   // phase cycles of the register eigensolver
       CUADMM_HIP_TRY(hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)nwg));
       CUADMM_HIP_TRY(hipMemset(dbg, 0, sizeof(long long) * 8 * (size_t)nwg));
       a.dbg = dbg;
@@ -649,19 +712,25 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
       // one wavefront per block (psd_sign_wave.h) from psd_wave4_min blocks on, else one workgroup per block (latency); option
       // psd_mid = 2 forces the one-workgroup kernels, 1 the register eigensolver
       if (wave4) {
-        rc = launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz);
-        if (!rc) rc = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz);
+        SignFuse f4, f3;
+        if (fz) { f4 = *fz; f3 = *fz; f4.full = range_full[3]; f3.full = range_full[2]; }
+        rc = launch_sign_wave<4, 1>(a, 0, cls4_big, st, fz ? &f4 : nullptr);
+        if (!rc) rc = launch_sign_wave<3, 2>(a, cls4_big, cls_count[c] - cls4_big, st, fz ? &f3 : nullptr);
       } else {
         const bool triple = opt.lds_triple != 0 && cls_count[c] <= 256;
         rc = launch_sign_lds<64>(a, 0, cls4_big, st, triple);
         if (!rc) rc = launch_sign_lds<48>(a, cls4_big, cls_count[c] - cls4_big, st, triple);
       }
     } else if (c == 3 && sign32 && eig_rank == 0) {
-      rc = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz);
-    } else if (c == 2 && sign16 && eig_rank == 0 && !psd_debug) {
+      SignFuse f2;
+      if (fz) { f2 = *fz; f2.full = range_full[1]; }
+      rc = launch_sign_wave32(a, 0, cls_count[c], st, opt, fz ? &f2 : nullptr);
+    } else if (c == 2 && sign16 && eig_rank == 0 && opt.debug != 1) {
       // 9 <= n <= 16: the same iteration on ONE 16 x 16 sub-tile, eight wavefronts per SIMD (the register eigensolver needs
       // ~20 us of dependent rotations per block; here a block is 8 MFMAs per step)
-      rc = launch_sign_wave<1, 8>(a, 0, cls_count[c], st, fz);
+      SignFuse f1;
+      if (fz) { f1 = *fz; f1.full = range_full[0]; }
+      rc = launch_sign_wave<1, 8>(a, 0, cls_count[c], st, fz ? &f1 : nullptr);
     } else if (c == 6) {
       // blocks beyond one workgroup's LDS that need EIGENVALUES (the rank-limited projection; everything else of this size takes
       // the matrix-sign path): one block at a time on the whole chip (eig_large.hip)
@@ -706,6 +775,24 @@ int PsdPlan::project(const double* Xb, double* Xproj, hipStream_t st, const Sign
     for (int c = 0; c < kNumPsdClasses; ++c)
       if (cls_count[c] > 0 && c != main_class && (!one_side || c == last_class)) CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_done[c], 0));
   return CUADMM_OK;
+}
+
+// pad[0] of every descriptor <- aux[block id] (the engine's closed-block header, psd_fuse.h: closed_hdr_pack); the reordering
+// moves whole descriptors, so it stays with its block
+int PsdPlan::set_desc_aux(const std::vector<int>& aux_of_block) {
+  if ((int)aux_of_block.size() != nblk) { set_error("psd: set_desc_aux: %d values for %d blocks", (int)aux_of_block.size(), nblk); return CUADMM_ERR_INVALID; }
+  if (h_desc.empty() || !d_desc) return CUADMM_OK;
+  for (auto& d : h_desc) d.pad[0] = aux_of_block[(size_t)d.id];
+  return staged_h2d(d_desc, h_desc.data(), sizeof(PsdDesc) * h_desc.size());
+}
+
+// entry e of the tile table of the one-wavefront geometry that serves a block of size n (psd_sign_closed.h: SwcTab<NT>)
+unsigned psd_closed_tab_entry(int n, int e) {
+  static const SwcTab<1> t1; static const SwcTab<2> t2; static const SwcTab<3> t3; static const SwcTab<4> t4;
+  if (n <= 16) return e < SwcTab<1>::N ? t1.v[e] : 0u;
+  if (n <= 32) return e < SwcTab<2>::N ? t2.v[e] : 0u;
+  if (n <= 48) return e < SwcTab<3>::N ? t3.v[e] : 0u;
+  return e < SwcTab<4>::N ? t4.v[e] : 0u;
 }
 
 int PsdPlan::fail_count(hipStream_t st) const {

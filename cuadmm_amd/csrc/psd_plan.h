@@ -15,6 +15,7 @@ namespace cuadmm {
 
 constexpr int kNumPsdClasses = 7;   // n<=4, <=8, <=16, <=32, <=64 (register kernels) | LDS workgroup | HBM workgroup
 int psd_class_of(int n);
+unsigned psd_closed_tab_entry(int n, int e);
 
 // class member -> block, 32 bytes (one scalar load).  `slot`: the block's partial-sum slot in the fused iteration -- fixed at
 // build time, so the sums of an iteration do not depend on the order in which the members are launched (longest block first
@@ -54,6 +55,7 @@ struct PsdPlan {
   int n_free = 0;
   long long *d_free_off = nullptr, *d_free_len = nullptr;
   mutable SignPsd sign;
+  bool range_full[4] = {false, false, false, false};   // every member of the NT = 1 / 2 / 3 / 4 range has n = 16 NT
   int cls4_big = 0;            // members of class 4 (32 < n <= 64) with n > 48: NP = 64 kernel, the rest NP = 48
   bool overlap = false;        // engine-owned plans: classes on their own streams (fork / join on the caller's stream)
   mutable hipEvent_t ev_fork = nullptr, ev_done[kNumPsdClasses] = {};
@@ -67,6 +69,7 @@ struct PsdPlan {
   int* d_rest = nullptr;
   long long n_rest = 0;
   bool fusable() const;
+  int set_desc_aux(const std::vector<int>& aux_of_block);
   int fused_blocks() const { return (sign16 ? cls_count[2] : 0) + cls_count[3] + (wave4 ? cls_count[4] : 0); }
   // Several iterations per launch run one persistent workgroup per CU and tile geometry (psd_sign_closed_cu_kernel); workgroups
   // of different geometries cannot share a CU's LDS, so their launches would run one after the other instead of side by side

@@ -108,6 +108,23 @@ __device__ __forceinline__ void swc_lower_read(const double* __restrict__ M, int
       for (int r = 0; r < 4; ++r) t[j][i][r] = M[(16 * i + kk + 4 * r) * LD + 16 * j + r16];
 }
 
+// a wave-uniform double into scalar registers (a VALU result lives in a VGPR even when every lane holds the same bits: across
+// the iteration it would cost two of the 128, i.e. a spill)
+__device__ __forceinline__ double swc_uniform(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+#else
+  return v;
+#endif
+}
+// keeps the slots of a walk apart in the schedule: without it the compiler forms the LDS addresses of all slots up front
+// (18 registers) and spills them
+__device__ __forceinline__ void swc_sched_split() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // e -> byte offsets into the tile of the element's slot in the upper triangle (bits 0..15; bit 0 set: a diagonal element) and of
 // its Rd1 slot (bits 16..31), e = c (c + 1) / 2 + r, r <= c; one table per tile geometry, 64 NSLOT entries (a lane's slots are
 // e = lane + 64 u: entries past the last element are never used for an access that matters)
@@ -142,6 +159,7 @@ struct ClosedArgs {
   long long pstride;
   int mode, iters, first, count;
   int iter0;                                          // iterations run before this launch (the schedule hints age with it)
+  int dcache;                                         // persistent launches: the workgroup keeps its members' descriptors in LDS
 };
 
 #define CUADMM_SWC_STAMP(k) \
@@ -152,15 +170,22 @@ struct ClosedArgs {
 // allocations): every slot of a batch then shares one address register and immediate offsets.
 // TASK_LOOP: the body is inlined into the task loop of psd_sign_closed_cu_kernel, where everything derived from the lane id is
 // loop-invariant -- hoisted out of the loop it would stay live across the whole body; the lane id is made opaque instead.
-template <int NT, bool TASK_LOOP = false>
-__device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n, double* S, int* steps_out, int* hint, long long* dbg,
-                                                     long long off, int slot, long long poff, int it_local = 0) {
+// FULL: every block of the launch has n = NP (BASELINE configs[1]: 32): the length of the svec range and with it the validity of
+// every slot of the walks is known at compile time -- no masks, no branches around the slots.  (On this chip everything a
+// wavefront issues on the vector ALU takes its cycles from the port the fp64 MFMAs issue on, tools/ubench/mfma_coissue.hip: an
+// integer VALU instruction costs ~2 cycles of matrix-core time, an fp64 one ~4, a v_readlane ~4.5 -- the prologue and epilogue
+// of a task are paid in matrix-core cycles, not hidden behind them.)
+template <int NT, bool TASK_LOOP = false, bool FULL = false>
+__device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n_arg, double* S, int* steps_out, int* hint, long long* dbg,
+                                                     long long off, int slot, long long poff, int hdr, int it_local = 0) {
   using Cfg = SignWaveT<NT>;
   constexpr int LD = Cfg::LD, NP = Cfg::NP, U = Cfg::U, NSLOT = Cfg::NSLOT;
   constexpr int NB = (NSLOT + U - 1) / U;                 // batches of the flat walk
+  const int n = FULL ? NP : n_arg;
   int lane_p = lane_id();
 #if defined(__HIP_DEVICE_COMPILE__)
   if (TASK_LOOP) asm volatile("" : "+v"(lane_p));
+  __builtin_assume(lane_p >= 0 && lane_p < 64);
 #endif
   const int lane = lane_p;
   const int r16 = lane & 15, kk = lane >> 4;
@@ -173,31 +198,40 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   const double* __restrict__ Cl = fz.C + off + lane;
   auto at = [&](unsigned byte_off) -> double& { return *reinterpret_cast<double*>(reinterpret_cast<char*>(S) + byte_off); };
 
-  // ---- trip 2: the record, the block's rows of [A X | A (S - C)], and the first batch of table / X / C
-  const int nk = rec->nk, nnz = rec->nnz, nrounds = rec->nrounds;          // wave-uniform (scalar loads)
+  // ---- trip 2: the record, the block's rows of [A X | A (S - C)], and the first batch of table / X / C.  Every address is known
+  // from the descriptor (the record's header rides in PsdDesc::pad[0]: closed_hdr_*), and no load is conditional on a loaded
+  // value -- the first version read nk from the record and only then issued the loads of the factor, X and C: two dependent
+  // round trips of ~6 k ticks each where one does
+  const int nk = closed_hdr_nk(hdr), nnz = closed_hdr_nnz(hdr), nrounds = closed_hdr_nrounds(hdr);   // wave-uniform
   const int l8 = lane & 7;
   const bool mine = lane < nk;
   const double nzv = rec->v[lane];
-  const int nze = rec->e[lane], nzrk = rec->rk[lane];
+  const unsigned nzt = rec->nzt[lane];
+  const int nzrk = rec->rk[lane];
   const int row = rec->rows[l8];
   const double dk = rec->D[l8], bk = rec->b[l8];
   const double ax_old = fz.cl_out[16 * (long long)slot + l8], as_old = fz.cl_out[16 * (long long)slot + 8 + l8];
   double lrow[kClosedMaxRows], lcol[kClosedMaxRows];
 #pragma unroll
-  for (int q = 0; q < kClosedMaxRows; ++q) {
-    lrow[q] = (mine && q < lane) ? rec->L[lane * kClosedMaxRows + q] : 0.0;               // L[lane][q]
-    lcol[q] = (mine && q > lane && q < nk) ? rec->L[q * kClosedMaxRows + lane] : 0.0;     // L[q][lane]
+  for (int q = 0; q < kClosedMaxRows; ++q) {      // rows / columns l8 of the factor for every lane (lanes >= 8 repeat them): masked below
+    lrow[q] = rec->L[l8 * kClosedMaxRows + q];                                            // L[lane][q]
+    lcol[q] = rec->L[q * kClosedMaxRows + l8];                                            // L[q][lane]
   }
   unsigned tb[U];
   double xv[U], cv[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) { tb[u] = tabl[64 * u]; xv[u] = Xl[64 * u]; cv[u] = Cl[64 * u]; }
-  const unsigned nzt = g_swc_tab<NT>.v[nze];
+  // (no masks on the factor: the record holds the STRICT lower triangle and zeros everywhere else, rows and columns >= nk
+  // included, and D = 1 there -- lanes >= 8 repeat lanes 0..7 and are never read)
   // the whole tile starts at zero: the padding of a block smaller than the tile, and the Rd1 slots A^T y is summed into
   {
     sl_v2f64* S2 = reinterpret_cast<sl_v2f64*>(S);
+    double zero = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (TASK_LOOP) asm volatile("" : "+v"(zero));            // formed here: hoisted out of the task loop the four registers are spilled
+#endif
 #pragma unroll 1
-    for (int i = lane; i < NP * LD / 2; i += 64) S2[i] = sl_v2f64{0.0, 0.0};
+    for (int i = lane; i < NP * LD / 2; i += 64) S2[i] = sl_v2f64{zero, zero};
     wave_fence();
   }
   // y_B = (L D L^T)^-1 rhs_B, one lane per row, the serial order and the unfused arithmetic of forest_solve_kernel
@@ -205,23 +239,25 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   if (nk > 0) {
     const double rp = __dadd_rn(-ax_old, bk);                                             // Rp = -A X + b
     double x = mine ? __dadd_rn(-as_old, __dmul_rn(fz.isig, rp)) : 0.0;
+    // both sweeps column by column: 7 + 7 broadcasts from a compile-time lane (v_readlane; the first version's row-oriented
+    // backward sweep needed 28 dependent ds_bpermute round trips), unfused multiply and subtract as in forest_solve_kernel
 #pragma unroll
-    for (int j = 0; j < kClosedMaxRows; ++j) {                                            // L z = rhs
-      const double xj = __shfl(x, j, 64);
-      if (j < nk && lane > j) x = __dsub_rn(x, __dmul_rn(lrow[j], xj));
+    for (int j = 0; j < kClosedMaxRows - 1; ++j) {                                        // L z = rhs
+      const double xj = sw_readlane(x, j);
+      x = __dsub_rn(x, __dmul_rn(lrow[j], xj));                                           // lrow[j] = 0 for lanes <= j
     }
     double yv = x / dk;                                                                   // D^-1, then L^T y = z
 #pragma unroll
-    for (int j = kClosedMaxRows - 2; j >= 0; --j) {
-#pragma unroll
-      for (int i = j + 1; i < kClosedMaxRows; ++i) {
-        const double yi = __shfl(yv, i, 64);
-        if (lane == j && i < nk) yv = __dsub_rn(yv, __dmul_rn(lcol[i], yi));
-      }
+    for (int i = kClosedMaxRows - 1; i >= 1; --i) {
+      const double yi = sw_readlane(yv, i);                                               // final: rows > i are done
+      yv = __dsub_rn(yv, __dmul_rn(lcol[i], yi));                                         // lcol[i] = L[i][lane] = 0 for lanes >= i
     }
     yk = mine ? yv : 0.0;
     if (mine) fz.y_out[row] = yv;
   }
+  // the rows' share of b^T y (rp_stats_partial_kernel's expression) while y is at hand: wave-uniform, so it waits in scalar
+  // registers for the epilogue (the first version re-read the row indices and then y after the iteration: two dependent loads)
+  const double pby_sum = upd ? swc_uniform(wave_sum(mine ? bk * yk : 0.0)) : 0.0;
   CUADMM_SWC_STAMP(4);
   // ---- A^T y scattered into the Rd1 slots, one round per multiplicity of an svec slot (rows ascending: the CSR gather's order)
   {
@@ -245,7 +281,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e_ = base + 64 * u + lane;
-      const bool ok_ = e_ < len;
+      const bool ok_ = (FULL && base + 64 * u + 63 < Cfg::MAXLEN) || e_ < len;
       const unsigned up = tb[u] & 0xfff8u, lo = tb[u] >> 16;
       const double r1 = at(lo) - cv[u];
       const double xb = xv[u] + r1 * fz.sig;
@@ -358,10 +394,6 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   const double* __restrict__ Cl_e = fz.C + off + lane_e;
   const int l8e = lane_e & 7;
   const bool mine_e = lane_e < nk;
-  const double nzv_e = rec->v[lane_e];
-  const unsigned nzt_e = g_swc_tab<NT>.v[rec->e[lane_e]];
-  const int row_e = rec->rows[l8e];
-  const double bk_e = rec->b[l8e], yk_e = mine_e ? fz.y_out[row_e] : 0.0;
 #pragma unroll
   for (int u = 0; u < U; ++u) { tb[u] = tabl_e[64 * u]; xv[u] = Xl_e[64 * u]; }
   swc_frags<NT>(S, r16, kk, f);
@@ -378,7 +410,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
       const int e_ = base + 64 * u + lane_e;
       const unsigned up = tb[u] & 0xfff8u, lo = tb[u] >> 16;
       const double xb = xv[u] + at(lo) * fz.sig;
-      if (e_ < len) at(up) = (tb[u] & 1u) ? xb : xb * kSqrt2Inv;     // the zero padding of the prologue is still in place
+      if ((FULL && base + 64 * u + 63 < Cfg::MAXLEN) || e_ < len) at(up) = (tb[u] & 1u) ? xb : xb * kSqrt2Inv;     // the zero padding of the prologue is still in place
     }
   }
   wave_fence();
@@ -386,6 +418,13 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   if (NB > 1) {                                              // several batches: the first one's table again for the final walk
 #pragma unroll
     for (int u = 0; u < U; ++u) tb[u] = tabl_e[64 * u];
+  } else {
+    // one batch: the table entries stay, but the LDS addresses formed from them are NOT kept across the final product for the
+    // final walk (18 registers: spilled at this kernel's budget) -- the entries are made opaque, two VALU operations re-form an address
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(tb[u]));
+#endif
   }
   {
     sl_v4f64 p[NT][NT];
@@ -419,6 +458,14 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
     wave_fence();
     swc_store_upper<NT>(S, r16, kk, p);
   }
+  // what the block's constraint rows need from the record, loaded behind the final product too (nothing here depends on a
+  // loaded value; held across the product these registers would be spilled)
+  const double nzv_e = rec->v[lane_e];
+  const unsigned nzt_e = rec->nzt[lane_e];
+  const int row_e = rec->rows[l8e];
+  const double bk_e = rec->b[l8e];
+  const double nrmA_e = rec->normA[l8e];
+  const int kb = rec->nzp[l8e], ke = rec->nzp[l8e + 1];
   wave_fence();
   CUADMM_SWC_STAMP(8);
   // ---- the projection leaves through the flat walk: S, Rd, X updates and the two sums (the expressions of post_kernel); the
@@ -437,7 +484,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e_ = base + 64 * u + lane_e;
-      const bool ok_ = e_ < len;
+      const bool ok_ = (FULL && base + 64 * u + 63 < Cfg::MAXLEN) || e_ < len;
       const unsigned up = tb[u] & 0xfff8u, lo = tb[u] >> 16;
       const double pm = at(up), r1 = at(lo);
       bad |= ok_ && !(fabs(pm) <= 1.7976931348623157e308);
@@ -458,6 +505,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
         at(up) = sv - cv[u];
         at(lo) = xn;
       }
+      if ((u % 3) == 2) swc_sched_split();
     }
   }
   CUADMM_SWC_STAMP(9);
@@ -467,10 +515,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
     wave_fence();
     const double ps = nzv_e * at(nzt_e & 0xfff8u);
     const double px = nzv_e * at(nzt_e >> 16);
-    const int kb = rec->nzp[l8e], ke = rec->nzp[l8e + 1];
-    int maxlen = 0;
-#pragma unroll
-    for (int q = 0; q < kClosedMaxRows; ++q) { const int lq = (int)rec->nzp[q + 1] - (int)rec->nzp[q]; maxlen = (q < nk && lq > maxlen) ? lq : maxlen; }
+    const int maxlen = closed_hdr_maxlen(hdr);                 // longest row of the block
     double as = 0.0, ax = 0.0;
     for (int t = 0; t < maxlen; ++t) {
       const int src = (kb + t) & 63;
@@ -483,11 +528,10 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
       if (upd) { fz.outX[row_e] = ax; fz.cl_out[16 * (long long)slot + lane_e] = ax; }
     }
     if (upd) {
-      const double nrmA = rec->normA[l8e];
-      const double ro = nrmA * (bk_e - ax) * fz.bscale;
-      double pr = mine_e ? ro * ro : 0.0, pby = mine_e ? bk_e * yk_e : 0.0;
+      const double ro = nrmA_e * (bk_e - ax) * fz.bscale;
+      double pr = mine_e ? ro * ro : 0.0;
       pr = wave_sum(pr);
-      pby = wave_sum(pby);
+      const double pby = pby_sum;
       s_rd = wave_sum(s_rd);
       s_cx = wave_sum(s_cx);
       if (lane_e == 0) {

@@ -22,6 +22,7 @@ namespace cuadmm {
 
 typedef double sl_v4f64 __attribute__((ext_vector_type(4)));
 typedef double sl_v2f64 __attribute__((ext_vector_type(2)));
+typedef int sl_v4i32 __attribute__((ext_vector_type(4)));
 
 
 template <int NP> struct SignLdsCfg;
