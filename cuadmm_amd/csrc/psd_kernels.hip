@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 __host__ __device__ constexpr int closed_cu_ctl_ints(int nb_max) { return (nb_max + 2 + 3) & ~3; }
 static_assert(sizeof(PsdDesc) == 32, "the LDS descriptor cache copies a descriptor as two 16-byte words");
 
-template <int NT, int WAVES, int OCC, bool FULL>
+template <int NT, int WAVES, int OCC, bool FULL, bool DBG>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void psd_sign_closed_cu_kernel(ClosedArgs a) {
   extern __shared__ double swt_smem[];
   constexpr int TILE = SignWaveT<NT>::NP * SignWaveT<NT>::LD;
@@ -200,14 +200,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
     }
   __syncthreads();
   const int ntask = nb * a.iters;
-  const long long clk0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0, rt0 = a.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const long long clk0 = (DBG && a.dbg) ? (long long)__builtin_readcyclecounter() : 0, rt0 = (DBG && a.dbg) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   // The kernel arguments are re-read from the kernarg segment for every task (scalar loads, cached): held in SGPRs across the
   // task loop they would be spilled at this kernel's register budget.
   using KArgC = __attribute__((address_space(4))) const char;
   KArgC* ka = (KArgC*)__builtin_amdgcn_kernarg_segment_ptr();
 #pragma unroll 1
   for (;;) {
-    const long long tk0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    const long long tk0 = (DBG && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
     int t = 0;
     if (lane_id() == 0) t = atomicAdd(&ctl[0], 1);
     t = __builtin_amdgcn_readfirstlane(t);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
       while (__hip_atomic_load(ctl + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const long long tk1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    const long long tk1 = (DBG && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(ka));                       // opaque: nothing loaded through it is kept across tasks
     const ClosedArgs al = *reinterpret_cast<__attribute__((address_space(4))) const ClosedArgs*>(ka);
@@ -239,21 +239,30 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC,
     asm volatile("" : "+v"(toff));                     // not hoisted out of the task loop (it would stay live across the body)
 #endif
     double* tile = swt_smem + toff;
-    const long long tk2 = al.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    psd_sign_closed_body<NT, true, FULL>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
-                             al.dbg ? al.dbg + 16 * (long long)(g + j * G) : nullptr, d.off, d.slot, (long long)it * al.pstride, d.pad[0], it);
-    const long long tk3 = al.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    const long long tk2 = (DBG && al.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    psd_sign_closed_body<NT, true, FULL, DBG>(al, d.n, tile, al.steps ? al.steps + d.id : nullptr, al.hint ? al.hint + d.id : nullptr,
+                             (DBG && al.dbg) ? al.dbg + 16 * (long long)(g + j * G) : nullptr, d.off, d.slot, (long long)it * al.pstride, d.pad[0], it, ka);
+    const long long tk3 = (DBG && al.dbg) ? (long long)__builtin_readcyclecounter() : 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane_id() == 0) __hip_atomic_store(ctl + 1 + j, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (al.dbg && lane_id() == 0) {   // developer aid (psd_debug = 2): what a task spends outside its body
+    if (DBG && al.dbg && lane_id() == 0) {   // developer aid (psd_debug = 2): what a task spends outside its body
       long long* q = al.dbg + 16 * (long long)(g + j * G);
       q[10] = tk1 - tk0; q[11] = tk2 - tk1; q[12] = tk3 - tk2; q[13] = (long long)__builtin_readcyclecounter() - tk3;
     }
   }
-  if (a.dbg && threadIdx.x == 0) {   // the shader clock over the launch: s_memtime ticks per 100 MHz real-time tick
+  if (DBG && a.dbg && threadIdx.x == 0) {   // the shader clock over the launch: s_memtime ticks per 100 MHz real-time tick
     long long* q = a.dbg + 16 * (long long)g;
     q[14] = (long long)__builtin_readcyclecounter() - clk0; q[15] = (long long)__builtin_amdgcn_s_memrealtime() - rt0;
   }
+}
+
+// one persistent launch; the LDS cap is raised once per kernel and device
+template <void (*KERN)(ClosedArgs)>
+static int launch_closed_cu(dim3 grid, dim3 block, size_t lds, hipStream_t st, const ClosedArgs& ca) {
+  static LdsCapOnce once;
+  CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(KERN)));
+  hipLaunchKernelGGL(KERN, grid, block, lds, st, ca);
+  return CUADMM_OK;
 }
 
 // fz != nullptr: the fused variant (SignFuse, psd_sign_wave.h); the partial-sum slot of a member comes with its descriptor
@@ -285,17 +294,14 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
       ca.dcache = lds + sizeof(PsdDesc) * nb_max <= kMaxLdsBytes;     // the members' descriptors in LDS when they fit
       if (ca.dcache) lds += sizeof(PsdDesc) * nb_max;
       if (lds > kMaxLdsBytes) { set_error("psd: %d blocks per workgroup do not fit the batched launch", (int)nb_max); return CUADMM_ERR_INVALID; }
-      if (fz->full) {
-        auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC, true>;
-        static LdsCapOnce once;
-        CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
-      } else {
-        auto kern = psd_sign_closed_cu_kernel<NT, WAVES, OCC, false>;
-        static LdsCapOnce once;
-        CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(kern)));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, ca);
-      }
+      constexpr bool HAS_DBG = NT == 2 && OCC == 4;     // the tick stamps exist for the C2 geometry only
+      const dim3 gr(grid), bl(64 * WAVES);
+      int rc;
+      if (HAS_DBG && ca.dbg) rc = fz->full ? launch_closed_cu<psd_sign_closed_cu_kernel<NT, WAVES, OCC, true, HAS_DBG>>(gr, bl, lds, st, ca)
+                                           : launch_closed_cu<psd_sign_closed_cu_kernel<NT, WAVES, OCC, false, HAS_DBG>>(gr, bl, lds, st, ca);
+      else rc = fz->full ? launch_closed_cu<psd_sign_closed_cu_kernel<NT, WAVES, OCC, true, false>>(gr, bl, lds, st, ca)
+                         : launch_closed_cu<psd_sign_closed_cu_kernel<NT, WAVES, OCC, false, false>>(gr, bl, lds, st, ca);
+      if (rc) return rc;
     } else if (fz->full) {
       hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
     } else {

@@ -162,6 +162,21 @@ struct ClosedArgs {
   int dcache;                                         // persistent launches: the workgroup keeps its members' descriptors in LDS
 };
 
+// The kernel arguments again, from the kernarg segment (persistent launches: scalar loads, cached): a phase of a task takes a
+// fresh copy instead of keeping the previous phase's scalar registers alive across the iteration -- at this kernel's budget
+// those are spilled into VGPR lanes, and every v_writelane / v_readlane takes ~4.5 cycles from the port the MFMAs issue on.
+using SwcKArg = __attribute__((address_space(4))) const char*;
+template <bool TASK_LOOP>
+__device__ __forceinline__ ClosedArgs swc_args(const ClosedArgs& fz, SwcKArg& ka) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (TASK_LOOP) {
+    asm volatile("" : "+s"(ka));
+    return *reinterpret_cast<__attribute__((address_space(4))) const ClosedArgs*>(ka);
+  }
+#endif
+  return fz;
+}
+
 #define CUADMM_SWC_STAMP(k) \
   if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) dbg[k] = (long long)__builtin_readcyclecounter() - c0; }
 
@@ -175,9 +190,12 @@ struct ClosedArgs {
 // wavefront issues on the vector ALU takes its cycles from the port the fp64 MFMAs issue on, tools/ubench/mfma_coissue.hip: an
 // integer VALU instruction costs ~2 cycles of matrix-core time, an fp64 one ~4, a v_readlane ~4.5 -- the prologue and epilogue
 // of a task are paid in matrix-core cycles, not hidden behind them.)
-template <int NT, bool TASK_LOOP = false, bool FULL = false>
-__device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n_arg, double* S, int* steps_out, int* hint, long long* dbg,
-                                                     long long off, int slot, long long poff, int hdr, int it_local = 0) {
+// DBG: the tick stamps of the developer aid (psd_debug = 2) are compiled into their own instantiation -- a run-time "if (dbg)" keeps
+// the stamps' registers and v_writelanes in the production kernel.
+template <int NT, bool TASK_LOOP = false, bool FULL = false, bool DBG = false>
+__device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n_arg, double* S, int* steps_out, int* hint, long long* dbg_arg,
+                                                     long long off, int slot, long long poff, int hdr, int it_local = 0, SwcKArg ka = nullptr) {
+  long long* const dbg = DBG ? dbg_arg : nullptr;
   using Cfg = SignWaveT<NT>;
   constexpr int LD = Cfg::LD, NP = Cfg::NP, U = Cfg::U, NSLOT = Cfg::NSLOT;
   constexpr int NB = (NSLOT + U - 1) / U;                 // batches of the flat walk
@@ -390,8 +408,10 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   asm volatile("" : "+v"(lane_e));
 #endif
   const unsigned* __restrict__ tabl_e = g_swc_tab<NT>.v + lane_e;
-  const double* __restrict__ Xl_e = fz.X + off + lane_e;
-  const double* __restrict__ Cl_e = fz.C + off + lane_e;
+  const ClosedArgs fe = swc_args<TASK_LOOP>(fz, ka);      // a fresh copy: none of the prologue's scalar registers lives across the iteration
+  const ClosedRec* __restrict__ rec_e = fe.rec + slot;
+  const double* __restrict__ Xl_e = fe.X + off + lane_e;
+  const double* __restrict__ Cl_e = fe.C + off + lane_e;
   const int l8e = lane_e & 7;
   const bool mine_e = lane_e < nk;
 #pragma unroll
@@ -409,7 +429,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
     for (int u = 0; u < U; ++u) {
       const int e_ = base + 64 * u + lane_e;
       const unsigned up = tb[u] & 0xfff8u, lo = tb[u] >> 16;
-      const double xb = xv[u] + at(lo) * fz.sig;
+      const double xb = xv[u] + at(lo) * fe.sig;
       if ((FULL && base + 64 * u + 63 < Cfg::MAXLEN) || e_ < len) at(up) = (tb[u] & 1u) ? xb : xb * kSqrt2Inv;     // the zero padding of the prologue is still in place
     }
   }
@@ -460,20 +480,21 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   }
   // what the block's constraint rows need from the record, loaded behind the final product too (nothing here depends on a
   // loaded value; held across the product these registers would be spilled)
-  const double nzv_e = rec->v[lane_e];
-  const unsigned nzt_e = rec->nzt[lane_e];
-  const int row_e = rec->rows[l8e];
-  const double bk_e = rec->b[l8e];
-  const double nrmA_e = rec->normA[l8e];
-  const int kb = rec->nzp[l8e], ke = rec->nzp[l8e + 1];
+  const double nzv_e = rec_e->v[lane_e];
+  const unsigned nzt_e = rec_e->nzt[lane_e];
+  const int row_e = rec_e->rows[l8e];
+  const double bk_e = rec_e->b[l8e];
+  const double nrmA_e = rec_e->normA[l8e];
+  const int kb = rec_e->nzp[l8e], ke = rec_e->nzp[l8e + 1];
   wave_fence();
   CUADMM_SWC_STAMP(8);
   // ---- the projection leaves through the flat walk: S, Rd, X updates and the two sums (the expressions of post_kernel); the
   // slot of P(r, c) then takes S - C and the slot of Rd1(r, c) the new X -- the staging the block's constraint rows read
   bool bad = false;
   double s_rd = 0.0, s_cx = 0.0;
-  double* __restrict__ Sg = fz.S + off + lane_e;
-  double* __restrict__ Xg = fz.X + off + lane_e;
+  const ClosedArgs fw = swc_args<TASK_LOOP>(fz, ka);
+  double* __restrict__ Sg = fw.S + off + lane_e;
+  double* __restrict__ Xg = fw.X + off + lane_e;
 #pragma unroll 1
   for (int bt = 0; bt < NB; ++bt) {
     const int base = 64 * U * bt;
@@ -491,10 +512,10 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
       const double xp = (tb[u] & 1u) ? pm : pm * kSqrt2;     // Xproj[e]
       const double x = xv[u];
       const double xdiff = xp - x;
-      const double sv = fz.inv_sig * xdiff - r1;
+      const double sv = fw.inv_sig * xdiff - r1;
       double xn = x;
       double rd = 0.0;
-      if (upd) { rd = r1 + sv; xn = x + fz.tau_sig * rd; }
+      if (upd) { rd = r1 + sv; xn = x + fw.tau_sig * rd; }
       if (ok_) {
         Sg[base + 64 * u] = sv;
         if (upd) {
@@ -523,24 +544,24 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
       if (mine_e && kb + t < ke) { as += vs; ax += vx; }
     }
     if (mine_e) {
-      fz.outS[row_e] = as;
-      fz.cl_out[16 * (long long)slot + 8 + lane_e] = as;
-      if (upd) { fz.outX[row_e] = ax; fz.cl_out[16 * (long long)slot + lane_e] = ax; }
+      fw.outS[row_e] = as;
+      fw.cl_out[16 * (long long)slot + 8 + lane_e] = as;
+      if (upd) { fw.outX[row_e] = ax; fw.cl_out[16 * (long long)slot + lane_e] = ax; }
     }
     if (upd) {
-      const double ro = nrmA_e * (bk_e - ax) * fz.bscale;
+      const double ro = nrmA_e * (bk_e - ax) * fw.bscale;
       double pr = mine_e ? ro * ro : 0.0;
       pr = wave_sum(pr);
       const double pby = pby_sum;
       s_rd = wave_sum(s_rd);
       s_cx = wave_sum(s_cx);
       if (lane_e == 0) {
-        fz.partials2[poff + 2 * (long long)slot] = pr; fz.partials2[poff + 2 * (long long)slot + 1] = pby;
-        fz.partials[poff + 2 * (long long)slot] = s_rd; fz.partials[poff + 2 * (long long)slot + 1] = s_cx;
+        fw.partials2[poff + 2 * (long long)slot] = pr; fw.partials2[poff + 2 * (long long)slot + 1] = pby;
+        fw.partials[poff + 2 * (long long)slot] = s_rd; fw.partials[poff + 2 * (long long)slot + 1] = s_cx;
       }
     }
   }
-  if (bad && fz.fail) atomicAdd(fz.fail, 1);
+  if (bad && fw.fail) atomicAdd(fw.fail, 1);
   if (dbg && lane == 0) {   // developer aid (CUADMM_CU_DBG): ticks of prologue / iteration / epilogue, steps
     const long long c3 = (long long)__builtin_readcyclecounter();
     dbg[0] = c1 - c0; dbg[1] = c2 - c1; dbg[2] = c3 - c2; dbg[3] = sched.steps;

@@ -60,10 +60,19 @@ with open(os.path.join(out, "%s_pmc_hbm_traffic.json" % tag), "w") as f:
 print(json.dumps(summary, indent=1)[:3000])
 if sqd:
     sq = {}
-    for counter in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"):
-        for k, (v, n) in mean_counter(sqd, counter).items():
-            if k.startswith("void cuadmm") or k.startswith("cuadmm"):
-                sq.setdefault(k, {})[counter] = v
-                sq[k]["launches_sampled"] = n
+    # every counter found in the SQ pass directories (several directories separated by ':' -- one rocprofv3 run per counter group)
+    names = set()
+    dirs = [d for d in sqd.split(":") if d and os.path.isdir(d)]
+    for d in dirs:
+        for f in os.listdir(d):
+            if f.endswith("counter_collection.csv"):
+                for r in csv.DictReader(open(os.path.join(d, f))):
+                    names.add(r["Counter_Name"])
+    for d in dirs:
+        for counter in sorted(names):
+            for k, (v, n) in mean_counter(d, counter).items():
+                if k.startswith("void cuadmm") or k.startswith("cuadmm"):
+                    sq.setdefault(k, {})[counter] = v
+                    sq[k]["launches_sampled"] = n
     with open(os.path.join(out, "%s_pmc_sq_counters.json" % tag), "w") as f:
         json.dump(sq, f, indent=1)
