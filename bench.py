@@ -172,7 +172,7 @@ def projection_only(args, lib):
     import ctypes as C
     from cuadmm_amd import synthetic
     from cuadmm_amd._lib import check
-    from tests.helpers import Dev
+    from cuadmm_amd.devbuf import Dev
     blk = {"c2": np.full(args.blocks_per_gpu, BLOCK_N), "c3": np.array([2000]), "c4": synthetic.config_c4_blk(args.blocks_per_gpu)}.get(args.config)
     if blk is None:
         d = np.load(os.path.join(ROOT, "tests", "golden", "problems", {"c1": "PlanarHand_N=1_MOMENT", "c5": "pendulum_N=80"}[args.config] + ".npz"))
@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--option", action="append", help="engine option key=value (cuadmm_set_option), repeatable: A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-allreduce-path", action="store_true", help="N > 1, c2 / c4: skip the supplementary run of the general sharded path")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
     if args.steps is None:
@@ -299,7 +300,7 @@ def main():
                     "c5": "BASELINE configs[4]: examples/pendulum N=80 (159 x 10 + 80 x 55, m = 112 028; the largest horizon the reference ships)"}[args.config]
     else:
         prob = synthetic.config_c3(2000)
-        workload = "BASELINE configs[2]: max-cut relaxation, one PSD block n=2000 (N independent replicas at N GPUs)"
+        workload = "BASELINE configs[2]: max-cut relaxation of G(2000, p = 0.01) (SURVEY 8d), one PSD block n=2000 (N independent replicas at N GPUs)"
     workload += ", " + ("ADMM-only (switch_admm=0)" if args.mode == "admm" else "sGS-ADMM")
     eng_world, eng_rank = (1, 0) if replicas else (world, rank)
     engine_options = {}
@@ -389,6 +390,22 @@ def main():
         t = torch.tensor([dt_ss], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_ss = float(t.item())
+    # Supplementary, NOT `value`: the timed region runs with stop_tol = 0 (exactly K iterations), so the engine takes no checkpoint
+    # before a launch of several iterations; a solve WITH a tolerance checkpoints X, S, y, [A X | A (S - C)] at the start of every
+    # batch (one copy kernel).  The same solver continued with a tolerance that is never met: the rate production solves see.
+    ck = None
+    if args.config in ("c2", "c4") and not args.no_breakdown:
+        ck_steps = ss_steps
+        sync()
+        t0 = time.perf_counter()
+        solver.solve(ck_steps, 1e-300, 0, 50, 100, switch, 1.05, if_first=False)
+        sync()
+        dt_ck = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_ck], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ck = float(t.item())
+        ck = (ck_steps, dt_ck, solver.info_iter_num)
     # Supplementary, NOT `value`: the boundary takes host arrays in init and hands X, y, S back to host arrays -- the PCIe-inclusive
     # rate of the whole job (init with its uploads + the timed iterations + the read-back of the results), DESIGN.md section 6
     sync()
@@ -409,6 +426,49 @@ def main():
         solver.solve(nb, 0.0, 0, 50, 100, switch, 1.05, if_first=False)
         sync()
         breakdown = {k: v["ms"] / nb for k, v in solver.profile().items() if v["launches"]}
+
+    # Supplementary at N > 1 on the block-diagonal configurations: `value` is the owned-constraints path (each rank keeps the
+    # constraints of its own blocks: 4 scalars all-reduced per iteration); the collective the north star names -- [A X | sums |
+    # A (S - C)] (2m+2 doubles) all-reduced before every replicated y-solve -- runs here on the SAME problem in the same process
+    # group (engine option local_constraints = 0), so that one line carries both.
+    ar_path = None
+    if use_comm and not replicas and world > 1 and args.sharding == "owned" and args.config in ("c2", "c4") and not args.no_allreduce_path:
+        opts2 = dict(engine_options)
+        opts2["local_constraints"] = 0
+        s3 = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, profile=2, force_comm=force_dist, options=opts2)
+        if args.comm == "rccl":
+            uid = ctypes.create_string_buffer(128)
+            if rank == 0:
+                cuadmm_amd._lib.check(lib.cuadmm_rccl_unique_id(uid))
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0)
+            cuadmm_amd._lib.check(lib.cuadmm_use_rccl(s3._h, box[0], rank, world))
+        else:
+            s3.set_allreduce(keep[0])
+        s3.init_problem(cuadmm_amd.Problem(prob.vec_len, prob.con_num, prob.blk, prob.At_col_ptrs, prob.At_row_ids,
+                                           prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals))
+        s3.solve(args.warmup, 0.0, 0, 50, 100, switch, 1.05)
+        sync()
+        t0 = time.perf_counter()
+        s3.solve(args.steps, 0.0, 0, 50, 100, switch, 1.05, if_first=False)
+        sync()
+        dt3 = time.perf_counter() - t0
+        t = torch.tensor([dt3], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt3 = float(t.item())
+        cuadmm_amd._lib.check(lib.cuadmm_set_option(s3._h, b"profile", 1.0))
+        s3.reset_profile()
+        nb3 = max(5, min(50, args.steps))
+        s3.solve(nb3, 0.0, 0, 50, 100, switch, 1.05, if_first=False)
+        sync()
+        bd3 = {k: v["ms"] / nb3 for k, v in s3.profile().items() if v["launches"]}
+        ar_path = {"value": (world if args.scaling == "weak" else 1) * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                   "allreduce_ms_per_iter": bd3.get("allreduce", 0.0), "allreduce_doubles": 2 * int(prob.con_num) + 2,
+                   "breakdown_ms_per_iter": bd3,
+                   "sharding": "blocks by index; all-reduce of [A X | sums | A(S-C)] (2m+2 doubles) before every replicated y-solve "
+                               "(engine option local_constraints = 0), same problem, same ranks",
+                   "note": "supplementary: the general sharded path of SURVEY 8e on the configuration whose `value` takes the owned-constraints shortcut"}
+        del s3
 
     time_to_tol = None
     if args.time_to_tol is None and args.config in ("c1", "c5"):
@@ -488,8 +548,9 @@ def main():
                            "replicas only (one block does not shard)" if replicas else (
                                "blocks by index; all-reduce of [A X | sums | A(S-C)] (2m+2 doubles) before every replicated host y-solve"
                                if args.sharding == "allreduce" else
-                               "blocks by index; constraints owned by the rank whose blocks they touch when the problem is block-diagonal "
-                               "(one all-reduce of 4 scalars per iteration), else the 2m+2 all-reduce (DESIGN.md section 5)")),
+                               "`value`: blocks by index, constraints owned by the rank whose blocks they touch when the problem is block-diagonal "
+                               "(one all-reduce of 4 scalars per iteration, or per launch of several), else the 2m+2 all-reduce (DESIGN.md section 5); "
+                               "`allreduce_path` (c2 / c4): the same problem on the general path, 2m+2 doubles all-reduced before every replicated y-solve")),
                        "comm": args.comm if use_comm else None, "init_s": t_init},
             # `achieved` uses the ALGORITHMIC flops of SURVEY 8d (10.67 n^3 per block, what an eigendecomposition-based
             # projection needs) over the measured launch time of the projection; the flops the kernels really issue on the
@@ -524,6 +585,12 @@ def main():
         out["pcie_inclusive"] = {"value": (world if (args.scaling == "weak" or replicas) else 1) * args.steps / (t_init + dt + t_readback),
                                  "init_s": t_init, "readback_s": t_readback,
                                  "note": "supplementary: init (host arrays uploaded, A A^T factored) + the timed iterations + X, y, S read back to host arrays"}
+        if ck is not None:
+            out["with_checkpoint"] = {"value": (world if (args.scaling == "weak" or replicas) else 1) * ck[0] / ck[1], "steps": ck[0], "ms_per_step": ck[1] / ck[0] * 1e3,
+                                      "note": "supplementary: continued with stop_tol = 1e-300 (never met): every launch of several iterations starts from a "
+                                              "device-side checkpoint of X, S, y, [A X | A (S - C)], as in any solve with a tolerance; `value` (stop_tol = 0) takes none"}
+        if ar_path is not None:
+            out["allreduce_path"] = ar_path
         out["engine_plan"] = plan
         if args.time_to_tol:
             out["time_to_tol"] = time_to_tol

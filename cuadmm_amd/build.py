@@ -20,7 +20,7 @@ INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(LIBDIR, "libcuadmm_amd.so")
 EXE = os.path.join(LIBDIR, "cuadmm_exe")
 
-HIP_SOURCES = ["psd_kernels.hip", "psd_large.hip", "tail_solve.hip", "eig_large.hip", "lead_solve.hip", "vec_kernels.hip", "staging.hip", "engine.hip"]
+HIP_SOURCES = ["psd_kernels.hip", "psd_large.hip", "tail_solve.hip", "eig_large.hip", "lead_solve.hip", "vec_kernels.hip", "staging.hip", "engine.hip", "duo_group.hip"]
 CPP_SOURCES = ["io.cpp", "blocks.cpp", "aat_ldlt.cpp", "mex_entry.cpp"]
 HEADERS = None   # every header under csrc/ plus the public C header (computed in build())
 ARCH = "gfx950"

@@ -45,5 +45,5 @@ struct LdsCapOnce {
     return e;
   }
 };
-constexpr int kMaxBlockSize = 4000;           // largest block the projection plans accept
+constexpr int kMaxBlockSize = 8192;           // largest block the projection plans accept (= the explicit eigensolver's limit, eig_large.h)
 }  // namespace cuadmm

@@ -26,6 +26,7 @@
 #include "tail_solve.h"
 #include "lead_solve.h"
 #include "vec_kernels.h"
+#include "duo_group.h"
 
 using namespace cuadmm;
 
@@ -201,6 +202,12 @@ struct cuadmm_solver {
   // (0 / 1: off).  bt_p1 / bt_p2: the per-iteration partial arrays, bt_h: the four scalars of every iteration of the batch
   // (pinned, written by the reduction through its device mapping when no collective is needed), ck_*: the checkpoint a batch
   // starts from (restored when the stopping test or the tau rule fires inside it).
+  // SDPDuoSolver's N-devices-from-one-process mode (duo_group.hip): this handle is rank 0 of a group; `in_group_call` marks the
+  // calls the group makes on its own ranks.  option_log: every cuadmm_set_option so far (replayed on the group's children).
+  void* group = nullptr;
+  bool in_group_call = false;
+  int duo_share_device = 0;
+  std::vector<std::pair<std::string, double>> option_log;
   struct Batch {
     int max_iters = 64;
     bool allow_mixed = false;      // option "batch_mixed": batches although several tile geometries share the work (tests)
@@ -210,6 +217,9 @@ struct cuadmm_solver {
     PinnedBuf<double> h;
     double* h_dev = nullptr;
     long long pstride = 0;
+    int cap = 0;                   // iterations the partial / scalar buffers were sized for (batch_alloc); K never exceeds it
+    bool peers_agree = true;       // every rank of the communicator can batch (agreed at the start of each solve: a rank that batches
+                                   // issues ONE collective of 4 K scalars per batch, a rank that does not issues one of 4 per iteration)
     int len = 0, pos = 0;          // iterations launched / consumed by the host loop
     bool have_ck = false;          // this batch started from a checkpoint (taken whenever something could invalidate it)
     double tau = 0, sig = 0;
@@ -538,17 +548,43 @@ struct cuadmm_solver {
   }
   // --- several iterations per launch ---------------------------------------------------------------------------------
   bool can_batch() const {
+    return can_batch_local() && bt.peers_agree;
+  }
+  bool can_batch_local() const {
     return bt.max_iters >= 2 && fuse && closed.active && dev_solve && !lead.ready && plan.n_rest == 0 && eig_rank == 0 && !out_mapped &&
            plan.fused_blocks() > 0 && (bt.allow_mixed || plan.one_dominant_geometry());
   }
+  // Ranks must take the batching decision TOGETHER: it decides which collective a rank issues (shards of a heterogeneous problem
+  // can differ: no dominant geometry on one, a block with more than 8 rows on another, no blocks at all on a third).  One small
+  // all-reduce at the start of every solve (options may have changed since the last one).
+  int batch_agree() {
+    bt.peers_agree = true;
+    const int cw = local_mode ? comm_world : world;
+    if (cw <= 1 && !force_comm) return CUADMM_OK;
+    if (!allreduce && !rccl_comm) return CUADMM_OK;      // no transport yet: the first collective of the solve reports it
+    h_scal.p[0] = can_batch_local() ? 1.0 : 0.0;
+    h_scal.p[1] = 1.0;
+    CUADMM_HIP_TRY(hipMemcpyAsync(scal_d.p, h_scal.p, sizeof(double) * 2, hipMemcpyHostToDevice, st));
+    int rc = comm_allreduce(scal_d.p, 2);
+    if (rc) return rc;
+    CUADMM_HIP_TRY(hipMemcpyAsync(h_scal.p, scal_d.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    bt.peers_agree = h_scal.p[0] >= h_scal.p[1] - 0.5;    // every rank said yes
+    return CUADMM_OK;
+  }
   int batch_alloc() {
-    if (bt.p1.p) return CUADMM_OK;
+    // sized for the CURRENT option value: "batch" may be raised between solves, and a launch of K iterations writes K partial
+    // arrays and 4 K scalars
+    if (bt.p1.p && bt.cap >= bt.max_iters) return CUADMM_OK;
     bt.pstride = 2 * (long long)plan.fused_blocks() + 2;
+    bt.cap = 0; bt.h_dev = nullptr;
     int rc;
     if ((rc = bt.p1.alloc((size_t)bt.pstride * bt.max_iters)) || (rc = bt.p2.alloc((size_t)bt.pstride * bt.max_iters)) ||
-        (rc = bt.scal_d.alloc(4 * (size_t)bt.max_iters)) || (rc = bt.h.alloc(4 * (size_t)bt.max_iters)) || (rc = bt.ck_X.alloc(L)) ||
-        (rc = bt.ck_S.alloc(L)) || (rc = bt.ck_y.alloc(std::max(m, 1))) || (rc = bt.ck_out.alloc(2 * (size_t)m + 2)))
+        (rc = bt.scal_d.alloc(4 * (size_t)bt.max_iters)) || (rc = bt.h.alloc(4 * (size_t)bt.max_iters)))
       return rc;
+    if (!bt.ck_X.p && ((rc = bt.ck_X.alloc(L)) || (rc = bt.ck_S.alloc(L)) || (rc = bt.ck_y.alloc(std::max(m, 1))) || (rc = bt.ck_out.alloc(2 * (size_t)m + 2))))
+      return rc;
+    bt.cap = bt.max_iters;
     void* dp = nullptr;
     if (sw.mapped_out && hipHostGetDevicePointer(&dp, bt.h.p, 0) == hipSuccess && dp) bt.h_dev = static_cast<double*>(dp);
     else { hipError_t e = hipGetLastError(); (void)e; }
@@ -558,14 +594,17 @@ struct cuadmm_solver {
     prof_begin(K_COPY);
     struct { double* live; double* ck; size_t n; } v[4] = {{X.p, bt.ck_X.p, (size_t)L}, {S.p, bt.ck_S.p, (size_t)L}, {y_d.p, bt.ck_y.p, (size_t)m},
                                                            {out_d.p, bt.ck_out.p, 2 * (size_t)m + 2}};
+    CopyJobs jobs{};                       // ONE launch for the whole checkpoint (five copies of ~0.03 ms each were 1.3 % of a batch of 44)
     for (auto& q : v) {
-      int rc = launch_copy(save ? q.ck : q.live, save ? q.live : q.ck, (long long)q.n, st);
-      if (rc) return rc;
+      jobs.dst[jobs.count] = save ? q.ck : q.live; jobs.src[jobs.count] = save ? q.live : q.ck; jobs.nbytes[jobs.count] = (long long)(q.n * sizeof(double));
+      ++jobs.count;
     }
     if (hint_d.p) {   // the schedule hints are part of the state an iteration reads and writes
       if (!bt.ck_hint.p) { int rc = bt.ck_hint.alloc(hint_d.n); if (rc) return rc; }
-      CUADMM_HIP_TRY(hipMemcpyAsync(save ? bt.ck_hint.p : hint_d.p, save ? hint_d.p : bt.ck_hint.p, sizeof(int) * hint_d.n, hipMemcpyDeviceToDevice, st));
+      jobs.dst[jobs.count] = save ? bt.ck_hint.p : hint_d.p; jobs.src[jobs.count] = save ? hint_d.p : bt.ck_hint.p; jobs.nbytes[jobs.count] = (long long)(sizeof(int) * hint_d.n);
+      ++jobs.count;
     }
+    { int rc = launch_copy_multi(jobs, st); if (rc) return rc; }
     if (save) bt.ck_iters_done = closed.iters_done; else closed.iters_done = bt.ck_iters_done;
     prof_end(K_COPY, 16.0 * (2.0 * (double)L + 3.0 * m + 2));
     return CUADMM_OK;
@@ -1244,11 +1283,17 @@ int cuadmm_create(cuadmm_solver** out) {
   *out = new cuadmm_solver();
   return CUADMM_OK;
 }
-void cuadmm_destroy(cuadmm_solver* s) { delete s; }
+void cuadmm_destroy(cuadmm_solver* s) {
+  if (s && s->group) { duo_group_destroy(s->group); s->group = nullptr; }
+  delete s;
+}
 
 int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   if (!s || !key) { set_error("set_option: null"); return CUADMM_ERR_INVALID; }
   std::string k(key);
+  s->option_log.emplace_back(k, value);
+  if (s->group && !s->in_group_call && k != "device" && k != "rank" && k != "world" && k != "verbose")   // a group handle: every rank follows
+    for (int r = 1; r < duo_group_world(s->group); ++r) { int rc = cuadmm_set_option(duo_group_rank(s->group, r), key, value); if (rc) return rc; }
   if (k == "device") s->device = (int)value;
   else if (k == "verbose") s->verbose = (int)value;
   else if (k == "rank") s->rank = (int)value;
@@ -1279,9 +1324,10 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "lazy_unscale") s->lazy_unscale = (int)value;
   else if (k == "psd_hint") s->opt_hint = (int)value;
   else if (k == "duo_cpu_eig_on_gpu") s->duo_cpu_eig_on_gpu = (int)value;
+  else if (k == "duo_share_device") s->duo_share_device = (int)value;   // duo_init(device_num_requested = N) from one process: all N engines on this solver's device
   else if (k == "tiny_sign") s->opt_tiny_sign = (int)value;                               // n <= 8 on the sign kernel (before init)                                     // schedule warm start (before init)                            // 0: unscale X, y, S at the end of every solve
   else if (k == "graph") {}
-  else { set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
+  else { s->option_log.pop_back(); set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
   return CUADMM_OK;
 }
 
@@ -1424,6 +1470,13 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
                  int sig_update_stage_2, int switch_admm, double sigscale, int if_first) {
   if (!s || !s->initialised) { set_error("solve: solver not initialised"); return CUADMM_ERR_INVALID; }
   if (sig_update_stage_1 <= 0 || sig_update_stage_2 <= 0) { set_error("solve: sig_update stages must be positive"); return CUADMM_ERR_INVALID; }
+  if (s->group && !s->in_group_call)      // the leader of an in-process group (duo_group.hip): every rank solves, on its own host thread
+    return duo_group_run(s->group, [&](cuadmm_solver* q, int) {
+      q->in_group_call = true;
+      int r2 = cuadmm_solve(q, max_iter, stop_tol, sig_update_threshold, sig_update_stage_1, sig_update_stage_2, switch_admm, sigscale, if_first);
+      q->in_group_call = false;
+      return r2;
+    });
   int rc = check_device(s->device);
   if (rc) return rc;
   const int m = s->m;
@@ -1459,6 +1512,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
     std::cout << " -------------------------------------------------------------------------------" << std::endl;
   }
 
+  if ((rc = s->batch_agree())) return rc;
   const bool lpt_enabled = s->sw.lpt != 0;
   long long& lpt_ev = s->lpt_next;             // counts iterations over all solve calls of this solver
   if (!lpt_enabled) lpt_ev = 0;
@@ -1533,7 +1587,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if ((rc = s->batch_rollback(s->bt.pos))) return rc;
     }
     if (s->bt.len == 0 && iter > switch_admm && !s->have_best && !snapshot && s->can_batch()) {
-      int K = std::min(s->bt.max_iters, max_iter - iter + 1);
+      if ((rc = s->batch_alloc())) return rc;
+      int K = std::min(std::min(s->bt.max_iters, s->bt.cap), max_iter - iter + 1);
       for (int j = 0; j < K; ++j) {          // the batch may END on a sigma-update iteration, not contain one
         const int i = iter + j;
         if ((i <= sig_update_threshold && i % sig_update_stage_1 == 1) || (i > sig_update_threshold && i % sig_update_stage_2 == 1)) { K = j + 1; break; }
@@ -1541,7 +1596,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       if (K >= 2) {
         // a batch can only be invalidated by the stopping test or the errRd < stop_tol rule for tau: no checkpoint without a tolerance
         s->bt.have_ck = stop_tol > 0.0;
-        if ((rc = s->batch_alloc()) || (s->bt.have_ck && (rc = s->batch_copy(true)))) return rc;
+        if (s->bt.have_ck && (rc = s->batch_copy(true))) return rc;
         s->bt.tau = tau; s->bt.sig = s->sig;
         // longest block first without a stall: the step counts are fetched behind one batch; the next one is launched in the new
         // order (the copy of the sorted descriptors is queued on the stream ahead of the launch; the host sort takes ~0.1 ms)
@@ -1748,11 +1803,29 @@ int cuadmm_duo_init(cuadmm_solver* s, int if_gpu_eig_mom, int device_num_request
               "(set option duo_cpu_eig_on_gpu = 1 to run the GPU projection for such a call)");
     return CUADMM_ERR_INVALID;
   }
-  // duo_solver.cu:487-577 spreads the moment matrices over device_num_requested GPUs from ONE process; here a GPU is a
-  // rank (options "rank" / "world", one process per GPU), so the request must agree with the sharding in force
+  // duo_solver.cu:487-577 spreads the moment matrices over device_num_requested GPUs from ONE process (threads + P2P copies,
+  // check_gpus.cu:29-43).  Here a GPU is a rank of the block-sharded engine: with rank / world already set by the caller (one
+  // process per GPU) the request must agree with them; from a single process (world = 1) the handle becomes rank 0 of a GROUP of
+  // N engines on N host threads with an in-process all-reduce (duo_group.hip).
+  if (device_num_requested > 1 && s->world == 1 && !s->in_group_call) {
+    if (s->group) { set_error("duo_init: this handle already leads a group of %d engines", duo_group_world(s->group)); return CUADMM_ERR_INVALID; }
+    if (s->initialised) { set_error("duo_init: already initialised"); return CUADMM_ERR_INVALID; }
+    int rc = duo_group_create(s, device_num_requested, s->device, s->duo_share_device != 0, s->option_log, &s->group);
+    if (rc) return rc;
+    s->world = device_num_requested; s->rank = 0;
+    rc = duo_group_run(s->group, [&](cuadmm_solver* q, int) {
+      q->in_group_call = true;
+      int r2 = cuadmm_duo_init(q, if_gpu_eig_mom, device_num_requested, eig_stream_num_per_gpu, cpu_eig_thread_num, vec_len, con_num, At_cp, At_ri,
+                               At_vx, At_nnz, b_idx, b_vals, b_nnz, C_idx, C_vals, C_nnz, blk, mat_num, X0, y0, S0, sig);
+      q->in_group_call = false;
+      return r2;
+    });
+    if (rc) { duo_group_destroy(s->group); s->group = nullptr; s->world = 1; s->allreduce = nullptr; s->allreduce_user = nullptr; }
+    return rc;
+  }
   if (device_num_requested > 1 && device_num_requested != s->world) {
-    set_error("duo_init: device_num_requested = %d but this engine runs one process per GPU: launch %d ranks and set the options rank / world",
-              device_num_requested, device_num_requested);
+    set_error("duo_init: device_num_requested = %d but this handle is rank %d of %d: one process per GPU needs world = device_num_requested "
+              "(or leave world = 1 and let duo_init build the in-process group)", device_num_requested, s->rank, s->world);
     return CUADMM_ERR_INVALID;
   }
   std::vector<int> sizes, nums;
@@ -1800,8 +1873,28 @@ static int get_vec(cuadmm_solver* s, const DevBuf<double>& v, double* out) {
   return CUADMM_OK;
 }
 // world>1: writes this rank's shard (length svec_end - svec_begin) at out[0..)
-int cuadmm_get_X(cuadmm_solver* s, double* out) { return get_vec(s, s->X, out); }
-int cuadmm_get_S(cuadmm_solver* s, double* out) { return get_vec(s, s->S, out); }
+// the leader of an in-process group gathers the shards: out has the caller's vec_len doubles
+static int group_gather(cuadmm_solver* s, double* out, int (*get)(cuadmm_solver*, double*)) {
+  for (int r = 0; r < duo_group_world(s->group); ++r) {
+    cuadmm_solver* q = duo_group_rank(s->group, r);
+    int64_t b = 0, e = 0;
+    int rc = cuadmm_get_shard(q, &b, &e, nullptr, nullptr);
+    if (rc) return rc;
+    q->in_group_call = true;
+    rc = e > b ? get(q, out + b) : CUADMM_OK;
+    q->in_group_call = false;
+    if (rc) return rc;
+  }
+  return CUADMM_OK;
+}
+int cuadmm_get_X(cuadmm_solver* s, double* out) {
+  if (s && s->group && !s->in_group_call) return group_gather(s, out, cuadmm_get_X);
+  return get_vec(s, s->X, out);
+}
+int cuadmm_get_S(cuadmm_solver* s, double* out) {
+  if (s && s->group && !s->in_group_call) return group_gather(s, out, cuadmm_get_S);
+  return get_vec(s, s->S, out);
+}
 int cuadmm_get_y(cuadmm_solver* s, double* out) {
   if (!s || !s->initialised || !out) { set_error("get_y: bad arguments"); return CUADMM_ERR_INVALID; }
   { int rc = s->materialise(); if (rc) return rc; }
@@ -1816,6 +1909,16 @@ int cuadmm_get_y(cuadmm_solver* s, double* out) {
 
 int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const double* S, double sig) {
   if (!s || !s->initialised) { set_error("set_XyS: not initialised"); return CUADMM_ERR_INVALID; }
+  if (s->group && !s->in_group_call) {      // every rank of the group takes its range of the caller's vectors
+    for (int r = 0; r < duo_group_world(s->group); ++r) {
+      cuadmm_solver* q = duo_group_rank(s->group, r);
+      q->in_group_call = true;
+      int rc = cuadmm_set_XyS(q, X, y, S, sig);
+      q->in_group_call = false;
+      if (rc) return rc;
+    }
+    return CUADMM_OK;
+  }
   int rc = check_device(s->device);
   if (rc) return rc;
   if ((rc = s->materialise())) return rc;       // the vectors NOT replaced must be in the caller's units too
@@ -1837,6 +1940,13 @@ int cuadmm_get_device_ptrs(cuadmm_solver* s, double** X, double** y, double** S)
 
 int cuadmm_get_shard(const cuadmm_solver* s, int64_t* b, int64_t* e, int* kb, int* ke) {
   if (!s || !s->initialised) { set_error("get_shard: not initialised"); return CUADMM_ERR_INVALID; }
+  if (s->group && !s->in_group_call) {      // the leader's getters return whole vectors
+    if (b) *b = 0;
+    if (e) *e = s->local_mode ? s->L_caller : s->L_full;
+    if (kb) *kb = 0;
+    if (ke) *ke = s->local_mode ? s->nblk_caller : s->nblk_full;
+    return CUADMM_OK;
+  }
   if (b) *b = s->sv_off + s->sv_begin;
   if (e) *e = s->sv_off + s->sv_end;
   if (kb) *kb = s->blk_off + s->blk_begin;

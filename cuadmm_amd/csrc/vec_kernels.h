@@ -65,6 +65,8 @@ int launch_spmv_rows(int rows, double avg_nnz, const int* rp, const int* ci, con
 
 int launch_scale(double* v, long long n, double s, hipStream_t st);
 int launch_copy(double* dst, const double* src, long long n, hipStream_t st);   // device to device, 16-byte aligned pointers
+struct CopyJobs { void* dst[6]; const void* src[6]; long long nbytes[6]; int count; };   // lengths: multiples of 4 bytes
+int launch_copy_multi(const CopyJobs& jobs, hipStream_t st);                    // all of them in one launch
 // y = (L D L^T)^-1 (-A(S-C) + (b - A X) / sigma) on the device, one thread per tree of the elimination forest
 int launch_forest_solve(int ntrees, const int* tree_ptr, const int* tree_cols, const long long* Lp, const int* Li, const double* Lx,
                         const double* D, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st);

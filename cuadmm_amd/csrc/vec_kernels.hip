@@ -699,6 +699,37 @@ int launch_copy(double* dst, const double* src, long long n, hipStream_t st) {
   return CUADMM_OK;
 }
 
+typedef unsigned sl_copy16 __attribute__((ext_vector_type(4)));
+// several device-to-device copies in ONE launch (the checkpoint of a batch: X, S, y, [A X | sums | A (S - C)], the schedule hints):
+// 16-byte words where the length allows, 4-byte words for the tail; pointers 16-byte aligned (hipMalloc)
+__global__ __launch_bounds__(kVecThreads) void copy_multi_kernel(CopyJobs j) {
+  const long long stride = (long long)gridDim.x * kVecThreads;
+  for (int q = 0; q < j.count; ++q) {
+    const sl_copy16* __restrict__ s = reinterpret_cast<const sl_copy16*>(j.src[q]);
+    sl_copy16* __restrict__ d = reinterpret_cast<sl_copy16*>(j.dst[q]);
+    const long long n16 = j.nbytes[q] >> 4;
+    for (long long i = (long long)blockIdx.x * kVecThreads + threadIdx.x; i < n16; i += stride) d[i] = s[i];
+    const int tail4 = (int)((j.nbytes[q] & 15) >> 2);
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail4)
+      reinterpret_cast<unsigned*>(j.dst[q])[4 * n16 + threadIdx.x] = reinterpret_cast<const unsigned*>(j.src[q])[4 * n16 + threadIdx.x];
+  }
+}
+int launch_copy_multi(const CopyJobs& jobs, hipStream_t st) {
+  long long most = 0;
+  for (int q = 0; q < jobs.count; ++q) {
+    if (jobs.nbytes[q] & 3) { set_error("copy_multi: length %lld is not a multiple of 4 bytes", jobs.nbytes[q]); return CUADMM_ERR_INVALID; }
+    most = std::max(most, jobs.nbytes[q] >> 4);
+  }
+  if (jobs.count <= 0 || most <= 0) {
+    bool any = false;
+    for (int q = 0; q < jobs.count; ++q) any = any || jobs.nbytes[q] > 0;
+    if (!any) return CUADMM_OK;
+  }
+  hipLaunchKernelGGL(copy_multi_kernel, dim3(grid_for(most + 1, kVecThreads, 256 * 8)), dim3(kVecThreads), 0, st, jobs);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 int launch_scale(double* v, long long n, double s, hipStream_t st) {
   if (n <= 0) return CUADMM_OK;
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, kVecThreads)), dim3(kVecThreads), 0, st, v, n, s);

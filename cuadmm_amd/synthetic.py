@@ -108,21 +108,19 @@ def config_c4(n_blocks=100000, seed=20240601):
     return make_synthetic(config_c4_blk(n_blocks, seed), cons_per_block=3, seed=seed)
 
 
-def config_c3(n=2000, degree=8, seed=20240601):
-    """BASELINE config 3: max-cut relaxation of a random graph, one PSD block of size n.
+def config_c3(n=2000, p=0.01, seed=20240601):
+    """BASELINE config 3 as SURVEY.md section 8d specifies it: max-cut relaxation of an Erdos-Renyi graph G(n, p), p = 0.01
+    (about 20 neighbours per node at n = 2000), unit weights, one PSD block of size n (examples/max-cut/genMAXCUT.m:28-31).
 
         min <C, X>  s.t.  X_ii = 1 (i = 1..n),  X >= 0,     C = -(Diag(W 1) - W) / 4
 
-    W: symmetric 0/1 adjacency with about `degree` neighbours per node.  m = n constraints, each a single svec slot.
+    W: symmetric 0/1 adjacency, every pair i < j an edge with probability p (one uniform draw per pair, pairs in row-major order
+    of the strict upper triangle).  m = n constraints, each a single svec slot.
     """
     rng = np.random.Generator(np.random.PCG64(seed + 2))
-    n_edges = n * degree // 2
-    i = rng.integers(0, n, n_edges)
-    j = rng.integers(0, n, n_edges)
-    keep = i != j
-    lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
-    pairs = np.unique(np.stack([lo, hi], 1), axis=0)
-    lo, hi = pairs[:, 0], pairs[:, 1]
+    lo, hi = np.triu_indices(n, 1)
+    keep = rng.random(lo.size) < p
+    lo, hi = lo[keep].astype(np.int64), hi[keep].astype(np.int64)
     deg = np.bincount(lo, minlength=n) + np.bincount(hi, minlength=n)
     L = n * (n + 1) // 2
     diag_slot = (np.arange(n, dtype=np.int64) * (np.arange(n, dtype=np.int64) + 1)) // 2 + np.arange(n)   # (col i, row i)

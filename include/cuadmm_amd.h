@@ -102,9 +102,14 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol,
 /* SDPDuoSolver::init / ::solve  (reference include/cuadmm/duo_solver.h:236-276, src/duo_solver.cu): the
  * two-block-size specialisation (moment + localizing matrices).  Same iteration; the reference differs only in
  * where the moment-matrix eigendecompositions run (`if_gpu_eig_mom`: N GPUs through threads + P2P copies, or
- * `cpu_eig_thread_num` host LAPACK threads).  Here every block is projected by the fused kernels of this
- * engine, so both arguments are accepted and ignored; like the reference (analyze_blk.cu:39-43) init rejects
- * inputs that do not have exactly two distinct block sizes.  Multi-GPU goes through rank/world + the hook. */
+ * `cpu_eig_thread_num` host LAPACK threads).  Here every block is projected by the kernels of this engine:
+ *   if_gpu_eig_mom = 0 (host-LAPACK moment matrices) is REFUSED with CUADMM_ERR_INVALID unless option
+ *     "duo_cpu_eig_on_gpu" = 1 says that running them on the GPU instead is what the caller wants;
+ *   device_num_requested = N > 1 from ONE process runs N engines on N host threads (devices 0 .. N-1, or all on
+ *     this solver's device with option "duo_share_device" = 1), blocks sharded by index, the exchange step an
+ *     in-process all-reduce through peer-visible staging buffers; with rank / world already
+ *     set by the caller (one process per GPU) N must equal world.
+ * Like the reference (analyze_blk.cu:39-43) init rejects inputs that do not have exactly two distinct block sizes. */
 int cuadmm_duo_init(cuadmm_solver* s,
                     int if_gpu_eig_mom, int device_num_requested,
                     int eig_stream_num_per_gpu, int cpu_eig_thread_num,

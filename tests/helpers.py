@@ -7,36 +7,7 @@ import cuadmm_amd
 from cuadmm_amd._lib import check
 
 
-class Dev:
-    """numpy array mirrored in device memory via cuadmm_dev_malloc / memcpy."""
-
-    def __init__(self, arr=None, shape=None, dtype=np.float64):
-        self.lib = cuadmm_amd.load()
-        if arr is not None:
-            arr = np.ascontiguousarray(arr)
-            shape, dtype = arr.shape, arr.dtype
-        self.shape, self.dtype = tuple(np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape, np.dtype(dtype)
-        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
-        p = C.c_void_p()
-        check(self.lib.cuadmm_dev_malloc(C.byref(p), max(self.nbytes, 8)))
-        self.ptr = p
-        if arr is not None and self.nbytes:
-            check(self.lib.cuadmm_memcpy_h2d(self.ptr, arr.ctypes.data_as(C.c_void_p), self.nbytes))
-
-    def get(self):
-        out = np.empty(self.shape, self.dtype)
-        check(self.lib.cuadmm_dev_sync())
-        if self.nbytes:
-            check(self.lib.cuadmm_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
-        return out
-
-    def __del__(self):
-        try:
-            if self.ptr:
-                self.lib.cuadmm_dev_free(self.ptr)
-                self.ptr = None
-        except Exception:
-            pass
+from cuadmm_amd.devbuf import Dev  # noqa: E402,F401  (the tests' device buffers are the package's)
 
 
 def psd_project_gpu(x, blk, eig_rank=0):

@@ -135,3 +135,22 @@ def test_deferred_unscaling_is_invisible_to_the_caller():
     info = o.solve(5, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
     assert np.max(np.abs(s2.info_arr("errRp")[-5:] - np.array(info.errRp)[-5:]) / (1e-9 + np.abs(np.array(info.errRp)[-5:]))) <= 1e-7
     assert np.max(np.abs(s2.X - o.X)) <= 1e-8 * (1 + np.max(np.abs(o.X)))
+
+
+def test_batch_option_raised_between_solves_resizes_the_batch_buffers():
+    """'batch' may be changed after a batched solve: the per-iteration partial arrays and the pinned scalars follow it
+    (the first version sized them once: 16 -> 256 wrote past both)."""
+    p = make_synthetic([32] * 320, cons_per_block=3, seed=9)
+    a = cuadmm_amd.SDPSolver(verbose=False, options={"batch": 4})
+    a.init_problem(_amd(p))
+    a.solve(30, 0.0, 0, 50, 100, 0, 1.05)
+    a.set_option("batch", 200)
+    a.solve(230, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
+    b = cuadmm_amd.SDPSolver(verbose=False, options={"batch": 0})
+    b.init_problem(_amd(p))
+    b.solve(30, 0.0, 0, 50, 100, 0, 1.05)
+    b.solve(230, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
+    assert a.counters()["batch_launches"] > 0 and b.counters()["batch_launches"] == 0
+    for nm in ("errRp", "errRd", "pobj", "dobj"):
+        assert np.array_equal(a.info_arr(nm), b.info_arr(nm)), nm
+    assert np.array_equal(a.X, b.X)

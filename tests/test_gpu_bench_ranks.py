@@ -32,3 +32,13 @@ def test_bench_two_ranks_on_one_gpu(args, port):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == int(args[args.index("--steps") + 1])
     assert d["roofline"]["frac"] > 0 and d["config"]["comm"] == "torch"
     assert d["scaling"] == ("weak" if "--config" not in args else "strong")
+    block_diagonal = "--config" not in args or "c4" in args
+    if block_diagonal and "--sharding" not in args:
+        # `value` took the owned-constraints shortcut; the collective the north star names is in the same line
+        ar = d["allreduce_path"]
+        assert ar["value"] > 0 and ar["allreduce_ms_per_iter"] > 0 and ar["allreduce_doubles"] == 2 * d["config"]["con_num"] + 2
+        assert "owned" in d["config"]["sharding"] and "allreduce_path" in d["config"]["sharding"]
+        assert "--config" in args or d["engine_plan"]["closed_blocks"] == 1.0     # C2: every block closed on every rank
+        assert d["with_checkpoint"]["value"] > 0
+    else:
+        assert "allreduce_path" not in d

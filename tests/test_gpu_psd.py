@@ -391,6 +391,22 @@ def test_project_sign_path_full_size_properties():
     assert np.max(np.abs(p1 - ref)) <= 1e-12 * scale
 
 
+def test_project_sign_path_beyond_the_old_fence_properties():
+    """One block of n = 5000 (rounds 1-3 refused blocks above 4000; Xsyevd has no such fence, include/cuadmm/cusolver.h:76-95):
+    the size-independent properties of a projection -- idempotence, Moreau decomposition X = P(X) - P(-X), complementarity."""
+    n = 5000
+    blk = np.array([n], dtype=np.int32)
+    x = _rand_svec(blk, 23)
+    p1 = psd_project_gpu(x, blk)
+    pm = psd_project_gpu(-x, blk)
+    p2 = psd_project_gpu(p1, blk)
+    scale = 2.0 * np.sqrt(n) / np.sqrt(2.0)                                 # ~ ||X||_2 of this input
+    assert np.max(np.abs(p2 - p1)) <= 1e-12 * scale
+    assert np.max(np.abs((p1 - pm) - x)) <= 1e-12 * scale
+    assert abs(np.dot(p1, pm)) <= 1e-10 * np.dot(x, x)
+    assert np.dot(p1, p1) > 0.2 * np.dot(x, x)
+
+
 def test_project_sign_path_flags_non_finite_input():
     import cuadmm_amd
     blk = np.array([100, 16], dtype=np.int32)

@@ -89,6 +89,48 @@ def test_two_shards_match_single_engine(sw, iters, mode, monkeypatch):
     assert np.max(np.abs(solvers[0].y - ref.y)) <= 1e-8 * (1 + np.max(np.abs(ref.y)))
 
 
+def test_ranks_agree_on_batching_when_only_one_shard_can_batch():
+    """Heterogeneous shards under owned-constraints sharding: rank 0 holds only 32 x 32 blocks (closed, one tile geometry: it
+    could run several iterations per launch), rank 1 a mix of geometries (it cannot).  A rank that batches all-reduces 4 K
+    scalars once per batch, one that does not 4 per iteration: the decision is taken together at the start of the solve
+    (Solver::batch_agree), here against it on BOTH ranks -- and the trajectory is the single engine's."""
+    blk = [32] * 600 + [45] * 100 + [12] * 400 + [28] * 100      # >= 256 blocks per rank: the y-solve runs on the device, blocks are closed
+    p = make_synthetic(blk, cons_per_block=3, seed=5)
+    iters = 40
+    ref = cuadmm_amd.SDPSolver(verbose=False)
+    ref.init_problem(_amd(p))
+    ref.solve(iters, 0.0, 0, 50, 100, 0, 1.05)
+    world = 2
+    ar = HostAllReduce(world)
+    solvers = [cuadmm_amd.SDPSolver(verbose=False, rank=r, world=world) for r in range(world)]
+    errs = []
+
+    def run(r):
+        try:
+            solvers[r].set_allreduce(ar.hook(r))
+            solvers[r].init_problem(_amd(p))
+            solvers[r].solve(iters, 0.0, 0, 50, 100, 0, 1.05)
+        except Exception as e:          # pragma: no cover
+            errs.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    shards = [s.shard() for s in solvers]
+    assert all(b == 32 for b in blk[:shards[0][3]])                          # rank 0: 32 x 32 blocks only
+    assert [s.counters()["batch_launches"] for s in solvers] == [0.0, 0.0]   # neither rank batched
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig"):
+        a, b0, b1 = ref.info_arr(nm), solvers[0].info_arr(nm), solvers[1].info_arr(nm)
+        assert np.array_equal(b0, b1), nm
+        assert np.max(np.abs(a - b0) / (1e-12 + np.abs(a))) <= 1e-9, nm
+    # ... and alone, rank 0's kind of shard does batch (the agreement, not the planner, held it back)
+    alone = cuadmm_amd.SDPSolver(verbose=False)
+    alone.init_problem(_amd(make_synthetic([32] * shards[0][3], cons_per_block=3, seed=5)))
+    alone.solve(iters, 0.0, 0, 50, 100, 0, 1.05)
+    assert alone.counters()["batch_launches"] > 0
+
+
 @pytest.mark.parametrize("name", ["truss5", "hinf12"])
 def test_coupled_constraints_fall_back_to_the_replicated_solve(name, problem_dirs):
     """truss5 (34 blocks, every constraint couples several of them): no constraint is owned by one rank, the general

@@ -179,6 +179,41 @@ def test_duo_solver_front(problem_dirs):
                                                      b.C_vals, b.C_nnz, b.blk_vals, b.mat_num)
 
 
+@pytest.mark.parametrize("name,sw", [("ros_2000", 11000), ("ros_2000", 0), ("pendulum_N=80", 11000), ("biggs", 0)])
+def test_duo_solver_n_devices_from_one_process(name, sw, problem_dirs):
+    """duo_init(if_gpu_eig_mom = true, device_num_requested = 2) from ONE process (duo_solver.cu:487-577, check_gpus.cu:29-43): the
+    handle leads a group of two engines on two host threads, blocks sharded by index, the exchange step an in-process all-reduce
+    (csrc/duo_group.hip); option duo_share_device = 1 puts both engines on device 0 (the GPU box has one).  Same trajectory as the
+    single engine at 1e-9, X / y / S of the caller's handle are the WHOLE vectors.  ros_2000: block-diagonal (owned constraints,
+    four scalars exchanged); pendulum N = 80 (159 x 10 + 80 x 55) and biggs (47 x 13 + 91): coupled (2m+2 doubles, replicated
+    solve with the GPU tail of the factor on every rank)."""
+    a = problem_to_amd(load_npz_problem(name) if name.startswith("pendulum") else orc.load_problem_txt(problem_dirs[name]))
+    iters = 30
+
+    def run(ndev):
+        s = cuadmm_amd.SDPSolver(verbose=False, options={"duo_share_device": 1})
+        s.duo_init(True, ndev, 15, 30, a.vec_len, a.con_num, a.At_csc_col_ptrs, a.At_csc_row_ids, a.At_csc_vals, a.At_nnz,
+                   a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
+        s.solve(iters, 0.0, 0, 50, 100, sw, 1.05)
+        return s
+    one, two = run(1), run(2)
+    assert two.info_iter_num == one.info_iter_num == iters
+    assert two.shard() == (0, a.vec_len, 0, a.mat_num) and two.dims() == (a.vec_len, a.con_num, a.mat_num)
+    for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+        _cmp("duo2:" + nm, two.info_arr(nm), one.info_arr(nm), rtol=1e-9, atol=1e-12)
+    assert np.array_equal(two.info_arr("sig"), one.info_arr("sig"))
+    for va, vb in ((two.X, one.X), (two.y, one.y), (two.S, one.S)):
+        assert va.shape == vb.shape and np.max(np.abs(va - vb)) <= 1e-9 * (1 + np.max(np.abs(vb)))
+    # a warm restart through the leader reaches every rank
+    two.solve(10, 0.0, 0, 50, 100, sw, 1.05, if_first=False)
+    one.solve(10, 0.0, 0, 50, 100, sw, 1.05, if_first=False)
+    _cmp("duo2:pobj (continued)", two.info_arr("pobj"), one.info_arr("pobj"), rtol=1e-9, atol=1e-12)
+    # more engines than devices without the option: refused, with the way out in the message
+    with pytest.raises(cuadmm_amd.CuadmmError, match="duo_share_device"):
+        cuadmm_amd.SDPSolver(verbose=False).duo_init(True, 64, 15, 30, a.vec_len, a.con_num, a.At_csc_col_ptrs, a.At_csc_row_ids, a.At_csc_vals,
+                                                     a.At_nnz, a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
+
+
 def test_device_side_y_solve_matches_the_host_solve(monkeypatch):
     """Block-diagonal A A^T (every constraint touches one block): the elimination forest of the factor is one small tree per
     block and the y-solve runs on the device, one thread per tree (forest_solve_kernel), with y, A X, A(S-C) and b resident
