@@ -162,7 +162,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   const int m = (int)blockIdx.x;
   if (m >= a.count) return;
   const PsdDesc d = a.desc[a.first + m];
-  psd_sign_closed_body<NT, false, FULL>(a, d.n, swt_smem, a.steps ? a.steps + d.id : nullptr, a.hint ? a.hint + d.id : nullptr, nullptr, d.off, d.slot, 0, d.pad[0]);
+  // the epilogue re-reads the arguments from the kernarg segment (psd_sign_closed.h: swc_args) instead of keeping them in scalar
+  // registers across the iteration
+  SwcKArg ka = (SwcKArg)__builtin_amdgcn_kernarg_segment_ptr();
+  psd_sign_closed_body<NT, false, FULL>(a, d.n, swt_smem, a.steps ? a.steps + d.id : nullptr, a.hint ? a.hint + d.id : nullptr, nullptr, d.off, d.slot, 0, d.pad[0], 0, ka);
 }
 
 // SEVERAL ADMM ITERATIONS PER LAUNCH (ClosedArgs::iters; closed blocks): one PERSISTENT WORKGROUP PER CU (WAVES = the CU's

@@ -166,10 +166,10 @@ struct ClosedArgs {
 // fresh copy instead of keeping the previous phase's scalar registers alive across the iteration -- at this kernel's budget
 // those are spilled into VGPR lanes, and every v_writelane / v_readlane takes ~4.5 cycles from the port the MFMAs issue on.
 using SwcKArg = __attribute__((address_space(4))) const char*;
-template <bool TASK_LOOP>
+template <bool RELOAD>
 __device__ __forceinline__ ClosedArgs swc_args(const ClosedArgs& fz, SwcKArg& ka) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (TASK_LOOP) {
+  if (RELOAD) {
     asm volatile("" : "+s"(ka));
     return *reinterpret_cast<__attribute__((address_space(4))) const ClosedArgs*>(ka);
   }
@@ -194,7 +194,7 @@ __device__ __forceinline__ ClosedArgs swc_args(const ClosedArgs& fz, SwcKArg& ka
 // the stamps' registers and v_writelanes in the production kernel.
 template <int NT, bool TASK_LOOP = false, bool FULL = false, bool DBG = false>
 __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n_arg, double* S, int* steps_out, int* hint, long long* dbg_arg,
-                                                     long long off, int slot, long long poff, int hdr, int it_local = 0, SwcKArg ka = nullptr) {
+                                                     long long off, int slot, long long poff, int hdr, int it_local, SwcKArg ka) {
   long long* const dbg = DBG ? dbg_arg : nullptr;
   using Cfg = SignWaveT<NT>;
   constexpr int LD = Cfg::LD, NP = Cfg::NP, U = Cfg::U, NSLOT = Cfg::NSLOT;
@@ -208,6 +208,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   const int lane = lane_p;
   const int r16 = lane & 15, kk = lane >> 4;
   const int len = n * (n + 1) / 2;
+  const int ksteps = FULL ? 4 * NT : ((n + 3) >> 2);      // k-steps with at least one real row
   const long long c0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   const bool upd = fz.mode == 0;
   const ClosedRec* __restrict__ rec = fz.rec + slot;
@@ -342,10 +343,12 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
       for (int j = i; j < NT; ++j) y[i][j] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4 * NT; ++s)
+      if (s < ksteps) {                                     // k-steps of pure padding are skipped (swt_mma_regB)
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = i; j < NT; ++j) y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][i], f[s][j], y[i][j], 0, 0, 0);
+          for (int j = i; j < NT; ++j) y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][i], f[s][j], y[i][j], 0, 0, 0);
+      }
     // statistics only where the schedule reads them: nothing on the steps whose scale is fixed in advance, ||S - S Y||^2 alone
     // in the plain / finishing phases, tr Y and ||Y||_F^2 as well on the first step and after a probe (wave-uniform)
     const bool stats = sched.needs_stats(), stats_ab = stats && sched.needs_ab();
@@ -363,9 +366,9 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
     }
     sl_v4f64 z[NT][NT];
     swc_lower_write<NT>(S, r16, kk, y);
-    swt_mma_regB<NT, 0, 1>(f, y, z);                        // row block 0 of Y: upper sub-tiles only
+    swt_mma_regB<NT, 0, 1>(f, y, z, ksteps);                        // row block 0 of Y: upper sub-tiles only
     swc_lower_read<NT>(S, r16, kk, y);
-    swt_mma_regB<NT, 1, NT>(f, y, z);
+    swt_mma_regB<NT, 1, NT>(f, y, z, ksteps);
     double mu;
     if (stats) {
       double ta = 0.0, tbv = 0.0;
@@ -408,7 +411,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   asm volatile("" : "+v"(lane_e));
 #endif
   const unsigned* __restrict__ tabl_e = g_swc_tab<NT>.v + lane_e;
-  const ClosedArgs fe = swc_args<TASK_LOOP>(fz, ka);      // a fresh copy: none of the prologue's scalar registers lives across the iteration
+  const ClosedArgs fe = swc_args<true>(fz, ka);      // a fresh copy: none of the prologue's scalar registers lives across the iteration
   const ClosedRec* __restrict__ rec_e = fe.rec + slot;
   const double* __restrict__ Xl_e = fe.X + off + lane_e;
   const double* __restrict__ Cl_e = fe.C + off + lane_e;
@@ -463,7 +466,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
           for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = i; j < NT; ++j)
-              p[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[4 * b + s][i], xb[b][j][s], p[i][j], 0, 0, 0);
+              if (4 * b + s < ksteps) p[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[4 * b + s][i], xb[b][j][s], p[i][j], 0, 0, 0);
     }
     // the loads of the final walk's first batch ride behind the matrix pipe (X once more: keeping it live across the product
     // costs spills at 128 registers)
@@ -492,7 +495,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   // slot of P(r, c) then takes S - C and the slot of Rd1(r, c) the new X -- the staging the block's constraint rows read
   bool bad = false;
   double s_rd = 0.0, s_cx = 0.0;
-  const ClosedArgs fw = swc_args<TASK_LOOP>(fz, ka);
+  const ClosedArgs fw = swc_args<true>(fz, ka);
   double* __restrict__ Sg = fw.S + off + lane_e;
   double* __restrict__ Xg = fw.X + off + lane_e;
 #pragma unroll 1

@@ -103,8 +103,11 @@ __device__ __forceinline__ void swt_lower_read(const double* __restrict__ scr, i
 
 // acc(upper sub-tiles) (+)= A * B over the row blocks [B0, B1) of B: A symmetric, given by its fragments; B by its sub-tiles
 // in accumulator layout.  Row block 0 of B needs no lower sub-tile.
+// ksteps: k-steps (of 4 rows / columns) that hold at least one REAL row of the block, (n + 3) / 4 -- the steps beyond are exact
+// zeros in both operands (the padding of the tile) and are skipped: a wave-uniform scalar branch instead of 64 matrix-core cycles
+// (n = 28 on the 32 x 32 tile: one step in eight; n = 10 on 16 x 16: one in four; the tiny blocks of a closed plan: up to three)
 template <int NT, int B0, int B1>
-__device__ __forceinline__ void swt_mma_regB(const double (&fa)[4 * NT][NT], const sl_v4f64 (&yb)[NT][NT], sl_v4f64 (&acc)[NT][NT]) {
+__device__ __forceinline__ void swt_mma_regB(const double (&fa)[4 * NT][NT], const sl_v4f64 (&yb)[NT][NT], sl_v4f64 (&acc)[NT][NT], int ksteps = 4 * NT) {
   if (B0 == 0) {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -115,11 +118,13 @@ __device__ __forceinline__ void swt_mma_regB(const double (&fa)[4 * NT][NT], con
   for (int b = B0; b < B1; ++b)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
+      if (4 * b + s < ksteps) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = i; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[4 * b + s][i], yb[b][j][s], acc[i][j], 0, 0, 0);
+          for (int j = i; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[4 * b + s][i], yb[b][j][s], acc[i][j], 0, 0, 0);
+      }
 }
 
 // mirrored store of the upper sub-tiles (on a diagonal sub-tile the upper triangle decides)
@@ -159,6 +164,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   const int lane = lane_id();
   const int r16 = lane & 15, kk = lane >> 4;
   const int len = n * (n + 1) / 2;
+  const int ksteps = (n + 3) >> 2;                        // k-steps with at least one real row (the rest of the tile is exact zeros)
   const unsigned short* __restrict__ tab = g_swt_tab.v;
   const long long c0 = dbg ? (long long)__builtin_readcyclecounter() : 0;
   // ---- prologue: the tile takes X (fused: Xb = X + sigma (A^T y - C), formed here); ||X||_F is the 2-norm of the svec (the
@@ -244,10 +250,12 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       for (int j = i; j < NT; ++j) y[i][j] = sl_v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4 * NT; ++s)
+      if (s < ksteps) {                                     // k-steps of pure padding are skipped (swt_mma_regB)
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = i; j < NT; ++j) y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][i], f[s][j], y[i][j], 0, 0, 0);
+          for (int j = i; j < NT; ++j) y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][i], f[s][j], y[i][j], 0, 0, 0);
+      }
     // tr Y and ||Y||_F^2 (off-diagonal sub-tiles count twice) -- only when the schedule will look at them
     const bool stats = sched.needs_stats();                 // wave-uniform
     double pa = 0.0, pb = 0.0;
@@ -264,9 +272,9 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
     }
     sl_v4f64 z[NT][NT];
     swt_lower_write<NT>(S, r16, kk, y);
-    swt_mma_regB<NT, 0, 1>(f, y, z);                        // row block 0 of Y: upper sub-tiles only
+    swt_mma_regB<NT, 0, 1>(f, y, z, ksteps);                        // row block 0 of Y: upper sub-tiles only
     swt_lower_read<NT>(S, r16, kk, y);
-    swt_mma_regB<NT, 1, NT>(f, y, z);
+    swt_mma_regB<NT, 1, NT>(f, y, z, ksteps);
     double mu;
     if (stats) {
       const double ta = wave_sum(pa), tb = wave_sum(pb);
@@ -333,7 +341,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) xb[b][j][r] = S[(16 * b + kk + 4 * r) * LD + 16 * j + r16];
-    swt_mma_regB<NT, 0, NT>(f, xb, p);
+    swt_mma_regB<NT, 0, NT>(f, xb, p, ksteps);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll

@@ -1,0 +1,66 @@
+"""Soak test of the one-launch matrix-sign kernel's barriers (csrc/psd_large.hip: lg_sign_cluster_kernel, lg_member_barrier).
+
+Its XCD-local barrier was once wrong for a week while every bit-identity test passed -- correct "by eviction": the workgroup-scope
+invalidate did not drop the L1, and a phase streamed enough operands through a CU to push the stale lines out.  What exposed it
+was a CHANGE OF CACHE FOOTPRINT (a two-rank run).  So this test varies the footprint on purpose: >= 200 solves that alternate
+PlanarHand_N=1 (nine blocks of 66 / 91 / 120), taha1a (ten of 126, one of 252, three of 56) and a 70 / 126 / 252 synthetic
+between the three barrier modes -- members on one XCD through the shared L2 (psd_lg_cluster = 1), agent-scope release / acquire
+(2), one launch per product (0) -- with other kernels' traffic in between (a C2-like bulk projection), all in one process.  Every
+solve of a problem must leave the bits of its first solve in launch mode."""
+import os
+
+import numpy as np
+import pytest
+
+import cuadmm_amd
+from cuadmm_amd import synthetic
+from tests.conftest import load_npz_problem
+from tests.helpers import problem_to_amd, psd_project_gpu
+
+pytestmark = pytest.mark.gpu
+
+ROUNDS = int(os.environ.get("CUADMM_SOAK_ROUNDS", "23"))          # 23 rounds x 3 problems x 3 modes = 207 solves
+
+
+def _taha1a():
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "problems", "taha1a.npz"))
+    from oracle import cuadmm_oracle as orc
+    cp, ri, v = orc.coo_to_csc(d["At_col"], d["At_row"], d["At_val"], int(d["con_num"]))
+    blk = d["blk"]
+    L = int(orc.svec_block_offsets(blk)[-1])
+    return problem_to_amd(orc.Problem(L, int(d["con_num"]), blk.astype(np.int32), cp, ri, v, d["b_idx"], d["b_val"], d["C_idx"], d["C_val"]))
+
+
+def _solve(prob, mode, iters):
+    s = cuadmm_amd.SDPSolver(verbose=False, options={"psd_lg_cluster": mode})
+    s.init_problem(prob)
+    s.solve(iters, 0.0, 0, 50, 100, 11000, 1.05)
+    return tuple(np.array(s.info_arr(nm)) for nm in ("pobj", "dobj", "errRp", "errRd")) + (s.X,)
+
+
+def test_one_launch_barriers_soak_over_changing_cache_footprints():
+    sp = synthetic.make_synthetic([70, 126, 252, 70, 126, 70], cons_per_block=5, dense_C=True, seed=4)
+    problems = {
+        "PlanarHand_N=1": (problem_to_amd(load_npz_problem("PlanarHand_N=1_MOMENT")), 12),
+        "taha1a": (_taha1a(), 14),
+        "synthetic 70/126/252": (cuadmm_amd.Problem(sp.vec_len, sp.con_num, sp.blk, sp.At_col_ptrs, sp.At_row_ids, sp.At_vals, sp.b_idx, sp.b_vals,
+                                                    sp.C_idx, sp.C_vals), 16),
+    }
+    ref = {name: _solve(p, 0, it) for name, (p, it) in problems.items()}
+    rng = np.random.default_rng(7)
+    bulk_blk = np.full(3000, 32, np.int32)
+    bulk = rng.standard_normal(3000 * 528)
+    n_solves = 0
+    for rnd in range(ROUNDS):
+        order = list(problems)
+        rng.shuffle(order)
+        for name in order:
+            p, it = problems[name]
+            for mode in rng.permutation([1, 2, 0]):
+                got = _solve(p, int(mode), it)
+                n_solves += 1
+                for a, b, what in zip(got, ref[name], ("pobj", "dobj", "errRp", "errRd", "X")):
+                    assert np.array_equal(a, b), "%s, psd_lg_cluster = %d, round %d: %s differs from the launch-mode bits" % (name, mode, rnd, what)
+                if (rnd + n_solves) % 4 == 0:            # somebody else's lines through every L1 / L2 now and then
+                    psd_project_gpu(bulk[: 528 * (500 + 250 * (n_solves % 9))], bulk_blk[: 500 + 250 * (n_solves % 9)])
+    assert n_solves >= 200 or ROUNDS < 23
