@@ -43,6 +43,13 @@ struct cuadmm_aat {
   // sweeps of different chunks touch disjoint entries, so cuadmm_aat_solve_permuted runs them on a few host threads
   // with bit-identical results (used for large block-diagonal systems, e.g. weak-scaled runs with m = 400 000).
   std::vector<std::vector<int>> chunks;
+  // Split factor: the trees of the LEADING columns' elimination forest grouped into kLeadChunks chunks (columns ascending within a
+  // chunk).  The forward sweep of a chunk updates its own leading entries and a tail accumulator of its own (length tail_k); the
+  // accumulators are added to the tail in chunk order (deterministic, independent of the thread count); the backward sweep of a
+  // chunk reads the solved tail and its own entries.  For forests of many trees whose sweeps are milliseconds on one core (PushBox
+  // N = 30: 4 953 trees, deepest 1 135 levels -- too deep for the device-side sweeps --, 1.6 ms per sweep serial).
+  std::vector<std::vector<int>> lead_chunks;
+  mutable std::vector<double> lead_acc;      // kLeadChunks x tail_k
   std::vector<int> nzcols;   // columns j < m - tail_k with at least one sub-diagonal entry, ascending (block-diagonal A A^T: few)
   int tail_k = 0;
   std::vector<int64_t> schur_ptr;
@@ -90,6 +97,15 @@ void min_degree_order(int n, const std::vector<int64_t>& Bp, const std::vector<i
   int mindeg = 0;
   for (int k = 0; k < n; ++k) {
     while (head[mindeg] < 0) ++mindeg;
+    // What is left is (nearly) a clique: the smallest external degree reaches 70 % of the remaining variables.  Any order of
+    // them fills the trailing block completely -- it becomes the dense tail the GPU factors -- while the quotient-graph updates of
+    // this phase are the expensive ones (every pivot walks thousands of long lists: PushT_N=30, A A^T with 77 M nonzeros on
+    // m = 53 290, spent 36 of its 45 s of analysis here).  The rest is ordered by current degree.
+    if (n - k > 2048 && (long long)mindeg * 10 >= 7LL * (n - k - 1)) {
+      for (int d = mindeg; d <= n && k < n; ++d)
+        for (int v = head[d]; v >= 0; v = nxt[v]) perm[k++] = v;
+      break;
+    }
     int p = head[mindeg];
     bucket_remove(p);
     perm[k] = p;
@@ -530,6 +546,32 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     f->D[k] = dk;
   }
   for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->nzcols.push_back(j);
+  // split factor with a large forest of leading trees: chunks for the threaded leading sweeps
+  if (tail_k > 0 && n1 >= 20000 && f->Lp[n1] >= 300000) {
+    std::vector<int> root(n1);
+    for (int j = n1 - 1; j >= 0; --j) root[j] = (parent[j] < 0 || parent[j] >= n1) ? j : root[parent[j]];   // parent[j] > j
+    std::vector<int64_t> weight(n1, 0);
+    for (int j = 0; j < n1; ++j) weight[root[j]] += 1 + (f->Lp[j + 1] - f->Lp[j]);
+    int64_t total = 0, biggest = 0;
+    for (int j = 0; j < n1; ++j) if (root[j] == j) { total += weight[j]; biggest = std::max(biggest, weight[j]); }
+    constexpr int T = 16;
+    if (biggest * 4 < total) {
+      // longest-processing-time assignment of the trees (heaviest first onto the lightest chunk): deterministic
+      std::vector<int> roots;
+      for (int j = 0; j < n1; ++j) if (root[j] == j) roots.push_back(j);
+      std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+      std::vector<int64_t> load(T, 0);
+      std::vector<int> chunk_of_root(n1, -1);
+      for (int r : roots) {
+        int best = 0;
+        for (int c = 1; c < T; ++c) if (load[c] < load[best]) best = c;
+        chunk_of_root[r] = best; load[best] += weight[r];
+      }
+      f->lead_chunks.assign(T, {});
+      for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->lead_chunks[chunk_of_root[root[j]]].push_back(j);
+      f->lead_acc.assign((size_t)T * (size_t)tail_k, 0.0);
+    }
+  }
   // chunks of independent etree subtrees for the threaded solve (whole factor on the host, large m, many subtrees)
   if (tail_k == 0 && m >= 20000) {
     std::vector<int> root(m);
@@ -706,6 +748,29 @@ int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x) {
     }
     return CUADMM_OK;
   }
+  if (!f->lead_chunks.empty() && host_pool().size() > 1) {
+    const int nchunk = (int)f->lead_chunks.size(), T = host_pool().size();
+    double* acc_all = f->lead_acc.data();
+    host_pool().run([&](int t) {
+      for (int c = t; c < nchunk; c += T) {
+        double* acc = acc_all + (size_t)c * (size_t)k - n1;       // acc[i] for tail rows i >= n1
+        std::memset(acc + n1, 0, sizeof(double) * (size_t)k);
+        for (int j : f->lead_chunks[c]) {
+          const double xj = x[j];
+          if (xj != 0.0)
+            for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
+              const int i = Li[p];
+              if (i < n1) x[i] -= Lx[p] * xj; else acc[i] -= Lx[p] * xj;
+            }
+        }
+      }
+    });
+    for (int c = 0; c < nchunk; ++c) {                              // chunk order: the same bits for every thread count
+      const double* acc = acc_all + (size_t)c * (size_t)k;
+      for (int i = 0; i < k; ++i) x[n1 + i] += acc[i];
+    }
+    return CUADMM_OK;
+  }
   for (int j : f->nzcols) {
     const double xj = x[j];
     if (xj != 0.0)
@@ -729,6 +794,21 @@ int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
       for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
       x[j] = s;
     }
+    return CUADMM_OK;
+  }
+  if (!f->lead_chunks.empty() && host_pool().size() > 1) {       // a chunk reads the solved tail and its own trees' entries
+    const int nchunk = (int)f->lead_chunks.size(), T = host_pool().size();
+    host_pool().run([&](int t) {
+      for (int c = t; c < nchunk; c += T) {
+        const std::vector<int>& cols = f->lead_chunks[c];
+        for (size_t q = cols.size(); q-- > 0;) {
+          const int j = cols[q];
+          double s = x[j];
+          for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
+          x[j] = s;
+        }
+      }
+    });
     return CUADMM_OK;
   }
   for (size_t q = f->nzcols.size(); q-- > 0;) {

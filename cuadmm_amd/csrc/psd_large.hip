@@ -745,14 +745,27 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   auto part_of = [](const Group& g) { return (size_t)g.count * 2 * (size_t)(g.N / 32) * (size_t)(g.N / 32 + 1) / 2; };
   size_t max_part = 0, side_elems = 0, side_part = 0;
   int side_members = 0, n_merged = 0, wgs = 0;
+  // per-XCD load of the merged launch: member q of a non-spread group sits on XCD q % 8 (every group's first workgroup is a
+  // multiple of 8), a spread group's workgroups go round the XCDs.  lg_path bounds one group's share of an XCD (96 workgroups, the
+  // XCD's CUs hold ~128); several groups must respect it TOGETHER, or a later group's workgroups wait for CUs while the resident
+  // ones spin in lg_member_barrier (no deadlock -- barriers are per member -- but serial, and the ~2 s give-up budget runs)
+  int xcd_load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (Group& g : groups) {
     const LgPath p = lg_path(opt, g.N, g.count);
-    if (opt.lg_merge != 0 && !opt.debug && p.cluster && g.N <= 512 && n_merged < kClusterMaxGroups &&
-        wgs + g.count * p.ntiles <= kClusterMaxWgs) {   // the workgroups that stay (the grid's others leave at once)
-      wgs += g.count * p.ntiles;
-      g.merged = true;
-      g.slot = 1 + n_merged++;
+    if (!(opt.lg_merge != 0 && !opt.debug && p.cluster && g.N <= 512 && n_merged < kClusterMaxGroups &&
+          wgs + g.count * p.ntiles <= kClusterMaxWgs))   // the workgroups that stay (the grid's others leave at once)
+      continue;
+    int add[8];
+    bool fits = true;
+    for (int x = 0; x < 8; ++x) {
+      add[x] = p.spread ? (g.count * p.ntiles + 7 - x) / 8 : ((g.count > x ? (g.count - x + 7) / 8 : 0) * p.ntiles);
+      fits = fits && xcd_load[x] + add[x] <= 96;
     }
+    if (!fits) continue;
+    for (int x = 0; x < 8; ++x) xcd_load[x] += add[x];
+    wgs += g.count * p.ntiles;
+    g.merged = true;
+    g.slot = 1 + n_merged++;
   }
   if (n_merged < 2)                             // nothing to merge: the plain path
     for (Group& g : groups) { g.merged = false; g.slot = 0; }

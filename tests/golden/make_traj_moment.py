@@ -37,6 +37,10 @@ RUNS = {
     # 14 blocks of 56 / 126 / 252, m = 3 002: the merged one-launch sign-path groups and the whole factor as the dense GPU tail
     "taha1a/switch=0": ("taha1a", 0, 60, 400),
     "taha1a/switch=11000": ("taha1a", 11000, 60, 400),
+    # round 4: the reference's largest shipped moment relaxations (examples/SPOT/data/MOSEK/*.mat through make_large_moment.py)
+    "PushBox_N=30_MOMENT/switch=11000": ("PushBox_N=30_MOMENT", 11000, 60, 200),
+    "PushBox_N=50_MOMENT/switch=11000": ("PushBox_N=50_MOMENT", 11000, 60, 200),
+    "PlanarHand_N=10_MOMENT/switch=11000": ("PlanarHand_N=10_MOMENT", 11000, 40, 60),
 }
 
 
@@ -86,7 +90,7 @@ def main():
     for key in want:
         prob, sw, head, late = RUNS[key]
         p = load(prob)
-        host_factor = prob == "PushT_N=30_MOMENT"
+        host_factor = prob in ("PushT_N=30_MOMENT", "PlanarHand_N=10_MOMENT")      # factors SuperLU cannot hold
         if host_factor:
             # SuperLU runs out of memory on this A A^T (m = 53 290, also in symmetric mode with minimum degree; the reference's
             # CHOLMOD needed 369 s).  The exact sparse solve of this one trajectory is the library's HOST factor instead (CPU code:

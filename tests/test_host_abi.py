@@ -309,6 +309,34 @@ def test_aat_split_factor_schur_complement(name, frac, problem_dirs):
     lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
 
 
+def test_aat_split_factor_threaded_leading_sweeps_on_a_large_forest():
+    """PushBox_N=30 (examples/SPOT/data/MOSEK, m = 154 256): the leading columns of the split factor form ~5 000 trees, the deepest
+    > 1 000 levels (too deep for the device-side sweeps), 1 M nonzeros -- the host sweeps run per chunk of trees on the host pool,
+    tail updates through per-chunk accumulators added in chunk order.  Same result as the serial sweeps of the one-piece factor to
+    roundoff (the tail's sums are associated differently), and the same bits call after call."""
+    from tests.conftest import load_npz_problem
+    p = load_npz_problem("PushBox_N=30_MOMENT")
+    m = p.con_num
+    h, A = _aat(p)
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    hs = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(hs)))
+    k = lib.cuadmm_aat_tail_k(hs)
+    assert 1024 <= k < m // 4
+    rhs = np.random.default_rng(3).standard_normal(m)
+    a, b, b2 = rhs.copy(), rhs.copy(), rhs.copy()
+    check(lib.cuadmm_aat_solve_leading_forward(h, k, P(a)))       # one-piece factor asked for this split: the serial walk
+    check(lib.cuadmm_aat_solve_leading_forward(hs, k, P(b)))
+    check(lib.cuadmm_aat_solve_leading_forward(hs, k, P(b2)))
+    assert np.array_equal(b, b2)
+    assert np.array_equal(a[:m - k], b[:m - k])                   # leading entries: the same arithmetic per entry
+    assert np.max(np.abs(a[m - k:] - b[m - k:])) <= 1e-12 * max(1.0, np.max(np.abs(a[m - k:])))
+    b[m - k:] = a[m - k:]                                         # the same tail for the backward sweeps
+    check(lib.cuadmm_aat_solve_leading_backward(h, k, P(a))); check(lib.cuadmm_aat_solve_leading_backward(hs, k, P(b)))
+    assert np.array_equal(a, b)
+    lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
+
+
 def test_aat_threaded_solve_is_bitwise_identical_to_serial(tmp_path):
     """Large block-diagonal system (weak-scaled C2 structure, m = 200 000): the solve runs independent etree subtrees
     on the host pool; the result must not depend on the number of threads (bit for bit)."""
