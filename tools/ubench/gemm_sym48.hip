@@ -94,6 +94,78 @@ __global__ __launch_bounds__(64 * NWY * NWX) void gemm_sym_kernel(int N, const d
       for (int r = 0; r < 4; ++r) C[(size_t)(row0 + wy * WR + i * 16 + kk + 4 * r) * N + col0 + wx * WC + j * 16 + r16] = acc[i][j][r];
 }
 
+// 32 x 32 tiles with LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, ONE barrier per k-tile, two LDS buffers.
+// The instruction writes wave-uniform base + lane x 16 B, so the tile is unpadded; the four k-rows of a fragment read are kept on
+// disjoint banks by swizzling the SOURCE column with the row's parity (col ^ 16 for odd k-rows) and reading with the same swizzle.
+__global__ __launch_bounds__(256) void gemm_sym_glds_kernel(int N, const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C) {
+  constexpr int TM = 32, BK = 32;
+  __shared__ double smem[4 * BK * TM];                     // A0 | B0 | A1 | B1
+  int bx, by;
+  {
+    const int grid_x = (int)gridDim.x, tile_x = (int)blockIdx.x;
+    const int per_xcd = grid_x / 8;
+    const int L = (tile_x % 8) * per_xcd + tile_x / 8;
+    int sbx, sby;
+    tri_decode(L / 64, sbx, sby);
+    by = sby * 8 + (L % 64) / 8;
+    bx = sbx * 8 + (L % 64) % 8;
+    if (bx < by || bx >= N / TM) return;
+  }
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int row0 = by * TM, col0 = bx * TM;
+  const int r16 = lane & 15, kk = lane >> 4;
+  v4f64 acc = {0, 0, 0, 0};
+  // this lane's part of a chunk: k-row 4 c + (lane >> 4), 16-byte unit lane & 15 of the row, source column swizzled by the row parity
+  const int kr_in = lane >> 4, p16 = lane & 15;
+  auto issue = [&](int k0, int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = 2 * wave + q, kr = 4 * c + kr_in;
+      const int col = (2 * p16) ^ (16 * (kr & 1));
+      const double* ga = A + (size_t)(k0 + kr) * N + row0 + col;
+      const double* gb = B + (size_t)(k0 + kr) * N + col0 + col;
+      double* la = smem + buf * 2 * BK * TM + c * 128;
+      double* lb = smem + buf * 2 * BK * TM + BK * TM + c * 128;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga, (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb, (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  const int nkt = N / BK;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) issue((kt + 1) * BK, (kt + 1) & 1);
+    const double* As = smem + (kt & 1) * 2 * BK * TM;
+    const double* Bs = As + BK * TM;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      const int sw = 16 * ((ks + kk) & 1);
+      const double af = As[(ks + kk) * TM + ((wy * 16 + r16) ^ sw)];
+      const double bf = Bs[(ks + kk) * TM + ((wx * 16 + r16) ^ sw)];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) C[(size_t)(row0 + wy * 16 + kk + 4 * r) * N + col0 + wx * 16 + r16] = acc[r];
+}
+
+static void run_glds(int N, const double* A, const double* B, double* C) {
+  const int nb = N / 32, sb = (nb + 7) / 8, tiles = sb * (sb + 1) / 2 * 64;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    for (int q = 0; q < 10; ++q) hipLaunchKernelGGL(gemm_sym_glds_kernel, dim3(tiles), dim3(256), 0, 0, N, A, B, C);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double flops = 2.0 * N * 32.0 * 32.0 * (nb * (nb + 1) / 2);
+  printf("  N = %4d  %-34s %5d tiles: %7.1f us per product, %5.1f TFLOP/s (upper-triangle tiles)\n", N, "32 x 32, LDS-DMA, 1 barrier / k-tile", nb * (nb + 1) / 2, best * 100.0, flops / (best * 1e-4) / 1e12);
+}
+
 template <int TM, int NWY, int NWX, int BK>
 static void run(const char* name, int N, const double* A, const double* B, double* C) {
   const int nb = N / TM, sb = (nb + 7) / 8, tiles = sb * (sb + 1) / 2 * 64;
@@ -106,8 +178,8 @@ static void run(const char* name, int N, const double* A, const double* B, doubl
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
-  const double flops = 2.0 * N * (double)TM * TM * tiles;
-  printf("  N = %4d  %-34s %5d tiles: %7.1f us per product, %5.1f TFLOP/s\n", N, name, tiles, best * 100.0, flops / (best * 1e-4) / 1e12);
+  const double flops = 2.0 * N * (double)TM * TM * (nb * (nb + 1) / 2);
+  printf("  N = %4d  %-34s %5d tiles: %7.1f us per product, %5.1f TFLOP/s (upper-triangle tiles)\n", N, name, nb * (nb + 1) / 2, best * 100.0, flops / (best * 1e-4) / 1e12);
 }
 
 int main() {
@@ -120,6 +192,7 @@ int main() {
   hipMemcpy(B, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   for (int N : {2016, 2112}) {
     if (N % 32 == 0) run<32, 2, 2, 32>("32 x 32, 4 waves (shipped)", N, A, B, C);
+    if (N % 32 == 0) run_glds(N, A, B, C);
     if (N % 48 == 0) run<48, 3, 1, 32>("48 x 48, 3 waves of 16 x 48", N, A, B, C);
     if (N % 48 == 0) run<48, 1, 3, 32>("48 x 48, 3 waves of 48 x 16", N, A, B, C);
     if (N % 64 == 0) run<64, 2, 2, 16>("64 x 64, 4 waves of 32 x 32", N, A, B, C);
@@ -128,6 +201,7 @@ int main() {
   }
   for (int N : {1056, 1024, 1152}) {
     if (N % 32 == 0) run<32, 2, 2, 32>("32 x 32, 4 waves (shipped)", N, A, B, C);
+    if (N % 32 == 0) run_glds(N, A, B, C);
     if (N % 48 == 0) run<48, 3, 1, 32>("48 x 48, 3 waves of 16 x 48", N, A, B, C);
     if (N % 64 == 0) run<64, 2, 2, 16>("64 x 64, 4 waves of 32 x 32", N, A, B, C);
   }
