@@ -66,12 +66,49 @@ namespace {
 
 using cuadmm::set_error;
 
+void min_degree_order_core(int n, const std::vector<int64_t>& Bp, const std::vector<int>& Bi, std::vector<int>& perm);
+
 // ---------------------------------------------------------------------------------------
 // Approximate minimum degree on the pattern of a symmetric matrix (diagonal ignored).
 // Quotient graph: variables keep a list of adjacent variables (edges not yet covered by an
 // element) and a list of adjacent elements; an element keeps its variable list.
 // ---------------------------------------------------------------------------------------
-void min_degree_order(int n, const std::vector<int64_t>& Bp, const std::vector<int>& Bi, std::vector<int>& perm) {
+void min_degree_order(int n_all, const std::vector<int64_t>& Bp, const std::vector<int>& Bi, std::vector<int>& perm) {
+  perm.resize(n_all);
+  // Dense rows first (the rule of AMD, Amestoy / Davis / Duff): a row with more than max(16, 10 sqrt(n)) entries takes no part in
+  // the elimination graph and is ordered last, by degree.  PushT_N=30: 8 560 of the 53 290 rows of A A^T hold 74 of its 77 M
+  // nonzeros (8 600 entries each); they end up in the dense tail whatever the order, and carrying them through the quotient
+  // graph cost 26 of the 36 s of the analysis.  Inputs without such rows (every other fixture) keep their ordering bit for bit.
+  const long long dense_thr = std::max<long long>(16, (long long)(10.0 * std::sqrt((double)n_all)));
+  std::vector<char> dense(n_all, 0);
+  int n_dense = 0;
+  for (int i = 0; i < n_all; ++i)
+    if (Bp[i + 1] - Bp[i] - 1 > dense_thr) { dense[i] = 1; ++n_dense; }
+  if (n_dense > 0) {
+    // the sparse part is ordered on its own graph (dense neighbours dropped); recursion depth one
+    std::vector<int> map_new(n_all, -1), map_old;
+    for (int i = 0; i < n_all; ++i) if (!dense[i]) { map_new[i] = (int)map_old.size(); map_old.push_back(i); }
+    const int ns = (int)map_old.size();
+    std::vector<int64_t> Sp((size_t)ns + 1, 0);
+    std::vector<int> Si;
+    for (int q = 0; q < ns; ++q) {
+      const int i = map_old[q];
+      for (int64_t p = Bp[i]; p < Bp[i + 1]; ++p) if (!dense[Bi[p]]) Si.push_back(map_new[Bi[p]]);
+      Sp[(size_t)q + 1] = (int64_t)Si.size();
+    }
+    std::vector<int> sperm;
+    min_degree_order_core(ns, Sp, Si, sperm);                 // one level: what is dense relative to the sparse part stays in it
+    for (int q = 0; q < ns; ++q) perm[q] = map_old[sperm[q]];
+    std::vector<int> dl;
+    for (int i = 0; i < n_all; ++i) if (dense[i]) dl.push_back(i);
+    std::stable_sort(dl.begin(), dl.end(), [&](int a, int b) { return Bp[a + 1] - Bp[a] < Bp[b + 1] - Bp[b]; });
+    for (size_t q = 0; q < dl.size(); ++q) perm[(size_t)ns + q] = dl[q];
+    return;
+  }
+  min_degree_order_core(n_all, Bp, Bi, perm);
+}
+
+void min_degree_order_core(int n, const std::vector<int64_t>& Bp, const std::vector<int>& Bi, std::vector<int>& perm) {
   perm.resize(n);
   std::vector<std::vector<int>> adj(n), elems(n), evars(n);
   for (int i = 0; i < n; ++i) {
@@ -495,7 +532,18 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
   double t_lead = 0;
   const double t_alloc = now_s() - t0;
   long long upd = 0;
-  for (int k = 0; k < m; ++k) {
+  // The TAIL rows on the host pool (round 4).  Row k >= n1 of the up-looking factorisation needs the leading factor (complete
+  // after row n1 - 1) and, for its Schur-complement entries, the L21 entries of the tail rows before it.  Two parallel phases with
+  // the serial arithmetic, entry by entry:
+  //   A  every tail row on its own: reach in the elimination tree, the sparse solve against the LEADING rows of the touched columns
+  //      -> its row of L21 (column i, L(k, i), the solve's y_i) and what column k of C leaves in the tail positions;
+  //   -- the rows of L21 are appended to the columns in row order (sequential, one pass) --
+  //   B  every tail row on its own: its Schur row, C's entries first, then  -= L(j, i) y_i  over the touched columns in the
+  //      row's pattern order and each column's tail entries j < k -- the order of the serial loop.
+  // PlanarHand_N=10 (m = 483 707, 32 768 tail rows, 28.5 G updates): 11 of the 12 s of the numeric phase were these rows.
+  const bool par_tail = tail_k >= 512 && host_pool().size() > 1;
+  const int k_serial_end = par_tail ? n1 : m;
+  for (int k = 0; k < k_serial_end; ++k) {
     if (k == n1) t_lead = now_s() - t0;
     int top = m;
     flag[k] = k;
@@ -544,6 +592,100 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
       return CUADMM_ERR_FACTOR;
     }
     f->D[k] = dk;
+  }
+  if (par_tail) {
+    t_lead = now_s() - t0;
+    struct TailRow { std::vector<int> col; std::vector<double> l, y; std::vector<int> tj; std::vector<double> tc; double dk = 0; };
+    std::vector<TailRow> rows((size_t)tail_k);
+    std::vector<int> lead_cnt(Lnz.begin(), Lnz.begin() + n1);          // leading entries of every leading column
+    const int T = host_pool().size();
+    std::atomic<int> next{0};
+    // ---- phase A
+    host_pool().run([&](int) {
+      std::vector<double> Yt((size_t)m, 0.0);
+      std::vector<int> flg((size_t)m, -1), pat((size_t)m);
+      for (;;) {
+        const int r0 = next.fetch_add(16);
+        if (r0 >= tail_k) break;
+        for (int r = r0; r < std::min(tail_k, r0 + 16); ++r) {
+          const int k = n1 + r;
+          TailRow& R = rows[(size_t)r];
+          int top = m;
+          flg[k] = k;
+          for (int64_t p = Cp[k]; p < Cp[k + 1]; ++p) {
+            int i = Ci[p];
+            Yt[i] += Cx[p];
+            int len = 0;
+            while (i < k && flg[i] != k) { pat[len++] = i; flg[i] = k; i = parent[i]; }
+            while (len > 0) pat[--top] = pat[--len];
+          }
+          double dk = Yt[k];
+          Yt[k] = 0.0;
+          for (int t = top; t < m; ++t) {
+            const int i = pat[t];
+            if (i >= n1) { R.tj.push_back(i); R.tc.push_back(Yt[i]); Yt[i] = 0.0; continue; }    // C's entry of a tail position
+            const double yi = Yt[i];
+            Yt[i] = 0.0;
+            const int64_t pb = f->Lp[i], pe = pb + lead_cnt[i];
+            const int* li = f->Li.data();
+            const double* lx = f->Lx.data();
+            for (int64_t p = pb; p < pe; ++p) Yt[li[p]] -= lx[p] * yi;
+            const double lki = yi / f->D[i];
+            dk -= lki * yi;
+            R.col.push_back(i); R.l.push_back(lki); R.y.push_back(yi);
+          }
+          R.dk = dk;
+        }
+      }
+    });
+    (void)T;
+    // ---- the rows of L21 into the columns, row order (what the serial loop appends row by row)
+    for (int r = 0; r < tail_k; ++r) {
+      const TailRow& R = rows[(size_t)r];
+      for (size_t q = 0; q < R.col.size(); ++q) {
+        const int i = R.col[q];
+        const int64_t p2 = f->Lp[i] + Lnz[i];
+        f->Li[p2] = n1 + r;
+        f->Lx[p2] = R.l[q];
+        Lnz[i]++;
+      }
+    }
+    // ---- phase B
+    std::vector<std::vector<int>> scol((size_t)tail_k);
+    std::vector<std::vector<double>> sval((size_t)tail_k);
+    next.store(0);
+    host_pool().run([&](int) {
+      std::vector<double> Y2((size_t)tail_k, 0.0);
+      for (;;) {
+        const int r0 = next.fetch_add(8);
+        if (r0 >= tail_k) break;
+        for (int r = r0; r < std::min(tail_k, r0 + 8); ++r) {
+          const int k = n1 + r;
+          const TailRow& R = rows[(size_t)r];
+          for (size_t q = 0; q < R.tj.size(); ++q) Y2[(size_t)(R.tj[q] - n1)] = R.tc[q];
+          const int* li = f->Li.data();
+          const double* lx = f->Lx.data();
+          for (size_t q = 0; q < R.col.size(); ++q) {
+            const int i = R.col[q];
+            const double yi = R.y[q];
+            const int64_t pe = f->Lp[i] + Lnz[i];
+            for (int64_t p = f->Lp[i] + lead_cnt[i]; p < pe && li[p] < k; ++p) Y2[(size_t)(li[p] - n1)] -= lx[p] * yi;
+          }
+          auto& sc = scol[(size_t)r];
+          auto& sv = sval[(size_t)r];
+          sc.reserve(R.tj.size() + 1); sv.reserve(R.tj.size() + 1);
+          for (size_t q = 0; q < R.tj.size(); ++q) { const int j = R.tj[q] - n1; sc.push_back(j); sv.push_back(Y2[(size_t)j]); Y2[(size_t)j] = 0.0; }
+          sc.push_back(r); sv.push_back(R.dk);
+        }
+      }
+    });
+    for (int r = 0; r < tail_k; ++r) {
+      f->schur_col.insert(f->schur_col.end(), scol[(size_t)r].begin(), scol[(size_t)r].end());
+      f->schur_val.insert(f->schur_val.end(), sval[(size_t)r].begin(), sval[(size_t)r].end());
+      f->schur_ptr[(size_t)r + 1] = (int64_t)f->schur_col.size();
+      std::vector<int>().swap(scol[(size_t)r]); std::vector<double>().swap(sval[(size_t)r]);
+      f->D[n1 + r] = 0.0;
+    }
   }
   for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->nzcols.push_back(j);
   // split factor with a large forest of leading trees: chunks for the threaded leading sweeps

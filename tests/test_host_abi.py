@@ -309,6 +309,34 @@ def test_aat_split_factor_schur_complement(name, frac, problem_dirs):
     lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
 
 
+def test_aat_split_factor_tail_rows_on_the_host_pool():
+    """From 512 tail rows on, the tail rows of the up-looking factorisation run on the host pool in two phases (their rows of
+    L21 against the leading factor, then their Schur rows) with the serial loop's arithmetic entry by entry: the Schur complement
+    equals L22 D2 L22^T of the one-piece factor and the leading columns -- L21 included -- are the one-piece factor's."""
+    from tests.conftest import load_npz_problem
+    p = load_npz_problem("PushBox_N=30_MOMENT")
+    m = p.con_num
+    h, A = _aat(p)
+    k = 1536
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    hs = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, -k, C.byref(hs)))
+    assert lib.cuadmm_aat_tail_k(hs) == k and lib.cuadmm_host_pool_threads() > 1
+    rp, ci, vv = C.POINTER(C.c_int64)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    check(lib.cuadmm_aat_tail_schur(hs, C.byref(rp), C.byref(ci), C.byref(vv)))
+    rp = np.ctypeslib.as_array(rp, shape=(k + 1,)).copy()
+    S = sp.csr_matrix((np.ctypeslib.as_array(vv, shape=(rp[-1],)).copy(), np.ctypeslib.as_array(ci, shape=(rp[-1],)).copy(), rp), shape=(k, k)).toarray()
+    L22 = np.empty((k, k)); D2 = np.empty(k)
+    check(lib.cuadmm_aat_tail_dense(h, k, P(L22), k, P(D2)))
+    ref = np.tril((L22 * D2) @ L22.T)
+    assert np.max(np.abs(np.tril(S) - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+    rhs = np.random.default_rng(4).standard_normal(m)
+    a, b = rhs.copy(), rhs.copy()
+    check(lib.cuadmm_aat_solve_leading_forward(h, k, P(a))); check(lib.cuadmm_aat_solve_leading_forward(hs, k, P(b)))
+    assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(a)))       # the sweeps read L21: its entries are the one-piece factor's
+    lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
+
+
 def test_aat_split_factor_threaded_leading_sweeps_on_a_large_forest():
     """PushBox_N=30 (examples/SPOT/data/MOSEK, m = 154 256): the leading columns of the split factor form ~5 000 trees, the deepest
     > 1 000 levels (too deep for the device-side sweeps), 1 M nonzeros -- the host sweeps run per chunk of trees on the host pool,
