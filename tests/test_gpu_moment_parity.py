@@ -39,7 +39,7 @@ TOL = {key: (1e-8, 1e-7) for key in TRAJ}
 # |pobj - oracle| <= 2e-7 on the first 60 iterations (3.0e-6 of the instantaneous value where the primal objective crosses zero;
 # every other quantity <= 2.3e-9) -- the measured floor of that path, stated here.  With the factor kept on the host (option
 # tail_k = 0, second test below) the same input agrees to 1.9e-9: the deviation is the explicit inverse and nothing else.
-POBJ_HEAD_TOL = {"PushT_N=30_MOMENT/switch=11000": 1e-5,
+POBJ_HEAD_TOL = {"PushT_N=30_MOMENT/switch=11000": 1e-6,      # round 4 (dense rows ordered last, device-side sweeps): measured 4.1e-7; was 1e-5
                  # PlanarHand_N=10 (round 4; m = 483 707, the tail at its cap of 32 768 columns): every quantity <= 7.5e-10 except pobj,
                  # 1.3e-8 on the head (5.8e-11 at the late checkpoint) -- the same explicit inverse, measured and stated
                  "PlanarHand_N=10_MOMENT/switch=11000": 3e-8}
@@ -113,7 +113,8 @@ def test_moment_relaxation_trajectory_matches_the_oracle(key, tmp_path):
 
 def test_pusht30_with_the_factor_on_the_host_is_exact(tmp_path):
     """the same input without the GPU tail: 1e-8 on every quantity (what POBJ_HEAD_TOL above is measured against)"""
-    run_and_compare("PushT_N=30_MOMENT/switch=11000", tmp_path, {"tail_k": 0}, None)
+    # every quantity at 1e-8; pobj measured 9.7e-9 since round 4's ordering (1.9e-9 with round 3's): 3e-8 stated for it alone
+    run_and_compare("PushT_N=30_MOMENT/switch=11000", tmp_path, {"tail_k": 0}, 3e-8)
 
 
 @pytest.mark.parametrize("name", ["pendulum_N=80", "PlanarHand_N=1_MOMENT"])
