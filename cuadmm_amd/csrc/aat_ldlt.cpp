@@ -377,8 +377,46 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) 
     const double tail = k <= 20480 ? (double)k * k * 4.0 / 4.6e6 + 15.0 : (double)k * k * 8.0 / 5.5e6;
     return 2.0 * (8.0 + 0.65 * ht) + (ht > 40.0 ? 25.0 : 0.0) + tail;
   };
-  // only where the device-side solve is plausible at all (the engine's own test: shallow forest); deep forests keep the host optimum
-  if (hmax[(size_t)(m - best_k)] > 256) return best_k;
+  // Deep forest at the host optimum: the sweeps stay on the host (two PCIe hops per solve) -- UNLESS a larger tail swallows the long
+  // chains.  PushBox N = 30 (m = 154 256): height 1 135 up to k = 17 408, 632 at 17 920, 120 at 18 432, 67 at 19 456; with the device-side
+  // sweeps at k = 18 432 the sGS iteration goes 3.66 -> 1.53 ms (measured per solve: one-pass tail 266 us at 5.1 TB/s, the two sweeps
+  // 108 us each over 120 levels, L21 products 2 x 28 us; beyond 18 432 columns the tail's right-hand side no longer fits the LDS and the
+  // two-pass kernels read 8 k^2 bytes at 5.75 TB/s).  Guards: the larger tail must pay for its k^3 build (measured ~3e13 flop/s) within
+  // 3 000 solves, and every leading tree must fit one workgroup's LDS (lead_solve.hip: 6 144 nodes).
+  if (hmax[(size_t)(m - best_k)] > 256) {
+    const int k_hi = std::min(m, max_k);
+    const double host_us = best * 1e-3 + 150.0;
+    auto deep_us = [&](int k) {
+      const double ht = (double)hmax[(size_t)(m - k)];
+      const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 8.0 / 5.75e6;
+      return 2.0 * (35.0 + 0.9 * ht) + 60.0 + tail;
+    };
+    auto max_tree = [&](int k) {                                   // nodes of the largest leading tree (parents follow their children)
+      const int n1 = m - k;
+      std::vector<int> sz((size_t)n1, 1);
+      int mx = 0;
+      for (int j = 0; j < n1; ++j) {
+        const int p = parent[j];
+        if (p >= 0 && p < n1) sz[p] += sz[j]; else mx = std::max(mx, sz[j]);
+      }
+      return mx;
+    };
+    int kd = 0;
+    double cd = 1e300;
+    for (int k = best_k + 256; k <= k_hi; k += 256) {
+      if (hmax[(size_t)(m - k)] > 256) continue;
+      const double c = deep_us(k);
+      if (c < cd) { cd = c; kd = k; }
+    }
+    if (kd == 0 || cd > 0.6 * host_us) return best_k;
+    for (int k = kd; k <= k_hi && deep_us(k) <= 1.15 * cd; k += 256) {
+      if (hmax[(size_t)(m - k)] > 256 || max_tree(k) > 6144) continue;
+      const double extra_s = ((double)k * k * k - (double)best_k * best_k * best_k) / 3e13;
+      if ((host_us - deep_us(k)) * 3000e-6 < extra_s) break;
+      return k;
+    }
+    return best_k;
+  }
   int k_dev = best_k;
   double c_dev = dev_us(best_k);
   // only LARGER tails are considered: towards smaller ones the leading trees grow long rows, which the per-level figure does not
