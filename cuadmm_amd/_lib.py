@@ -107,6 +107,8 @@ PROTOTYPES = {
     "cuadmm_aat_tail_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "cuadmm_aat_solve_leading_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "cuadmm_aat_solve_leading_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cuadmm_aat_solve_leading_forward11": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cuadmm_aat_solve_leading_backward11": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cuadmm_aat_free": (None, [C.c_void_p]),
     "cuadmm_op_vector_to_matrices": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "cuadmm_op_matrices_to_vector": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),

@@ -49,6 +49,7 @@ struct cuadmm_aat {
   // chunk reads the solved tail and its own entries.  For forests of many trees whose sweeps are milliseconds on one core (PushBox
   // N = 30: 4 953 trees, deepest 1 135 levels -- too deep for the device-side sweeps --, 1.6 ms per sweep serial).
   std::vector<std::vector<int>> lead_chunks;
+  std::vector<int64_t> lead_mid;             // split factor: first entry of leading column j in a TAIL row (rows ascend inside a column)
   mutable std::vector<double> lead_acc;      // kLeadChunks x tail_k
   std::vector<int> nzcols;   // columns j < m - tail_k with at least one sub-diagonal entry, ascending (block-diagonal A A^T: few)
   int tail_k = 0;
@@ -731,6 +732,11 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     }
   }
   for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->nzcols.push_back(j);
+  if (tail_k > 0) {
+    f->lead_mid.resize((size_t)n1);
+    for (int j = 0; j < n1; ++j)
+      f->lead_mid[j] = (int64_t)(std::lower_bound(f->Li.begin() + f->Lp[j], f->Li.begin() + f->Lp[j + 1], n1) - f->Li.begin());
+  }
   // split factor with a large forest of leading trees: chunks for the threaded leading sweeps
   if (tail_k > 0 && n1 >= 20000 && f->Lp[n1] >= 300000) {
     std::vector<int> root(n1);
@@ -1002,6 +1008,61 @@ int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x) {
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
     x[j] = s;
   }
+  return CUADMM_OK;
+}
+
+// The same two sweeps restricted to L11 (rows and columns < m - k) for a split factor whose L21 lives on the GPU (engine: lead_solve.hip,
+// hybrid mode -- PlanarHand_N=10: 70 % of the leading nonzeros are in the tail rows):
+//   forward11 : x1 <- L11^-1 x1; x[m-k..] is NOT touched (the GPU forms z2 = x2 - L21 x1)
+//   backward11: x1 <- L11^-T (D1^-1 x1 - w) with w = L21^T x2 from the GPU (m - k doubles); x[m-k..] is not read
+int cuadmm_aat_solve_leading_forward11(const cuadmm_aat* f, int k, double* x) {
+  if (!f || !x || f->tail_k <= 0 || k != f->tail_k || f->lead_mid.empty()) { set_error("aat_solve_leading_forward11: a split factor and its own tail size"); return CUADMM_ERR_INVALID; }
+  const int64_t* Lp = f->Lp.data();
+  const int64_t* Lm = f->lead_mid.data();
+  const int* Li = f->Li.data();
+  const double* Lx = f->Lx.data();
+  auto col = [&](int j) {
+    const double xj = x[j];
+    if (xj != 0.0)
+      for (int64_t p = Lp[j]; p < Lm[j]; ++p) x[Li[p]] -= Lx[p] * xj;
+  };
+  if (!f->lead_chunks.empty() && host_pool().size() > 1) {       // trees of different chunks share no leading row
+    const int nchunk = (int)f->lead_chunks.size(), T = host_pool().size();
+    host_pool().run([&](int t) {
+      for (int c = t; c < nchunk; c += T)
+        for (int j : f->lead_chunks[c]) col(j);
+    });
+    return CUADMM_OK;
+  }
+  for (int j : f->nzcols) col(j);
+  return CUADMM_OK;
+}
+
+int cuadmm_aat_solve_leading_backward11(const cuadmm_aat* f, int k, double* x, const double* w) {
+  if (!f || !x || !w || f->tail_k <= 0 || k != f->tail_k || f->lead_mid.empty()) { set_error("aat_solve_leading_backward11: a split factor and its own tail size"); return CUADMM_ERR_INVALID; }
+  const int n1 = f->m - k;
+  const int64_t* Lp = f->Lp.data();
+  const int64_t* Lm = f->lead_mid.data();
+  const int* Li = f->Li.data();
+  const double* Lx = f->Lx.data();
+  const double* D = f->D.data();
+  auto col = [&](int j) {
+    double s = x[j] / D[j] - w[j];
+    for (int64_t p = Lp[j]; p < Lm[j]; ++p) s -= Lx[p] * x[Li[p]];
+    x[j] = s;
+  };
+  if (!f->lead_chunks.empty() && host_pool().size() > 1) {
+    const int nchunk = (int)f->lead_chunks.size(), T = host_pool().size();
+    for (int j = 0; j < n1; ++j) if (Lp[j + 1] == Lp[j]) x[j] = x[j] / D[j] - w[j];        // columns without entries are in no chunk; others read them
+    host_pool().run([&](int t) {
+      for (int c = t; c < nchunk; c += T) {
+        const std::vector<int>& cols = f->lead_chunks[c];
+        for (size_t q = cols.size(); q-- > 0;) col(cols[q]);
+      }
+    });
+    return CUADMM_OK;
+  }
+  for (int j = n1 - 1; j >= 0; --j) col(j);
   return CUADMM_OK;
 }
 

@@ -244,6 +244,7 @@ struct cuadmm_solver {
     int aty_post2 = 1;            // "aty_post2": the sGS second half in one pass
     int lead_stream = 0;          // "lead_stream": the leading sweeps on the streaming kernels only (no LDS-resident trees; A/B, tests)
     int tail_one_pass = 1;        // "tail_one_pass": the GPU tail applied in one pass over inv(L22) (0: two triangular GEMVs)
+    int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
     int debug_eig = 0;            // developer aid
   } sw;
@@ -405,13 +406,14 @@ struct cuadmm_solver {
     if (tail.k == 0) {
       rc = cuadmm_aat_solve_permuted(fac, y_p.data(), y_p.data());     // solver.cu:494
     } else {   // sparse leading columns here, dense trailing triangle on the GPU
-      rc = cuadmm_aat_solve_leading_forward(fac, tail.k, y_p.data());
+      // hybrid (lead_solve.h): L21 lives on the device with the tail, the host sweeps L11 only
+      rc = lead.hybrid ? cuadmm_aat_solve_leading_forward11(fac, tail.k, y_p.data()) : cuadmm_aat_solve_leading_forward(fac, tail.k, y_p.data());
       double t1 = wall_s();
-      if (!rc) rc = tail.solve(y_p.data() + (m - tail.k), st);
+      if (!rc) rc = lead.hybrid ? lead.apply_l21(y_p.data(), y_registered, tail, st) : tail.solve(y_p.data() + (m - tail.k), st);
       double t2 = wall_s();
       prof_host(K_TAIL, t2 - t1);
       t0 += t2 - t1;
-      if (!rc) rc = cuadmm_aat_solve_leading_backward(fac, tail.k, y_p.data());
+      if (!rc) rc = lead.hybrid ? cuadmm_aat_solve_leading_backward11(fac, tail.k, y_p.data(), lead.h_w) : cuadmm_aat_solve_leading_backward(fac, tail.k, y_p.data());
     }
     prof_host(K_HOST, wall_s() - t0);
     return rc;
@@ -1093,12 +1095,15 @@ static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
     if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
     s->lead.stream_only = s->sw.lead_stream != 0;
     s->lead.debug = s->sw.lead_debug != 0;
-    if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D))) return rc;
+    s->lead.force_hybrid = s->sw.l21_device == 2;
+    if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D, s->sw.l21_device != 0))) return rc;
     const double host_us = 1.2e-3 * (double)Lp[m - s->tail.k] + 150.0;
     if (s->lead.ready && s->lead.est_us < 0.7 * host_us) {
       s->dev_solve = true;
       if (s->local_mode && s->comm_world > 1) s->dev_scalars = true;
       if (s->verbose) printf(" y-solve on the device: leading sweeps over %d trees (depth <= %d) around the GPU tail\n", s->lead.ntrees, s->lead.max_levels);
+    } else if (s->lead.hybrid || (s->lead.ready && s->sw.l21_device && s->lead.demote_to_hybrid())) {
+      if (s->verbose) printf(" y-solve: L11 sweeps on the host (forest depth %d); L21 (%lld nonzeros) and the tail on the device\n", s->lead.max_levels, s->lead.nnz21);
     } else {
       s->lead.release();
     }
@@ -1317,6 +1322,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "aty_post2") s->sw.aty_post2 = (int)value;
   else if (k == "lead_stream") s->sw.lead_stream = (int)value;
   else if (k == "lead_debug") s->sw.lead_debug = (int)value;
+  else if (k == "l21_device") s->sw.l21_device = (int)value;
   else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;
   else if (s->plan.opt.set(k, value)) {}                      // "psd_*": the projection planner's switches (psd_options.h)
@@ -1987,7 +1993,7 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap) {
 int cuadmm_get_counters(const cuadmm_solver* s, double o[8]) {
   if (!s || !o) { set_error("get_counters: null"); return CUADMM_ERR_INVALID; }
   o[0] = (double)s->bt.launches; o[1] = (double)s->bt.iters; o[2] = (double)s->bt.rollbacks; o[3] = (double)cuadmm_host_pool_threads();
-  o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? 1 : 0; o[7] = (double)s->tail.k;
+  o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? 1 : (s->lead.hybrid ? 2 : 0); o[7] = (double)s->tail.k;
   return CUADMM_OK;
 }
 int cuadmm_reset_profile(cuadmm_solver* s) {

@@ -41,9 +41,29 @@ struct LeadSolve {
   bool stream_only = false;     // option lead_stream = 1: every tree on the streaming kernels (A/B, tests)
   bool ready = false;
   double est_us = 0;            // cost model used to decide (per solve)
+  // HYBRID solve: the forest is too deep for the device (or its sweeps lose to the host's), but most leading nonzeros sit in the tail
+  // rows (PlanarHand_N=10 at k = 32 768: L11 13.7 M, L21 31.9 M).  Then only L21 lives here: the host sweeps L11
+  // (cuadmm_aat_solve_leading_forward11 / _backward11), the device forms z2 = rhs2 - L21 z1, solves the tail and returns w = L21^T x2.
+  bool hybrid = false;
+  long long nnz21 = 0;
+  double* zfull = nullptr;      // device, m doubles: [z1 | rhs2] of the current solve
+  double* h_w = nullptr;        // pinned, n1 doubles: w = L21^T x2
+  double* h_z = nullptr;        // pinned, m doubles: staging for a caller vector that is not page-locked
+  // per solve: the host saves two passes over L21 (~0.4 ns per nonzero on the pool), the device pays two m-vectors over PCIe and two SpMVs
+  bool force_hybrid = false;    // option l21_device = 2 (tests, A/B)
+  bool l21_pays() const {
+    if (force_hybrid) return k > 0 && n1 > 0;
+    const double save_us = 0.8e-3 * (double)nnz21;
+    const double cost_us = 2.0 * (double)m * 8.0 / 20e3 + 2.0 * (double)nnz21 * 12.0 / 3.5e6 + 60.0;
+    return k > 0 && n1 > 0 && save_us > 2.0 * cost_us;
+  }
+  // after build(): drop everything but L21 (the engine rejected the device-side sweeps); false when L21 on the device does not pay
+  bool demote_to_hybrid();
+  // x (host, m doubles): in [z1 | rhs2] (z1 = L11^-1 rhs1), out [z1 | x2]; h_w <- L21^T x2.  Synchronous on `st`.
+  int apply_l21(double* x, bool x_pinned, TailSolve& tail, hipStream_t st);
 
   // Lp / Li / Lx / D: the split factor (cuadmm_aat_factor_arrays), k = its tail size
-  int build(int m, int k, const int64_t* Lp, const int* Li, const double* Lx, const double* D);
+  int build(int m, int k, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid = false);
   // y <- (L D L^T)^-1 (-asmc + (b - ax) * isig): everything on `st`, nothing synchronises
   int solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const;
   void release();

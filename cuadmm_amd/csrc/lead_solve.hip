@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void lead_tail_rhs_kernel(int k, int n1, const
   if (sub == 0) z2[i] = lead_rhs(ax, asmc, b, isig, n1 + i) - s;
 }
 
+// hybrid solve: z2[i] = z[n1 + i] - sum_j L21[i][j] z[j] with z = [z1 | rhs2] uploaded by the host; LANES lanes per tail row (64 where the
+// rows are long: PlanarHand_N=10 has ~1 000 entries per tail row), fixed summation order
+template <int LANES>
+__global__ __launch_bounds__(256) void lead_tail_rhs_vec_kernel(int k, int n1, const long long* __restrict__ rp, const int* __restrict__ ci,
+                                                                const double* __restrict__ v, const double* __restrict__ z, double* __restrict__ z2) {
+  const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(gt / LANES), sub = (int)(gt % LANES);
+  if (i >= k) return;
+  double s = 0.0;
+  for (long long q = rp[i] + sub; q < rp[i + 1]; q += LANES) s += v[q] * z[ci[q]];
+#pragma unroll
+  for (int o = LANES / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (sub == 0) z2[i] = z[n1 + i] - s;
+}
+
 // w[j] = sum over the TAIL rows of column j:  L21[i][j] x2[i]   (8 lanes per leading column; independent of the sweeps)
 __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long* __restrict__ tp, const int* __restrict__ tr, const double* __restrict__ tv,
                                                         const double* __restrict__ x2, double* __restrict__ w) {
@@ -274,10 +289,60 @@ void LeadSolve::release() {
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
   if (aux) { hipError_t e = hipStreamDestroy(aux); (void)e; e = hipEventDestroy(ev_fork); (void)e; e = hipEventDestroy(ev_join); (void)e; aux = nullptr; ev_fork = ev_join = nullptr; }
   desc_small_f = desc_small_b = desc_big_f = desc_big_b = nullptr; trees_stream = nullptr; n_small = n_big = n_stream = 0;
+  if (zfull) { hipError_t e = hipFree(zfull); (void)e; zfull = nullptr; }
+  if (h_w) { hipError_t e = hipHostFree(h_w); (void)e; h_w = nullptr; }
+  if (h_z) { hipError_t e = hipHostFree(h_z); (void)e; h_z = nullptr; }
+  hybrid = false; nnz21 = 0;
   ready = false;
 }
 
-int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D) {
+static int hybrid_buffers(LeadSolve& L) {
+  CUADMM_HIP_TRY(hipMalloc(&L.zfull, sizeof(double) * (size_t)std::max(L.m, 1)));
+  CUADMM_HIP_TRY(hipHostMalloc(&L.h_w, sizeof(double) * (size_t)std::max(L.n1, 1), hipHostMallocDefault));
+  CUADMM_HIP_TRY(hipHostMalloc(&L.h_z, sizeof(double) * (size_t)std::max(L.m, 1), hipHostMallocDefault));
+  if (!L.wvec) CUADMM_HIP_TRY(hipMalloc(&L.wvec, sizeof(double) * (size_t)std::max(L.n1, 1)));
+  return CUADMM_OK;
+}
+
+bool LeadSolve::demote_to_hybrid() {
+  if (!ready || !l21_pays() || !rp21 || !tptr) { release(); return false; }
+  // keep rp21 / ci21 / v21, tptr / tri / tv_ and wvec; everything of the sweeps goes
+  for (void* p : {(void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)D1, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f,
+                  (void*)lvl_ptr_b, (void*)lvl_off_f, (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b,
+                  (void*)desc_big_f, (void*)desc_big_b, (void*)trees_stream})
+    if (p) { hipError_t e = hipFree(p); (void)e; }
+  fptr = bptr = nullptr; fci = bci = nullptr; fv_ = bv_ = D1 = nullptr;
+  nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
+  desc_small_f = desc_small_b = desc_big_f = desc_big_b = nullptr; trees_stream = nullptr; n_small = n_big = n_stream = 0;
+  ready = false;
+  if (hybrid_buffers(*this)) { release(); return false; }
+  hybrid = true;
+  return true;
+}
+
+int LeadSolve::apply_l21(double* x, bool x_pinned, TailSolve& tail, hipStream_t st) {
+  if (!hybrid) { set_error("lead_solve: hybrid mode not built"); return CUADMM_ERR_INVALID; }
+  const double* src = x;
+  if (!x_pinned) { std::copy(x, x + m, h_z); src = h_z; }          // the runtime never reads pageable caller memory (staging.hip)
+  CUADMM_HIP_TRY(hipMemcpyAsync(zfull, src, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, st));
+  if (nnz21 >= 256ll * k)
+    hipLaunchKernelGGL(lead_tail_rhs_vec_kernel<64>, dim3((unsigned)(((long long)k * 64 + 255) / 256)), dim3(256), 0, st, k, n1, rp21, ci21, v21, zfull, tail.vin);
+  else
+    hipLaunchKernelGGL(lead_tail_rhs_vec_kernel<8>, dim3((unsigned)(((long long)k * 8 + 255) / 256)), dim3(256), 0, st, k, n1, rp21, ci21, v21, zfull, tail.vin);
+  CUADMM_HIP_TRY(hipGetLastError());
+  int rc = tail.solve_device(st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lead_l21t_kernel, dim3((unsigned)(((long long)n1 * 8 + 255) / 256)), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
+  CUADMM_HIP_TRY(hipGetLastError());
+  CUADMM_HIP_TRY(hipMemcpyAsync(h_w, wvec, sizeof(double) * (size_t)n1, hipMemcpyDeviceToHost, st));
+  double* dst = x_pinned ? x + n1 : h_z + n1;
+  CUADMM_HIP_TRY(hipMemcpyAsync(dst, tail.vin, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, st));
+  CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  if (!x_pinned) std::copy(h_z + n1, h_z + m, x + n1);
+  return CUADMM_OK;
+}
+
+int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid) {
   release();
   m = m_; k = k_; n1 = m - k;
   if (k <= 0 || n1 < 0) return CUADMM_OK;
@@ -422,7 +487,17 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
   }
   // cost model: per level two dependent global-memory latencies (~2 us) in the deepest tree, per sweep, plus the streaming part
   est_us = 2.0 * 2.0 * max_levels + 40.0 + (double)nnz * 2e-4;
-  if (max_nodes > 6144 || max_levels > 2048) { est_us = 1e30; return CUADMM_OK; }     // LDS budget of one wavefront's tree
+  nnz21 = r21[k];
+  if (max_nodes > 6144 || max_levels > 2048) {                                        // LDS budget of one wavefront's tree
+    est_us = 1e30;
+    if (allow_hybrid && l21_pays()) {
+      int rc_;
+      if ((rc_ = to_device(rp21, r21)) || (rc_ = to_device(ci21, c21)) || (rc_ = to_device(v21, w21)) ||
+          (rc_ = to_device(tptr, tp)) || (rc_ = to_device(tri, tr)) || (rc_ = to_device(tv_, tv)) || (rc_ = hybrid_buffers(*this))) { release(); return rc_; }
+      hybrid = true;
+    }
+    return CUADMM_OK;
+  }
   lds_bytes = sizeof(double) * (size_t)max_nodes + sizeof(int) * (2 * (size_t)max_levels + 2);
   // classes by the LDS a tree needs with its stream resident (the larger of the two sweeps): small trees share a CU in numbers,
   // the few big ones get a launch of their own, anything beyond one workgroup's LDS keeps the streaming kernels

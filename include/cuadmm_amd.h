@@ -168,7 +168,8 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
 /* Counters of the engine's execution plan (diagnostics; what bench.py reports beside its numbers):
  *   [0] launches that ran several ADMM iterations (option "batch"), [1] iterations run by them, [2] batches rolled back because
  *   the stopping test fired inside them, [3] threads of the host pool, [4] 1 if the iteration is fused into the projection
- *   kernels, [5] 1 if every block solves for its own multipliers (closed blocks), [6] 1 if the y-solve runs on the device,
+ *   kernels, [5] 1 if every block solves for its own multipliers (closed blocks), [6] 1 if the y-solve runs on the device (2: hybrid --
+ *   L11 sweeps on the host, L21 products and the tail on the device),
  *   [7] size of the GPU tail of the A A^T factor. */
 int cuadmm_get_counters(const cuadmm_solver* s, double out8[8]);
 
@@ -264,6 +265,12 @@ void cuadmm_aat_tail_schur_release(cuadmm_aat* f);
 int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, double* D2);
 int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x);
 int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x);
+/* The same sweeps restricted to L11 (rows and columns < m-k) of a SPLIT factor whose L21 the engine keeps on the GPU (hybrid solve:
+ * deep leading forest, most leading nonzeros in the tail rows):
+ *   forward11 : x1 <- L11^-1 x1, x[m-k..] untouched (the GPU forms z2 = x2 - L21 x1)
+ *   backward11: x1 <- L11^-T (D1^-1 x1 - w), w = L21^T x2 (m-k doubles, from the GPU); x[m-k..] is not read */
+int cuadmm_aat_solve_leading_forward11(const cuadmm_aat* f, int k, double* x);
+int cuadmm_aat_solve_leading_backward11(const cuadmm_aat* f, int k, double* x, const double* w);
 void cuadmm_aat_free(cuadmm_aat* f);
 
 /* ------------------------------------------------------------------------------------ */

@@ -95,6 +95,12 @@ def run_and_compare(key, tmp_path, options, pobj_head_tol):
         assert c["tail_k"] > 0 and c["dev_solve"] == 1          # the paths this test is about are the ones that ran
     if not options and rec["problem"] == "PushT_N=30_MOMENT":
         assert c["tail_k"] > 0                                  # GPU tail between host-side leading sweeps
+    if not options and rec["problem"] in ("PushBox_N=30_MOMENT", "PushBox_N=50_MOMENT"):
+        assert c["dev_solve"] == 1                              # round 4: the planner's larger tail makes the leading forest shallow
+    if not options and rec["problem"] == "PlanarHand_N=10_MOMENT":
+        assert c["dev_solve"] == 2                              # hybrid: L11 sweeps on the host, L21 and the tail on the device
+    if options and options.get("l21_device") == 2:
+        assert c["dev_solve"] == 2
     assert sig_ok
     th, tl = TOL[key]
     for nm in SIX:
@@ -115,6 +121,28 @@ def test_pusht30_with_the_factor_on_the_host_is_exact(tmp_path):
     """the same input without the GPU tail: 1e-8 on every quantity (what POBJ_HEAD_TOL above is measured against)"""
     # every quantity at 1e-8; pobj measured 9.7e-9 since round 4's ordering (1.9e-9 with round 3's): 3e-8 stated for it alone
     run_and_compare("PushT_N=30_MOMENT/switch=11000", tmp_path, {"tail_k": 0}, 3e-8)
+
+
+def test_pushbox30_hybrid_solve_with_l21_on_the_device_matches_the_oracle(tmp_path):
+    """The hybrid y-solve (lead_solve.h: host sweeps over L11, L21 products and the tail on the device) forced on PushBox_N=30 at the
+    HOST optimum of the tail size (10 240 columns: forest 1 135 levels deep, the case the mode exists for) -- the same oracle
+    trajectory at the same tolerance as the default plan."""
+    run_and_compare("PushBox_N=30_MOMENT/switch=11000", tmp_path, {"tail_k": 10240, "l21_device": 2}, None)
+
+
+def test_pushbox30_host_sweeps_and_hybrid_agree(tmp_path):
+    """the same input with the whole leading part on the host (l21_device = 0) and in hybrid mode: iterates agree to the rounding of
+    the differently associated L21 sums"""
+    p = load_problem("PushBox_N=30_MOMENT", tmp_path)
+    out = []
+    for opt, mode in (({"tail_k": 10240, "l21_device": 0}, 0), ({"tail_k": 10240, "l21_device": 2}, 2)):
+        s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
+        s.init_problem(problem_to_amd(p))
+        s.solve(40, 0.0, 0, 50, 100, 20, 1.05)
+        assert s.counters()["dev_solve"] == mode and s.counters()["tail_k"] == 10240
+        out.append({nm: s.info_arr(nm).copy() for nm in SIX})
+    for nm in SIX:
+        assert rel_dev(out[1][nm], out[0][nm], nm) <= 1e-8, nm
 
 
 @pytest.mark.parametrize("name", ["pendulum_N=80", "PlanarHand_N=1_MOMENT"])

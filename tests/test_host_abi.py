@@ -338,8 +338,9 @@ def test_aat_split_factor_tail_rows_on_the_host_pool():
 
 
 def test_aat_split_factor_threaded_leading_sweeps_on_a_large_forest():
-    """PushBox_N=30 (examples/SPOT/data/MOSEK, m = 154 256): the leading columns of the split factor form ~5 000 trees, the deepest
-    > 1 000 levels (too deep for the device-side sweeps), 1 M nonzeros -- the host sweeps run per chunk of trees on the host pool,
+    """PushBox_N=30 (examples/SPOT/data/MOSEK, m = 154 256) at the HOST optimum of the tail size (10 240 columns, forced: the planner
+    itself now takes 18 432, see the next test): the leading columns form ~5 000 trees, the deepest > 1 000 levels (too deep for the
+    device-side sweeps), 1 M nonzeros -- the host sweeps run per chunk of trees on the host pool,
     tail updates through per-chunk accumulators added in chunk order.  Same result as the serial sweeps of the one-piece factor to
     roundoff (the tail's sums are associated differently), and the same bits call after call."""
     from tests.conftest import load_npz_problem
@@ -348,9 +349,9 @@ def test_aat_split_factor_threaded_leading_sweeps_on_a_large_forest():
     h, A = _aat(p)
     cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
     hs = C.c_void_p()
-    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(hs)))
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, -10240, C.byref(hs)))   # the host optimum, forced
     k = lib.cuadmm_aat_tail_k(hs)
-    assert 1024 <= k < m // 4
+    assert k == 10240
     rhs = np.random.default_rng(3).standard_normal(m)
     a, b, b2 = rhs.copy(), rhs.copy(), rhs.copy()
     check(lib.cuadmm_aat_solve_leading_forward(h, k, P(a)))       # one-piece factor asked for this split: the serial walk
@@ -363,6 +364,96 @@ def test_aat_split_factor_threaded_leading_sweeps_on_a_large_forest():
     check(lib.cuadmm_aat_solve_leading_backward(h, k, P(a))); check(lib.cuadmm_aat_solve_leading_backward(hs, k, P(b)))
     assert np.array_equal(a, b)
     lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
+
+
+def _forest_stats(Lp, Li, m, k):
+    """height and largest tree of the elimination forest over the leading m - k columns (parent = first sub-diagonal row of a column)"""
+    n1 = m - k
+    parent = np.full(m, -1, np.int64)
+    nz = np.diff(Lp) > 0
+    parent[nz] = Li[Lp[:-1][nz]]
+    h = np.ones(n1, np.int64); sz = np.ones(n1, np.int64)
+    height = big = 0
+    for j in range(n1):
+        pj = parent[j]
+        if 0 <= pj < n1:
+            h[pj] = max(h[pj], h[j] + 1); sz[pj] += sz[j]
+        else:
+            height = max(height, h[j]); big = max(big, sz[j])
+    return int(height), int(big)
+
+
+def test_aat_tail_plan_takes_a_larger_tail_when_it_makes_a_deep_forest_shallow():
+    """plan_tail's deep-forest branch (csrc/aat_ldlt.cpp): PushBox_N=30's host optimum (k = 10 240) leaves a leading forest 1 135 levels
+    deep -- sweeps on the host, two PCIe hops per solve.  A tail of 18 432 columns swallows the long chains (height 120, largest tree
+    ~1 100 nodes: inside lead_solve.hip's LDS budget of 6 144), so the whole y-solve runs on the device (measured 3.66 -> 1.53 ms per
+    sGS iteration).  The planner must find it, and stay inside the one-pass tail kernel's 18 432-column limit."""
+    from tests.conftest import load_npz_problem
+    p = load_npz_problem("PushBox_N=30_MOMENT")
+    m = p.con_num
+    h, A = _aat(p)
+    Lp = np.ctypeslib.as_array(lib.cuadmm_aat_factor_colptr(h), shape=(m + 1,)).copy()
+    Lpp = C.c_void_p(); Lip = C.c_void_p(); Lxp = C.c_void_p(); Dp = C.c_void_p()
+    check(lib.cuadmm_aat_factor_arrays(h, C.byref(Lpp), C.byref(Lip), C.byref(Lxp), C.byref(Dp)))
+    Li = np.ctypeslib.as_array(C.cast(Lip, C.POINTER(C.c_int)), shape=(int(Lp[-1]),)).copy()
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    hs = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(hs)))
+    k = lib.cuadmm_aat_tail_k(hs)
+    assert k % 256 == 0 and 10240 < k <= 18432
+    height, big = _forest_stats(Lp, Li, m, k)
+    assert height <= 256 and big <= 6144
+    assert _forest_stats(Lp, Li, m, 10240)[0] > 1000                 # what the host optimum would have left
+    # a cap below the shallow region keeps the host optimum
+    hc = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 16384, C.byref(hc)))
+    assert lib.cuadmm_aat_tail_k(hc) == 10240
+    lib.cuadmm_aat_free(hc); lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
+
+
+@pytest.mark.parametrize("name,k", [("PushBox_N=30_MOMENT", 10240), ("pendulum_N=80", 0)])
+def test_aat_leading_sweeps_restricted_to_l11(name, k):
+    """Hybrid y-solve (engine: lead_solve.h): the host sweeps L11 only, L21 products happen elsewhere (the GPU; numpy here).
+    forward11 + (z2 = rhs2 - L21 z1) must reproduce the full forward sweep, backward11 with w = L21^T x2 the full backward sweep --
+    threaded chunks (PushBox_N=30: 16 chunks of trees) and the serial walk (pendulum: below the chunking threshold) alike."""
+    from tests.conftest import load_npz_problem
+    p = load_npz_problem(name)
+    m = p.con_num
+    At = sp.csc_matrix((p.At_vals, p.At_row_ids, p.At_col_ptrs), shape=(p.vec_len, p.con_num))
+    A = At.T.tocsc(); A.sort_indices()
+    cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    hs = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, -k if k else 32768, C.byref(hs)))
+    k = lib.cuadmm_aat_tail_k(hs)
+    assert k > 0
+    n1 = m - k
+    Lpp = C.c_void_p(); Lip = C.c_void_p(); Lxp = C.c_void_p(); Dp = C.c_void_p()
+    check(lib.cuadmm_aat_factor_arrays(hs, C.byref(Lpp), C.byref(Lip), C.byref(Lxp), C.byref(Dp)))
+    Lp = np.ctypeslib.as_array(C.cast(Lpp, C.POINTER(C.c_int64)), shape=(m + 1,))
+    nnz = int(Lp[n1])
+    Li = np.ctypeslib.as_array(C.cast(Lip, C.POINTER(C.c_int)), shape=(nnz,))
+    Lx = np.ctypeslib.as_array(C.cast(Lxp, C.POINTER(C.c_double)), shape=(nnz,))
+    Lfull = sp.csc_matrix((Lx, Li, np.concatenate([Lp[:n1 + 1], np.full(m - n1, Lp[n1])])), shape=(m, m))
+    L21 = Lfull[n1:, :n1].tocsr()
+    rhs = np.random.default_rng(5).standard_normal(m)
+    full, part = rhs.copy(), rhs.copy()
+    check(lib.cuadmm_aat_solve_leading_forward(hs, k, P(full)))
+    check(lib.cuadmm_aat_solve_leading_forward11(hs, k, P(part)))
+    assert np.array_equal(part[n1:], rhs[n1:])                                  # the tail part is not touched
+    assert np.array_equal(part[:n1], full[:n1])                                 # the same arithmetic per leading entry
+    z2 = rhs[n1:] - L21 @ part[:n1]
+    assert np.max(np.abs(z2 - full[n1:])) <= 1e-12 * max(1.0, np.max(np.abs(full[n1:])))
+    x2 = np.random.default_rng(6).standard_normal(k)
+    full[n1:] = x2; part[n1:] = np.nan                                           # backward11 must not read the tail part
+    w = np.ascontiguousarray(L21.T @ x2)
+    check(lib.cuadmm_aat_solve_leading_backward(hs, k, P(full)))
+    check(lib.cuadmm_aat_solve_leading_backward11(hs, k, P(part), P(w)))
+    assert np.max(np.abs(part[:n1] - full[:n1])) <= 1e-11 * max(1.0, np.max(np.abs(full[:n1])))
+    # a one-piece factor has no L21 to leave out
+    h, _ = _aat(p)
+    with pytest.raises(cuadmm_amd.CuadmmError):
+        check(lib.cuadmm_aat_solve_leading_forward11(h, k, P(part)))
+    lib.cuadmm_aat_free(h); lib.cuadmm_aat_free(hs)
 
 
 def test_aat_threaded_solve_is_bitwise_identical_to_serial(tmp_path):
