@@ -325,7 +325,8 @@ static int usable_cpus() {
   return std::max(1, n);
 }
 
-// Threads of the host pool: CUADMM_HOST_THREADS if set (1 = serial), else min(8, usable CPUs / ranks on this node) -- the
+// Threads of the host pool: CUADMM_HOST_THREADS if set (1 = serial), else min(16, usable CPUs / ranks on this node) (16 since the
+// largest inputs of round 4: PlanarHand_N=10's L11 sweeps 24.8 -> 10.0 ms per iteration from 8 to 16 threads on the 16-CPU box) -- the
 // launcher's LOCAL_WORLD_SIZE (torch.distributed.run) or cuadmm_host_pool_hint() say how many ranks share the node.  Created on
 // first use, lives until process exit.
 static std::atomic<int> g_pool_ranks_hint{0};
@@ -336,7 +337,7 @@ HostPool& host_pool() {
     int ranks = g_pool_ranks_hint.load();
     if (ranks <= 0) { const char* l = getenv("LOCAL_WORLD_SIZE"); ranks = l ? atoi(l) : 1; }
     ranks = std::max(1, ranks);
-    return std::max(1, std::min(8, usable_cpus() / ranks));
+    return std::max(1, std::min(16, usable_cpus() / ranks));
   }());
   return pool;
 }
