@@ -382,15 +382,16 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) 
   // Deep forest at the host optimum: the sweeps stay on the host (two PCIe hops per solve) -- UNLESS a larger tail swallows the long
   // chains.  PushBox N = 30 (m = 154 256): height 1 135 up to k = 17 408, 632 at 17 920, 120 at 18 432, 67 at 19 456; with the device-side
   // sweeps at k = 18 432 the sGS iteration goes 3.66 -> 1.53 ms (measured per solve: one-pass tail 266 us at 5.1 TB/s, the two sweeps
-  // 108 us each over 120 levels, L21 products 2 x 28 us; beyond 18 432 columns the tail's right-hand side no longer fits the LDS and the
-  // two-pass kernels read 8 k^2 bytes at 5.75 TB/s).  Guards: the larger tail must pay for its k^3 build (measured ~3e13 flop/s) within
+  // 108 us each over 120 levels, L21 products 2 x 28 us; beyond 18 432 columns the tail's right-hand side no longer fits the LDS and
+  // four workgroups share a row).  Guards: the larger tail must pay for its k^3 build (measured ~3e13 flop/s) within
   // 3 000 solves, and every leading tree must fit one workgroup's LDS (lead_solve.hip: 6 144 nodes).
   if (hmax[(size_t)(m - best_k)] > 256) {
     const int k_hi = std::min(m, max_k);
     const double host_us = best * 1e-3 + 150.0;
     auto deep_us = [&](int k) {
       const double ht = (double)hmax[(size_t)(m - k)];
-      const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 8.0 / 5.75e6;
+      // one workgroup per row up to 18 432 columns (5.1 TB/s), four per row beyond (tail_solve.hip: measured 4.2 / 3.8 TB/s)
+      const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 4.0 / (k <= 24576 ? 4.2e6 : 3.8e6) + 40.0;
       return 2.0 * (35.0 + 0.9 * ht) + 60.0 + tail;
     };
     auto max_tree = [&](int k) {                                   // nodes of the largest leading tree (parents follow their children)

@@ -10,6 +10,7 @@ struct TailSolve {
   double* h_vec = nullptr;     // pinned staging vector
   double* xpart = nullptr;     // one-pass variant: n_wg partial result vectors
   int n_wg = 0;
+  unsigned long long* part = nullptr;   // 18 432 < K <= 32 768: per row and member, the exchanged parts of u = W z (ts_onepass_group_kernel)
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   int apply(hipStream_t st);   // vin <- W^T diag(dinv) W vin

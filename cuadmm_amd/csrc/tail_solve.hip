@@ -210,9 +210,124 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
 #pragma unroll
   for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)g * K + col] = xa[c]; }
 }
-__global__ __launch_bounds__(64) void ts_onepass_reduce_kernel(const double* __restrict__ P, int K, int G, double* __restrict__ x) {
+// The one-pass product for tails BEYOND one workgroup's reach (18 432 < K <= 32 768: PushT_N=30 27 136, PushBox N=50 30 720, PlanarHand
+// N=10 32 768).  A row of W no longer fits one CU's registers beside its accumulators (3 x 256 KB at K = 32 768 against 512 KB of
+// registers + 160 KB of LDS), so Q = 4 workgroups share a row: member q owns the column segments (wave * Q + q) * 64 NC ... (interleaved:
+// equal shares of the triangle), forms its part of u_i = W_i z, publishes it in a slot of its own (one double per row and member:
+// a single atomic word, valid as soon as it is not the sentinel NaN -- no flag, no fence) and reads the three others; the sum is taken
+// in member order, so it does not depend on who arrives first.  RB rows share one exchange (lane q of the first wavefront handles row
+// q: the polls of a round are in flight together), z sits in LDS words only the owning thread touches, and either two workgroups share
+// a CU (64 VGPRs) or one keeps four rows in flight (128), so the ~2 us exchange is amortised or covered.  The four members of a group
+// are workgroups g, g + 8, g + 16, g + 24: one XCD (round-robin dispatch), one L2.  A group's members lie within 32 consecutive
+// workgroup ids, so the dispatcher (in id order) always has whole groups resident; a member that waits ~seconds gives up and poisons the
+// result with NaN instead of hanging.  W is read once: 4 K^2 bytes instead of the 8 K^2 of the two triangular GEMVs.
+constexpr unsigned long long TS_SENTINEL = 0x7ff8dead5eed0001ull;      // a quiet NaN that no sum produces
+__global__ void ts_fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+template <int NC, int Q, int RB, int OCC = 8>
+__global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
+                                                                   const double* __restrict__ dinv, double* __restrict__ P,
+                                                                   unsigned long long* __restrict__ part) {
+  extern __shared__ double ts_zs[];          // z of this thread's own columns: word (c * 1024 + tid); nobody else reads it
+  __shared__ double red[2][RB][16];
+  __shared__ double ush[2][RB];
+  static_assert(Q == 2 || Q == 4 || Q == 8, "members per row");
+  constexpr int LQ = Q == 8 ? 3 : Q == 4 ? 2 : 1;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = (int)blockIdx.x;
+  const int member = (g >> 3) & (Q - 1), group = (g & 7) + 8 * (g >> (3 + LQ));
+  const int G = (int)gridDim.x / Q;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int col0 = (wave * Q + member) * (64 * NC) + lane;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) ts_zs[c * 1024 + tid] = col0 + 64 * c < K ? z[col0 + 64 * c] : 0.0;
+  double xa[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) xa[c] = 0.0;
+  int it = 0;
+  for (int r0 = group * RB; r0 < K; r0 += G * RB, ++it) {
+    double w[RB][NC];
+    const int seg0 = (wave_u * Q + member) * (64 * NC);   // this wavefront's segment: uniform
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int i = K - 1 - (r0 + q);            // < 0: no such row (all-zero contribution)
+      const double* row = W + (size_t)(i < 0 ? 0 : i) * ld + col0;
+      // a wavefront's segment is inside the triangle (plain loads), outside it (nothing to read) or crosses the diagonal (one segment
+      // per row: per-slot predicates): a scalar branch, so the common case carries no exec-mask juggling
+      if (seg0 + 64 * NC - 1 <= i) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) w[q][c] = row[64 * c];
+      } else if (seg0 > i) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) w[q][c] = 0.0;
+      } else {
+        const int lim = i - col0;                // slot c is inside the triangle iff 64 c <= lim
+#pragma unroll
+        for (int c = 0; c < NC; ++c) w[q][c] = 64 * c <= lim ? row[64 * c] : 0.0;
+      }
+    }
+    // lane q of the first wavefront exchanges row q: its pivot is in flight across the barrier
+    const int iq = K - 1 - (r0 + (tid < RB ? tid : 0));
+    const double dv = (tid < RB && iq >= 0) ? dinv[iq] : 0.0;
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) s += w[q][c] * ts_zs[c * 1024 + tid];
+      s = wave_sum(s);
+      if (lane == 0) red[it & 1][q][wave] = s;
+    }
+    __syncthreads();
+    if (tid < RB) {
+      const double* rr = red[it & 1][tid];
+      const double own = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
+                         (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
+      double u = 0.0;
+      if (iq >= 0) {
+        unsigned long long* slot = part + (size_t)iq * Q;
+        __hip_atomic_store(slot + member, (unsigned long long)__double_as_longlong(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the others' parts: all loads of a round in flight together; a round repeats only for those not there yet
+        unsigned long long b[Q];
+#pragma unroll
+        for (int m = 0; m < Q; ++m) b[m] = m == member ? 0ull : __hip_atomic_load(slot + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long spins = 0;
+        for (;;) {
+          bool missing = false;
+#pragma unroll
+          for (int m = 0; m < Q; ++m) missing = missing || (m != member && b[m] == TS_SENTINEL);
+          if (!missing || ++spins > (1ll << 22)) break;   // still the sentinel after ~seconds: NaN, loudly wrong instead of a hang
+          __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int m = 0; m < Q; ++m)
+            if (m != member && b[m] == TS_SENTINEL) b[m] = __hip_atomic_load(slot + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double v[Q];
+#pragma unroll
+        for (int m = 0; m < Q; ++m) v[m] = m == member ? own : __longlong_as_double((long long)b[m]);
+        u = Q == 8 ? ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4 % Q] + v[5 % Q]) + (v[6 % Q] + v[7 % Q])) : Q == 4 ? (v[0] + v[1]) + (v[2 % Q] + v[3 % Q]) : v[0] + v[1];
+      }
+      ush[it & 1][tid] = u * dv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const double vq = ush[it & 1][q];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) xa[c] += vq * w[q][c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)group * K + col] = xa[c]; }
+}
+
+// `part` (with Q slots per row): the exchange slots of ts_onepass_group_kernel, reset to the sentinel for the next solve
+__global__ __launch_bounds__(64) void ts_onepass_reduce_kernel(const double* __restrict__ P, int K, int G, double* __restrict__ x,
+                                                               unsigned long long* __restrict__ part = nullptr, int Q = 0) {
   const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (col >= K) return;
+  for (int m = 0; m < Q; ++m) part[(size_t)col * Q + m] = TS_SENTINEL;
   double s = 0.0;
   int g = 0;
   for (; g + 8 <= G; g += 8) {                                  // eight loads in flight; workgroup order: fixed
@@ -375,7 +490,8 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 }
 
 void TailSolve::release() {
-  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  part = nullptr;
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
   attr_set = false;
@@ -400,6 +516,12 @@ int TailSolve::alloc(int k_) {
     n_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   CUADMM_HIP_TRY(hipMalloc(&xpart, sizeof(double) * (size_t)K * (size_t)n_wg));
+  if (K > 18432 && K <= 32768) {        // exchange slots of the four-workgroups-per-row one-pass kernel
+    CUADMM_HIP_TRY(hipMalloc(&part, sizeof(unsigned long long) * (size_t)K * 8));
+    hipLaunchKernelGGL(ts_fill_u64_kernel, dim3((unsigned)(((size_t)K * 8 + 255) / 256)), dim3(256), 0, nullptr, part, (size_t)K * 8, TS_SENTINEL);
+    CUADMM_HIP_TRY(hipGetLastError());
+    CUADMM_HIP_TRY(hipDeviceSynchronize());
+  }
   CUADMM_HIP_TRY(hipHostMalloc(&h_vec, sizeof(double) * (size_t)K, hipHostMallocDefault));
   return CUADMM_OK;
 }
@@ -582,7 +704,24 @@ int TailSolve::apply(hipStream_t st) {
       default: rc = launch(ts_onepass_kernel<20, 1>); break;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, n_wg, vin);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);
+  } else if (one_pass && xpart && part && K <= 32768) {
+    constexpr int Q = 4;
+    // measured (tail_solve class per sGS iteration, two solves; two triangular GEMVs for comparison): K = 24 576 (PushBox N = 30, forced)
+    // 1.99 -> 1.36 ms with 6 columns per thread, two rows per exchange, two workgroups per CU; K = 27 136 (PushT_N=30) 2.83 -> 2.10 and
+    // K = 30 720 (PushBox N = 50) 3.1 -> 2.16 with 8 columns per thread, FOUR rows per exchange and one workgroup per CU (128 VGPRs) --
+    // one row per exchange at 64 VGPRs: 2.24 / 2.27; two rows spill; eight members of 4 columns: 2.67 (the group waits for its slowest)
+    const bool small = K <= 1024 * Q * 6;
+    const size_t lds2 = sizeof(double) * 1024 * (size_t)(small ? 6 : 8);
+    const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
+    auto launch = [&](auto kern) -> int {
+      if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part);
+      return CUADMM_OK;
+    };
+    int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, G, vin, part, Q);
   } else {
     hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
     hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
