@@ -201,6 +201,27 @@ def test_tail_solve_op_vs_triangular_solves(k):
     assert np.linalg.norm(got - ref) <= 1e-13 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("k", [18500, 24700])
+def test_tail_solve_op_beyond_one_workgroups_reach(k):
+    """K > 18 432: four workgroups share a row of inv(L) and exchange their parts of u = W z through sentinel slots
+    (ts_onepass_group_kernel: 6 columns per thread up to 24 576, 8 beyond); three solves in a row, so the slots are reset and reused.
+    Same tolerance as the small sizes; the second and third right-hand sides repeat the first, and must reproduce it bit for bit."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(k)
+    L = rng.random((k, k), dtype=np.float32).astype(np.float64)
+    L -= 0.5
+    L *= 1.0 / np.sqrt(k)
+    L = np.tril(L, -1)
+    L[np.diag_indices(k)] = 1.0
+    D = rng.uniform(0.1, 2.0, k) * rng.choice([1.0, 1.0, 1.0, -1.0], k)
+    z0 = rng.standard_normal(k)
+    ref = sl.solve_triangular(L.T, sl.solve_triangular(L, z0, lower=True, unit_diagonal=True) / D, lower=False, unit_diagonal=True)
+    got = np.stack([z0, z0, z0]).copy()
+    check(lib.cuadmm_op_tail_solve(L.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p), k, got.ctypes.data_as(C.c_void_p), 3))
+    assert np.linalg.norm(got[0] - ref) <= 1e-13 * np.linalg.norm(ref)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
 @pytest.mark.parametrize("k", [1, 50, 64, 130, 1000, 2000])
 def test_tail_factor_solve_op_dense_ldlt_on_gpu(k):
     """Dense LDL^T (no pivoting) + inverse + two GEMVs on the GPU for a Schur complement given as sparse lower triangle
