@@ -1757,6 +1757,10 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   // collective, so there it happens here, where every rank is.
   s->pending_unscale = true;
   if (s->lazy_unscale == 0 || (s->local_mode && s->comm_world > 1)) { if ((rc = s->materialise())) return rc; }
+  if (s->tail.k > 0) {
+    const int tf = s->tail.fail_count(s->st);
+    if (tf != 0) { set_error("solve: the dense tail of the A*A^T solve lost %d row exchanges (workgroups of a row not co-resident for seconds): y is not valid", tf); return CUADMM_ERR_FACTOR; }
+  }
   s->eig_fail_total = s->plan.fail_count(s->st);
   if (s->eig_fail_total > 0) {
     set_error("solve: %d block projections hit the QL sweep cap", s->eig_fail_total);

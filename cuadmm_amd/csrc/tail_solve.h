@@ -10,6 +10,8 @@ struct TailSolve {
   double* h_vec = nullptr;     // pinned staging vector
   double* xpart = nullptr;     // one-pass variant: n_wg partial result vectors
   int n_wg = 0;
+  int* d_fail = nullptr;       // raised by a workgroup of that kernel that waited seconds for its partners in vain
+  int fail_count(hipStream_t st);
   unsigned long long* part = nullptr;   // 18 432 < K <= 32 768: per row and member, the exchanged parts of u = W z (ts_onepass_group_kernel)
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)

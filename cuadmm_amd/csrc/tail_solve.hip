@@ -229,7 +229,7 @@ __global__ void ts_fill_u64_kernel(unsigned long long* p, size_t n, unsigned lon
 template <int NC, int Q, int RB, int OCC = 8>
 __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                                    const double* __restrict__ dinv, double* __restrict__ P,
-                                                                   unsigned long long* __restrict__ part) {
+                                                                   unsigned long long* __restrict__ part, int* __restrict__ fail) {
   extern __shared__ double ts_zs[];          // z of this thread's own columns: word (c * 1024 + tid); nobody else reads it
   __shared__ double red[2][RB][16];
   __shared__ double ush[2][RB];
@@ -297,7 +297,9 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
           bool missing = false;
 #pragma unroll
           for (int m = 0; m < Q; ++m) missing = missing || (m != member && b[m] == TS_SENTINEL);
-          if (!missing || ++spins > (1ll << 22)) break;   // still the sentinel after ~seconds: NaN, loudly wrong instead of a hang
+          if (!missing) break;
+          if (++spins > (1ll << 22)) { if (fail) atomicAdd(fail, 1); break; }   // still the sentinel after ~seconds: NaN and a raised counter
+                                                                                // (TailSolve::fail_count) instead of a hang
           __builtin_amdgcn_s_sleep(1);
 #pragma unroll
           for (int m = 0; m < Q; ++m)
@@ -492,6 +494,7 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 void TailSolve::release() {
   for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part}) if (p) { hipError_t e = hipFree(p); (void)e; }
   part = nullptr;
+  if (d_fail) { hipError_t e = hipFree(d_fail); (void)e; d_fail = nullptr; }
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
   attr_set = false;
@@ -518,6 +521,8 @@ int TailSolve::alloc(int k_) {
   CUADMM_HIP_TRY(hipMalloc(&xpart, sizeof(double) * (size_t)K * (size_t)n_wg));
   if (K > 18432 && K <= 32768) {        // exchange slots of the four-workgroups-per-row one-pass kernel
     CUADMM_HIP_TRY(hipMalloc(&part, sizeof(unsigned long long) * (size_t)K * 8));
+    CUADMM_HIP_TRY(hipMalloc(&d_fail, sizeof(int)));
+    CUADMM_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
     hipLaunchKernelGGL(ts_fill_u64_kernel, dim3((unsigned)(((size_t)K * 8 + 255) / 256)), dim3(256), 0, nullptr, part, (size_t)K * 8, TS_SENTINEL);
     CUADMM_HIP_TRY(hipGetLastError());
     CUADMM_HIP_TRY(hipDeviceSynchronize());
@@ -658,6 +663,15 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   return rc;
 }
 
+// workgroups of the four-per-row kernel that gave up waiting for a partner (0 unless the device could not keep a group resident for
+// seconds); synchronises `st`
+int TailSolve::fail_count(hipStream_t st) {
+  if (!d_fail) return 0;
+  int h = 0;
+  if (hipStreamSynchronize(st) != hipSuccess || staged_d2h(&h, d_fail, sizeof(int), st)) return -1;
+  return h;
+}
+
 // x2 = L22^-T D2^-1 L22^-1 z2, host vector in place (k doubles); synchronous on `st`
 int TailSolve::solve(double* z2, hipStream_t st) {
   if (!W) { set_error("tail_solve: not built"); return CUADMM_ERR_INVALID; }
@@ -716,7 +730,7 @@ int TailSolve::apply(hipStream_t st) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
     auto launch = [&](auto kern) -> int {
       if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part);
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail);
       return CUADMM_OK;
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
