@@ -19,7 +19,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 lib = cuadmm_amd.load()
 coupled = sys.argv[2] == "coupled"
-moment = sys.argv[2] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a")
+moment = sys.argv[2] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a", "PushBox_N=30_MOMENT", "PushBox_N=30_MOMENT:hybrid")
 rng = np.random.default_rng(2)
 blk = list(np.array([32] * 20 + [7] * 15 + [15] * 11 + [40, 3, 28])[rng.permutation(49)])
 p = make_synthetic(blk, cons_per_block=3, seed=11)
@@ -51,8 +51,11 @@ if moment:
     # 2m+2 all-reduce per half iteration; compared with the committed ORACLE trajectory by the test
     from tests.conftest import load_npz_problem
     from tests.helpers import problem_to_amd
-    prob = problem_to_amd(load_npz_problem(sys.argv[2]))
-    s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world)
+    name, _, variant = sys.argv[2].partition(":")
+    prob = problem_to_amd(load_npz_problem(name))
+    # ":hybrid": the host-optimal tail with L21 on the device and the L11 sweeps on the host (lead_solve.h), forced -- on every rank
+    opts = {"tail_k": 10240, "l21_device": 2} if variant == "hybrid" else None
+    s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world, options=opts)
     s.set_allreduce(hook)
     s.init_problem(prob)
     s.solve(60, 0.0, 0, 50, 100, 11000, 1.05)
