@@ -2,8 +2,9 @@
 """Benchmark of the SDP-ADMM iteration hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
 
     python bench.py --gpus 1 --steps 200 --warmup 20                       # the headline line (BASELINE configs[1])
+    python bench.py --gpus N --steps K --warmup W                          # N > 1 as typed: starts its own N ranks (launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                             # the same under a launcher (the driver's form)
     python bench.py --config c1            # PlanarHand_N=1 moment relaxation (BASELINE configs[0]; inputs rebuilt from the shipped .mat)
     python bench.py --config c3            # max-cut, one block n = 2000 (BASELINE configs[2])
     python bench.py --config c4            # 100 000 mixed moment-SOS blocks (BASELINE configs[3]; --scaling strong at N > 1)
@@ -209,6 +210,51 @@ def projection_only(args, lib):
     lib.cuadmm_psd_plan_destroy(plan)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), relay rank 0's JSON line, return the
+    worst exit code.  The counterpart of the reference's one-process multi-device launch (src/duo_solver.cu:487-577,
+    src/utils/check_gpus.cu:29-43).  The caller has not initialised the GPU: the ranks are children, nothing is exec'ed."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:                          # a free port for the rendezvous
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies takes the job with it (the others would wait in a collective for ever)
+        rcs = [None] * n
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+            if any(rc not in (None, 0) for rc in rcs):
+                time.sleep(2.0)                             # let the others report before they are stopped
+                for r, p in enumerate(procs):
+                    if p.poll() is None:
+                        p.kill()
+                    rcs[r] = p.wait()
+                break
+            time.sleep(0.05)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        return max(abs(rc) for rc in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,8 +289,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` as typed: this process becomes the launcher.  It has not touched the GPU, torch or the
+            # engine (a process that has may not be replaced, and a forked HIP runtime is unusable): N fresh rank processes.
+            sys.exit(launch_ranks(args.gpus))
         args.gpus = world
 
     # CUADMM_BENCH_FORCE_DIST=1 exercises the torch.distributed/RCCL hook with a single rank (transport check)

@@ -42,3 +42,19 @@ def test_bench_two_ranks_on_one_gpu(args, port):
         assert d["with_checkpoint"]["value"] > 0
     else:
         assert "allreduce_path" not in d
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` AS TYPED (no torch.distributed.run): the parent starts the two rank processes itself
+    (bench.launch_ranks; the one-process launch of the reference's src/duo_solver.cu:487-577) and relays rank 0's line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUADMM_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--blocks-per-gpu", "600",
+                        "--steps", "12", "--warmup", "3"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 12
+    assert d["allreduce_path"]["value"] > 0
