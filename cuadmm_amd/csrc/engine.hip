@@ -1721,6 +1721,16 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         } else if (s->dev_scalars || s->dev_solve) { for (int q = 0; q < 4; ++q) v[q] = s->h_scal.p[q]; }   // formed (and summed over ranks) on the device
         else if ((rc = s->allreduce_scalars(v, 4))) return rc;
         nr = v[0]; bty = v[1]; s->h_out.p[(size_t)m] = v[2]; s->h_out.p[(size_t)m + 1] = v[3];
+        // a lost row exchange of the four-workgroups-per-row tail kernel leaves NaN in y and with it in these sums: stop NOW (not at
+        // max_iter), report once, and leave the handle on the two-GEMV path (TailSolve::take_failure)
+        if (s->tail.d_fail && !(std::fabs(nr) <= 1.7976931348623157e308 && std::fabs(bty) <= 1.7976931348623157e308)) {
+          const int tf = s->tail.take_failure(s->st);
+          if (tf != 0) {
+            set_error("solve: the dense tail of the A*A^T solve lost %d row exchanges at iteration %d (workgroups of a row not co-resident for seconds): "
+                      "y is not valid; the handle now uses the two-pass tail kernels", tf, iter);
+            return CUADMM_ERR_FACTOR;
+          }
+        }
       }
       s->errRp = std::sqrt(nr) / s->norm_borg;
       s->pobj = s->h_out.p[(size_t)m + 1] * s->objscale;
@@ -1758,7 +1768,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   s->pending_unscale = true;
   if (s->lazy_unscale == 0 || (s->local_mode && s->comm_world > 1)) { if ((rc = s->materialise())) return rc; }
   if (s->tail.k > 0) {
-    const int tf = s->tail.fail_count(s->st);
+    const int tf = s->tail.take_failure(s->st);
     if (tf != 0) { set_error("solve: the dense tail of the A*A^T solve lost %d row exchanges (workgroups of a row not co-resident for seconds): y is not valid", tf); return CUADMM_ERR_FACTOR; }
   }
   s->eig_fail_total = s->plan.fail_count(s->st);
@@ -2032,6 +2042,30 @@ int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, d
   int rc = t.build(L22_host, D2_host, k, nullptr);
   for (int r = 0; r < nrhs && !rc; ++r) rc = t.solve(z2_host + (size_t)r * k, nullptr);
   return rc;
+}
+
+// Failure drill of the four-workgroups-per-row tail kernel (18 432 < K <= 32 768), see the protocol above ts_onepass_group_kernel:
+// out[0] = the plain solve of z; out[1] = the solve of z with a NaN carrying the exchange sentinel's bits in z[0] (must come back as
+// NaN promptly, no exchange lost: counts[0] = 0); out[2] = the solve with the failure counter raised beforehand (NaN at once,
+// counts[1] = the count take_failure() found and cleared); out[3] = the solve after that, on the two-GEMV path the object retired to
+// (counts[2] = 1).  Test hook only.
+int cuadmm_op_tail_solve_drill(const double* L22_host, const double* D2_host, int k, const double* z_host, double* out_host, int* counts) {
+  if (!L22_host || !D2_host || !z_host || !out_host || !counts || k < 1) { set_error("tail_solve_drill: bad arguments"); return CUADMM_ERR_INVALID; }
+  TailSolve t;
+  int rc = t.build(L22_host, D2_host, k, nullptr);
+  if (rc) return rc;
+  if (!t.d_fail) { set_error("tail_solve_drill: k = %d does not use the row-sharing kernel", k); return CUADMM_ERR_INVALID; }
+  for (int q = 0; q < 4; ++q) std::copy(z_host, z_host + k, out_host + (size_t)q * k);
+  if ((rc = t.solve(out_host, nullptr))) return rc;
+  { const unsigned long long bits = 0x7ff8dead5eed0001ull; std::memcpy(out_host + (size_t)k, &bits, sizeof bits); }
+  if ((rc = t.solve(out_host + (size_t)k, nullptr))) return rc;
+  counts[0] = t.fail_count(nullptr);
+  CUADMM_HIP_TRY(hipMemset(t.d_fail, 0, sizeof(int)));
+  { const int one = 1; CUADMM_HIP_TRY(hipMemcpy(t.d_fail, &one, sizeof one, hipMemcpyHostToDevice)); }
+  if ((rc = t.solve(out_host + 2 * (size_t)k, nullptr))) return rc;
+  counts[1] = t.take_failure(nullptr);
+  counts[2] = t.group_retired ? 1 : 0;
+  return t.solve(out_host + 3 * (size_t)k, nullptr);
 }
 
 int cuadmm_op_psd_project(const double* Xb, double* Xproj, const int* blk_host, int mat_num, void* stream) {

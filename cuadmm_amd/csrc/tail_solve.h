@@ -12,6 +12,8 @@ struct TailSolve {
   int n_wg = 0;
   int* d_fail = nullptr;       // raised by a workgroup of that kernel that waited seconds for its partners in vain
   int fail_count(hipStream_t st);
+  int take_failure(hipStream_t st);      // fail_count, then: counter cleared, exchange slots reset, group kernel retired
+  bool group_retired = false;  // a row exchange was lost once: apply() uses the two triangular GEMVs from then on
   unsigned long long* part = nullptr;   // 18 432 < K <= 32 768: per row and member, the exchanged parts of u = W z (ts_onepass_group_kernel)
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)

@@ -221,7 +221,13 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
 // are workgroups g, g + 8, g + 16, g + 24: one XCD (round-robin dispatch), one L2.  A group's members lie within 32 consecutive
 // workgroup ids, so the dispatcher (in id order) always has whole groups resident; a member that waits ~seconds gives up and poisons the
 // result with NaN instead of hanging.  W is read once: 4 K^2 bytes instead of the 8 K^2 of the two triangular GEMVs.
-constexpr unsigned long long TS_SENTINEL = 0x7ff8dead5eed0001ull;      // a quiet NaN that no sum produces
+// Failure protocol (HIP does not PROMISE co-residency): a member that gives up raises *fail and returns the canonical NaN; every
+// other waiter polls *fail between its spins and gives up with it, a launch that starts with *fail != 0 writes NaN and returns at
+// once (no further 4 s budgets), and a member never PUBLISHES the sentinel: a NaN of its own -- hardware propagates payloads, so a
+// poisoned right-hand side could carry the sentinel's bits back in -- is canonicalised before the store.  The engine sees the NaN in
+// the iteration's scalars, reads the counter, clears it and moves the handle to the two-GEMV path (engine.hip, TailSolve::take_failure).
+constexpr unsigned long long TS_SENTINEL = 0x7ff8dead5eed0001ull;      // a quiet NaN that no sum is allowed to publish
+constexpr unsigned long long TS_CANON_NAN = 0x7ff8000000000000ull;
 __global__ void ts_fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -241,6 +247,11 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
   const int G = (int)gridDim.x / Q;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int col0 = (wave * Q + member) * (64 * NC) + lane;
+  if (fail && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // an earlier exchange was lost: no more waiting
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)group * K + col] = __longlong_as_double((long long)TS_CANON_NAN); }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) ts_zs[c * 1024 + tid] = col0 + 64 * c < K ? z[col0 + 64 * c] : 0.0;
   double xa[NC];
@@ -287,7 +298,9 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
       double u = 0.0;
       if (iq >= 0) {
         unsigned long long* slot = part + (size_t)iq * Q;
-        __hip_atomic_store(slot + member, (unsigned long long)__double_as_longlong(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // own != own: a NaN (whatever its payload, the sentinel's included) leaves as the canonical one -- never as "not there yet"
+        const unsigned long long own_bits = own != own ? TS_CANON_NAN : (unsigned long long)__double_as_longlong(own);
+        __hip_atomic_store(slot + member, own_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the others' parts: all loads of a round in flight together; a round repeats only for those not there yet
         unsigned long long b[Q];
 #pragma unroll
@@ -298,8 +311,15 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
 #pragma unroll
           for (int m = 0; m < Q; ++m) missing = missing || (m != member && b[m] == TS_SENTINEL);
           if (!missing) break;
-          if (++spins > (1ll << 22)) { if (fail) atomicAdd(fail, 1); break; }   // still the sentinel after ~seconds: NaN and a raised counter
-                                                                                // (TailSolve::fail_count) instead of a hang
+          // still the sentinel after ~seconds, or somebody else gave up (polled every 256th spin): NaN and a raised counter
+          // (TailSolve::fail_count) instead of a hang
+          ++spins;
+          if (spins > (1ll << 22) || (fail && (spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (fail) atomicAdd(fail, 1);
+#pragma unroll
+            for (int m = 0; m < Q; ++m) if (m != member && b[m] == TS_SENTINEL) b[m] = TS_CANON_NAN;
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
 #pragma unroll
           for (int m = 0; m < Q; ++m)
@@ -498,6 +518,7 @@ void TailSolve::release() {
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
   attr_set = false;
+  group_retired = false;
   k = K = 0;
 }
 
@@ -672,6 +693,22 @@ int TailSolve::fail_count(hipStream_t st) {
   return h;
 }
 
+// Reads the counter and, when it is raised, clears it, resets the exchange slots and retires the four-workgroups-per-row kernel for
+// the rest of this object's life (apply() then runs the two triangular GEMVs, which need nothing co-resident): the caller reports
+// the lost solve once, the handle stays usable.  Returns the count that was found (-1: the device could not be read).
+int TailSolve::take_failure(hipStream_t st) {
+  const int h = fail_count(st);
+  if (h <= 0) return h;
+  group_retired = true;
+  if (hipMemsetAsync(d_fail, 0, sizeof(int), st) != hipSuccess) return -1;
+  if (part) {
+    const size_t n = (size_t)K * 8;
+    hipLaunchKernelGGL(ts_fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, TS_SENTINEL);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  return h;
+}
+
 // x2 = L22^-T D2^-1 L22^-1 z2, host vector in place (k doubles); synchronous on `st`
 int TailSolve::solve(double* z2, hipStream_t st) {
   if (!W) { set_error("tail_solve: not built"); return CUADMM_ERR_INVALID; }
@@ -719,7 +756,7 @@ int TailSolve::apply(hipStream_t st) {
     }
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);
-  } else if (one_pass && xpart && part && K <= 32768) {
+  } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
     // measured (tail_solve class per sGS iteration, two solves; two triangular GEMVs for comparison): K = 24 576 (PushBox N = 30, forced)
     // 1.99 -> 1.36 ms with 6 columns per thread, two rows per exchange, two workgroups per CU; K = 27 136 (PushT_N=30) 2.83 -> 2.10 and

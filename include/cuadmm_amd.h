@@ -323,6 +323,11 @@ int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, do
 /* The GPU part of the A*A^T solve on its own (tail_solve.hip): z <- L22^-T D2^-1 L22^-1 z for `nrhs` host vectors
  * of length k (contiguous), L22 dense k x k row-major unit lower triangular and D2 the pivots (host pointers). */
 int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs);
+/* Test hook: failure drill of the row-sharing tail kernel (18 432 < k <= 32 768).  out_host: 4 x k doubles -- the plain solve, the
+ * solve of a right-hand side poisoned with a NaN that carries the exchange sentinel's bits, the solve with the lost-exchange
+ * counter raised beforehand (NaN), the solve after the object retired to the two-pass kernels; counts[3] = {exchanges lost by the
+ * poisoned solve (0), count found and cleared after the third solve (>= 1), retired flag (1)}. */
+int cuadmm_op_tail_solve_drill(const double* L22_host, const double* D2_host, int k, const double* z_host, double* out_host, int* counts);
 /* Same with the factorisation on the GPU too: z <- S^-1 z for a symmetric S given by its lower triangle with
  * diagonal (CSR over k rows, host pointers), dense LDL^T without pivoting (what cuadmm_aat_create_split hands over). */
 int cuadmm_op_tail_factor_solve(const int64_t* row_ptr, const int* col, const double* val, int k, double* z_host, int nrhs);

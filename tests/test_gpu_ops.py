@@ -222,6 +222,36 @@ def test_tail_solve_op_beyond_one_workgroups_reach(k):
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
 
 
+def test_tail_solve_lost_exchange_protocol():
+    """What happens when the row-sharing kernel cannot rely on co-residency (HIP does not promise it): a NaN with the sentinel's
+    bits in the right-hand side does not stall the exchange (it is canonicalised before it is published); a raised failure
+    counter makes the next launch return NaN at once instead of spending seconds per row round; take_failure() reports and clears
+    it and the object continues on the two triangular GEMVs -- with the right answer."""
+    import time
+    import scipy.linalg as sl
+    k = 18500
+    rng = np.random.default_rng(5)
+    L = rng.random((k, k), dtype=np.float32).astype(np.float64)
+    L -= 0.5
+    L *= 1.0 / np.sqrt(k)
+    L = np.tril(L, -1)
+    L[np.diag_indices(k)] = 1.0
+    D = rng.uniform(0.1, 2.0, k)
+    z = rng.standard_normal(k)
+    ref = sl.solve_triangular(L.T, sl.solve_triangular(L, z, lower=True, unit_diagonal=True) / D, lower=False, unit_diagonal=True)
+    out = np.zeros((4, k))
+    counts = np.zeros(3, np.int32)
+    t0 = time.time()
+    check(lib.cuadmm_op_tail_solve_drill(L.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p), k, z.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
+    assert time.time() - t0 < 60.0                       # build + four solves; one lost round alone used to cost ~4 s, sixty per solve
+    assert np.linalg.norm(out[0] - ref) <= 1e-13 * np.linalg.norm(ref)
+    assert np.isnan(out[1]).any() and counts[0] == 0     # poisoned right-hand side: NaN out, no exchange lost
+    assert np.isnan(out[2]).all() and counts[1] >= 1     # counter raised beforehand: every workgroup leaves NaN and returns
+    assert counts[2] == 1
+    assert np.linalg.norm(out[3] - ref) <= 1e-13 * np.linalg.norm(ref)
+
+
 @pytest.mark.parametrize("k", [1, 50, 64, 130, 1000, 2000])
 def test_tail_factor_solve_op_dense_ldlt_on_gpu(k):
     """Dense LDL^T (no pivoting) + inverse + two GEMVs on the GPU for a Schur complement given as sparse lower triangle
