@@ -59,8 +59,11 @@ def load(name):
     return load_npz_problem(name)
 
 
-def host_ldlt_solver(At_csr):
-    """y = (A A^T + 1e-15 I)^-1 rhs through the library's host LDL^T (CPU only)."""
+def host_ldlt_solver(At_csr, relres_log):
+    """y = (A A^T + 1e-15 I)^-1 rhs through the library's host LDL^T (CPU only).  The product code is only the SOLVER here: every y it
+    returns is checked with scipy alone -- || (A A^T + 1e-15 I) y - rhs || / || rhs || by two sparse matrix-vector products, appended to
+    `relres_log` -- so the trajectory does not rest on the library being right (tests/test_oracle_pinning.py asserts <= 1e-10 on what
+    was recorded; contract: include/cuadmm/cholesky_cpu.h:146-155)."""
     import ctypes as C
     import cuadmm_amd
     from cuadmm_amd._lib import check
@@ -72,13 +75,17 @@ def host_ldlt_solver(At_csr):
     h = C.c_void_p()
     check(lib.cuadmm_aat_create(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), 1e-15, C.byref(h)))
     perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)).copy()
+    A_csr = At_csr.T.tocsr()                             # scipy's own copy: the check shares no code with the factor
 
     def solve(rhs):
-        r = np.ascontiguousarray(np.asarray(rhs, np.float64)[perm])
+        rhs = np.asarray(rhs, np.float64)
+        r = np.ascontiguousarray(rhs[perm])
         out = np.empty(m)
         check(lib.cuadmm_aat_solve_permuted(h, r.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
         y = np.empty(m)
         y[perm] = out
+        nr = float(np.linalg.norm(rhs))
+        relres_log.append(float(np.linalg.norm(A_csr @ (At_csr @ y) + 1e-15 * y - rhs)) / nr if nr > 0 else 0.0)
         return y
     solve._keep = (h, rp, ci, v)
     return solve
@@ -105,7 +112,8 @@ def main():
         s = orc.OracleSolver().init_problem(p)
         if host_factor:
             orc.spla.factorized = _real_factorized
-            s._solve = host_ldlt_solver(s.At_csr)
+            relres = []
+            s._solve = host_ldlt_solver(s.At_csr, relres)
         t1 = time.time()
         info = s.solve(late, 0.0, 0, 50, 100, sw, 1.05)
         t2 = time.time()
@@ -120,6 +128,12 @@ def main():
         rec["late_X_norm"] = repr(float(np.linalg.norm(s.X)))
         rec["late_y_norm"] = repr(float(np.linalg.norm(s.y)))
         rec["late_S_norm"] = repr(float(np.linalg.norm(s.S)))
+        if host_factor:
+            # one entry per y-solve, in call order (two per sGS iteration), scipy-only residual of the library's host factor
+            rec["ysolve_solver"] = "cuadmm_aat_create / cuadmm_aat_solve_permuted (host LDL^T); verified per solve by scipy matvecs"
+            rec["ysolve_count"] = len(relres)
+            rec["ysolve_relres_max"] = repr(max(relres))
+            rec["ysolve_relres_head"] = ["%.3e" % x for x in relres[:2 * head]]
         traj[key] = rec
         print("%s: init %.1fs, %d iterations %.1fs" % (key, t1 - t0, late, t2 - t1), flush=True)
         with open(out_path, "w") as f:

@@ -214,3 +214,68 @@ def test_synthetic_generator_is_feasible():
     s.solve(60, 0.0, 0, 50, 100, 0, 1.05)
     print(s.errRp, s.errRd)
     assert s.errRp < 5e-2 and s.errRd < 5e-2
+
+
+# ---- the y-solves of the two trajectories whose factor SuperLU cannot hold (What's weak #1) -------------------------
+def test_host_factor_solves_of_the_large_trajectories_were_verified_by_scipy():
+    """PushT_N=30 and PlanarHand_N=10: tests/golden/make_traj_moment.py takes y from the library's host LDL^T (the only solver here
+    that can factor those A A^T) but checks EVERY solve with scipy alone -- || (A A^T + 1e-15 I) y - rhs || / || rhs || by two sparse
+    matrix-vector products, recorded per solve.  The trajectories therefore rest on verified solutions of the reference's linear
+    system (include/cuadmm/cholesky_cpu.h:146-155), whoever computed them."""
+    import json
+    traj = json.load(open(os.path.join(GOLDEN, "oracle_traj_moment.json")))
+    seen = 0
+    for key, rec in traj.items():
+        if rec["problem"] not in ("PushT_N=30_MOMENT", "PlanarHand_N=10_MOMENT"):
+            assert "ysolve_solver" not in rec          # every other trajectory: scipy's SuperLU inside the oracle itself
+            continue
+        seen += 1
+        sgs = min(rec["late"], rec["params"]["switch_admm"])
+        assert rec["ysolve_count"] == 1 + 2 * sgs + max(0, rec["late"] - sgs)     # one at init, two per sGS iteration, one per ADMM one
+        assert float(rec["ysolve_relres_max"]) <= 1e-10
+        assert max(float(x) for x in rec["ysolve_relres_head"]) <= 1e-10
+    assert seen == 2
+
+
+@pytest.mark.parametrize("name", ["PushT_N=10_MOMENT", "PushBox_N=30_MOMENT"])
+def test_host_factor_against_superlu(name, problem_dirs):
+    """cuadmm_aat_create / cuadmm_aat_solve_permuted (CHOLMOD's contract: no permutation inside, test/cholesky_cpu_test.hpp:57-100)
+    against scipy.sparse.linalg.splu on the scaled A A^T + 1e-15 I of a moment relaxation -- PushBox_N=30 (m = 154 256) is the largest
+    shipped input SuperLU still factors.  A A^T is numerically SINGULAR there (dependent constraints), so y itself is not unique:
+    the comparison is on what the iteration consumes -- the residual of each solver on consistent right-hand sides, and A^T y."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import cuadmm_amd
+    from cuadmm_amd._lib import check
+    p = orc.load_problem_txt(problem_dirs[name]) if name in problem_dirs else load_npz_problem(name)
+    real = orc.spla.factorized
+    orc.spla.factorized = lambda M: None                   # scaling only: the test factors on its own
+    try:
+        s = orc.OracleSolver().init_problem(p)
+    finally:
+        orc.spla.factorized = real
+    At = s.At_csr
+    L, m = At.shape
+    A = At.T.tocsr()
+    M = (A @ At + 1e-15 * sp.identity(m)).tocsc()
+    lu = spla.splu(M)
+    lib = cuadmm_amd.load()
+    rp, ci, v = (np.ascontiguousarray(At.indptr, np.int32), np.ascontiguousarray(At.indices, np.int32), np.ascontiguousarray(At.data))
+    h = C.c_void_p()
+    check(lib.cuadmm_aat_create(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), 1e-15, C.byref(h)))
+    try:
+        perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)).copy()
+        rng = np.random.default_rng(3)
+        for _ in range(3):
+            r = A @ rng.standard_normal(L)                  # consistent: in the range of A, as every right-hand side of the iteration
+            y_lu = lu.solve(r)
+            rr, out = np.ascontiguousarray(r[perm]), np.empty(m)
+            check(lib.cuadmm_aat_solve_permuted(h, rr.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+            y = np.empty(m)
+            y[perm] = out
+            nr = np.linalg.norm(r)
+            assert np.linalg.norm(M @ y - r) <= 1e-12 * nr
+            assert np.linalg.norm(M @ y_lu - r) <= 1e-12 * nr
+            assert np.linalg.norm(At @ (y - y_lu)) <= 1e-11 * np.linalg.norm(At @ y_lu)
+    finally:
+        lib.cuadmm_aat_free(h)
