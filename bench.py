@@ -57,46 +57,72 @@ def cpu_baseline(prob, threads, budget_s=20.0):
     # warm-up + choice of engine on a slice of the blocks (LAPACK from scipy's OpenBLAS vs the scalar tridiagonal-QL port)
     nslice = max(1, min(blk.size, 8 * threads if blk.max() <= 64 else 1))
     Ls = int(np.sum(blk[:nslice].astype(np.int64) * (blk[:nslice] + 1) // 2))
-    best = None
-    # LAPACK leg: the reference's own thread count (cpu_eig_thread_num = 30, main.cu:11) -- the bundled OpenBLAS is built for
-    # at most 64 caller threads and aborts beyond ("too many memory regions"); the scalar port runs on every core
+    # LAPACK leg (the reference's own CPU path: dsyevd('V','U') per block, eig_cpu.h:31-51) at the reference's thread count
+    # (cpu_eig_thread_num = 30, main.cu:11) -- the bundled OpenBLAS is built for at most 64 caller threads and aborts beyond
+    # ("too many memory regions").  It is the baseline whenever a LAPACK can be dlopen'ed; the build's own scalar
+    # Householder + implicit-QL port on every usable core is timed beside it and reported as `port_ql` (it wins on tiny blocks).
     tcount = {"lapack": min(threads, 30), "ql": threads}
+    timing = {}
     for eng in ("lapack", "ql"):
         if eng == "ql" and blk.max() > 512:
             continue                                       # the scalar port is far off LAPACK's blocked code at n ~ 2000
-        cb.psd_project(xb[:Ls], blk[:nslice], tcount[eng], engine=eng)
-        _, secs = cb.psd_project(xb[:Ls], blk[:nslice], tcount[eng], engine=eng)
-        if best is None or secs < best[1]:
-            best = (eng, secs)
-    eng = best[0]
-    threads = tcount[eng]
-    per_block = best[1] / nslice
-    n_proj = blk.size if per_block * blk.size <= budget_s / 4 else max(1, int(budget_s / 4 / per_block))
-    Lp = int(np.sum(blk[:n_proj].astype(np.int64) * (blk[:n_proj] + 1) // 2))
-    _, secs = cb.psd_project(xb[:Lp], blk[:n_proj], threads, engine=eng)
+        try:
+            cb.psd_project(xb[:Ls], blk[:nslice], tcount[eng], engine=eng)
+            _, secs = cb.psd_project(xb[:Ls], blk[:nslice], tcount[eng], engine=eng)
+        except Exception as exc:                           # no LAPACK on this box: the port alone
+            if eng == "lapack":
+                timing["lapack_error"] = str(exc)
+                continue
+            raise
+        timing[eng] = secs / nslice
+    eng = "lapack" if "lapack" in timing else "ql"
+    threads_eng = tcount[eng]
+
+    def timed_projection(e):
+        per_block = timing[e]
+        n_proj = blk.size if per_block * blk.size <= budget_s / 4 else max(1, int(budget_s / 4 / per_block))
+        Lp = int(np.sum(blk[:n_proj].astype(np.int64) * (blk[:n_proj] + 1) // 2))
+        _, secs = cb.psd_project(xb[:Lp], blk[:n_proj], tcount[e], engine=e)
+        return n_proj, secs
+
+    n_proj, secs = timed_projection(eng)
     blocks_per_s = n_proj / secs
     proj_s_full = blk.size / blocks_per_s
+    port_ql = None
+    if eng == "lapack" and "ql" in timing:
+        nq, sq = timed_projection("ql")
+        port_ql = {"projection_blocks_per_s": nq / sq, "projection_ms": blk.size / (nq / sq) * 1e3, "cores": tcount["ql"],
+                   "engine": "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native)"}
 
     def eig_fn(_bidx, x):
-        return cb.psd_project(x, blk, threads, engine=eng)[0]
+        return cb.psd_project(x, blk, threads_eng, engine=eng)[0]
 
     s = orc.OracleSolver(eig_fn=eig_fn).init(prob.vec_len, prob.con_num, prob.At_col_ptrs, prob.At_row_ids,
                                              prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals, prob.blk)
     t0 = time.perf_counter()
     s.solve(1, 0.0, 0, 50, 100, 0, 1.05)                   # first iteration (also measures the per-iteration cost)
     t_it = time.perf_counter() - t0
-    n_iters = int(max(1, min(20, (budget_s * 0.7) / max(t_it, 1e-3))))
+    n_iters = int(max(1, min(20, (budget_s * 0.5) / max(t_it, 1e-3))))
     t0 = time.perf_counter()
     s.solve(n_iters, 0.0, 0, 50, 100, 0, 1.05, if_first=False)
     dt = time.perf_counter() - t0
-    return {"value": n_iters / dt, "unit": "iters/s", "cores": threads, "kind": "port",
+    # `value`: the projection-bound rate.  In the reference's eig_cpu mode (src/duo_solver.cu:578-618,793-834) ONLY the eigendecompositions
+    # run on the host; every vector stage stays on the GPU, so one iteration costs at least one pass of the host projection (plus the
+    # D2H / H2D of the matrices, not charged here).  The numpy oracle's whole iteration (its vector stages are single-threaded numpy,
+    # not what the reference would run) is reported beside it as `oracle_iters_per_s`.
+    return {"value": 1.0 / proj_s_full, "unit": "iters/s", "cores": threads_eng, "kind": "port",
+            "eig_engine": "lapack_dsyevd" if eng == "lapack" else "port_ql",
             "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
             "projection_blocks_per_s": blocks_per_s, "projection_ms": proj_s_full * 1e3,
-            "engine": "LAPACK dsyevd (scipy OpenBLAS, BLAS threads = 1) + DGEMM" if eng == "lapack" else
-                      "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native)",
-            "sample": "%d ADMM iterations of the same problem on the numpy oracle with the per-block projection in C on %d "
-                      "host threads (static contiguous split as duo_solver.cu:344-371), %.1f s; projection-only: %d blocks in %.2f s"
-                      % (n_iters, threads, dt, n_proj, secs)}
+            "oracle_iters_per_s": n_iters / dt,
+            "port_ql": port_ql,
+            "engine": "LAPACK dsyevd('V','U') per block from scipy's bundled OpenBLAS (dlopen, BLAS threads = 1) + DGEMM, static contiguous split over "
+                      "the host threads (duo_solver.cu:344-371)" if eng == "lapack" else
+                      "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native); no LAPACK could be loaded: "
+                      + timing.get("lapack_error", ""),
+            "sample": "projection-only: %d of %d blocks in %.2f s on %d host threads -> value = 1 / (host projection of all blocks): the rate "
+                      "the reference's eig_cpu mode is bounded by; oracle_iters_per_s: %d whole ADMM iterations of the numpy oracle with that "
+                      "projection, %.1f s" % (n_proj, blk.size, secs, threads_eng, n_iters, dt)}
 
 
 def _as_synth(p):

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cuadmm_get_profile": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cuadmm_reset_profile": (C.c_int, [C.c_void_p]),
     "cuadmm_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cuadmm_get_group_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cuadmm_problem_from_txt": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "cuadmm_problem_view_get": (C.c_int, [C.c_void_p, C.POINTER(ProblemView)]),
     "cuadmm_problem_free": (None, [C.c_void_p]),

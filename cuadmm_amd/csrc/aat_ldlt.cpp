@@ -50,7 +50,9 @@ struct cuadmm_aat {
   // N = 30: 4 953 trees, deepest 1 135 levels -- too deep for the device-side sweeps --, 1.6 ms per sweep serial).
   std::vector<std::vector<int>> lead_chunks;
   std::vector<int64_t> lead_mid;             // split factor: first entry of leading column j in a TAIL row (rows ascend inside a column)
-  mutable std::vector<double> lead_acc;      // kLeadChunks x tail_k
+  mutable std::vector<double> lead_acc;      // kLeadChunks x tail_k: scratch of cuadmm_aat_solve_leading_forward.  SINGLE CALLER: two threads
+                                             // sweeping the same factor at once would share it (the engine has one solve in flight per handle;
+                                             // include/cuadmm_amd.h says so at the entry point)
   std::vector<int> nzcols;   // columns j < m - tail_k with at least one sub-diagonal entry, ascending (block-diagonal A A^T: few)
   int tail_k = 0;
   std::vector<int64_t> schur_ptr;
@@ -144,10 +146,26 @@ void min_degree_order_core(int n, const std::vector<int64_t>& Bp, const std::vec
     // them fills the trailing block completely -- it becomes the dense tail the GPU factors -- while the quotient-graph updates of
     // this phase are the expensive ones (every pivot walks thousands of long lists: PushT_N=30, A A^T with 77 M nonzeros on
     // m = 53 290, spent 36 of its 45 s of analysis here).  The rest is ordered by current degree.
+    // `mindeg` is the APPROXIMATE degree (an upper bound: |adj| + |L_p| - 1 + the external parts of the other elements, which may
+    // overlap), so the test is confirmed with the exact external degree of the candidate -- the distinct live variables it reaches --
+    // before the ordering is cut short; an approximate degree that overshoots must not end it while the rest is far from a clique.
     if (n - k > 2048 && (long long)mindeg * 10 >= 7LL * (n - k - 1)) {
-      for (int d = mindeg; d <= n && k < n; ++d)
-        for (int v = head[d]; v >= 0; v = nxt[v]) perm[k++] = v;
-      break;
+      const int c = head[mindeg];
+      const int stamp = -2 - k;                     // a stamp of its own: `mark` holds step indices >= 0 (and -1)
+      long long exact = 0;
+      mark[c] = stamp;
+      for (int v : adj[c])
+        if (state[v] == 0 && mark[v] != stamp) { mark[v] = stamp; ++exact; }
+      for (int e : elems[c]) {
+        if (state[e] != 1) continue;
+        for (int v : evars[e])
+          if (state[v] == 0 && mark[v] != stamp) { mark[v] = stamp; ++exact; }
+      }
+      if (exact * 10 >= 7LL * (n - k - 1)) {
+        for (int d = mindeg; d <= n && k < n; ++d)
+          for (int v = head[d]; v >= 0; v = nxt[v]) perm[k++] = v;
+        break;
+      }
     }
     int p = head[mindeg];
     bucket_remove(p);
@@ -639,7 +657,11 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     }
     f->D[k] = dk;
   }
-  if (par_tail) {
+  // (the working set of the two parallel phases -- a second copy of L21 by rows, per-thread m-sized work vectors, the Schur rows --
+  // is allocated inside them: an allocation that fails, on this thread or on a pool worker, ends the factorisation with an error
+  // code instead of std::terminate)
+  std::atomic<bool> tail_oom{false};
+  if (par_tail) try {
     t_lead = now_s() - t0;
     struct TailRow { std::vector<int> col; std::vector<double> l, y; std::vector<int> tj; std::vector<double> tc; double dk = 0; };
     std::vector<TailRow> rows((size_t)tail_k);
@@ -648,11 +670,12 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     std::atomic<int> next{0};
     // ---- phase A
     host_pool().run([&](int) {
+     try {
       std::vector<double> Yt((size_t)m, 0.0);
       std::vector<int> flg((size_t)m, -1), pat((size_t)m);
       for (;;) {
         const int r0 = next.fetch_add(16);
-        if (r0 >= tail_k) break;
+        if (r0 >= tail_k || tail_oom.load(std::memory_order_relaxed)) break;
         for (int r = r0; r < std::min(tail_k, r0 + 16); ++r) {
           const int k = n1 + r;
           TailRow& R = rows[(size_t)r];
@@ -683,8 +706,10 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
           R.dk = dk;
         }
       }
+     } catch (const std::bad_alloc&) { tail_oom.store(true); }
     });
     (void)T;
+    if (tail_oom.load()) throw std::bad_alloc();
     // ---- the rows of L21 into the columns, row order (what the serial loop appends row by row)
     for (int r = 0; r < tail_k; ++r) {
       const TailRow& R = rows[(size_t)r];
@@ -701,10 +726,11 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
     std::vector<std::vector<double>> sval((size_t)tail_k);
     next.store(0);
     host_pool().run([&](int) {
+     try {
       std::vector<double> Y2((size_t)tail_k, 0.0);
       for (;;) {
         const int r0 = next.fetch_add(8);
-        if (r0 >= tail_k) break;
+        if (r0 >= tail_k || tail_oom.load(std::memory_order_relaxed)) break;
         for (int r = r0; r < std::min(tail_k, r0 + 8); ++r) {
           const int k = n1 + r;
           const TailRow& R = rows[(size_t)r];
@@ -724,7 +750,9 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
           sc.push_back(r); sv.push_back(R.dk);
         }
       }
+     } catch (const std::bad_alloc&) { tail_oom.store(true); }
     });
+    if (tail_oom.load()) throw std::bad_alloc();
     for (int r = 0; r < tail_k; ++r) {
       f->schur_col.insert(f->schur_col.end(), scol[(size_t)r].begin(), scol[(size_t)r].end());
       f->schur_val.insert(f->schur_val.end(), sval[(size_t)r].begin(), sval[(size_t)r].end());
@@ -732,6 +760,10 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
       std::vector<int>().swap(scol[(size_t)r]); std::vector<double>().swap(sval[(size_t)r]);
       f->D[n1 + r] = 0.0;
     }
+  } catch (const std::bad_alloc&) {
+    set_error("aat_create: the working set of the %d tail rows of the factor (%lld nonzeros) does not fit in host memory", tail_k, (long long)f->Lp[m]);
+    delete f;
+    return CUADMM_ERR_FACTOR;
   }
   for (int j = 0; j < n1; ++j) if (f->Lp[j + 1] > f->Lp[j]) f->nzcols.push_back(j);
   if (tail_k > 0) {

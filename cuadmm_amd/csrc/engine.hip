@@ -207,6 +207,8 @@ struct cuadmm_solver {
   void* group = nullptr;
   bool in_group_call = false;
   int duo_share_device = 0;
+  int duo_exchange = -1;              // -1: device-side exchange when the ranks' devices can read each other, else host-staged
+  long long duo_inject = 0;           // test hook: duo_group.hip, DuoGroup::inject
   std::vector<std::pair<std::string, double>> option_log;
   struct Batch {
     int max_iters = 64;
@@ -643,6 +645,16 @@ struct cuadmm_solver {
 };
 
 using Solver = cuadmm_solver;
+
+// keeps the calling thread's current device across an entry point that visits several devices (the in-process group's leader):
+// a caller that shares the thread with another HIP user (torch) finds its device as it left it
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 static int check_device(int device) {
   int n = 0;
@@ -1297,8 +1309,6 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   if (!s || !key) { set_error("set_option: null"); return CUADMM_ERR_INVALID; }
   std::string k(key);
   s->option_log.emplace_back(k, value);
-  if (s->group && !s->in_group_call && k != "device" && k != "rank" && k != "world" && k != "verbose")   // a group handle: every rank follows
-    for (int r = 1; r < duo_group_world(s->group); ++r) { int rc = cuadmm_set_option(duo_group_rank(s->group, r), key, value); if (rc) return rc; }
   if (k == "device") s->device = (int)value;
   else if (k == "verbose") s->verbose = (int)value;
   else if (k == "rank") s->rank = (int)value;
@@ -1332,8 +1342,17 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "duo_cpu_eig_on_gpu") s->duo_cpu_eig_on_gpu = (int)value;
   else if (k == "duo_share_device") s->duo_share_device = (int)value;   // duo_init(device_num_requested = N) from one process: all N engines on this solver's device
   else if (k == "tiny_sign") s->opt_tiny_sign = (int)value;                               // n <= 8 on the sign kernel (before init)                                     // schedule warm start (before init)                            // 0: unscale X, y, S at the end of every solve
+  else if (k == "duo_exchange") s->duo_exchange = (int)value;           // in-process group: -1 choose, 0 host-staged, 1 device-side exchange
+  else if (k == "duo_inject_fail") { s->duo_inject = (long long)value; if (s->group) duo_group_inject(s->group, s->duo_inject); }   // test hook
   else if (k == "graph") {}
   else { s->option_log.pop_back(); set_error("set_option: unknown key '%s'", key); return CUADMM_ERR_INVALID; }
+  // a group handle: every rank follows -- AFTER the key has been validated on the leader; a child that refuses leaves the option
+  // out of the log (it is not replayed on later children) and the error with the caller
+  if (s->group && !s->in_group_call && k != "device" && k != "rank" && k != "world" && k != "verbose" && k != "duo_inject_fail")
+    for (int r = 1; r < duo_group_world(s->group); ++r) {
+      int rc = cuadmm_set_option(duo_group_rank(s->group, r), key, value);
+      if (rc) { s->option_log.pop_back(); return rc; }
+    }
   return CUADMM_OK;
 }
 
@@ -1476,13 +1495,15 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
                  int sig_update_stage_2, int switch_admm, double sigscale, int if_first) {
   if (!s || !s->initialised) { set_error("solve: solver not initialised"); return CUADMM_ERR_INVALID; }
   if (sig_update_stage_1 <= 0 || sig_update_stage_2 <= 0) { set_error("solve: sig_update stages must be positive"); return CUADMM_ERR_INVALID; }
-  if (s->group && !s->in_group_call)      // the leader of an in-process group (duo_group.hip): every rank solves, on its own host thread
+  if (s->group && !s->in_group_call) {    // the leader of an in-process group (duo_group.hip): every rank solves, on its own host thread
+    DeviceGuard keep_device;
     return duo_group_run(s->group, [&](cuadmm_solver* q, int) {
       q->in_group_call = true;
       int r2 = cuadmm_solve(q, max_iter, stop_tol, sig_update_threshold, sig_update_stage_1, sig_update_stage_2, switch_admm, sigscale, if_first);
       q->in_group_call = false;
       return r2;
     });
+  }
   int rc = check_device(s->device);
   if (rc) return rc;
   const int m = s->m;
@@ -1830,8 +1851,10 @@ int cuadmm_duo_init(cuadmm_solver* s, int if_gpu_eig_mom, int device_num_request
   if (device_num_requested > 1 && s->world == 1 && !s->in_group_call) {
     if (s->group) { set_error("duo_init: this handle already leads a group of %d engines", duo_group_world(s->group)); return CUADMM_ERR_INVALID; }
     if (s->initialised) { set_error("duo_init: already initialised"); return CUADMM_ERR_INVALID; }
-    int rc = duo_group_create(s, device_num_requested, s->device, s->duo_share_device != 0, s->option_log, &s->group);
+    DeviceGuard keep_device;                // the ranks' devices are made current on this thread: leave the caller's as it was
+    int rc = duo_group_create(s, device_num_requested, s->device, s->duo_share_device != 0, s->duo_exchange, s->option_log, &s->group);
     if (rc) return rc;
+    duo_group_inject(s->group, s->duo_inject);
     s->world = device_num_requested; s->rank = 0;
     rc = duo_group_run(s->group, [&](cuadmm_solver* q, int) {
       q->in_group_call = true;
@@ -1895,13 +1918,13 @@ static int get_vec(cuadmm_solver* s, const DevBuf<double>& v, double* out) {
 // world>1: writes this rank's shard (length svec_end - svec_begin) at out[0..)
 // the leader of an in-process group gathers the shards: out has the caller's vec_len doubles
 static int group_gather(cuadmm_solver* s, double* out, int (*get)(cuadmm_solver*, double*)) {
+  DeviceGuard keep_device;                  // every rank's getter makes its device current on this thread
   for (int r = 0; r < duo_group_world(s->group); ++r) {
     cuadmm_solver* q = duo_group_rank(s->group, r);
     int64_t b = 0, e = 0;
+    q->in_group_call = true;                // rank 0 IS the leader: without the mark get_shard would answer for the whole group
     int rc = cuadmm_get_shard(q, &b, &e, nullptr, nullptr);
-    if (rc) return rc;
-    q->in_group_call = true;
-    rc = e > b ? get(q, out + b) : CUADMM_OK;
+    if (!rc) rc = e > b ? get(q, out + b) : CUADMM_OK;
     q->in_group_call = false;
     if (rc) return rc;
   }
@@ -1930,6 +1953,7 @@ int cuadmm_get_y(cuadmm_solver* s, double* out) {
 int cuadmm_set_XyS(cuadmm_solver* s, const double* X, const double* y, const double* S, double sig) {
   if (!s || !s->initialised) { set_error("set_XyS: not initialised"); return CUADMM_ERR_INVALID; }
   if (s->group && !s->in_group_call) {      // every rank of the group takes its range of the caller's vectors
+    DeviceGuard keep_device;
     for (int r = 0; r < duo_group_world(s->group); ++r) {
       cuadmm_solver* q = duo_group_rank(s->group, r);
       q->in_group_call = true;
@@ -2008,6 +2032,14 @@ int cuadmm_get_counters(const cuadmm_solver* s, double o[8]) {
   if (!s || !o) { set_error("get_counters: null"); return CUADMM_ERR_INVALID; }
   o[0] = (double)s->bt.launches; o[1] = (double)s->bt.iters; o[2] = (double)s->bt.rollbacks; o[3] = (double)cuadmm_host_pool_threads();
   o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? 1 : (s->lead.hybrid ? 2 : 0); o[7] = (double)s->tail.k;
+  return CUADMM_OK;
+}
+int cuadmm_get_group_info(const cuadmm_solver* s, double o[4]) {
+  if (!s || !o) { set_error("get_group_info: null"); return CUADMM_ERR_INVALID; }
+  o[0] = s->group ? (double)duo_group_world(s->group) : 1.0;
+  o[1] = s->group ? (double)duo_group_exchange(s->group) : 0.0;
+  o[2] = s->group ? (double)duo_group_distinct_devices(s->group) : 1.0;
+  o[3] = s->group ? (double)duo_group_allreduces(s->group) : 0.0;
   return CUADMM_OK;
 }
 int cuadmm_reset_profile(cuadmm_solver* s) {

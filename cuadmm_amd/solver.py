@@ -106,6 +106,12 @@ class SDPSolver:
         keys = ["batch_launches", "batch_iters", "batch_rollbacks", "host_pool_threads", "fused", "closed_blocks", "dev_solve", "tail_k"]
         return dict(zip(keys, o.tolist()))
 
+    def group_info(self):
+        """The in-process group this handle leads after duo_init(device_num_requested = N) from one process."""
+        o = np.zeros(4)
+        check(self._lib.cuadmm_get_group_info(self._h, _p(o)))
+        return {"engines": int(o[0]), "exchange": "device" if o[1] else "host", "distinct_devices": int(o[2]), "allreduces": int(o[3])}
+
     def set_allreduce(self, fn):
         """fn(dev_ptr:int, count:int, hip_stream:int) -> None : in-place sum over ranks on that stream."""
         def tramp(_user, buf, count, stream):

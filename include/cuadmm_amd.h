@@ -30,6 +30,8 @@ extern "C" {
 #define CUADMM_ERR_FACTOR (-4)     /* A A^T factorisation failed                        */
 #define CUADMM_ERR_EIG (-5)        /* an eigen-iteration hit its iteration cap          */
 #define CUADMM_ERR_COMM (-6)       /* collective hook failed                            */
+#define CUADMM_ERR_ALLOC (-7)      /* out of host memory (std::bad_alloc caught at the boundary) */
+#define CUADMM_ERR_INTERNAL (-8)   /* a C++ exception other than bad_alloc reached the boundary  */
 
 const char* cuadmm_last_error(void);
 const char* cuadmm_version(void);
@@ -172,6 +174,11 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
  *   L11 sweeps on the host, L21 products and the tail on the device),
  *   [7] size of the GPU tail of the A A^T factor. */
 int cuadmm_get_counters(const cuadmm_solver* s, double out8[8]);
+/* The in-process group a handle leads after cuadmm_duo_init(device_num_requested = N) from one process (reference
+ * src/duo_solver.cu:487-577): [0] engines in the group (1: no group), [1] exchange of its all-reduce -- 1 = device side (each
+ * rank's kernel adds the N staging buffers out of its peers' memory: one shared device, or peer access over xGMI as
+ * src/utils/check_gpus.cu:29-43), 0 = host-staged fallback --, [2] distinct devices, [3] all-reduces so far. */
+int cuadmm_get_group_info(const cuadmm_solver* s, double out4[4]);
 
 /* ------------------------------------------------------------------------------------ */
 /* TXT problem loader: Problem::from_txt (reference src/problem.cu:11-83, src/utils/io.cu). */
@@ -263,6 +270,7 @@ int cuadmm_aat_forest(cuadmm_aat* f, int* n_trees, int* max_cols, const int** tr
 int cuadmm_aat_tail_schur(const cuadmm_aat* f, const int64_t** row_ptr, const int** col, const double** val);
 void cuadmm_aat_tail_schur_release(cuadmm_aat* f);
 int cuadmm_aat_tail_dense(const cuadmm_aat* f, int k, double* L22, int64_t ld, double* D2);
+/* (the leading sweeps of ONE factor are single-caller: they share per-factor scratch; different factors are independent) */
 int cuadmm_aat_solve_leading_forward(const cuadmm_aat* f, int k, double* x);
 int cuadmm_aat_solve_leading_backward(const cuadmm_aat* f, int k, double* x);
 /* The same sweeps restricted to L11 (rows and columns < m-k) of a SPLIT factor whose L21 the engine keeps on the GPU (hybrid solve:

@@ -214,6 +214,51 @@ def test_duo_solver_n_devices_from_one_process(name, sw, problem_dirs):
                                                      a.At_nnz, a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
 
 
+def _duo_pendulum(options):
+    a = problem_to_amd(load_npz_problem("pendulum_N=80"))
+    s = cuadmm_amd.SDPSolver(verbose=False, options=dict({"duo_share_device": 1}, **options))
+    s.duo_init(True, 2, 15, 30, a.vec_len, a.con_num, a.At_csc_col_ptrs, a.At_csc_row_ids, a.At_csc_vals, a.At_nnz,
+               a.b_indices, a.b_vals, a.b_nnz, a.C_indices, a.C_vals, a.C_nnz, a.blk_vals, a.mat_num, sig=1.0)
+    return s
+
+
+def test_duo_group_exchanges_through_device_memory_by_default():
+    """The group's all-reduce: by default each rank's kernel adds the ranks' device staging buffers in rank order (peer reads --
+    one shared device here, xGMI peers on a node: the reference's P2P copies, check_gpus.cu:29-43, duo_solver.cu:598-606); option
+    duo_exchange = 0 forces the host-staged fallback.  Both sum in rank order: the trajectories are IDENTICAL bit for bit."""
+    runs = {}
+    for ex in (-1, 0, 1):
+        s = _duo_pendulum({"duo_exchange": ex})
+        s.solve(25, 0.0, 0, 50, 100, 11000, 1.05)
+        gi = s.group_info()
+        assert gi["engines"] == 2 and gi["distinct_devices"] == 1 and gi["allreduces"] > 25
+        assert gi["exchange"] == ("host" if ex == 0 else "device")
+        runs[ex] = [s.info_arr(n).copy() for n in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")] + [s.X, s.y, s.S]
+    for ex in (0, 1):
+        for va, vb in zip(runs[ex], runs[-1]):
+            assert np.array_equal(va, vb)
+    assert cuadmm_amd.SDPSolver(verbose=False).group_info()["engines"] == 1
+
+
+@pytest.mark.parametrize("exchange", [0, 1])
+@pytest.mark.parametrize("inject", [1 * 1000000 + 7, 7, -(1 * 1000000 + 7)])
+def test_duo_group_rank_failure_does_not_hang(exchange, inject):
+    """A rank of the in-process group fails in the middle of a solve (test hook duo_inject_fail: rank r's k-th collective returns an
+    error -- or, negative, throws std::bad_alloc on the rank's host thread): every other rank leaves its barrier with an error, the
+    threads are joined, solve() returns a code instead of hanging or calling std::terminate, and the handle can still be destroyed.
+    Rank 1 (a child thread) and rank 0 (the caller's thread) both."""
+    import time
+    s = _duo_pendulum({"duo_exchange": exchange, "duo_inject_fail": inject})
+    t0 = time.time()
+    with pytest.raises(cuadmm_amd.CuadmmError) as ei:
+        s.solve(50, 0.0, 0, 50, 100, 11000, 1.05)
+    assert time.time() - t0 < 60.0
+    assert "duo group, rank" in str(ei.value)
+    if inject < 0:
+        assert "bad_alloc" in str(ei.value)
+    del s
+
+
 def test_device_side_y_solve_matches_the_host_solve(monkeypatch):
     """Block-diagonal A A^T (every constraint touches one block): the elimination forest of the factor is one small tree per
     block and the y-solve runs on the device, one thread per tree (forest_solve_kernel), with y, A X, A(S-C) and b resident

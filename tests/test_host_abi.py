@@ -529,3 +529,44 @@ def test_host_pool_survives_two_concurrent_solvers():
     env = dict(os.environ, CUADMM_HOST_THREADS="6", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name,m,nnzL,tail_k,perm_sha", [
+    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c"),
+    ("pendulum_N=80", 112028, 929430, 10496, "53e3efdb51729949"),
+    ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3"),
+    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a"),
+    ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176"),
+])
+def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha):
+    """The fill-reducing ordering (own minimum degree with the near-clique exit -- confirmed by an EXACT degree count since round 5 --
+    and the dense-row rule) and the tail planner decide nnz(L), the size of the GPU tail and with them every timing and tolerance
+    stated for these inputs: a change to either must show up here first (the job of CHOLMOD's analyze in the reference,
+    include/cuadmm/cholesky_cpu.h:62-140)."""
+    import hashlib
+    import scipy.sparse.linalg as spla
+    from oracle import cuadmm_oracle as orc
+    from tests.conftest import load_npz_problem
+    p = load_npz_problem(name)
+    real = orc.spla.factorized
+    orc.spla.factorized = lambda M: None
+    try:
+        s = orc.OracleSolver().init_problem(p)
+    finally:
+        orc.spla.factorized = real
+    At = s.At_csr
+    L, mm = At.shape
+    assert mm == m
+    rp, ci, v = (np.ascontiguousarray(At.indptr, np.int32), np.ascontiguousarray(At.indices, np.int32), np.ascontiguousarray(At.data))
+    h = C.c_void_p()
+    lib.cuadmm_aat_factor_nnz.restype = C.c_int64
+    check(lib.cuadmm_aat_create_split(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                      1e-15, 32768, C.byref(h)))
+    try:
+        perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)).copy()
+        assert sorted(perm.tolist()) == list(range(m))
+        assert int(lib.cuadmm_aat_factor_nnz(h)) == nnzL
+        assert int(lib.cuadmm_aat_tail_k(h)) == tail_k
+        assert hashlib.sha256(perm.tobytes()).hexdigest()[:16] == perm_sha
+    finally:
+        lib.cuadmm_aat_free(h)
