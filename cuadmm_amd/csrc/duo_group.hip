@@ -214,13 +214,14 @@ void duo_group_inject(void* p, long long v) { if (p) duo_group_of(p)->inject = v
 // `fn(rank_handle)` on every rank through duo_group_run (init, solve).
 int duo_group_create(cuadmm_solver* parent, int world, int parent_device, bool share_device, int exchange,
                      const std::vector<std::pair<std::string, double>>& option_log, void** out) {
-  if (world > 16) { set_error("duo_init: at most 16 engines per group (%d requested)", world); return CUADMM_ERR_INVALID; }
+
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("duo_init: no HIP device"); return CUADMM_ERR_NO_DEVICE; }
   if (!share_device && world > ndev) {
     set_error("duo_init: device_num_requested = %d but %d device(s) are visible (option duo_share_device = 1 runs every engine on device %d)", world, ndev, parent_device);
     return CUADMM_ERR_INVALID;
   }
+  if (world > 16) { set_error("duo_init: at most 16 engines per group (%d requested)", world); return CUADMM_ERR_INVALID; }
   DuoGroup* g = new DuoGroup();
   g->world = world;
   g->child.assign((size_t)world, nullptr);

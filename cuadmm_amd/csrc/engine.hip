@@ -246,6 +246,8 @@ struct cuadmm_solver {
     int aty_post2 = 1;            // "aty_post2": the sGS second half in one pass
     int lead_stream = 0;          // "lead_stream": the leading sweeps on the streaming kernels only (no LDS-resident trees; A/B, tests)
     int tail_one_pass = 1;        // "tail_one_pass": the GPU tail applied in one pass over inv(L22) (0: two triangular GEMVs)
+    int tail_shard = 1;           // "tail_shard": world > 1, replicated solve: every rank applies 1 / world of the tail's rows, the K partial
+                                  // results are all-reduced (0: every rank applies the whole tail)
     int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
     int debug_eig = 0;            // developer aid
@@ -395,7 +397,7 @@ struct cuadmm_solver {
       prof_begin(K_TAIL);
       int rc = lead.ready ? lead.solve(out_d.p, out_d.p + (size_t)m + 2, b_d.p, isig, y_d.p, tail, st) : launch_forest_solve(forest_trees, f_tree_ptr.p, f_tree_cols.p, f_Lp.p, f_Li.p, f_Lx.p, f_D.p, out_d.p, out_d.p + (size_t)m + 2,
                                    b_d.p, isig, y_d.p, st);
-      prof_end(K_TAIL, 0.0);
+      prof_end(K_TAIL, tail.k > 0 ? tail.shard_bytes : 0.0);     // bytes of inv(L22) this rank read (1 / world of 4 K^2 when the tail is sharded)
       return rc;
     }
     // the right-hand side is formed in y_p from the pinned result buffer (A(S-C) lives at h_out[m+2..) since the last
@@ -1334,6 +1336,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "lead_debug") s->sw.lead_debug = (int)value;
   else if (k == "l21_device") s->sw.l21_device = (int)value;
   else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
+  else if (k == "tail_shard") s->sw.tail_shard = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;
   else if (s->plan.opt.set(k, value)) {}                      // "psd_*": the projection planner's switches (psd_options.h)
   else if (k == "batch_mixed") s->bt.allow_mixed = value != 0;
@@ -1506,6 +1509,14 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   }
   int rc = check_device(s->device);
   if (rc) return rc;
+  // the dense tail of the replicated y-solve: split by rows over the ranks of a sharded engine (tail_solve.h)
+  if (s->tail.k > 0) {
+    const bool shard = s->world > 1 && !s->local_mode && s->sw.tail_shard != 0;
+    s->tail.shard_rank = shard ? s->rank : 0;
+    s->tail.shard_world = shard ? s->world : 1;
+    s->tail.reduce_user = s;
+    s->tail.reduce_fn = [](void* user, double* buf, size_t count, hipStream_t) -> int { return static_cast<cuadmm_solver*>(user)->comm_allreduce(buf, count); };
+  }
   const int m = s->m;
   const long long L = s->L;
   const bool verbose = s->verbose && s->rank == 0;

@@ -109,6 +109,7 @@ __device__ __forceinline__ double lg_reduce_decide(const SignArgs& sa, int membe
     bool last;
     v.mu = v.sched.decide<true>(v.n, a, b, 0.0, last);
     red[12] = v.mu;
+    red[13] = v.sched.cm;                 // > 0: a mega-lift (sign_sched.h), coefficients -cm, 1 + cm
     if (writer) {
       sa.st[(size_t)(par ^ 1) * sa.count + member] = v;
       if (last) {
@@ -196,13 +197,15 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   const int nbt = N / TM, ntiles = nbt * (nbt + 1) / 2;
   if (ROLE == 2) {
     const double mu = lg_reduce_decide(sg, member, ntiles, bx == 0 && by == 0, red);
-    alpha = -0.5 * mu * mu * mu;
-    beta = 1.5 * mu;
+    const double cm = red[13];
+    alpha = cm > 0.0 ? -cm : -0.5 * mu * mu * mu;
+    beta = cm > 0.0 ? 1.0 + cm : 1.5 * mu;
   }
   if (ROLE == 4) {
-    const double mu = sg.st[(size_t)((sg.step & 1) ^ 1) * sg.count + member].mu;
-    alpha = -0.5 * mu * mu * mu;
-    beta = 1.5 * mu;
+    const SignDevState& v = sg.st[(size_t)((sg.step & 1) ^ 1) * sg.count + member];
+    const double mu = v.mu, cm = v.sched.cm;
+    alpha = cm > 0.0 ? -cm : -0.5 * mu * mu * mu;
+    beta = cm > 0.0 ? 1.0 + cm : 1.5 * mu;
   }
 
   lg_v4f64 acc[NTW][NTW];

@@ -388,13 +388,14 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
     } else {
       mu = sched.decide<false>(n, 0.0, 0.0, 0.0, last);
     }
-    const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
+    double alpha, beta;
+    sched.coefs(mu, alpha, beta);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = i; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[i][j][r] = alpha * z[i][j][r] + beta * f[4 * i + r][j];
+        for (int r = 0; r < 4; ++r) z[i][j][r] = fma(alpha, z[i][j][r], beta * f[4 * i + r][j]);   // one contraction, spelled out: every instantiation rounds alike
     wave_fence();                                            // the transposition scratch has been read
     swc_store_upper<NT>(S, r16, kk, z);
     wave_fence();

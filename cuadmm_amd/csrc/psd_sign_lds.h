@@ -170,10 +170,11 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
     } else {
       mu = sched.decide<false>(n, 0.0, 0.0, 0.0, last);                              // the scale of this step was fixed in advance
     }
-    const double alpha = -0.5 * mu * mu * mu, beta = 1.5 * mu;
+    double alpha, beta;
+    sched.coefs(mu, alpha, beta);
     sl_v4f64 t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = alpha * z[r] + beta * e[r];                   // T = 1.5 mu S - 0.5 mu^3 S*Y
+    for (int r = 0; r < 4; ++r) t[r] = fma(alpha, z[r], beta * e[r]);                     // T = 1.5 mu S - 0.5 mu^3 S*Y
     sl_store<NP>(S2, t, ti, tj, lane);                                               // the sub-tile and its mirror image (TRIPLE: beside S, else in place)
     __syncthreads();
     if (TRIPLE) { double* u = S; S = S2; S2 = u; }

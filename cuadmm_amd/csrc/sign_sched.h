@@ -27,6 +27,19 @@
 // ||X||_1.  Any mu in [1, 1.53] keeps [0.5, 1] invariant, so the heuristics only cost steps, never accuracy: the exit
 // tests are the rigorous part, and kCap bounds the work (the result is then what the fixed schedule would have given).
 //
+// MEGA-LIFT (round 5).  A lift step multiplies an unresolved eigenvalue by 2.295, whatever its size: a block whose spectrum has a GAP
+// -- eigenvalues of order one and a cluster at 1e-6 ... 1e-11 relative, every moment matrix of a relaxation whose iterate is numerically
+// low-rank -- spends 15 ... 30 steps carrying the cluster up.  Once g = ||S - S Y||_F is small the spectrum is SPLIT, rigorously: every
+// eigenvalue is <= gb = g (1 + 1.5 g^2) ("tiny") or within eb of 1 ("basin").  The cubic  q_c(x) = (1 + c) x - c x^3  -- the same two
+// products, other coefficients -- has q_c(1) = 1, q_c'(1) = 1 - 2 c and q_c(x) = (1 + c) x (1 - O(x^2)) near 0: it multiplies the whole
+// tiny cluster by 1 + c in ONE step and pays with the basin's error, eb -> |1 - 2 c| eb.  c is chosen so that the cluster's top lands at
+// <= kMegaTiny and the basin stays within kMegaBasin of 1; the two probe steps that follow bring both into [0.5, 1] (q(1.309 x) maps
+// [0.95, 1.05] into [0.76, 0.91] and 0.3 to 0.56).  Rounding: c (S - S Y) amplifies the products' roundoff to c eps, which is eps / G in
+// the units of the ORIGINAL matrix (G = growth so far >= 1): the perturbation every ordinary step adds, three decades below the
+// resolution.  The basin bound: eb = gb / 2 from g alone; after a plain step on a split spectrum 0.375 gb_prev^2 (what the lagged
+// variant always used) -- so when the basin is what limits c, one more plain step (needed by the terminal phase anyway) squares it.
+// Everything here is a choice of coefficients for steps the kernels run anyway; the exit tests are untouched.
+//
 // LAGGED variant (batched-GEMM path, psd_large.hip): there g2 of iterate k is only complete after the launch that
 // applies mu_k, so decisions at step k use (a_k, b_k) and g2 of iterate k-1 (plain phase: g_k <= 0.75 g_{k-1}^2).
 //
@@ -58,8 +71,26 @@ struct SignSched {
   static constexpr double kGExit = 2.3e-7;     // g at which one more plain update leaves an error <= 2e-14
   static constexpr int kLift0 = 3;
   static constexpr int kCap = 64;
+  static constexpr double kMegaTiny = 0.3;     // where a mega-lift puts the top of the tiny cluster
+  static constexpr double kMegaBasin = 0.05;   // how far from 1 it may push the basin
+  static constexpr double kMegaMin = 5.3;      // worth it from two lift steps' growth on (2.295^2)
+  static constexpr double kMegaCMax = 600.0;   // c of one mega-lift, and
+  static constexpr double kMegaCSum = 600.0;   // ... summed over the mega-lifts of one projection.  c (S - S Y) amplifies the products' roundoff to
+                                               // c eps, and the part of that noise that couples the basin to the lifted cluster ROTATES the resolved
+                                               // eigenvectors by ~c eps: an error of ~0.16 c eps ||X|| in the projection (matrix-level replica on
+                                               // low-rank + noise spectra: 3.5e-14 at sum c = 2 014; uncapped, c = 2e9 gave 4e-7 on a PSD input).
+                                               // 600 keeps it at 1e-14 ||X||, a tenth of the resolution contract; a mega-lift cleaned of the
+                                               // coupling, (I - Y)(S - S Y)(I - Y), would lift the cap for two more products (not built)
+
 
   double G = 1.0, gprev = -1.0, muprev = 1.0;
+  double cm = 0.0;                             // > 0: the step just decided is a mega-lift, S <- (1 + cm) S - cm S Y
+  double gbl = -1.0;                           // gb of the PREVIOUS iterate when the step taken from it was plain (else -1)
+  int megas = 0, waits = 0;
+  double tbk = -1.0, ebk = -1.0;               // after a mega-lift: propagated bounds of the NEXT iterate (tiny <= tbk, basin within ebk of 1)
+  double csum = 0.0;                           // sum of the mega-lifts' c so far
+  bool chain = false;                          // the next step is decided from (tbk, ebk) alone: a further mega-lift or the first probe
+  bool mega_on = true;                         // host model only: +8 on the mode switches it off (the schedule of rounds 2-4, for comparison)
   int k = 0, j = 0, fin = 0, steps = 0;
   // Warm start of the SCHEDULE (not of the iterate): consecutive ADMM iterations project nearly the same spectrum, so the
   // number of lift steps a block needed last time can serve as the length of its first lift phase now.  lift0 = hint from the
@@ -85,6 +116,7 @@ struct SignSched {
   // scale is fixed in advance: the one-wavefront kernels then skip the three wave reductions and call decide with zeros
   // (same decisions, same step counts -- a third of a step's latency on two steps out of three).
   CUADMM_SCHED_HD bool needs_stats() const {
+    if (chain) return false;
     if (steps == 0 || fin > 0 || plain) return true;
     if (k > 0 && G * kTol < 0.5) return false;
     return !(j == 0 || j == 1);
@@ -95,7 +127,30 @@ struct SignSched {
   // Returns mu of this step; `last` = this update is the final one.
   // Which statistics does the next decision read?  needs_stats(): any at all; needs_ab(): tr Y and ||Y||_F^2 as well (the first
   // step and the decision after a probe); in the plain and finishing phases only g2 is read -- one wave reduction, not three.
-  CUADMM_SCHED_HD bool needs_ab() const { return steps == 0 || (fin == 0 && !plain); }
+  CUADMM_SCHED_HD bool needs_ab() const { return steps == 0 || (fin == 0 && !plain && !chain); }
+
+  // takes a mega-lift of (at most) c_want from an iterate whose tiny part is <= tb and whose basin is within eb of 1: sets cm, the
+  // propagated bounds and whether the next step continues the chain; false when what the caps leave is not worth a step
+  CUADMM_SCHED_HD bool take_mega(int n, double c_want, double tb, double eb) {
+    double c = c_want;
+    c = c < kMegaCMax ? c : kMegaCMax;
+    c = c < kMegaCSum - csum ? c : kMegaCSum - csum;
+    if (!(1.0 + c >= kMegaMin)) return false;
+    cm = c;
+    csum += c;
+    ++megas;
+    tbk = (1.0 + c) * tb;
+    ebk = 2.14 * c * eb + c * 2.3e-16 * sqrt((double)n);
+    chain = true;                                        // the next decision reads (tbk, ebk): a further mega-lift or the first probe
+    k = 0; j = 0; waits = 0;
+    return true;
+  }
+
+  // coefficients of the step decide() returned mu for:  S <- alpha S Y + beta S
+  CUADMM_SCHED_HD void coefs(double mu, double& alpha, double& beta) const {
+    if (cm > 0.0) { alpha = -cm; beta = 1.0 + cm; }
+    else { alpha = -0.5 * mu * mu * mu; beta = 1.5 * mu; }
+  }
 
   template <bool LAG>
   CUADMM_SCHED_HD double decide(int n, double a, double b, double g2, bool& last) {
@@ -105,8 +160,10 @@ struct SignSched {
     const double g2c = g2 > 0.0 ? g2 : 0.0;
     double mu = 1.0;
     last = false;
+    cm = 0.0;
     const bool was_plain = plain;
     double g_now = -1.0;                // !LAG: sqrt(g2) once a branch below needed it (kept in gprev for the host model)
+    double gb_now = -1.0;               // the split bound of THIS iterate, where a branch formed it
     if (steps == 0) {
       if (!(b > 0.0)) { last = true; }  // zero (or non-finite) block: one harmless update
       else {
@@ -116,6 +173,12 @@ struct SignSched {
         k = (lift0 > 1 ? (lift0 < kCap ? lift0 : kCap) : 1) - 1;
         j = 0;
       }
+    } else if (chain) {
+      // right after a mega-lift: no statistics are read.  What the caps left of the allowed factor is taken now; then the probes.
+      chain = false;
+      const double f1 = kMegaTiny / tbk, f2 = 1.0 + kMegaBasin / (2.14 * ebk + 1e-300);
+      const double f = f1 < f2 ? f1 : f2;
+      if (!(G * kTol < 0.5 && tbk > kTol * G && take_mega(n, f - 1.0, tbk, ebk))) { k = 0; mu = kMuP1; j = 1; }
     } else if (fin > 0) {
       --fin;
       last = fin == 0;
@@ -147,7 +210,18 @@ struct SignSched {
         gb = 1.5 * gq;
         eb = 0.375 * gq * gq;
       }
+      gb_now = gb;
       const bool at_limit = G * kTol >= 0.5;             // whatever is still unresolved is below the resolution
+      // mega-lift: the factor the split allows (tiny cluster to kMegaTiny, basin kept within kMegaBasin of 1)
+      double f_tiny = 0.0, f_all = 0.0, ebm_used = eb;
+      if (mega_on && gb > 0.0 && !at_limit && gb > kTol * G) {
+        double ebm = eb;
+        if (!LAG && gbl >= 0.0) { const double e2 = 0.4 * gbl * gbl; ebm = e2 < ebm ? e2 : ebm; }   // 1.5 e^2 + 0.5 e^3, e <= gbl / 2 <= 0.16, either side of 1
+        f_tiny = kMegaTiny / gb;
+        const double f_basin = 1.0 + kMegaBasin / (2.14 * ebm + 1e-300);
+        f_all = f_tiny < f_basin ? f_tiny : f_basin;
+        ebm_used = ebm;
+      }
       if (at_limit || (gb >= 0.0 && gb <= kTol * G)) {
         // finish the basin and stop: plain steps until the error bound is <= 1.15e-7, then the last update
         int c;
@@ -172,8 +246,18 @@ struct SignSched {
         if (frac > 0.05 || frac < -0.05 || j >= 6) {     // mid-range eigenvalues (s > 0.16) present: keep lifting
           k = 2; mu = kMu; --k; j = 0;
         } else if (exact || v > 2.0 * noise) {
-          k = burst_len(exact ? gb : sqrt(v + 2.0 * noise));
-          mu = kMu; --k; j = 0;
+          // something unresolved is VISIBLE (g alone cannot tell a tiny cluster from the basin's own error: exactly rank-deficient
+          // blocks must keep taking plain steps until gb <= tol G): the whole cluster in one step where the split allows it
+          const double s_hat = sqrt(v + 2.0 * noise);    // what the cluster weighs by the statistics of THIS iterate
+          const bool stale = gb > 4.0 * s_hat && waits < 3;   // the bound still carries the basin's error (the lagged g: a step old)
+          if (f_all >= kMegaMin && !stale && take_mega(n, f_all - 1.0, gb, ebm_used)) {
+            // (the probes that follow the chain restore [0.5, 1])
+          } else if (f_tiny >= kMegaMin || (mega_on && stale && gb >= 0.0 && kMegaTiny / s_hat >= kMegaMin)) {
+            ++j; ++waits;                                // a plain step squares the basin's share of the bound (and is not wasted)
+          } else {
+            k = burst_len(exact ? gb : sqrt(v + 2.0 * noise));
+            mu = kMu; --k; j = 0;
+          }
         } else {
           ++j;                                           // below the probe's noise floor: one more plain step
         }
@@ -183,7 +267,8 @@ struct SignSched {
     plain_prev = was_plain;
     muprev = mu;
     if (!LAG) gprev = g_now;              // only where it was formed; the one-wavefront kernels never read it
-    G *= 1.5 * mu;
+    gbl = (mu == 1.0 && cm == 0.0) ? gb_now : -1.0;
+    G *= cm > 0.0 ? 1.0 + cm : 1.5 * mu;
     ++steps;
     if (steps >= kCap) last = true;
     return mu;
@@ -197,6 +282,7 @@ struct SignSched {
 // statistics passed on every step (the reference for the claim that skipping them changes nothing)
 inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int lift0 = 0, int* lifts_out = nullptr) {
   SignSched st;
+  if (lag & 8) { st.mega_on = false; lag &= 7; }
   if (lift0 > 0) st.lift0 = lift0;
   double orig_max_err = 0.0;
   double* s0 = new double[n > 0 ? n : 1];
@@ -221,7 +307,9 @@ inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int l
       mu = st.needs_stats() ? st.decide<false>(n, a, b, g2, last) : st.decide<false>(n, 0.0, 0.0, 0.0, last);
     }
     g2_prev = g2; a_prev = a; b_prev = b;
-    for (int i = 0; i < n; ++i) s[i] = 1.5 * mu * s[i] - 0.5 * mu * mu * mu * s[i] * s[i] * s[i];
+    double al, be;
+    st.coefs(mu, al, be);
+    for (int i = 0; i < n; ++i) s[i] = be * s[i] + al * s[i] * s[i] * s[i];
   }
   for (int i = 0; i < n; ++i) {
     const double e = s0[i] * fabs(1.0 - s[i]) * 0.5;

@@ -18,6 +18,15 @@ struct TailSolve {
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   int apply(hipStream_t st);   // vin <- W^T diag(dinv) W vin
+  // Rows of W split over the ranks of a sharded engine (reference's device split: src/duo_solver.cu:269-295): rank p applies the rows
+  // of its share of the triangle (equal numbers of entries) and the K partial results are summed by reduce_fn -- the engine's
+  // all-reduce, on the stream --, so a rank reads 1 / world of the 4 K^2 bytes per solve.  world = 1: the whole triangle, no reduction.
+  int shard_rank = 0, shard_world = 1;
+  int (*reduce_fn)(void* user, double* buf, size_t count, hipStream_t st) = nullptr;
+  void* reduce_user = nullptr;
+  int shard_rows = 0;          // rows this rank applied in the last solve
+  double shard_bytes = 0;      // bytes of W it read for them
+  int apply_rows(hipStream_t st, int r_begin, int r_end);
   double build_s = 0, factor_s = 0;
   int build(const double* L22, const double* D2, int k, hipStream_t st);                                        // host factor
   int build_from_schur(const long long* row_ptr, const int* col, const double* val, int k, hipStream_t st);    // GPU factor

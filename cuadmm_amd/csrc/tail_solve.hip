@@ -128,15 +128,17 @@ __global__ __launch_bounds__(256) void ts_transpose_kernel(const double* __restr
 }
 
 // out[i] = scale[i] * sum_{c in range(i)} Mx[i][c] * in[c];  LOWER: c <= i,  else c >= i.  One wavefront per row.
+// Sharded solve (ranks split the rows of W, TailSolve::shard_*): the LOWER pass leaves 0 in the rows r = K - 1 - i outside [r_begin, r_end).
 template <bool LOWER>
 __global__ __launch_bounds__(256) void ts_tri_gemv_kernel(const double* __restrict__ Mx, long long ld, int K,
                                                           const double* __restrict__ in, const double* __restrict__ scale,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int r_begin = 0, int r_end = 1 << 30) {
   const int lane = (int)threadIdx.x & 63;
   // long rows first (they decide the tail of the launch)
   const int slot = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
   if (slot >= K) return;
   const int i = LOWER ? K - 1 - slot : slot;
+  if (LOWER && (slot < r_begin || slot >= r_end)) { if (lane == 0) out[i] = 0.0; return; }
   const int lo = LOWER ? 0 : (i & ~1), hi = LOWER ? i + 1 : K;   // even start keeps the double2 loads aligned
   const double* row = Mx + (size_t)i * ld;
   double s = 0.0;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void ts_tri_gemv_kernel(const double* __restri
 // in workgroup order by ts_onepass_reduce_kernel.  Deterministic; half the HBM traffic.
 template <int NC, int RB>
 __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
-                                                          const double* __restrict__ dinv, double* __restrict__ P) {
+                                                          const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end) {
   extern __shared__ double ts_zs[];          // z, K doubles (zero beyond K up to 1024 NC)
   __shared__ double red[2][RB][16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,11 +179,12 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
   const double* zs = ts_zs + col0;
   const int G = (int)gridDim.x, g = (int)blockIdx.x;
   int it = 0;
-  for (int r0 = g * RB; r0 < K; r0 += G * RB, ++it) {
+  // rows r = K - 1 - i in [r_begin, r_end): the whole triangle, or this rank's share of it (TailSolve::shard_*)
+  for (int r0 = r_begin + g * RB; r0 < r_end; r0 += G * RB, ++it) {
     double w[RB][NC], part[RB];
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
-      const int i = K - 1 - (r0 + q);            // < 0: no such row (all-zero contribution)
+      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;            // < 0: no such row (all-zero contribution)
       const double* row = W + (size_t)(i < 0 ? 0 : i) * ld + col0;
       const int lim = i - col0;                  // slot c is inside the triangle iff 64 c <= lim
 #pragma unroll
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
-      const int i = K - 1 - (r0 + q);
+      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;
       const double* rr = red[it & 1][q];
       const double u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
                        (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
@@ -235,7 +238,7 @@ __global__ void ts_fill_u64_kernel(unsigned long long* p, size_t n, unsigned lon
 template <int NC, int Q, int RB, int OCC = 8>
 __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                                    const double* __restrict__ dinv, double* __restrict__ P,
-                                                                   unsigned long long* __restrict__ part, int* __restrict__ fail) {
+                                                                   unsigned long long* __restrict__ part, int* __restrict__ fail, int r_begin, int r_end) {
   extern __shared__ double ts_zs[];          // z of this thread's own columns: word (c * 1024 + tid); nobody else reads it
   __shared__ double red[2][RB][16];
   __shared__ double ush[2][RB];
@@ -258,12 +261,12 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
 #pragma unroll
   for (int c = 0; c < NC; ++c) xa[c] = 0.0;
   int it = 0;
-  for (int r0 = group * RB; r0 < K; r0 += G * RB, ++it) {
+  for (int r0 = r_begin + group * RB; r0 < r_end; r0 += G * RB, ++it) {
     double w[RB][NC];
     const int seg0 = (wave_u * Q + member) * (64 * NC);   // this wavefront's segment: uniform
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
-      const int i = K - 1 - (r0 + q);            // < 0: no such row (all-zero contribution)
+      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;            // < 0: no such row (all-zero contribution)
       const double* row = W + (size_t)(i < 0 ? 0 : i) * ld + col0;
       // a wavefront's segment is inside the triangle (plain loads), outside it (nothing to read) or crosses the diagonal (one segment
       // per row: per-slot predicates): a scalar branch, so the common case carries no exec-mask juggling
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
       }
     }
     // lane q of the first wavefront exchanges row q: its pivot is in flight across the barrier
-    const int iq = K - 1 - (r0 + (tid < RB ? tid : 0));
+    const int rq = r0 + (tid < RB ? tid : 0);
+    const int iq = rq < r_end ? K - 1 - rq : -1;
     const double dv = (tid < RB && iq >= 0) ? dinv[iq] : 0.0;
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
@@ -730,6 +734,31 @@ int TailSolve::solve_device(hipStream_t st) {
 
 // vin <- W^T diag(dinv) W vin
 int TailSolve::apply(hipStream_t st) {
+  // this rank's rows r = K - 1 - i (r = 0: the longest row): equal shares of the triangle's entries, boundaries on multiples of 8
+  int r_begin = 0, r_end = K;
+  if (shard_world > 1) {
+    auto bound = [&](int p) -> int {
+      if (p <= 0) return 0;
+      if (p >= shard_world) return K;
+      const double f = (double)p / (double)shard_world;
+      int r = (int)((double)K * (1.0 - std::sqrt(1.0 - f)));
+      r = (r + 7) / 8 * 8;
+      return r < K ? r : K;
+    };
+    r_begin = bound(shard_rank);
+    r_end = bound(shard_rank + 1);
+  }
+  shard_rows = r_end - r_begin;
+  shard_bytes = 8.0 * ((double)(r_end - r_begin) * (double)K - 0.5 * ((double)r_end * r_end - (double)r_begin * r_begin));   // entries of the rows read
+  { int rc_ = apply_rows(st, r_begin, r_end); if (rc_) return rc_; }
+  if (shard_world > 1) {
+    if (!reduce_fn) { set_error("tail_solve: sharded over %d ranks but no reduction installed", shard_world); return CUADMM_ERR_COMM; }
+    return reduce_fn(reduce_user, vin, (size_t)K, st);      // x = sum over ranks of W_r^T D_r^-1 W_r z: identical on every rank afterwards
+  }
+  return CUADMM_OK;
+}
+
+int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
   const int nc = (K + 1023) / 1024;
   const size_t lds = sizeof(double) * 1024 * (size_t)(nc + (nc & 1));
   if (one_pass && xpart && lds <= kMaxLdsBytes - 1024 && nc <= 20) {
@@ -738,7 +767,7 @@ int TailSolve::apply(hipStream_t st) {
         CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));   // process-wide per kernel: the maximum
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, (long long)K, K, vin, dinv, xpart);
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, (long long)K, K, vin, dinv, xpart, r_begin, r_end);
       return CUADMM_OK;
     };
     int rc;
@@ -767,15 +796,15 @@ int TailSolve::apply(hipStream_t st) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
     auto launch = [&](auto kern) -> int {
       if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail);
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
       return CUADMM_OK;
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, G, vin, part, Q);
   } else {
-    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid);
-    hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin);
+    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid, r_begin, r_end);
+    hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin, 0, 1 << 30);
   }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;

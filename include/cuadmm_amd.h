@@ -367,7 +367,7 @@ int cuadmm_op_psd_project_steps(const double* Xb, double* Xproj, const int* blk_
  * take on that spectrum and, in *max_err_out, max_i s_i(0) |1 - s_i| / 2 (projection error relative to ||X||_1).
  * lagged: 0 = the one-wavefront / one-workgroup kernels (decisions from the current iterate), 1 = the batched-GEMM path
  * (||S - S Y|| one step old), 2 = every statistic one step old (measured and rejected), 3 = as 0 with the statistics passed
- * on every step (reference for the steps on which the kernels skip them). */
+ * on every step (reference for the steps on which the kernels skip them); + 8: without the mega-lift of round 5 (sign_sched.h). */
 int cuadmm_sign_sched_simulate(double* s, int n, int lagged, double* max_err_out);
 /* same, with the schedule's warm start across ADMM iterations: lift0 = lift steps the previous projection of the block needed
  * (0: none), *lifts_out = the hint this run leaves */

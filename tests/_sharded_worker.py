@@ -19,7 +19,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 lib = cuadmm_amd.load()
 coupled = sys.argv[2] == "coupled"
-moment = sys.argv[2] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a", "PushBox_N=30_MOMENT", "PushBox_N=30_MOMENT:hybrid")
+moment = sys.argv[2].partition(":")[0] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a", "PushBox_N=30_MOMENT")
 rng = np.random.default_rng(2)
 blk = list(np.array([32] * 20 + [7] * 15 + [15] * 11 + [40, 3, 28])[rng.permutation(49)])
 p = make_synthetic(blk, cons_per_block=3, seed=11)
@@ -54,13 +54,15 @@ if moment:
     name, _, variant = sys.argv[2].partition(":")
     prob = problem_to_amd(load_npz_problem(name))
     # ":hybrid": the host-optimal tail with L21 on the device and the L11 sweeps on the host (lead_solve.h), forced -- on every rank
-    opts = {"tail_k": 10240, "l21_device": 2} if variant == "hybrid" else None
-    s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world, options=opts)
+    opts = {"tail_k": 10240, "l21_device": 2} if variant == "hybrid" else ({"tail_shard": 0} if variant == "noshard" else None)
+    s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world, options=opts, profile=1)
     s.set_allreduce(hook)
     s.init_problem(prob)
     s.solve(60, 0.0, 0, 50, 100, 11000, 1.05)
     if rank == 0:
+        pr = s.profile()
         np.savez(sys.argv[1], counters=np.array(list(s.counters().values())), shard=np.array(s.shard()),
+                 tail_bytes=pr["tail_solve"]["bytes_per_launch"], allreduce_launches=pr["allreduce"]["launches"],
                  **{nm: s.info_arr(nm) for nm in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")})
     dist.barrier()
     dist.destroy_process_group()

@@ -33,7 +33,8 @@ def test_two_processes_one_gpu(kind, port, tmp_path):
 
 
 @pytest.mark.parametrize("name,port", [("pendulum_N=80", 29643), ("PlanarHand_N=1_MOMENT", 29644), ("taha1a", 29645),
-                                       ("PushBox_N=30_MOMENT", 29646), ("PushBox_N=30_MOMENT:hybrid", 29647)])
+                                       ("PushBox_N=30_MOMENT", 29646), ("PushBox_N=30_MOMENT:hybrid", 29647),
+                                       ("PlanarHand_N=1_MOMENT:noshard", 29648), ("pendulum_N=80:noshard", 29649)])
 def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path):
     """BASELINE configs[4] (pendulum N = 80) and configs[0] (PlanarHand) on TWO ranks: blocks sharded by index, coupled
     constraints, the replicated y-solve with the GPU tail and the device-side leading sweeps on every rank -- against the
@@ -60,3 +61,11 @@ def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path
         dev = rel_dev(d[nm][:ref.size], ref, nm)
         assert dev <= th, (nm, dev)
     assert np.array_equal(d["sig"][:60], np.array([float(x) for x in rec["sig"]]))
+    # round 5: the dense tail of the replicated y-solve is split by rows over the ranks (tail_solve.h; the reference's device split
+    # src/duo_solver.cu:269-295): a rank reads HALF of inv(L22) per solve (equal shares of the triangle's entries) and the K partial
+    # results take one more all-reduce per solve; ":noshard" (option tail_shard = 0) is the replicated tail of rounds 2-4
+    tk = int(d["counters"][7])
+    if tk > 0 and d["counters"][6] == 1:
+        whole = 4.0 * tk * tk
+        frac = float(d["tail_bytes"]) / whole
+        assert (0.9 <= frac <= 1.15) if name.endswith(":noshard") else (0.45 <= frac <= 0.58), (tk, frac)

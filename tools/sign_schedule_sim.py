@@ -77,6 +77,36 @@ def spectra_from_oracle(problem, iters, sample_every=10):
     return out
 
 
+def report_engine(tag, samples):
+    """Step counts of the ENGINE's state machine (csrc/sign_sched.h through the C ABI's host model) on the sampled spectra: per
+    block the iterate starts at X / ||X||_F (one-wavefront kernels) -- with the mega-lift of round 5 and without it (mode + 8), in
+    the one-wavefront form (statistics of the current iterate) and the lagged form of the batched-GEMM path."""
+    import ctypes as C
+    import cuadmm_amd
+    lib = cuadmm_amd.load()
+
+    def run(spec, mode):
+        v = np.ascontiguousarray(np.abs(spec), dtype=np.float64).copy()
+        err = C.c_double()
+        return lib.cuadmm_sign_sched_simulate(v.ctypes.data_as(C.c_void_p), int(v.size), mode, C.byref(err)), err.value
+
+    for k, eigs, n1 in samples:
+        rows = []
+        for w in eigs:
+            for row in w:
+                nf = np.sqrt(np.sum(row * row))
+                if nf == 0:
+                    continue
+                sp = row / nf
+                rows.append((len(row), run(sp, 8)[0], run(sp, 0)[0], run(sp, 9)[0], run(sp, 1)[0], max(run(sp, 0)[1], run(sp, 1)[1])))
+        r = np.array(rows, float)
+        big = r[:, 0] > 16
+        print("%s it %4d: %5d blocks  steps (rounds 2-4 -> mega-lift)  wave %.2f -> %.2f   lagged %.2f -> %.2f   | n > 16 (%d blocks): wave %.2f -> %.2f, "
+              "lagged %.2f -> %.2f   max err %.1e" % (tag, k, len(r), r[:, 1].mean(), r[:, 2].mean(), r[:, 3].mean(), r[:, 4].mean(), int(big.sum()),
+                                                   r[big, 1].mean() if big.any() else 0, r[big, 2].mean() if big.any() else 0,
+                                                   r[big, 3].mean() if big.any() else 0, r[big, 4].mean() if big.any() else 0, r[:, 5].max()))
+
+
 def report(tag, samples, **kw):
     for k, eigs, n1 in samples:
         st, er = [], []
@@ -95,7 +125,9 @@ if __name__ == "__main__":
         from cuadmm_amd.synthetic import config_c2
         nb = int(sys.argv[2]) if len(sys.argv) > 2 else 200
         p = config_c2(nb)
-        report("c2", spectra_from_oracle(p, 150, 15))
+        samp = spectra_from_oracle(p, 150, 15)
+        report("c2", samp)
+        report_engine("c2", samp)
     elif what == "c4":
         from cuadmm_amd.synthetic import config_c4
         p = config_c4(600)
@@ -103,7 +135,9 @@ if __name__ == "__main__":
     elif what == "c3":
         from cuadmm_amd.synthetic import config_c3
         p = config_c3(int(sys.argv[2]) if len(sys.argv) > 2 else 400)
-        report("c3", spectra_from_oracle(p, 100, 10))
+        samp = spectra_from_oracle(p, 100, 10)
+        report("c3", samp)
+        report_engine("c3", samp)
     elif what == "trace":
         rng = np.random.default_rng(0)
         lam = rng.standard_normal(32)
@@ -112,4 +146,7 @@ if __name__ == "__main__":
     else:
         from tests.conftest import load_npz_problem as load_golden_problem
         p = load_golden_problem(what)
-        report(what, spectra_from_oracle(p, 60, 10))
+        iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+        samp = spectra_from_oracle(p, iters, max(1, iters // 6))
+        report(what, samp)
+        report_engine(what, samp)

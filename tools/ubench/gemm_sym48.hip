@@ -151,6 +151,108 @@ __global__ __launch_bounds__(256) void gemm_sym_glds_kernel(int N, const double*
   for (int r = 0; r < 4; ++r) C[(size_t)(row0 + wy * 16 + kk + 4 * r) * N + col0 + wx * 16 + r16] = acc[r];
 }
 
+// Round 5: the same 32 x 32 tiling with LDS-DMA as the guide prescribes it for a DMA that has to survive a barrier
+// (cdna_hip_programming.md, "Pipelining across barriers"): THREE LDS buffers, raw s_barrier + lgkmcnt(0) only (a __syncthreads()
+// fence waits vmcnt(0) and drains the DMA queue), counted vmcnt so that k-tile t + 2 stays in flight while t is multiplied:
+//   s_waitcnt vmcnt(NPT) -> tile t has landed, tile t + 1 stays in flight across the barrier ; s_barrier ; issue(t + 2) ; compute(t)
+// (NPT = DMA instructions per thread and k-tile = 4).  PERSIST: workgroups take tiles from an atomic counter (longest-first order
+// is the tile order itself: all tiles are equal), so a workgroup slot that finishes early takes the next tile instead of idling
+// through the 35 %-full second round of a static grid.
+template <bool PERSIST>
+__global__ __launch_bounds__(256) void gemm_sym_glds3_kernel(int N, const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int* counter, int ntile_slots) {
+  constexpr int TM = 32, BK = 32, NBUF = 3;
+  __shared__ double smem[NBUF * 2 * BK * TM];              // (A | B) x 3: 48 KB -> three workgroups per CU
+  __shared__ int next_tile;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int r16 = lane & 15, kk = lane >> 4;
+  const int kr_in = lane >> 4, p16 = lane & 15;
+  const int nkt = N / BK;
+  int tile_x = (int)blockIdx.x;
+  for (;;) {
+    if (PERSIST) {
+      if (tid == 0) next_tile = atomicAdd(counter, 1);
+      __syncthreads();
+      tile_x = next_tile;
+      __syncthreads();
+      if (tile_x >= ntile_slots) return;
+    }
+    int bx, by;
+    {
+      const int grid_x = ntile_slots;
+      const int per_xcd = grid_x / 8;
+      const int L = (tile_x % 8) * per_xcd + tile_x / 8;
+      int sbx, sby;
+      tri_decode(L / 64, sbx, sby);
+      by = sby * 8 + (L % 64) / 8;
+      bx = sbx * 8 + (L % 64) % 8;
+    }
+    if (!(bx < by || bx >= N / TM)) {
+      const int row0 = by * TM, col0 = bx * TM;
+      v4f64 acc = {0, 0, 0, 0};
+      auto issue = [&](int k0, int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = 2 * wave + q, kr = 4 * c + kr_in;
+          const int col = (2 * p16) ^ (16 * (kr & 1));
+          const double* ga = A + (size_t)(k0 + kr) * N + row0 + col;
+          const double* gb = B + (size_t)(k0 + kr) * N + col0 + col;
+          double* la = smem + buf * 2 * BK * TM + c * 128;
+          double* lb = smem + buf * 2 * BK * TM + BK * TM + c * 128;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga, (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb, (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
+        }
+      };
+      issue(0, 0);
+      issue(BK, 1);
+      for (int kt = 0; kt < nkt; ++kt) {
+        // this wavefront's part of tile kt has landed; tile kt + 1 (4 DMAs) stays in flight ACROSS the barrier
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // tile kt complete; everybody is done reading tile kt - 1 ...
+        if (kt + 2 < nkt) issue((kt + 2) * BK, (kt + 2) % NBUF); // ... whose buffer takes tile kt + 2
+        const double* As = smem + (kt % NBUF) * 2 * BK * TM;
+        const double* Bs = As + BK * TM;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 4) {
+          const int sw = 16 * ((ks + kk) & 1);
+          const double af = As[(ks + kk) * TM + ((wy * 16 + r16) ^ sw)];
+          const double bf = Bs[(ks + kk) * TM + ((wx * 16 + r16) ^ sw)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fragment reads of tile kt are done before this wavefront signals barrier kt + 1
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C[(size_t)(row0 + wy * 16 + kk + 4 * r) * N + col0 + wx * 16 + r16] = acc[r];
+    }
+    if (!PERSIST) return;
+  }
+}
+
+template <bool PERSIST>
+static void run_glds3(int N, const double* A, const double* B, double* C) {
+  const int nb = N / 32, sb = (nb + 7) / 8, tiles = sb * (sb + 1) / 2 * 64;
+  int* counter; hipMalloc(&counter, sizeof(int));
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  const int grid = PERSIST ? p.multiProcessorCount * 3 : tiles;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    for (int q = 0; q < 10; ++q) {
+      if (PERSIST) hipMemsetAsync(counter, 0, sizeof(int), 0);
+      hipLaunchKernelGGL(gemm_sym_glds3_kernel<PERSIST>, dim3(grid), dim3(256), 0, 0, N, A, B, C, counter, tiles);
+    }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double flops = 2.0 * N * 32.0 * 32.0 * (nb * (nb + 1) / 2);
+  printf("  N = %4d  %-34s %5d tiles: %7.1f us per product, %5.1f TFLOP/s (upper-triangle tiles)\n", N,
+         PERSIST ? "32 x 32, LDS-DMA x3, raw barrier, persistent" : "32 x 32, LDS-DMA x3, raw barrier", nb * (nb + 1) / 2, best * 100.0, flops / (best * 1e-4) / 1e12);
+  hipFree(counter);
+}
+
 static void run_glds(int N, const double* A, const double* B, double* C) {
   const int nb = N / 32, sb = (nb + 7) / 8, tiles = sb * (sb + 1) / 2 * 64;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -190,9 +292,19 @@ int main() {
   for (size_t i = 0; i < h.size(); ++i) h[i] = (double)((i * 2654435761u) % 1000) * 1e-3 - 0.5;
   hipMemcpy(A, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+  std::vector<double> cref((size_t)NMAX * NMAX), cgot((size_t)NMAX * NMAX);
+  auto compare = [&](int N, const char* what) {          // upper-triangle tiles against the shipped kernel's result, bit for bit (same k order)
+    hipMemcpy(cgot.data(), C, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int i = 0; i < N; ++i)
+      for (int j = (i / 32) * 32; j < N; ++j) { const double d = cgot[(size_t)i * N + j] - cref[(size_t)i * N + j]; worst = d > worst ? d : (-d > worst ? -d : worst); }
+    printf("        %s vs shipped: max |difference| %.3e\n", what, worst);
+  };
   for (int N : {2016, 2112}) {
-    if (N % 32 == 0) run<32, 2, 2, 32>("32 x 32, 4 waves (shipped)", N, A, B, C);
+    if (N % 32 == 0) { run<32, 2, 2, 32>("32 x 32, 4 waves (shipped)", N, A, B, C); hipMemcpy(cref.data(), C, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost); }
     if (N % 32 == 0) run_glds(N, A, B, C);
+    if (N % 32 == 0) { hipMemset(C, 0, sizeof(double) * (size_t)N * N); run_glds3<false>(N, A, B, C); compare(N, "LDS-DMA x3"); }
+    if (N % 32 == 0) { hipMemset(C, 0, sizeof(double) * (size_t)N * N); run_glds3<true>(N, A, B, C); compare(N, "LDS-DMA x3 persistent"); }
     if (N % 48 == 0) run<48, 3, 1, 32>("48 x 48, 3 waves of 16 x 48", N, A, B, C);
     if (N % 48 == 0) run<48, 1, 3, 32>("48 x 48, 3 waves of 48 x 16", N, A, B, C);
     if (N % 64 == 0) run<64, 2, 2, 16>("64 x 64, 4 waves of 32 x 32", N, A, B, C);
