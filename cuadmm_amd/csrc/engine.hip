@@ -2084,6 +2084,10 @@ int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, d
   TailSolve t;
   int rc = t.build(L22_host, D2_host, k, nullptr);
   for (int r = 0; r < nrhs && !rc; ++r) rc = t.solve(z2_host + (size_t)r * k, nullptr);
+  if (!rc) {
+    const int lost = t.fail_count(nullptr);
+    if (lost != 0) { set_error("tail_solve: %d row exchanges lost (workgroups of a row not co-resident)", lost); return CUADMM_ERR_FACTOR; }
+  }
   return rc;
 }
 
