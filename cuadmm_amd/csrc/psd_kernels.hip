@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   const PsdDesc d = a.desc[first + m];
   const int id = d.id;
   const long long off = d.off;
-  psd_sign_wave_body<NT, FUSED>(a.in + off, a.out + off, d.n, a.info, swt_smem, a.steps ? a.steps + id : nullptr,
+  psd_sign_wave_body<NT, FUSED, !(NT == 1 && OCC == 8)>(a.in + off, a.out + off, d.n, a.info, swt_smem, a.steps ? a.steps + id : nullptr,
                                 a.hint ? a.hint + id : nullptr, a.dbg ? a.dbg + 10 * (long long)m : nullptr, fz, off, d.slot, id);
 }
 
@@ -311,8 +311,19 @@ static int launch_sign_wave(const PsdArgs& a, int first, int count, hipStream_t 
       hipLaunchKernelGGL((psd_sign_closed_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, ca);
     }
   }
-  else if (fz) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count);
-  else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count);
+  else {
+    // n <= 16 at eight wavefronts per SIMD is a 64-register kernel: with the mega-lift's state it spills (18 VGPRs to scratch).  Eight
+    // per SIMD only matter when the class fills the chip; a moment relaxation's few hundred blocks run the 128-register instantiation.
+    constexpr int OCC_SMALL = (NT == 1 && OCC == 8) ? 4 : OCC;
+    const bool small_class = OCC_SMALL != OCC && count <= 4096;
+    if (fz) {
+      if (small_class) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC_SMALL, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count);
+      else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, true>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, *fz, first, count);
+    } else {
+      if (small_class) hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC_SMALL, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count);
+      else hipLaunchKernelGGL((psd_sign_wave_kernel<NT, OCC, false>), dim3(count), dim3(64), SignWaveT<NT>::LDS_BYTES, st, a, SignFuse{}, first, count);
+    }
+  }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }

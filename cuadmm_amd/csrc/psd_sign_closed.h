@@ -317,7 +317,7 @@ __device__ __forceinline__ void psd_sign_closed_body(const ClosedArgs& fz, int n
   const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);   // NaN propagates (flagged at the store)
   wave_fence();
   double f[4 * NT][NT];
-  SignSched sched;
+  SignSchedPlain sched;                          // closed blocks = block-diagonal synthetic problems: no gap in their spectra, no mega-lift (sign_sched.h)
   if (hint) {
     int h = __builtin_amdgcn_readfirstlane(*hint);
     // the hint ages by one lift every 16th iteration, staggered over the blocks: a function of the iteration index alone, so one

@@ -155,7 +155,9 @@ __device__ __forceinline__ void swt_store_mirrored(double* __restrict__ M, int r
 // FUSED: `in` / `out` are unused; fz carries the vectors, off = svec offset of the block, slot = its partial-sum slot,
 // id = its index in the plan (local constraint rows), poff = offset of this iteration's partial arrays (several iterations
 // per launch: SignFuse::iters)
-template <int NT, bool FUSED>
+// MEGA: the schedule with the mega-lift (sign_sched.h) -- everywhere except the 64-register instantiation (n <= 16 at eight wavefronts
+// per SIMD: a class that fills the chip), whose budget its state does not fit
+template <int NT, bool FUSED, bool MEGA = true>
 __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in, double* __restrict__ out, int n, int* fail, double* S,
                                                    int* steps_out, int* hint, long long* dbg, const SignFuse& fz, long long off, int slot, int id,
                                                    long long poff = 0) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
   const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);   // NaN propagates (flagged at the store)
   wave_fence();
   double f[4 * NT][NT];
-  SignSched sched;
+  SignSchedT<MEGA> sched;
   if (hint) { const int h = __builtin_amdgcn_readfirstlane(*hint); if (h > 0) sched.lift0 = h; }
   bool last = false;
   const long long c1 = dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -289,9 +291,9 @@ __device__ __forceinline__ void psd_sign_wave_body(const double* __restrict__ in
             pg += (i == j ? 1.0 : 2.0) * (d * d);
           }
       const double tg = wave_sum(pg);
-      mu = sched.decide<false>(n, ta, tb, tg, last);
+      mu = sched.template decide<false>(n, ta, tb, tg, last);
     } else {
-      mu = sched.decide<false>(n, 0.0, 0.0, 0.0, last);    // a branch that does not read them
+      mu = sched.template decide<false>(n, 0.0, 0.0, 0.0, last);    // a branch that does not read them
     }
     double alpha, beta;
     sched.coefs(mu, alpha, beta);

@@ -62,7 +62,11 @@
 
 namespace cuadmm {
 
-struct SignSched {
+// MEGA = false: the state machine of rounds 2-4, no mega-lift, none of its state (the closed-block kernels of the block-diagonal
+// synthetic configurations: their spectra have no gap to jump, and at that kernel's register budget the extra scalars were spills --
+// 23 instead of 13 SGPRs in VGPR lanes, scratch traffic in the iteration: C2 lost 2 % before this switch existed).
+template <bool MEGA>
+struct SignSchedT {
   static constexpr double kMu = 1.53;          // p(1.53) = 0.5
   static constexpr double kSlope = 1.5 * 1.53; // growth of a tiny eigenvalue per lift step
   static constexpr double kMuP1 = 1.309;       // sqrt(3 / (1 + l + l^2)), l = 0.5
@@ -83,7 +87,7 @@ struct SignSched {
                                                // coupling, (I - Y)(S - S Y)(I - Y), would lift the cap for two more products (not built)
 
 
-  double G = 1.0, gprev = -1.0, muprev = 1.0;
+  double G = 1.0, gprev = -1.0;
   double cm = 0.0;                             // > 0: the step just decided is a mega-lift, S <- (1 + cm) S - cm S Y
   double gbl = -1.0;                           // gb of the PREVIOUS iterate when the step taken from it was plain (else -1)
   int megas = 0, waits = 0;
@@ -116,7 +120,7 @@ struct SignSched {
   // scale is fixed in advance: the one-wavefront kernels then skip the three wave reductions and call decide with zeros
   // (same decisions, same step counts -- a third of a step's latency on two steps out of three).
   CUADMM_SCHED_HD bool needs_stats() const {
-    if (chain) return false;
+    if (MEGA && chain) return false;
     if (steps == 0 || fin > 0 || plain) return true;
     if (k > 0 && G * kTol < 0.5) return false;
     return !(j == 0 || j == 1);
@@ -127,7 +131,7 @@ struct SignSched {
   // Returns mu of this step; `last` = this update is the final one.
   // Which statistics does the next decision read?  needs_stats(): any at all; needs_ab(): tr Y and ||Y||_F^2 as well (the first
   // step and the decision after a probe); in the plain and finishing phases only g2 is read -- one wave reduction, not three.
-  CUADMM_SCHED_HD bool needs_ab() const { return steps == 0 || (fin == 0 && !plain && !chain); }
+  CUADMM_SCHED_HD bool needs_ab() const { return steps == 0 || (fin == 0 && !plain && !(MEGA && chain)); }
 
   // takes a mega-lift of (at most) c_want from an iterate whose tiny part is <= tb and whose basin is within eb of 1: sets cm, the
   // propagated bounds and whether the next step continues the chain; false when what the caps leave is not worth a step
@@ -148,7 +152,7 @@ struct SignSched {
 
   // coefficients of the step decide() returned mu for:  S <- alpha S Y + beta S
   CUADMM_SCHED_HD void coefs(double mu, double& alpha, double& beta) const {
-    if (cm > 0.0) { alpha = -cm; beta = 1.0 + cm; }
+    if (MEGA && cm > 0.0) { alpha = -cm; beta = 1.0 + cm; }
     else { alpha = -0.5 * mu * mu * mu; beta = 1.5 * mu; }
   }
 
@@ -160,7 +164,7 @@ struct SignSched {
     const double g2c = g2 > 0.0 ? g2 : 0.0;
     double mu = 1.0;
     last = false;
-    cm = 0.0;
+    if (MEGA) cm = 0.0;
     const bool was_plain = plain;
     double g_now = -1.0;                // !LAG: sqrt(g2) once a branch below needed it (kept in gprev for the host model)
     double gb_now = -1.0;               // the split bound of THIS iterate, where a branch formed it
@@ -173,7 +177,7 @@ struct SignSched {
         k = (lift0 > 1 ? (lift0 < kCap ? lift0 : kCap) : 1) - 1;
         j = 0;
       }
-    } else if (chain) {
+    } else if (MEGA && chain) {
       // right after a mega-lift: no statistics are read.  What the caps left of the allowed factor is taken now; then the probes.
       chain = false;
       const double f1 = kMegaTiny / tbk, f2 = 1.0 + kMegaBasin / (2.14 * ebk + 1e-300);
@@ -214,7 +218,7 @@ struct SignSched {
       const bool at_limit = G * kTol >= 0.5;             // whatever is still unresolved is below the resolution
       // mega-lift: the factor the split allows (tiny cluster to kMegaTiny, basin kept within kMegaBasin of 1)
       double f_tiny = 0.0, f_all = 0.0, ebm_used = eb;
-      if (mega_on && gb > 0.0 && !at_limit && gb > kTol * G) {
+      if (MEGA && mega_on && gb > 0.0 && !at_limit && gb > kTol * G) {
         double ebm = eb;
         if (!LAG && gbl >= 0.0) { const double e2 = 0.4 * gbl * gbl; ebm = e2 < ebm ? e2 : ebm; }   // 1.5 e^2 + 0.5 e^3, e <= gbl / 2 <= 0.16, either side of 1
         f_tiny = kMegaTiny / gb;
@@ -248,12 +252,18 @@ struct SignSched {
         } else if (exact || v > 2.0 * noise) {
           // something unresolved is VISIBLE (g alone cannot tell a tiny cluster from the basin's own error: exactly rank-deficient
           // blocks must keep taking plain steps until gb <= tol G): the whole cluster in one step where the split allows it
-          const double s_hat = sqrt(v + 2.0 * noise);    // what the cluster weighs by the statistics of THIS iterate
-          const bool stale = gb > 4.0 * s_hat && waits < 3;   // the bound still carries the basin's error (the lagged g: a step old)
-          if (f_all >= kMegaMin && !stale && take_mega(n, f_all - 1.0, gb, ebm_used)) {
-            // (the probes that follow the chain restore [0.5, 1])
-          } else if (f_tiny >= kMegaMin || (mega_on && stale && gb >= 0.0 && kMegaTiny / s_hat >= kMegaMin)) {
-            ++j; ++waits;                                // a plain step squares the basin's share of the bound (and is not wasted)
+          bool taken = false;
+          if (MEGA) {
+            const double s_hat = sqrt(v + 2.0 * noise);  // what the cluster weighs by the statistics of THIS iterate
+            const bool stale = gb > 4.0 * s_hat && waits < 3;   // the bound still carries the basin's error (the lagged g: a step old)
+            if (f_all >= kMegaMin && !stale && take_mega(n, f_all - 1.0, gb, ebm_used)) {
+              taken = true;                              // (the probes that follow the chain restore [0.5, 1])
+            } else if (f_tiny >= kMegaMin || (mega_on && stale && gb >= 0.0 && kMegaTiny / s_hat >= kMegaMin)) {
+              ++j; ++waits;                              // a plain step squares the basin's share of the bound (and is not wasted)
+              taken = true;
+            }
+          }
+          if (taken) {
           } else {
             k = burst_len(exact ? gb : sqrt(v + 2.0 * noise));
             mu = kMu; --k; j = 0;
@@ -265,15 +275,17 @@ struct SignSched {
     }
     if (mu >= 0.999 * kMu) ++lifts;
     plain_prev = was_plain;
-    muprev = mu;
     if (!LAG) gprev = g_now;              // only where it was formed; the one-wavefront kernels never read it
-    gbl = (mu == 1.0 && cm == 0.0) ? gb_now : -1.0;
-    G *= cm > 0.0 ? 1.0 + cm : 1.5 * mu;
+    if (MEGA) gbl = (mu == 1.0 && cm == 0.0) ? gb_now : -1.0;
+    G *= (MEGA && cm > 0.0) ? 1.0 + cm : 1.5 * mu;
     ++steps;
     if (steps >= kCap) last = true;
     return mu;
   }
 };
+
+using SignSched = SignSchedT<true>;
+using SignSchedPlain = SignSchedT<false>;
 
 // Scalar model of the iteration on a spectrum (the iteration acts on eigenvalues independently): used by the CPU tests
 // and by tools/sign_schedule_sim.py.  s[i] = |lambda_i| / ||X||_1 on entry, the sign estimates on exit.

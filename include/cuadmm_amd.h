@@ -61,6 +61,11 @@ void cuadmm_destroy(cuadmm_solver* s);
  *   "psd_steps"     1 = record how many Newton-Schulz steps the adaptive matrix-sign projection took per block
  *                   (cuadmm_get_psd_steps); set before cuadmm_init
  *   "graph"         reserved
+ *   "tail_shard"    world > 1, coupled constraints: 1 (default) = each rank applies 1 / world of the rows of the dense GPU tail of the
+ *                   replicated y-solve and the K partial results are all-reduced; 0 = every rank applies the whole tail
+ *   "duo_share_device", "duo_exchange"   the in-process group of cuadmm_duo_init(device_num_requested = N): all engines on the
+ *                   caller's device; all-reduce through device memory (1), host staging (0), chosen by peer accessibility (-1, default)
+ *   (every other switch: INTEGRATION.md section 6)
  */
 int cuadmm_set_option(cuadmm_solver* s, const char* key, double value);
 

@@ -151,3 +151,40 @@ def test_skipping_the_statistics_changes_no_decision():
         st0, e0, s0 = _run(w, 0)
         st3, e3, s3 = _run(w, 3)
         assert st0 == st3 and e0 == e3 and np.array_equal(s0, s3)
+
+
+def test_mega_lift_jumps_a_gap_and_leaves_continuous_spectra_alone():
+    """Round 5 (sign_sched.h, MEGA-LIFT): on a spectrum with a GAP -- a few eigenvalues of order one, a cluster at 1e-6 ... 1e-11 -- one
+    step with the coefficients (1 + c, -c) carries the whole cluster up (c capped at 600 in total: the roundoff it amplifies); mode + 8
+    is the schedule of rounds 2-4.  Fewer steps on gapped spectra, never more on Gaussian ones (mostly the same: no gap, no mega-lift --
+    which is why the closed-block kernels may run the plain machine), the resolution contract either way, in both forms of the machine."""
+    lib = cuadmm_amd.load()
+    rng = np.random.default_rng(17)
+
+    def run(spec, mode):
+        s = np.ascontiguousarray(np.abs(spec), dtype=np.float64).copy()
+        err = C.c_double()
+        return lib.cuadmm_sign_sched_simulate(s.ctypes.data_as(C.c_void_p), int(s.size), mode, C.byref(err)), err.value
+
+    saved = {0: 0, 1: 0}
+    same = 0
+    for trial in range(200):
+        n = int(rng.integers(12, 65))
+        top = rng.uniform(0.3, 1.0, max(2, n // 5))
+        gap = 10.0 ** rng.uniform(-11, -5)
+        low = gap * rng.uniform(0.05, 1.0, n - top.size)
+        spec = np.concatenate([top, low]) / rng.uniform(1.0, 3.0)
+        for lag in (0, 1):
+            new, e_new = run(spec, lag)
+            old, e_old = run(spec, lag + 8)
+            assert e_new <= 2.5e-13 and e_old <= 2.5e-13
+            assert new <= old + 1, (trial, lag, new, old)         # (+1: a wait for a tighter bound that did not pay)
+            saved[lag] += old - new
+        w = rng.standard_normal(n)
+        w /= np.abs(w).max() * rng.uniform(1.0, 3.0)
+        for lag in (0, 1):
+            a, b = run(w, lag)[0], run(w, lag + 8)[0]
+            assert a <= b                                             # a Gaussian spectrum has a gap now and then (its smallest eigenvalue alone)
+            same += a == b
+    assert saved[0] >= 200 * 3 and saved[1] >= 200 * 3                # >= 3 steps per gapped block on average
+    assert same >= 0.8 * 400                                          # ... but mostly not: same schedule as rounds 2-4
