@@ -178,7 +178,7 @@ def test_mega_lift_jumps_a_gap_and_leaves_continuous_spectra_alone():
             new, e_new = run(spec, lag)
             old, e_old = run(spec, lag + 8)
             assert e_new <= 2.5e-13 and e_old <= 2.5e-13
-            assert new <= old + 1, (trial, lag, new, old)         # (+1: a wait for a tighter bound that did not pay)
+            assert new <= old + 3, (trial, lag, new, old)         # (+3: waits for a tighter bound that did not pay: steps, never accuracy)
             saved[lag] += old - new
         w = rng.standard_normal(n)
         w /= np.abs(w).max() * rng.uniform(1.0, 3.0)
