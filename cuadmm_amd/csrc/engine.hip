@@ -457,6 +457,8 @@ struct cuadmm_solver {
         CUADMM_HIP_TRY(hipMemcpyAsync(h_out.p + first, out_d.p + first, sizeof(double) * count, hipMemcpyDeviceToHost, st));
       }
     }
+    // (measured and rejected, round 5: a one-thread kernel storing a sequence number into a mapped pinned word with the host spinning on
+    // it instead of this call -- c5 2 494 -> 2 476, c1 1 290 -> 1 274 iters/s: the runtime's wait already spins, the extra launch costs)
     CUADMM_HIP_TRY(hipStreamSynchronize(st));
     prof_collect();
     return CUADMM_OK;

@@ -48,6 +48,11 @@ __device__ __forceinline__ double group_sum(double s, int G) {
 // Dynamic LDS per workgroup: xs[max_nodes] doubles | s_off[max_levels + 1] ints | s_g[max_levels] ints.
 //
 // forward:  x[i] = rhs[i] - sum_{j < i} L11[i][j] x[j]
+__global__ __launch_bounds__(256) void lead_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(64) void lead_forward_kernel(const int* __restrict__ lvl_ptr, const int* __restrict__ lvl_off, const int* __restrict__ lvl_g,
                                                           const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
                                                           const double* __restrict__ v, const double* __restrict__ ax, const double* __restrict__ asmc,
@@ -186,16 +191,15 @@ struct LeadTreeDesc { int l0, nlev, first, cnt, nnz, pad; long long q0; };     /
 
 // NW wavefronts per tree: one for the many small trees; four for the few big ones (rows of a level are independent: the
 // wavefronts take them in turn and meet at a workgroup barrier per level; the copy-in runs four times as wide)
+// The body of one tree: `tid` counts the NW wavefronts that share it (NW = 1: the wavefront's lane), lead_smem is the tree's own LDS.
 template <bool BACKWARD, int NW>
-__global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeDesc* __restrict__ desc, const int* __restrict__ lvl_off,
-                                                            const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
-                                                            const int* __restrict__ ci, const double* __restrict__ v,
-                                                            const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
-                                                            const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
-  extern __shared__ double lead_smem[];
+__device__ __forceinline__ void lead_sweep_lds_body(const LeadTreeDesc d, double* __restrict__ lead_smem, const int tid, const int* __restrict__ lvl_off,
+                                                    const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
+                                                    const int* __restrict__ ci, const double* __restrict__ v,
+                                                    const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
+                                                    const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
   constexpr int NT = 64 * NW;
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const LeadTreeDesc d = desc[blockIdx.x];
+  const int lane = tid & 63, wave = tid >> 6;
   const int l0 = d.l0, nlev = d.nlev, first = d.first, cnt = d.cnt, nnz = d.nnz;
   const long long q0 = d.q0;
   double* xs = lead_smem;
@@ -276,6 +280,40 @@ __global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeD
   }
   // the solution leaves in one pass at the end
   for (int i = tid; i < cnt; i += NT) x[snode[i]] = xs[i];
+}
+
+template <bool BACKWARD, int NW>
+__global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeDesc* __restrict__ desc, const int* __restrict__ lvl_off,
+                                                            const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
+                                                            const int* __restrict__ ci, const double* __restrict__ v,
+                                                            const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
+                                                            const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
+  extern __shared__ double lead_smem[];
+  lead_sweep_lds_body<BACKWARD, NW>(desc[blockIdx.x], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x);
+}
+
+// The few big trees and the many small ones in ONE launch (round 5): workgroups [0, n_big) take a big tree each on four wavefronts,
+// the others FOUR small trees, one per wavefront (each with its own slice of the LDS; a small tree never meets a workgroup barrier).
+// Before: two launches on two streams between a fork and a join event -- each cross-stream wait costs ~10 us of idle queue (kernel
+// trace of pendulum N = 80: 14 us in front of the kernel behind the join), twice per solve.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void lead_sweep_merged_kernel(const LeadTreeDesc* __restrict__ desc_big, int n_big, const LeadTreeDesc* __restrict__ desc_small,
+                                                             int n_small, int small_doubles, const int* __restrict__ lvl_off,
+                                                             const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
+                                                             const int* __restrict__ ci, const double* __restrict__ v,
+                                                             const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
+                                                             const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
+  extern __shared__ double lead_smem[];
+  const int blk = (int)blockIdx.x;
+  if (blk < n_big) {
+    lead_sweep_lds_body<BACKWARD, 4>(desc_big[blk], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x);
+  } else {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int t = 4 * (blk - n_big) + wave;
+    if (t < n_small)
+      lead_sweep_lds_body<BACKWARD, 1>(desc_small[t], lead_smem + (size_t)wave * small_doubles, (int)threadIdx.x & 63, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig,
+                                       D, w, x);
+  }
 }
 
 }  // namespace
@@ -534,6 +572,10 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
     CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_sweep_lds_kernel<false, 4>)));
     CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_sweep_lds_kernel<true, 4>)));
   }
+  if (std::max(lds_big, 4 * ((lds_small + 7) / 8 * 8)) > 48 * 1024) {
+    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_sweep_merged_kernel<false>)));
+    CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_sweep_merged_kernel<true>)));
+  }
   // cost model of the resident variant: two bulk round trips, then ~0.15 us of LDS work per level
   if (n_stream == 0) est_us = 2.0 * (6.0 + 0.15 * max_levels) * (n_big > 0 ? 2.0 : 1.0) + 40.0 + (double)nnz * 2e-4;
   if ((rc = to_device(rp21, r21)) || (rc = to_device(ci21, c21)) || (rc = to_device(v21, w21)) ||
@@ -549,29 +591,28 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
     CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_forward_kernel)));
     CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(lead_backward_kernel)));
   }
-  if (n_big > 0 && n_small > 0) {
-    CUADMM_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-    CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
+  // (round 5: big and small trees share one launch, lead_sweep_merged_kernel: no side stream, no fork / join events)
   ready = true;
   return CUADMM_OK;
 }
 
 int LeadSolve::solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const {
   if (!ready) { set_error("lead_solve: not built"); return CUADMM_ERR_INVALID; }
-  // the few big trees (four wavefronts each) run beside the many small ones on a second stream
-  const bool side = n_big > 0 && n_small > 0 && aux != nullptr;
-  hipStream_t sb = side ? aux : st;
-  // the many small trees first, on the caller's stream (nothing to wait for: the first kernel of an iteration starts as soon as it is
-  // submitted); the few big ones beside them behind the fork event
-  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
-  if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_f), lvl_off_f,
-                                      lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
-  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0));
-  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_f), lvl_off_f, lvl_g_f,
-                                    nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
-  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_join, aux)); CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0)); }
+  // big trees (four wavefronts each) and small ones (one wavefront each, four per workgroup) in ONE launch when both exist
+  const bool merged = n_big > 0 && n_small > 0;
+  const int small_doubles = (int)((lds_small + 7) / 8);
+  const size_t lds_merged = std::max(lds_big, 4 * sizeof(double) * (size_t)small_doubles);
+  const unsigned grid_merged = (unsigned)(n_big + (n_small + 3) / 4);
+  if (merged)
+    hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(desc_big_f), n_big,
+                       static_cast<const LeadTreeDesc*>(desc_small_f), n_small, small_doubles, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig,
+                       (const double*)nullptr, (const double*)nullptr, y);
+  else if (n_small > 0)
+    hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_f), lvl_off_f,
+                       lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
+  else if (n_big > 0)
+    hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(n_big), dim3(256), lds_big, st, static_cast<const LeadTreeDesc*>(desc_big_f), lvl_off_f, lvl_g_f,
+                       nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
   if (n_stream > 0) hipLaunchKernelGGL(lead_forward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_f, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b,
                                        isig, y, max_nodes, max_levels, trees_stream);
   hipLaunchKernelGGL(lead_tail_rhs_kernel, dim3((k * 8 + 255) / 256), dim3(256), 0, st, k, n1, rp21, ci21, v21, ax, asmc, b, isig, y, tail.vin);
@@ -579,17 +620,23 @@ int LeadSolve::solve(const double* ax, const double* asmc, const double* b, doub
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
   if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
-  if (side) CUADMM_HIP_TRY(hipEventRecord(ev_fork, st));
-  if (n_small > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_b), lvl_off_b,
-                                      lvl_g_b, nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  if (side) CUADMM_HIP_TRY(hipStreamWaitEvent(aux, ev_fork, 0));
-  if (n_big > 0) hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(n_big), dim3(256), lds_big, sb, static_cast<const LeadTreeDesc*>(desc_big_b), lvl_off_b, lvl_g_b,
-                                    nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  if (side) { CUADMM_HIP_TRY(hipEventRecord(ev_join, aux)); CUADMM_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0)); }
+  if (merged)
+    hipLaunchKernelGGL(lead_sweep_merged_kernel<true>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(desc_big_b), n_big,
+                       static_cast<const LeadTreeDesc*>(desc_small_b), n_small, small_doubles, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_,
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
+  else if (n_small > 0)
+    hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_b), lvl_off_b,
+                       lvl_g_b, nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
+  else if (n_big > 0)
+    hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(n_big), dim3(256), lds_big, st, static_cast<const LeadTreeDesc*>(desc_big_b), lvl_off_b, lvl_g_b,
+                       nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
   if (n_stream > 0) hipLaunchKernelGGL(lead_backward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_b, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_, D1, wvec, y,
                                        max_nodes, max_levels, trees_stream);
   CUADMM_HIP_TRY(hipGetLastError());
-  CUADMM_HIP_TRY(hipMemcpyAsync(y + n1, tail.vin, sizeof(double) * (size_t)k, hipMemcpyDeviceToDevice, st));
+  // the solved tail into y: a kernel of its own, not hipMemcpyAsync -- the runtime's device-to-device copy is a blit behind ~15 us of
+  // command-processor work (kernel trace of pendulum N = 80: 14.7 us idle in front of every one, once per solve)
+  hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, tail.vin, y + n1, k);
+  CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
 
