@@ -56,7 +56,11 @@ struct DuoGroup {
   int left = 0;                            // ranks that have returned from the current duo_group_run call
   long long generation = 0;
   std::atomic<bool> abort{false};
-  std::vector<size_t> counts;              // what each rank brought to the current collective (must agree)
+  // what each rank brought to a collective (must agree) and, device exchange, where it staged it -- PUBLISHED per collective parity:
+  // with one barrier per collective a rank may already be publishing for collective k + 1 while a slower one still reads what was
+  // published for k (it cannot get further: barrier k + 1 needs everybody), so two sets suffice
+  std::vector<size_t> counts;              // [parity * world + rank]
+  std::vector<const double*> pub;          // [parity * world + rank]
   long long n_allreduce = 0;
   bool device_exchange = false;
   int distinct_devices = 1;
@@ -85,12 +89,17 @@ struct DuoGroup {
     ++left;
     if (arrived > 0) { abort.store(true); cv.notify_all(); }
   }
-  void set_count(int r, size_t c) { std::lock_guard<std::mutex> lk(mu); counts[(size_t)r] = c; }   // read by the others after the barrier
-  bool counts_agree(size_t c) {
+  void publish(int parity, int r, size_t c, const double* where) {   // read by the others after the barrier
     std::lock_guard<std::mutex> lk(mu);
-    for (int r = 0; r < world; ++r) if (counts[(size_t)r] != c) return false;
+    counts[(size_t)parity * world + r] = c;
+    pub[(size_t)parity * world + r] = where;
+  }
+  bool counts_agree(int parity, size_t c) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int r = 0; r < world; ++r) if (counts[(size_t)parity * world + r] != c) return false;
     return true;
   }
+  const double* published(int parity, int r) { std::lock_guard<std::mutex> lk(mu); return pub[(size_t)parity * world + r]; }
 };
 
 // buf[i] = sum over ranks (in rank order) of stage_r[i]: every rank runs it on its own stream, reading its peers' memory
@@ -132,11 +141,11 @@ static int duo_allreduce_device(DuoRank* me, double* buf, size_t count, hipStrea
     g->raise_abort();
     return 1;
   }
-  g->set_count(me->rank, count);
+  g->publish(slot, me->rank, count, me->dstage[slot]);
   if (!g->barrier()) return 1;
-  if (!g->counts_agree(count)) { g->raise_abort(); return 2; }               // ranks issued different collectives
+  if (!g->counts_agree(slot, count)) { g->raise_abort(); return 2; }         // ranks issued different collectives
   DuoPeers peers;
-  for (int r = 0; r < g->world; ++r) peers.p[r] = g->ranks[(size_t)r].dstage[slot];    // written before the barrier by their owners
+  for (int r = 0; r < g->world; ++r) peers.p[r] = g->published(slot, r);     // published before the barrier by their owners
   const unsigned grid = (unsigned)std::min<size_t>((count + 255) / 256, 1024);
   hipLaunchKernelGGL(duo_sum_kernel, dim3(grid), dim3(256), 0, st, peers, g->world, buf, count);
   if (hipGetLastError() != hipSuccess) { g->raise_abort(); return 1; }
@@ -160,9 +169,9 @@ static int duo_allreduce_host(DuoRank* me, double* buf, size_t count, hipStream_
     g->raise_abort();
     return 1;
   }
-  g->set_count(me->rank, count);
+  g->publish(0, me->rank, count, nullptr);                                   // (two barriers per collective here: one set is enough)
   if (!g->barrier()) return 1;
-  if (!g->counts_agree(count)) { g->raise_abort(); return 2; }               // ranks issued different collectives
+  if (!g->counts_agree(0, count)) { g->raise_abort(); return 2; }            // ranks issued different collectives
   // every rank forms the same sum in the same order
   const double* s0 = g->ranks[0].stage;
   for (size_t i = 0; i < count; ++i) me->sum[i] = s0[i];
@@ -226,7 +235,8 @@ int duo_group_create(cuadmm_solver* parent, int world, int parent_device, bool s
   g->world = world;
   g->child.assign((size_t)world, nullptr);
   g->ranks.assign((size_t)world, DuoRank{});
-  g->counts.assign((size_t)world, 0);
+  g->counts.assign(2 * (size_t)world, 0);
+  g->pub.assign(2 * (size_t)world, nullptr);
   g->child[0] = parent;
   for (int r = 0; r < world; ++r) {
     g->ranks[(size_t)r].g = g; g->ranks[(size_t)r].rank = r;
