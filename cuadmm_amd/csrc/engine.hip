@@ -246,6 +246,8 @@ struct cuadmm_solver {
     int aty_post2 = 1;            // "aty_post2": the sGS second half in one pass
     int lead_stream = 0;          // "lead_stream": the leading sweeps on the streaming kernels only (no LDS-resident trees; A/B, tests)
     int tail_one_pass = 1;        // "tail_one_pass": the GPU tail applied in one pass over inv(L22) (0: two triangular GEMVs)
+    int solve_next = 1;           // "solve_next": the y-solve of iteration k + 1 is enqueued before the host waits for iteration k (fetch_out)
+    int tail_max_k = 32768;       // "tail_max_k": cap of the planner's GPU tail (<= 65 536: 3 x 8 K^2 bytes while it is built, 2 x 8 K^2 afterwards)
     int tail_shard = 1;           // "tail_shard": world > 1, replicated solve: every rank applies 1 / world of the tail's rows, the K partial
                                   // results are all-reduced (0: every rank applies the whole tail)
     int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
@@ -435,8 +437,16 @@ struct cuadmm_solver {
     return CUADMM_OK;
   }
 
-  // D2H of out_d[first, first+count) after the optional all-reduce; blocks until it has landed
-  int fetch_out(size_t first, size_t count) {
+  // D2H of out_d[first, first+count) after the optional all-reduce; blocks until it has landed.
+  // solve_next (round 5): the y-solve of the NEXT iteration is enqueued behind this iteration's last kernel BEFORE the host waits --
+  // and the host then waits for an event recorded in front of it, not for the stream.  The reference solves for y at the top of every
+  // pass through the loop, the breaking one included (solver.cu:478-500 precede the break), so that solve is never speculative; its only
+  // host input is sigma, which the caller knows will not change in this iteration's step 5.  The GPU runs the solve (0.2 - 0.4 ms on the
+  // moment relaxations) while the host goes through the stopping test and enqueues the rest of the next iteration: the idle gap at
+  // the iteration boundary (kernel trace: the largest one of a latency-bound iteration) is gone.
+  bool y_early = false;           // y_d already holds the y-solve of the coming iteration
+  hipEvent_t ev_early = nullptr;
+  int fetch_out(size_t first, size_t count, bool solve_next = false) {
     if (!out_mapped) {
       int rc = do_allreduce(out_d.p + first, count);
       if (rc) return rc;
@@ -459,7 +469,15 @@ struct cuadmm_solver {
     }
     // (measured and rejected, round 5: a one-thread kernel storing a sequence number into a mapped pinned word with the host spinning on
     // it instead of this call -- c5 2 494 -> 2 476, c1 1 290 -> 1 274 iters/s: the runtime's wait already spins, the extra launch costs)
-    CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    if (solve_next && dev_solve && !out_mapped && st != nullptr) {
+      if (!ev_early) CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
+      CUADMM_HIP_TRY(hipEventRecord(ev_early, st));
+      { int rc = host_solve(); if (rc) return rc; }
+      y_early = true;
+      CUADMM_HIP_TRY(hipEventSynchronize(ev_early));
+    } else {
+      CUADMM_HIP_TRY(hipStreamSynchronize(st));
+    }
     prof_collect();
     return CUADMM_OK;
   }
@@ -755,8 +773,8 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
   // LDL^T) and inverted on the GPU and applied as two GEMVs per solve (tail_solve.hip).
   // CUADMM_TAIL_K: 0 = everything on the host, k > 0 forces the tail size (A/B measurements).
   {
-    int max_k = 32768;
-    if (s->sw.tail_k >= 0) max_k = -std::min(s->sw.tail_k, m);
+    int max_k = std::max(64, std::min(s->sw.tail_max_k, 65536));
+    if (s->sw.tail_k >= 0) max_k = -std::min(std::min(s->sw.tail_k, m), 65536);
     double t0 = wall_s();
     if (max_k == 0) rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
     else rc = cuadmm_aat_create_split(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, max_k, &s->fac);
@@ -1339,6 +1357,8 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "l21_device") s->sw.l21_device = (int)value;
   else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
   else if (k == "tail_shard") s->sw.tail_shard = (int)value;
+  else if (k == "tail_max_k") s->sw.tail_max_k = (int)value;
+  else if (k == "solve_next") s->sw.solve_next = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;
   else if (s->plan.opt.set(k, value)) {}                      // "psd_*": the projection planner's switches (psd_options.h)
   else if (k == "batch_mixed") s->bt.allow_mixed = value != 0;
@@ -1511,6 +1531,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
   }
   int rc = check_device(s->device);
   if (rc) return rc;
+  s->y_early = false;                       // (a solve that ended in an error may have left it set)
   // the dense tail of the replicated y-solve: split by rows over the ranks of a sharded engine (tail_solve.h)
   if (s->tail.k > 0) {
     const bool shard = s->world > 1 && !s->local_mode && s->sw.tail_shard != 0;
@@ -1584,7 +1605,8 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
 
     // ---- Step 1 (solver.cu:478-500): y = (AA^T)^-1 (Rp/sig - A(S-C)); with closed blocks the fused projection of this
     // iteration solves it (not on the last pass through the loop, which stops before the projection)
-    if (s->bt.len == 0 && (rc = s->host_solve(s->fuse && !breakyes))) return rc;
+    if (s->y_early) s->y_early = false;       // enqueued at the end of the previous iteration (fetch_out, solve_next)
+    else if (s->bt.len == 0 && (rc = s->host_solve(s->fuse && !breakyes))) return rc;
 
     if (breakyes) {   // solver.cu:567-576
       if (iter > switch_admm && s->have_best) {
@@ -1660,6 +1682,11 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
       }
     }
     const bool from_batch = s->bt.len > 0;
+    // the next iteration's y-solve may follow this iteration's last kernel at once (fetch_out, solve_next): the whole solve is on the
+    // device and belongs to the engine (not to a closed block's kernel), sigma does not change in this iteration's step 5, nothing of a
+    // batch is pending, and the per-class event timers (profile = 1) are off -- they are collected at the wait, before that solve ends
+    const bool sig_may_change = (iter <= sig_update_threshold && iter % sig_update_stage_1 == 1) || (iter > sig_update_threshold && iter % sig_update_stage_2 == 1);
+    const bool solve_next_ok = s->sw.solve_next != 0 && s->dev_solve && !from_batch && !sig_may_change && !(s->fuse && s->closed.active) && s->profile != 1;
     if (from_batch) {
       // consumed below (Step 5) from bt.h
     } else if ((rc = s->upload_y())) return rc;
@@ -1705,7 +1732,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         if ((rc = s->launch_post_mode(2, tau))) return rc;
       }
       if ((rc = s->launch_spmv(true, false))) return rc;
-      if ((rc = s->fetch_out(0, (size_t)m + 2))) return rc;            // [A*X | sums]; A*(S-C) unchanged since the half step
+      if ((rc = s->fetch_out(0, (size_t)m + 2, solve_next_ok))) return rc;   // [A*X | sums]; A*(S-C) unchanged since the half step
     } else {
       if (snapshot) {
         if (!s->X_best.p && L > 0) { if ((rc = s->X_best.alloc(L)) || (rc = s->S_best.alloc(L))) return rc; }
@@ -1726,7 +1753,7 @@ int cuadmm_solve(cuadmm_solver* s, int max_iter, double stop_tol, int sig_update
         if ((rc = s->launch_post_mode(0, tau))) return rc;
       }
       if ((rc = s->launch_spmv(true, true, s->fuse && !snapshot))) return rc;
-      if ((rc = s->fetch_out(0, 2 * (size_t)m + 2))) return rc;
+      if ((rc = s->fetch_out(0, 2 * (size_t)m + 2, solve_next_ok))) return rc;
     }
 
     // ---- Step 5 (solver.cu:764-799)

@@ -544,7 +544,7 @@ int TailSolve::alloc(int k_) {
     n_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   CUADMM_HIP_TRY(hipMalloc(&xpart, sizeof(double) * (size_t)K * (size_t)n_wg));
-  if (K > 18432 && K <= 32768) {        // exchange slots of the four-workgroups-per-row one-pass kernel
+  if (K > 18432 && K <= 65536) {        // exchange slots of the row-sharing one-pass kernel (four workgroups per row up to 32 768 columns, eight beyond)
     CUADMM_HIP_TRY(hipMalloc(&part, sizeof(unsigned long long) * (size_t)K * 8));
     CUADMM_HIP_TRY(hipMalloc(&d_fail, sizeof(int)));
     CUADMM_HIP_TRY(hipMemset(d_fail, 0, sizeof(int)));
@@ -785,6 +785,15 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     }
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);
+  } else if (one_pass && xpart && part && K > 32768 && K <= 65536 && !group_retired) {
+    // beyond 32 768 columns (round 5, option tail_max_k): EIGHT workgroups share a row, 8 columns per thread, four rows per exchange
+    constexpr int Q = 8;
+    const size_t lds2 = sizeof(double) * 1024 * 8;
+    const int G = std::max(8, 2 * n_wg / Q / 8 * 8);
+    auto kern = ts_onepass_group_kernel<8, Q, 4, 4>;
+    if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, G, vin, part, Q);
   } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
     // measured (tail_solve class per sGS iteration, two solves; two triangular GEMVs for comparison): K = 24 576 (PushBox N = 30, forced)

@@ -201,10 +201,11 @@ def test_tail_solve_op_vs_triangular_solves(k):
     assert np.linalg.norm(got - ref) <= 1e-13 * np.linalg.norm(ref)
 
 
-@pytest.mark.parametrize("k", [18500, 24700])
+@pytest.mark.parametrize("k", [18500, 24700, 33000])
 def test_tail_solve_op_beyond_one_workgroups_reach(k):
     """K > 18 432: four workgroups share a row of inv(L) and exchange their parts of u = W z through sentinel slots
-    (ts_onepass_group_kernel: 6 columns per thread up to 24 576, 8 beyond); three solves in a row, so the slots are reset and reused.
+    (ts_onepass_group_kernel: 6 columns per thread up to 24 576, 8 beyond; EIGHT workgroups per row beyond 32 768 columns -- round 5,
+    what option tail_max_k admits); three solves in a row, so the slots are reset and reused.
     Same tolerance as the small sizes; the second and third right-hand sides repeat the first, and must reproduce it bit for bit."""
     import scipy.linalg as sl
     rng = np.random.default_rng(k)
