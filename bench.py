@@ -272,7 +272,8 @@ def launch_ranks(n):
                 break
             time.sleep(0.05)
         out0.seek(0)
-        sys.stdout.write(out0.read())
+        for ln in out0.read().splitlines():                 # stdout carries the ONE JSON line; library chatter of the ranks goes to stderr
+            (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
         sys.stdout.flush()
     bad = [rc for rc in rcs if rc != 0]
     if bad:
