@@ -103,6 +103,8 @@ PROTOTYPES = {
     "cuadmm_aat_tail_plan": (C.c_int, [C.c_void_p, C.c_int]),
     "cuadmm_aat_create_split": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
     "cuadmm_aat_tail_k": (C.c_int, [C.c_void_p]),
+    "cuadmm_aat_tail_tops": (C.c_int, [C.c_void_p]),
+    "cuadmm_aat_plan_allow_tops": (None, [C.c_int]),
     "cuadmm_aat_tail_schur": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_double))]),
     "cuadmm_aat_tail_schur_release": (None, [C.c_void_p]),
     "cuadmm_aat_tail_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

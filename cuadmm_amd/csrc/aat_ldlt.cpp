@@ -55,6 +55,7 @@ struct cuadmm_aat {
                                              // include/cuadmm_amd.h says so at the entry point)
   std::vector<int> nzcols;   // columns j < m - tail_k with at least one sub-diagonal entry, ascending (block-diagonal A A^T: few)
   int tail_k = 0;
+  int plan_tops = 0;         // > 0: plan_tail chose this tail FOR the device-side solve with dense tree tops cut at this height (lead_solve.h)
   std::vector<int64_t> schur_ptr;
   std::vector<int> schur_col;
   std::vector<double> schur_val;
@@ -367,7 +368,17 @@ HostPool& host_pool() {
 // exist), the tail one pass over k^2 / 2 doubles (two GEMVs beyond 20 480 columns) -- a somewhat larger tail that halves the depth
 // wins (pendulum N = 80: k 9 728 -> 12 032, depth 61 -> 28, y-solve 0.26 -> 0.20 ms).  The height of the forest restricted to the
 // first n1 columns is a prefix maximum of the node heights (a parent always has the larger index): one pass for every k.
-int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) {
+// Round 5, DENSE TREE TOPS (lead_solve.h): with the nodes of height >= 32 of every leading tree solved through explicit inverses of their
+// diagonal blocks, the depth of the forest stops deciding the tail.  What a larger tail bought -- swallowing the long chains -- the tops do at
+// a fraction of the bytes: per solve the two passes over the packed inverses (measured ~4 TB/s), two SpMVs over what leaves the shallow rest,
+// 2 x 32 levels of sweeps, and a tail of HALF the size or less.  Measured per sGS iteration (profiles/r05_tops_scan.log): PushBox N = 30
+// k 18 688 -> 4 096 ... 10 240: 1.81 -> 0.96 ... 1.01 ms; N = 50 k 30 720 -> 8 192: 2.93 -> 1.16; PushT_N=30 27 136 -> 16 384: 2.44 -> 1.09;
+// PlanarHand_N=1 17 152 -> 8 192: 0.90 -> 0.75; PlanarHand_N=10 keeps its 32 768 columns (smaller tails grow 2 ... 5 GB of tops) but leaves
+// the host: 14.5 -> 4.7.  `tops_out` receives the height of the cut when the returned tail is meant for that solve (0 otherwise);
+// `allow_tops` = false is the planner of round 4.
+thread_local bool g_plan_allow_tops = true;
+int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, int* tops_out = nullptr) {
+  if (tops_out) *tops_out = 0;
   const double host_ns = 1.2, total = host_ns * (double)Lp[m];
   // Small systems: a host solve is its nonzeros plus two PCIe hops and a stream synchronisation (~35 us); the WHOLE factor as a dense
   // tail on the device is one pass over 8 m^2 bytes of explicit inverse behind a right-hand side that never leaves HBM (lead_solve.hip
@@ -392,6 +403,52 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) 
     const int p = parent[j];
     if (p >= 0 && h[p] < h[j] + 1) h[p] = h[j] + 1;
   }
+  // the device-side solve with dense tree tops at tail size k: model in us per solve, < 0 when it cannot be built
+  constexpr int kTopsLevel = 32;
+  auto tops_us = [&](int k) {
+    const int n1 = m - k;
+    if (n1 <= 0) return -1.0;
+    // roots of the leading forest; sizes of the tops (nodes of height >= kTopsLevel: h counts from 1) and of the rest's trees
+    std::vector<int> root((size_t)n1), tcnt((size_t)n1, 0), bcnt((size_t)n1, 0), broot((size_t)n1);
+    long long nnzT = 0;
+    int nT = 0;
+    for (int j = n1 - 1; j >= 0; --j) {
+      const int p = parent[j];
+      const bool top = h[j] > kTopsLevel;
+      root[j] = (p < 0 || p >= n1) ? j : root[p];
+      if (top) { tcnt[root[j]]++; nnzT += Lp[j + 1] - Lp[j]; ++nT; }
+      else { broot[j] = (p < 0 || p >= n1 || h[p] > kTopsLevel) ? j : broot[p]; bcnt[broot[j]]++; }
+    }
+    if (nT == 0) return -1.0;
+    double tri = 0.0;
+    for (int j = 0; j < n1; ++j) {
+      if (bcnt[j] > 6144) return -1.0;                              // lead_solve.hip: one tree per workgroup
+      tri += 0.5 * (double)tcnt[j] * ((double)tcnt[j] + 1.0);
+    }
+    if (tri * 16.0 > 2.0e9) return -1.0;                            // both triangles: memory, and the n^3-ish build on the host
+    // (the four-rows-per-exchange kernel beyond 24 576 columns: 897 us at k = 32 768 in profiles/r05_tops_PlanarHand_N=10_kernel_stats.csv)
+    const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 4.0 / (k <= 24576 ? 3.8e6 : 4.8e6) + 40.0;
+    return 2.0 * (20.0 + 0.9 * kTopsLevel) + 70.0 + tri * 16.0 / 4.0e6 + 24.0 * (double)Lp[n1] / 3.0e6 + tail;
+  };
+  // the best tail for that solve: not below half the host optimum (the host factors what the tail does not)
+  auto plan_tops = [&](int k_lo, double other_us) {
+    if (!g_plan_allow_tops || !tops_out) return 0;
+    int kb = 0;
+    double cb = 1e300;
+    std::vector<std::pair<int, double>> cand;
+    for (int k = std::max(1024, (k_lo / 2 + 255) / 256 * 256); k <= std::min(m - 1, max_k); k += 256) {
+      if (hmax[(size_t)(m - k)] <= kTopsLevel + 1) break;           // nothing left to cut
+      const double c = tops_us(k);
+      if (c < 0.0) continue;
+      cand.emplace_back(k, c);
+      if (c < cb) { cb = c; kb = k; }
+    }
+    if (kb == 0 || !(cb < 0.8 * other_us)) return 0;
+    // the model is good to ~10 %: of the tails within 8 % of the best the LARGEST (less for the host to factor, smaller tops)
+    for (const auto& kc : cand) if (kc.second <= 1.08 * cb) kb = std::max(kb, kc.first);
+    *tops_out = kTopsLevel;
+    return kb;
+  };
   auto dev_us = [&](int k) {
     const double ht = (double)hmax[(size_t)(m - k)];
     const double tail = k <= 20480 ? (double)k * k * 4.0 / 4.6e6 + 15.0 : (double)k * k * 8.0 / 5.5e6;
@@ -429,14 +486,20 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) 
       const double c = deep_us(k);
       if (c < cd) { cd = c; kd = k; }
     }
-    if (kd == 0 || cd > 0.6 * host_us) return best_k;
-    for (int k = kd; k <= k_hi && deep_us(k) <= 1.15 * cd; k += 256) {
-      if (hmax[(size_t)(m - k)] > 256 || max_tree(k) > 6144) continue;
-      const double extra_s = ((double)k * k * k - (double)best_k * best_k * best_k) / 3e13;
-      if ((host_us - deep_us(k)) * 3000e-6 < extra_s) break;
-      return k;
-    }
-    return best_k;
+    int k_deep = 0;
+    if (!(kd == 0 || cd > 0.6 * host_us))
+      for (int k = kd; k <= k_hi && deep_us(k) <= 1.15 * cd; k += 256) {
+        if (hmax[(size_t)(m - k)] > 256 || max_tree(k) > 6144) continue;
+        const double extra_s = ((double)k * k * k - (double)best_k * best_k * best_k) / 3e13;
+        if ((host_us - deep_us(k)) * 3000e-6 < extra_s) break;
+        k_deep = k;
+        break;
+      }
+    // against the larger tail where one was found, else against the solve the deep forest leaves (device sweeps over every level where
+    // the trees fit -- PushT_N=30 --, the host otherwise)
+    const double other = k_deep ? deep_us(k_deep) : std::min(host_us, deep_us(best_k));
+    if (const int kt = plan_tops(best_k, other)) return kt;
+    return k_deep ? k_deep : best_k;
   }
   int k_dev = best_k;
   double c_dev = dev_us(best_k);
@@ -446,6 +509,7 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr) 
     const double c = dev_us(k);
     if (c < 0.93 * c_dev) { c_dev = c; k_dev = k; }               // a clear gain only: the model is good to ~10 %
   }
+  if (const int kt = plan_tops(best_k, c_dev)) return kt;
   return k_dev;
 }
 
@@ -568,7 +632,7 @@ int aat_create_impl(int m, int L, const int* Acp, const int* Ari, const double* 
   for (int k = 0; k < m; ++k) f->Lp[k + 1] = f->Lp[k] + Lnz[k];
   f->analyze_s = now_s() - t0;
   t0 = now_s();
-  const int tail_k = split_max_k > 0 ? plan_tail(f->Lp.data(), m, split_max_k, parent.data()) : std::min(m, -split_max_k);
+  const int tail_k = split_max_k > 0 ? plan_tail(f->Lp.data(), m, split_max_k, parent.data(), &f->plan_tops) : std::min(m, -split_max_k);
   const int n1 = m - tail_k;                     // rows / columns >= n1 belong to the unfactored tail
   f->tail_k = tail_k;
   try {
@@ -830,6 +894,8 @@ int64_t cuadmm_aat_factor_nnz(const cuadmm_aat* f) { return f ? f->Lp[f->m] : 0;
 const int64_t* cuadmm_aat_factor_colptr(const cuadmm_aat* f) { return f ? f->Lp.data() : nullptr; }
 
 int cuadmm_aat_tail_k(const cuadmm_aat* f) { return f ? f->tail_k : 0; }
+int cuadmm_aat_tail_tops(const cuadmm_aat* f) { return f ? f->plan_tops : 0; }
+void cuadmm_aat_plan_allow_tops(int allow) { g_plan_allow_tops = allow != 0; }
 
 int cuadmm_aat_factor_arrays(const cuadmm_aat* f, const int64_t** Lp, const int** Li, const double** Lx, const double** D) {
   if (!f || !Lp || !Li || !Lx || !D) { set_error("aat_factor_arrays: null argument"); return CUADMM_ERR_INVALID; }

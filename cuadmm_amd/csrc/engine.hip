@@ -252,6 +252,8 @@ struct cuadmm_solver {
                                   // results are all-reduced (0: every rank applies the whole tail)
     int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
+    int lead_tops_refine = 0;     // "lead_tops_refine": one refinement step per direction in the dense tree tops (A/B: measured, no effect -- lead_solve.h)
+    int lead_tops = -1;           // "lead_tops": dense tree tops (lead_solve.h): -1 = when the forest is too deep for the sweeps, 0 = never, L = always, cut at height L
     int debug_eig = 0;            // developer aid
   } sw;
   cuadmm_solver() {
@@ -777,7 +779,12 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
     if (s->sw.tail_k >= 0) max_k = -std::min(std::min(s->sw.tail_k, m), 65536);
     double t0 = wall_s();
     if (max_k == 0) rc = cuadmm_aat_create(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, &s->fac);
-    else rc = cuadmm_aat_create_split(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, max_k, &s->fac);
+    else {
+      // the planner may choose a (smaller) tail for the solve with dense tree tops unless the options rule that solve out
+      cuadmm_aat_plan_allow_tops(s->sw.lead_tops != 0 && !s->sw.host_solve && s->sw.l21_device != 2);
+      rc = cuadmm_aat_create_split(m, vec_len, rp.data(), rci.data(), rv.data(), 1e-15, max_k, &s->fac);
+      cuadmm_aat_plan_allow_tops(1);
+    }
     if (rc) return rc;
     double t1 = wall_s();
     int tk = cuadmm_aat_tail_k(s->fac);
@@ -1130,12 +1137,21 @@ static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
     s->lead.stream_only = s->sw.lead_stream != 0;
     s->lead.debug = s->sw.lead_debug != 0;
     s->lead.force_hybrid = s->sw.l21_device == 2;
+    s->lead.tops_refine = s->sw.lead_tops_refine != 0;
+    s->lead.tops_level = s->sw.l21_device == 2 ? 0 : (s->sw.lead_tops >= 0 ? s->sw.lead_tops : (cuadmm_aat_tail_tops(s->fac) > 0 ? cuadmm_aat_tail_tops(s->fac) : -1));
     if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D, s->sw.l21_device != 0))) return rc;
     const double host_us = 1.2e-3 * (double)Lp[m - s->tail.k] + 150.0;
+    if (s->lead.ready && s->lead.tops && !(s->lead.est_us < 0.7 * host_us)) {      // the cut forest loses to the host: the plain paths decide
+      s->lead.tops_level = 0;
+      if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D, s->sw.l21_device != 0))) return rc;
+    }
     if (s->lead.ready && s->lead.est_us < 0.7 * host_us) {
       s->dev_solve = true;
       if (s->local_mode && s->comm_world > 1) s->dev_scalars = true;
-      if (s->verbose) printf(" y-solve on the device: leading sweeps over %d trees (depth <= %d) around the GPU tail\n", s->lead.ntrees, s->lead.max_levels);
+      if (s->verbose && s->lead.tops)
+        printf(" y-solve on the device: sweeps over %d trees (depth <= %d), %d dense tree tops (%d columns, %.0f MB of inverses), the GPU tail\n", s->lead.ntrees,
+               s->lead.max_levels, s->lead.tops_blocks, s->lead.nT, (double)s->lead.tops_bytes / 1e6);
+      else if (s->verbose) printf(" y-solve on the device: leading sweeps over %d trees (depth <= %d) around the GPU tail\n", s->lead.ntrees, s->lead.max_levels);
     } else if (s->lead.hybrid || (s->lead.ready && s->sw.l21_device && s->lead.demote_to_hybrid())) {
       if (s->verbose) printf(" y-solve: L11 sweeps on the host (forest depth %d); L21 (%lld nonzeros) and the tail on the device\n", s->lead.max_levels, s->lead.nnz21);
     } else {
@@ -1354,6 +1370,8 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "aty_post2") s->sw.aty_post2 = (int)value;
   else if (k == "lead_stream") s->sw.lead_stream = (int)value;
   else if (k == "lead_debug") s->sw.lead_debug = (int)value;
+  else if (k == "lead_tops") s->sw.lead_tops = (int)value;
+  else if (k == "lead_tops_refine") s->sw.lead_tops_refine = (int)value;
   else if (k == "l21_device") s->sw.l21_device = (int)value;
   else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
   else if (k == "tail_shard") s->sw.tail_shard = (int)value;
@@ -2071,7 +2089,7 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap) {
 int cuadmm_get_counters(const cuadmm_solver* s, double o[8]) {
   if (!s || !o) { set_error("get_counters: null"); return CUADMM_ERR_INVALID; }
   o[0] = (double)s->bt.launches; o[1] = (double)s->bt.iters; o[2] = (double)s->bt.rollbacks; o[3] = (double)cuadmm_host_pool_threads();
-  o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? 1 : (s->lead.hybrid ? 2 : 0); o[7] = (double)s->tail.k;
+  o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? (s->lead.tops ? 3 : 1) : (s->lead.hybrid ? 2 : 0); o[7] = (double)s->tail.k;
   return CUADMM_OK;
 }
 int cuadmm_get_group_info(const cuadmm_solver* s, double o[4]) {

@@ -62,11 +62,48 @@ struct LeadSolve {
   // x (host, m doubles): in [z1 | rhs2] (z1 = L11^-1 rhs1), out [z1 | x2]; h_w <- L21^T x2.  Synchronous on `st`.
   int apply_l21(double* x, bool x_pinned, TailSolve& tail, hipStream_t st);
 
+  // DENSE TREE TOPS (round 5; lead_solve.hip: build_tops).  A forest that is too deep for level-by-level sweeps (PlanarHand_N=10 at a
+  // 32 768-column tail: 36 big trees, 1 046 levels) is cut at height `tops_level`: the nodes at or above it -- the top T of every big
+  // tree, an upward-closed set -- leave the sweeps and become a block-diagonal MIDDLE stage with one explicit dense inverse per tree,
+  //     [ L_BB            ]       forward:  z_B = L_BB^-1 r_B (sweeps over the shallow rest B),  z_T = W_T (r_T - L_TB z_B),  W_T = L_TT^-1
+  //     [ L_TB  L_TT      ]                 z_K = r_K - L_KB z_B - L_KT z_T,  the tail,  and back in mirror order
+  //     [ L_KB  L_KT  L_KK]
+  // in a symmetric permutation B | T | K of the factor's order (lower triangular again: whatever a T column reaches is in T or K).
+  // Inside, everything is indexed in that order (`rid`: position -> row of the caller's vectors); `k` is then |T| + the tail.
+  int tops_level = -1;          // option lead_tops: -1 = when the forest is too deep for the sweeps, 0 = never, L > 0 = always, cut at height L
+  bool tops = false;
+  int nT = 0, k_tail = 0;
+  int* rid = nullptr;           // m: position in B | T | K order -> original index
+  double* xp = nullptr;         // m: the sweeps' vector in B | T | K order
+  double *zext = nullptr, *xext = nullptr, *zT = nullptr, *uT = nullptr, *DT = nullptr;   // nT + tail | same | nT | nT | nT
+  double *Wf = nullptr, *Wb = nullptr;                   // rows of W_T (lower, packed) and of W_T^T (upper, packed), block after block
+  long long *wf_off = nullptr, *wb_off = nullptr;        // per T row: where its packed row starts
+  int *wf_beg = nullptr, *wb_len = nullptr;              // per T row: first column of its block (row i of W spans wf_beg[i] .. i), length of its row of W^T
+  long long *kt_rp = nullptr, *tk_cp = nullptr;          // L_KT by tail rows (CSR) and by T columns (CSC), T-local / tail-local indices
+  int *kt_ci = nullptr, *tk_ri = nullptr;
+  double *kt_v = nullptr, *tk_v = nullptr;
+  // optional: one step of iterative refinement per direction with the SPARSE L_TT (z = W r; z += W (r - L z)).  Built to test whether the
+  // explicit inverses are what moves PushBox_N=50's primal objective by 9e-8 from the oracle's at a tail of 8 448 columns: they are not --
+  // with and without the step 8.0e-8 / 9.2e-8, and 9.0e-8 with the WHOLE leading part swept on the host at that tail (profiles/
+  // r05_tops_deviation.txt).  The inverses are benign (max |W| = 2.3); the deviation follows the tail's boundary among the 9 301 pivots
+  // at the regularisation (1e-15: dependent constraints; 5e-9 at 8 192 columns, 4e-8 at 8 704).  Off by default.
+  long long *tt_rp = nullptr, *tt_cp = nullptr;          // L_TT strictly lower by rows (CSR) and by columns (CSC), T-local
+  int *tt_ci = nullptr, *tt_ri = nullptr;
+  double *tt_v = nullptr, *tt_cv = nullptr;
+  bool tops_refine = false;     // option lead_tops_refine
+  long long tops_bytes = 0;
+  int tops_blocks = 0, tops_max = 0;
+  int solve_tops(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const;
+
   // Lp / Li / Lx / D: the split factor (cuadmm_aat_factor_arrays), k = its tail size
   int build(int m, int k, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid = false);
   // y <- (L D L^T)^-1 (-asmc + (b - ax) * isig): everything on `st`, nothing synchronises
   int solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const;
   void release();
+ private:
+  int build_core(int m, int k, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid);
+  int build_tops(int m, int k, const int64_t* Lp, const int* Li, const double* Lx, const double* D, int level);
+ public:
   ~LeadSolve() { release(); }
 };
 

@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <atomic>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -35,6 +37,12 @@ __device__ __forceinline__ double lead_rhs(const double* __restrict__ ax, const 
   return -asmc[i] + isig * (-ax[i] + b[i]);      // solver.cu:478-482
 }
 
+// the same with the row looked up (dense tree tops: the sweeps run in B | T | K order, the caller's vectors do not)
+__device__ __forceinline__ double lead_rhs_at(const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b,
+                                              double isig, const int* __restrict__ rid, int i) {
+  return lead_rhs(ax, asmc, b, isig, rid ? rid[i] : i);
+}
+
 // sum over a group of G lanes (G a power of two <= 64, groups aligned)
 __device__ __forceinline__ double group_sum(double s, int G) {
   for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(64) void lead_forward_kernel(const int* __restrict_
                                                           const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
                                                           const double* __restrict__ v, const double* __restrict__ ax, const double* __restrict__ asmc,
                                                           const double* __restrict__ b, double isig, double* __restrict__ x, int max_nodes,
-                                                          int max_levels, const int* __restrict__ tree_ids) {
+                                                          int max_levels, const int* __restrict__ tree_ids, const int* __restrict__ rid) {
   extern __shared__ double lead_smem[];
   double* xs = lead_smem;
   int* s_off = reinterpret_cast<int*>(xs + max_nodes);
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(64) void lead_forward_kernel(const int* __restrict_
       s = group_sum(s, G);
       if (idx < end && sub == 0) {
         const int i = nodes[idx];
-        const double xi = lead_rhs(ax, asmc, b, isig, i) - s;
+        const double xi = lead_rhs_at(ax, asmc, b, isig, rid, i) - s;
         xs[idx - first] = xi;
         x[i] = xi;
       }
@@ -197,7 +205,8 @@ __device__ __forceinline__ void lead_sweep_lds_body(const LeadTreeDesc d, double
                                                     const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
                                                     const int* __restrict__ ci, const double* __restrict__ v,
                                                     const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
-                                                    const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
+                                                    const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
+                                                    const int* __restrict__ rid) {
   constexpr int NT = 64 * NW;
   const int lane = tid & 63, wave = tid >> 6;
   const int l0 = d.l0, nlev = d.nlev, first = d.first, cnt = d.cnt, nnz = d.nnz;
@@ -235,7 +244,7 @@ __device__ __forceinline__ void lead_sweep_lds_body(const LeadTreeDesc d, double
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = tid + u * NT, nd = r_nd[u];
-      r_rhs[u] = i < cnt ? (BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs(ax, asmc, b, isig, nd)) : 0.0;
+      r_rhs[u] = i < cnt ? (BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs_at(ax, asmc, b, isig, rid, nd)) : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -257,7 +266,7 @@ __device__ __forceinline__ void lead_sweep_lds_body(const LeadTreeDesc d, double
   for (int i = tid + U * NT; i < cnt; i += NT) {
     const int nd = nodes[first + i];
     snode[i] = nd;
-    rhs[i] = BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs(ax, asmc, b, isig, nd);
+    rhs[i] = BACKWARD ? x[nd] / D[nd] - w[nd] : lead_rhs_at(ax, asmc, b, isig, rid, nd);
   }
   for (int q = tid + UV * NT; q < nnz; q += NT) { sv[q] = v[q0 + q]; sci[q] = ci[q0 + q]; }
   if (NW > 1) __syncthreads(); else wave_fence();
@@ -287,9 +296,10 @@ __global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeD
                                                             const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
                                                             const int* __restrict__ ci, const double* __restrict__ v,
                                                             const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
-                                                            const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
+                                                            const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
+                                                            const int* __restrict__ rid) {
   extern __shared__ double lead_smem[];
-  lead_sweep_lds_body<BACKWARD, NW>(desc[blockIdx.x], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x);
+  lead_sweep_lds_body<BACKWARD, NW>(desc[blockIdx.x], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x, rid);
 }
 
 // The few big trees and the many small ones in ONE launch (round 5): workgroups [0, n_big) take a big tree each on four wavefronts,
@@ -302,18 +312,101 @@ __global__ __launch_bounds__(256) void lead_sweep_merged_kernel(const LeadTreeDe
                                                              const int* __restrict__ lvl_g, const int* __restrict__ nodes, const long long* __restrict__ ptr,
                                                              const int* __restrict__ ci, const double* __restrict__ v,
                                                              const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
-                                                             const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x) {
+                                                             const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
+                                                             const int* __restrict__ rid) {
   extern __shared__ double lead_smem[];
   const int blk = (int)blockIdx.x;
   if (blk < n_big) {
-    lead_sweep_lds_body<BACKWARD, 4>(desc_big[blk], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x);
+    lead_sweep_lds_body<BACKWARD, 4>(desc_big[blk], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x, rid);
   } else {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int t = 4 * (blk - n_big) + wave;
     if (t < n_small)
       lead_sweep_lds_body<BACKWARD, 1>(desc_small[t], lead_smem + (size_t)wave * small_doubles, (int)threadIdx.x & 63, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig,
-                                       D, w, x);
+                                       D, w, x, rid);
   }
+}
+
+// ---- dense tree tops (lead_solve.h) -------------------------------------------------------------------------------------------------
+// rows of the extended tail [T | K] over the B columns: zext[e] = rhs(row e) - sum_j L[e][j] z_B[j]   (LANES lanes per row, fixed order)
+template <int LANES>
+__global__ __launch_bounds__(256) void lead_ext_rhs_kernel(int kext, int n1, const long long* __restrict__ rp, const int* __restrict__ ci,
+                                                           const double* __restrict__ v, const double* __restrict__ ax, const double* __restrict__ asmc,
+                                                           const double* __restrict__ b, double isig, const int* __restrict__ rid,
+                                                           const double* __restrict__ zB, double* __restrict__ zext) {
+  const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(gt / LANES), sub = (int)(gt % LANES);
+  if (e >= kext) return;
+  double s = 0.0;
+  for (long long q = rp[e] + sub; q < rp[e + 1]; q += LANES) s += v[q] * zB[ci[q]];
+#pragma unroll
+  for (int o = LANES / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (sub == 0) zext[e] = lead_rhs_at(ax, asmc, b, isig, rid, n1 + e) - s;
+}
+
+// out[i] = sum_c vals[off[i] + c] * in[start + c], c < len: a packed row of W_T (start = beg[i], the row ends at i) or of W_T^T (start = i,
+// len[i] entries); one wavefront per row, lanes stride the row (coalesced), xor butterfly: a fixed order
+__global__ __launch_bounds__(256) void tops_gemv_kernel(int nrows, const long long* __restrict__ off, const int* __restrict__ beg, const int* __restrict__ len,
+                                                        const double* __restrict__ vals, const double* __restrict__ in, double* __restrict__ out, int acc) {
+  const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (i >= nrows) return;
+  const int start = beg ? beg[i] : i, n = beg ? i - start + 1 : len[i];
+  const double* __restrict__ row = vals + off[i];
+  const double* __restrict__ x = in + start;
+  double s0 = 0.0, s1 = 0.0;
+  int c = lane;
+  for (; c + 64 < n; c += 128) { s0 += row[c] * x[c]; s1 += row[c + 64] * x[c + 64]; }
+  if (c < n) s0 += row[c] * x[c];
+  double s = s0 + s1;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[i] = acc ? out[i] + s : s;
+}
+
+// residual of the unit triangular system of the tops: out[i] = rhs[i] - x[i] - sum_c T[i][c] x[c], T = the strict part of L_TT by rows
+// (forward) or of L_TT^T by rows (backward: the CSC arrays); 32 lanes per row
+__global__ __launch_bounds__(256) void tops_resid_kernel(int n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                                                         const double* __restrict__ x, const double* __restrict__ rhs, double* __restrict__ out) {
+  const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int i = gt >> 5, sub = gt & 31;
+  if (i >= n) return;
+  double s = 0.0;
+  for (long long q = rp[i] + sub; q < rp[i + 1]; q += 32) s += v[q] * x[ci[q]];
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (sub == 0) out[i] = rhs[i] - x[i] - s;
+}
+
+// the tail's right-hand side: out[i] = zK[i] - sum_c L_KT[i][c] z_T[c]   (one wavefront per tail row: several hundred entries each)
+__global__ __launch_bounds__(256) void tops_k_rhs_kernel(int kt, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                                                         const double* __restrict__ zT, const double* __restrict__ zK, double* __restrict__ out) {
+  const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (i >= kt) return;
+  double s = 0.0;
+  for (long long q = rp[i] + lane; q < rp[i + 1]; q += 64) s += v[q] * zT[ci[q]];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[i] = zK[i] - s;
+}
+
+// u[c] = z_T[c] / D_T[c] - sum_i L_KT[i][c] x_K[i]   (one wavefront per T column)
+__global__ __launch_bounds__(256) void tops_u_kernel(int nT, const long long* __restrict__ cp, const int* __restrict__ ri, const double* __restrict__ v,
+                                                     const double* __restrict__ xK, const double* __restrict__ zT, const double* __restrict__ DT,
+                                                     double* __restrict__ u) {
+  const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (c >= nT) return;
+  double s = 0.0;
+  for (long long q = cp[c] + lane; q < cp[c + 1]; q += 64) s += v[q] * xK[ri[q]];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) u[c] = zT[c] / DT[c] - s;
+}
+
+// the solution back in the caller's order: y[rid[p]] = p < n1 ? xp[p] : xext[p - n1]
+__global__ __launch_bounds__(256) void tops_scatter_kernel(int m, int n1, const int* __restrict__ rid, const double* __restrict__ xp, const double* __restrict__ xext,
+                                                           double* __restrict__ y) {
+  const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (p < m) y[rid[p]] = p < n1 ? xp[p] : xext[p - n1];
 }
 
 }  // namespace
@@ -327,6 +420,13 @@ void LeadSolve::release() {
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
   if (aux) { hipError_t e = hipStreamDestroy(aux); (void)e; e = hipEventDestroy(ev_fork); (void)e; e = hipEventDestroy(ev_join); (void)e; aux = nullptr; ev_fork = ev_join = nullptr; }
   desc_small_f = desc_small_b = desc_big_f = desc_big_b = nullptr; trees_stream = nullptr; n_small = n_big = n_stream = 0;
+  for (void* p : {(void*)rid, (void*)xp, (void*)zext, (void*)xext, (void*)zT, (void*)uT, (void*)DT, (void*)Wf, (void*)Wb, (void*)wf_off, (void*)wb_off,
+                  (void*)wf_beg, (void*)wb_len, (void*)kt_rp, (void*)tk_cp, (void*)kt_ci, (void*)tk_ri, (void*)kt_v, (void*)tk_v, (void*)tt_rp, (void*)tt_cp,
+                  (void*)tt_ci, (void*)tt_ri, (void*)tt_v, (void*)tt_cv})
+    if (p) { hipError_t e = hipFree(p); (void)e; }
+  rid = wf_beg = wb_len = kt_ci = tk_ri = nullptr; xp = zext = xext = zT = uT = DT = Wf = Wb = kt_v = tk_v = nullptr;
+  wf_off = wb_off = kt_rp = tk_cp = tt_rp = tt_cp = nullptr; tt_ci = tt_ri = nullptr; tt_v = tt_cv = nullptr;
+  tops = false; nT = 0; k_tail = 0; tops_bytes = 0; tops_blocks = tops_max = 0;
   if (zfull) { hipError_t e = hipFree(zfull); (void)e; zfull = nullptr; }
   if (h_w) { hipError_t e = hipHostFree(h_w); (void)e; h_w = nullptr; }
   if (h_z) { hipError_t e = hipHostFree(h_z); (void)e; h_z = nullptr; }
@@ -343,6 +443,7 @@ static int hybrid_buffers(LeadSolve& L) {
 }
 
 bool LeadSolve::demote_to_hybrid() {
+  if (tops) { release(); return false; }              // built in B | T | K order: not what the host's sweeps index
   if (!ready || !l21_pays() || !rp21 || !tptr) { release(); return false; }
   // keep rp21 / ci21 / v21, tptr / tri / tv_ and wvec; everything of the sweeps goes
   for (void* p : {(void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)D1, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f,
@@ -382,6 +483,33 @@ int LeadSolve::apply_l21(double* x, bool x_pinned, TailSolve& tail, hipStream_t 
 
 int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid) {
   release();
+  if (k_ > 0 && m_ - k_ > 0 && tops_level != 0) {
+    int level = tops_level > 0 ? tops_level : 0;
+    if (tops_level < 0) {
+      // automatic: only where the plain sweeps cannot run at all (a tree beyond 6 144 nodes or 2 048 levels: build_core's limits)
+      const int n1o = m_ - k_;
+      std::vector<int> parent((size_t)n1o, -1), height((size_t)n1o, 0), cnt((size_t)n1o, 1);
+      int deepest = 0, largest = 0;
+      for (int j = 0; j < n1o; ++j) {
+        int pmin = -1;
+        for (long long p = Lp[j]; p < Lp[j + 1]; ++p) if (Li[p] < n1o && (pmin < 0 || Li[p] < pmin)) pmin = Li[p];
+        parent[j] = pmin;
+        if (pmin >= 0) { height[pmin] = std::max(height[pmin], height[j] + 1); cnt[pmin] += cnt[j]; }
+        else { deepest = std::max(deepest, height[j] + 1); largest = std::max(largest, cnt[j]); }
+      }
+      if (largest > 6144 || deepest > 2048) level = 32;
+    }
+    if (level > 0) {
+      const int rc = build_tops(m_, k_, Lp, Li, Lx, D, level);
+      if (rc == CUADMM_OK && ready) return CUADMM_OK;
+      if (rc != CUADMM_OK && rc != CUADMM_ERR_FACTOR) return rc;
+      release();                                       // the cut did not help (or an inverse failed its check): the plain paths decide
+    }
+  }
+  return build_core(m_, k_, Lp, Li, Lx, D, allow_hybrid);
+}
+
+int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid) {
   m = m_; k = k_; n1 = m - k;
   if (k <= 0 || n1 < 0) return CUADMM_OK;
   if (n1 == 0) {
@@ -596,46 +724,287 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
   return CUADMM_OK;
 }
 
+// Dense tree tops (lead_solve.h).  T = leading nodes of height >= `level` in the elimination forest (height of a node = its level in the
+// forward sweep): upward closed, one connected top per tree.  The factor is taken in the order B | T (tree after tree) | K; build_core then
+// sees B as the leading block and T | K as its tail rows, and the middle stage is built here: W_t = L_tt^-1 per tree (rows of the unit
+// lower-triangular inverse from the sparse rows of L_tt: W[r] = e_r - sum_c L[r][c] W[c]), packed by rows and, transposed, by columns;
+// L_KT by rows and by columns.  Every inverse is checked (L_tt (W_t v) = v to 1e-9) before it is trusted: CUADMM_ERR_FACTOR otherwise.
+int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D, int level) {
+  const int n1o = m_ - k_;
+  std::vector<int> parent((size_t)n1o, -1), height((size_t)n1o, 0), root((size_t)n1o);
+  for (int j = 0; j < n1o; ++j) {
+    int pmin = -1;
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p) if (Li[p] < n1o && (pmin < 0 || Li[p] < pmin)) pmin = Li[p];
+    parent[j] = pmin;
+    if (pmin >= 0) height[pmin] = std::max(height[pmin], height[j] + 1);
+  }
+  for (int j = n1o - 1; j >= 0; --j) root[j] = parent[j] < 0 ? j : root[parent[j]];
+  // T in the order (tree, index): the nodes of one top are contiguous
+  std::vector<int> tnodes;
+  for (int j = 0; j < n1o; ++j) if (height[j] >= level) tnodes.push_back(j);
+  const int nt = (int)tnodes.size();
+  if (nt == 0 || nt == n1o) return CUADMM_ERR_FACTOR;                 // nothing to cut / nothing left: not this path
+  std::stable_sort(tnodes.begin(), tnodes.end(), [&](int a, int b) { return root[a] < root[b]; });
+  const int nB = n1o - nt;
+  std::vector<int> newid((size_t)n1o), ridh((size_t)m_);
+  {
+    int pb = 0;
+    for (int j = 0; j < n1o; ++j) if (height[j] < level) { newid[j] = pb; ridh[pb++] = j; }
+    for (int t = 0; t < nt; ++t) { newid[tnodes[t]] = nB + t; ridh[(size_t)nB + t] = tnodes[t]; }
+    for (int r = n1o; r < m_; ++r) ridh[r] = r;
+  }
+  // blocks of T
+  std::vector<int> blk_ptr{0};
+  for (int t = 1; t <= nt; ++t) if (t == nt || root[tnodes[t]] != root[tnodes[t - 1]]) blk_ptr.push_back(t);
+  const int nblk = (int)blk_ptr.size() - 1;
+  long long tri_total = 0;
+  int bmax = 0;
+  for (int q = 0; q < nblk; ++q) { const long long n = blk_ptr[q + 1] - blk_ptr[q]; tri_total += n * (n + 1) / 2; bmax = std::max(bmax, (int)n); }
+  if (tri_total * 16 > (6ll << 30)) return CUADMM_ERR_FACTOR;          // both triangles beyond 6 GB: not this path
+  // the B columns in the new order (rows: B ascending, then T, then K -- T rows sorted by their new index)
+  std::vector<int64_t> Lp2((size_t)nB + 1, 0);
+  std::vector<int> Li2;
+  std::vector<double> Lx2, D2((size_t)m_);
+  for (int p = 0; p < m_; ++p) D2[p] = D[ridh[p]];
+  {
+    long long nz = 0;
+    for (int pb = 0; pb < nB; ++pb) { const int j = ridh[pb]; nz += Lp[j + 1] - Lp[j]; }
+    Li2.resize((size_t)nz); Lx2.resize((size_t)nz);
+    std::vector<std::pair<int, double>> trow;
+    long long q = 0;
+    for (int pb = 0; pb < nB; ++pb) {
+      const int j = ridh[pb];
+      trow.clear();
+      for (long long p = Lp[j]; p < Lp[j + 1]; ++p) {
+        const int i = Li[p];
+        if (i < n1o && height[i] < level) { Li2[(size_t)q] = newid[i]; Lx2[(size_t)q] = Lx[p]; ++q; }
+        else if (i < n1o) trow.emplace_back(newid[i], Lx[p]);
+      }
+      // B rows ascending in the old order are ascending in the new one; T rows are sorted here
+      std::sort(trow.begin(), trow.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+      for (const auto& e : trow) { Li2[(size_t)q] = e.first; Lx2[(size_t)q] = e.second; ++q; }
+      for (long long p = Lp[j]; p < Lp[j + 1]; ++p) if (Li[p] >= n1o) { Li2[(size_t)q] = Li[p]; Lx2[(size_t)q] = Lx[p]; ++q; }
+      Lp2[(size_t)pb + 1] = q;
+    }
+  }
+  int rc = build_core(m_, nt + k_, Lp2.data(), Li2.data(), Lx2.data(), D2.data(), false);
+  if (rc) return rc;
+  if (!ready) return CUADMM_ERR_FACTOR;                                // the rest is still too deep / too big for the sweeps
+  ready = false;
+  std::vector<int64_t>().swap(Lp2); std::vector<int>().swap(Li2); std::vector<double>().swap(Lx2);
+  // ---- the middle stage
+  // sparse rows of L_TT (T-local indices) and L_KT from the T columns
+  std::vector<long long> rpt((size_t)nt + 1, 0), krp((size_t)k_ + 1, 0), kcp((size_t)nt + 1, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int j = tnodes[t];
+    for (long long p = Lp[j]; p < Lp[j + 1]; ++p) {
+      const int i = Li[p];
+      if (i < n1o) rpt[(size_t)(newid[i] - nB) + 1]++;
+      else { krp[(size_t)(i - n1o) + 1]++; kcp[(size_t)t + 1]++; }
+    }
+  }
+  for (int t = 0; t < nt; ++t) { rpt[(size_t)t + 1] += rpt[t]; kcp[(size_t)t + 1] += kcp[t]; }
+  for (int i = 0; i < k_; ++i) krp[(size_t)i + 1] += krp[i];
+  std::vector<int> cit((size_t)rpt[nt]), kci((size_t)krp[k_]), kri((size_t)kcp[nt]);
+  std::vector<double> vt((size_t)rpt[nt]), kv((size_t)krp[k_]), kcv((size_t)kcp[nt]);
+  {
+    std::vector<long long> ft(rpt.begin(), rpt.end() - 1), fk(krp.begin(), krp.end() - 1);
+    for (int t = 0; t < nt; ++t) {                      // columns ascending => column indices ascending inside every row
+      const int j = tnodes[t];
+      long long qc = kcp[t];
+      for (long long p = Lp[j]; p < Lp[j + 1]; ++p) {
+        const int i = Li[p];
+        if (i < n1o) { const long long q = ft[(size_t)(newid[i] - nB)]++; cit[(size_t)q] = t; vt[(size_t)q] = Lx[p]; }
+        else {
+          const long long q = fk[(size_t)(i - n1o)]++;
+          kci[(size_t)q] = t; kv[(size_t)q] = Lx[p];
+          kri[(size_t)qc] = i - n1o; kcv[(size_t)qc] = Lx[p]; ++qc;
+        }
+      }
+    }
+  }
+  // packed inverses, block after block, on the host pool
+  std::vector<long long> offf((size_t)nt), offb((size_t)nt), base((size_t)nblk + 1, 0);
+  std::vector<int> begf((size_t)nt), lenb((size_t)nt);
+  for (int q = 0; q < nblk; ++q) { const long long n = blk_ptr[q + 1] - blk_ptr[q]; base[(size_t)q + 1] = base[q] + n * (n + 1) / 2; }
+  for (int q = 0; q < nblk; ++q) {
+    const int t0 = blk_ptr[q], n = blk_ptr[q + 1] - t0;
+    for (int r = 0; r < n; ++r) {
+      offf[(size_t)t0 + r] = base[q] + (long long)r * (r + 1) / 2;
+      begf[(size_t)t0 + r] = t0;
+      offb[(size_t)t0 + r] = base[q] + (long long)r * n - (long long)r * (r - 1) / 2;     // rows of W^T: n, n - 1, ... entries
+      lenb[(size_t)t0 + r] = n - r;
+    }
+  }
+  std::vector<double> wf((size_t)tri_total), wb((size_t)tri_total);
+  std::atomic<int> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&]() {
+    for (;;) {
+      const int q = next.fetch_add(1);
+      if (q >= nblk) return;
+      const int t0 = blk_ptr[q], n = blk_ptr[q + 1] - t0;
+      double* W = wf.data() + base[q];
+      for (int r = 0; r < n; ++r) {
+        double* wr = W + (long long)r * (r + 1) / 2;
+        std::fill(wr, wr + r, 0.0);
+        wr[r] = 1.0;
+        for (long long e = rpt[(size_t)t0 + r]; e < rpt[(size_t)t0 + r + 1]; ++e) {
+          const int c = cit[(size_t)e] - t0;            // a column of the same block, c < r
+          const double l = vt[(size_t)e];
+          const double* wc = W + (long long)c * (c + 1) / 2;
+          for (int x = 0; x <= c; ++x) wr[x] -= l * wc[x];
+        }
+      }
+      // the transposed copy: row r of W^T = column r of W, from the diagonal down
+      double* WT = wb.data() + base[q];
+      for (int r = 0; r < n; ++r) {
+        const double* wr = W + (long long)r * (r + 1) / 2;
+        for (int c = 0; c <= r; ++c) WT[(long long)c * n - (long long)c * (c - 1) / 2 + (r - c)] = wr[c];
+      }
+      // check: L_tt (W v) = v
+      std::vector<double> v((size_t)n), tvec((size_t)n);
+      unsigned long long seed = 0x9e3779b97f4a7c15ull + (unsigned long long)q;
+      for (int r = 0; r < n; ++r) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; v[r] = 0.5 + (double)(seed >> 11) * (1.0 / 9007199254740992.0); }
+      for (int r = 0; r < n; ++r) {
+        const double* wr = W + (long long)r * (r + 1) / 2;
+        double acc = 0.0;
+        for (int c = 0; c <= r; ++c) acc += wr[c] * v[c];
+        tvec[r] = acc;
+      }
+      double err = 0.0;
+      for (int r = 0; r < n; ++r) {
+        double acc = tvec[r];
+        for (long long e = rpt[(size_t)t0 + r]; e < rpt[(size_t)t0 + r + 1]; ++e) acc += vt[(size_t)e] * tvec[cit[(size_t)e] - t0];
+        err = std::max(err, std::fabs(acc - v[r]));
+      }
+      if (!(err <= 1e-9)) bad.fetch_add(1);
+    }
+  };
+  {
+    const int nth = std::max(1, std::min(std::min(cuadmm_host_pool_threads(), 16), nblk));
+    std::vector<std::thread> th;
+    for (int i = 1; i < nth; ++i) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  if (bad.load() > 0) { set_error("lead_solve: %d of %d dense tree tops fail the check of their inverse", bad.load(), nblk); return CUADMM_ERR_FACTOR; }
+  std::vector<double> dt((size_t)nt);
+  for (int t = 0; t < nt; ++t) dt[t] = D[tnodes[t]];
+  // L_TT by columns for the refinement of the backward solve (the rows of L_TT^T)
+  std::vector<long long> cpt((size_t)nt + 1, 0);
+  for (long long e = 0; e < rpt[nt]; ++e) cpt[(size_t)cit[(size_t)e] + 1]++;
+  for (int t = 0; t < nt; ++t) cpt[(size_t)t + 1] += cpt[t];
+  std::vector<int> rit((size_t)rpt[nt]);
+  std::vector<double> vct((size_t)rpt[nt]);
+  {
+    std::vector<long long> fc(cpt.begin(), cpt.end() - 1);
+    for (int r = 0; r < nt; ++r)
+      for (long long e = rpt[r]; e < rpt[(size_t)r + 1]; ++e) { const long long q = fc[(size_t)cit[(size_t)e]]++; rit[(size_t)q] = r; vct[(size_t)q] = vt[(size_t)e]; }
+  }
+  if ((rc = to_device(tt_rp, rpt)) || (rc = to_device(tt_ci, cit)) || (rc = to_device(tt_v, vt)) || (rc = to_device(tt_cp, cpt)) || (rc = to_device(tt_ri, rit)) ||
+      (rc = to_device(tt_cv, vct)))
+    return rc;
+  if ((rc = to_device(rid, ridh)) || (rc = to_device(Wf, wf)) || (rc = to_device(Wb, wb)) || (rc = to_device(wf_off, offf)) || (rc = to_device(wb_off, offb)) ||
+      (rc = to_device(wf_beg, begf)) || (rc = to_device(wb_len, lenb)) || (rc = to_device(kt_rp, krp)) || (rc = to_device(kt_ci, kci)) || (rc = to_device(kt_v, kv)) ||
+      (rc = to_device(tk_cp, kcp)) || (rc = to_device(tk_ri, kri)) || (rc = to_device(tk_v, kcv)) || (rc = to_device(DT, dt)))
+    return rc;
+  CUADMM_HIP_TRY(hipMalloc(&xp, sizeof(double) * (size_t)m_));
+  CUADMM_HIP_TRY(hipMalloc(&zext, sizeof(double) * (size_t)(nt + k_)));
+  CUADMM_HIP_TRY(hipMalloc(&xext, sizeof(double) * (size_t)(nt + k_)));
+  CUADMM_HIP_TRY(hipMalloc(&zT, sizeof(double) * (size_t)nt));
+  CUADMM_HIP_TRY(hipMalloc(&uT, sizeof(double) * (size_t)nt));
+  nT = nt; k_tail = k_; tops = true;
+  tops_bytes = tri_total * 16; tops_blocks = nblk; tops_max = bmax;
+  // cost model: the sweeps of the shallow rest (build_core's), the SpMVs (12 B per nonzero at 3.5 TB/s), the two dense passes at 4.5 TB/s, launches
+  est_us += 2.0 * (double)(krp[k_]) * 12.0 / 3.5e6 + (double)tops_bytes / 4.5e6 + 50.0;
+  if (debug)
+    fprintf(stderr, "[lead debug] dense tree tops at height %d: %d nodes in %d blocks (largest %d), %.0f MB of inverses; L_KT %lld nonzeros; rest: %d nodes, depth <= %d\n",
+            level, nt, nblk, bmax, (double)tops_bytes / 1e6, (long long)krp[k_], nB, max_levels);
+  ready = true;
+  return CUADMM_OK;
+}
+
+// the sweeps over the leading forest, one direction: big trees (four wavefronts each) and small ones (one wavefront each, four per
+// workgroup) in ONE launch when both exist, the streaming kernels for trees beyond a workgroup's LDS
+static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st) {
+  const bool merged = L.n_big > 0 && L.n_small > 0;
+  const int small_doubles = (int)((L.lds_small + 7) / 8);
+  const size_t lds_merged = std::max(L.lds_big, 4 * sizeof(double) * (size_t)small_doubles);
+  const unsigned grid_merged = (unsigned)(L.n_big + (L.n_small + 3) / 4);
+  const double* nul = nullptr;
+  if (!backward) {
+    if (merged)
+      hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.n_big,
+                         static_cast<const LeadTreeDesc*>(L.desc_small_f), L.n_small, small_doubles, L.lvl_off_f, L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig,
+                         nul, nul, x, L.rid);
+    else if (L.n_small > 0)
+      hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(L.n_small), dim3(64), L.lds_small, st, static_cast<const LeadTreeDesc*>(L.desc_small_f), L.lvl_off_f,
+                         L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+    else if (L.n_big > 0)
+      hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(L.n_big), dim3(256), L.lds_big, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.lvl_off_f, L.lvl_g_f,
+                         L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+    if (L.n_stream > 0) hipLaunchKernelGGL(lead_forward_kernel, dim3(L.n_stream), dim3(64), L.lds_bytes, st, L.lvl_ptr_f, L.lvl_off_f, L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_,
+                                           ax, asmc, b, isig, x, L.max_nodes, L.max_levels, L.trees_stream, L.rid);
+  } else {
+    if (merged)
+      hipLaunchKernelGGL(lead_sweep_merged_kernel<true>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_b), L.n_big,
+                         static_cast<const LeadTreeDesc*>(L.desc_small_b), L.n_small, small_doubles, L.lvl_off_b, L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_,
+                         nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+    else if (L.n_small > 0)
+      hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(L.n_small), dim3(64), L.lds_small, st, static_cast<const LeadTreeDesc*>(L.desc_small_b), L.lvl_off_b,
+                         L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+    else if (L.n_big > 0)
+      hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(L.n_big), dim3(256), L.lds_big, st, static_cast<const LeadTreeDesc*>(L.desc_big_b), L.lvl_off_b, L.lvl_g_b,
+                         L.nodes_b, L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+    if (L.n_stream > 0) hipLaunchKernelGGL(lead_backward_kernel, dim3(L.n_stream), dim3(64), L.lds_bytes, st, L.lvl_ptr_b, L.lvl_off_b, L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_,
+                                           L.D1, L.wvec, x, L.max_nodes, L.max_levels, L.trees_stream);
+  }
+}
+
 int LeadSolve::solve(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const {
   if (!ready) { set_error("lead_solve: not built"); return CUADMM_ERR_INVALID; }
-  // big trees (four wavefronts each) and small ones (one wavefront each, four per workgroup) in ONE launch when both exist
-  const bool merged = n_big > 0 && n_small > 0;
-  const int small_doubles = (int)((lds_small + 7) / 8);
-  const size_t lds_merged = std::max(lds_big, 4 * sizeof(double) * (size_t)small_doubles);
-  const unsigned grid_merged = (unsigned)(n_big + (n_small + 3) / 4);
-  if (merged)
-    hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(desc_big_f), n_big,
-                       static_cast<const LeadTreeDesc*>(desc_small_f), n_small, small_doubles, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig,
-                       (const double*)nullptr, (const double*)nullptr, y);
-  else if (n_small > 0)
-    hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_f), lvl_off_f,
-                       lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
-  else if (n_big > 0)
-    hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(n_big), dim3(256), lds_big, st, static_cast<const LeadTreeDesc*>(desc_big_f), lvl_off_f, lvl_g_f,
-                       nodes_f, fptr, fci, fv_, ax, asmc, b, isig, (const double*)nullptr, (const double*)nullptr, y);
-  if (n_stream > 0) hipLaunchKernelGGL(lead_forward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_f, lvl_off_f, lvl_g_f, nodes_f, fptr, fci, fv_, ax, asmc, b,
-                                       isig, y, max_nodes, max_levels, trees_stream);
+  if (tops) return solve_tops(ax, asmc, b, isig, y, tail, st);
+  launch_sweeps(*this, false, ax, asmc, b, isig, y, st);
   hipLaunchKernelGGL(lead_tail_rhs_kernel, dim3((k * 8 + 255) / 256), dim3(256), 0, st, k, n1, rp21, ci21, v21, ax, asmc, b, isig, y, tail.vin);
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
   if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
-  if (merged)
-    hipLaunchKernelGGL(lead_sweep_merged_kernel<true>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(desc_big_b), n_big,
-                       static_cast<const LeadTreeDesc*>(desc_small_b), n_small, small_doubles, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_,
-                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  else if (n_small > 0)
-    hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(n_small), dim3(64), lds_small, st, static_cast<const LeadTreeDesc*>(desc_small_b), lvl_off_b,
-                       lvl_g_b, nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  else if (n_big > 0)
-    hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(n_big), dim3(256), lds_big, st, static_cast<const LeadTreeDesc*>(desc_big_b), lvl_off_b, lvl_g_b,
-                       nodes_b, bptr, bci, bv_, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, D1, wvec, y);
-  if (n_stream > 0) hipLaunchKernelGGL(lead_backward_kernel, dim3(n_stream), dim3(64), lds_bytes, st, lvl_ptr_b, lvl_off_b, lvl_g_b, nodes_b, bptr, bci, bv_, D1, wvec, y,
-                                       max_nodes, max_levels, trees_stream);
+  launch_sweeps(*this, true, ax, asmc, b, isig, y, st);
   CUADMM_HIP_TRY(hipGetLastError());
   // the solved tail into y: a kernel of its own, not hipMemcpyAsync -- the runtime's device-to-device copy is a blit behind ~15 us of
   // command-processor work (kernel trace of pendulum N = 80: 14.7 us idle in front of every one, once per solve)
   hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, tail.vin, y + n1, k);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
+// Dense tree tops (lead_solve.h): B sweeps, the block-diagonal middle stage, the tail, and back.
+int LeadSolve::solve_tops(const double* ax, const double* asmc, const double* b, double isig, double* y, TailSolve& tail, hipStream_t st) const {
+  const int kt = k_tail, kext = k;                    // k = |T| + tail: what the B sweeps see as "the tail rows"
+  launch_sweeps(*this, false, ax, asmc, b, isig, xp, st);                                                       // z_B
+  hipLaunchKernelGGL(lead_ext_rhs_kernel<32>, dim3((unsigned)(((long long)kext * 32 + 255) / 256)), dim3(256), 0, st, kext, n1, rp21, ci21, v21, ax, asmc, b, isig, rid,
+                     xp, zext);                                                                                  // r_T - L_TB z_B | r_K - L_KB z_B
+  hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wf_off, wf_beg, (const int*)nullptr, Wf, zext, zT, 0);   // z_T = W_T (...)
+  if (tops_refine) {                                                                                             // z_T += W_T (r - L_TT z_T)
+    hipLaunchKernelGGL(tops_resid_kernel, dim3((unsigned)(((long long)nT * 32 + 255) / 256)), dim3(256), 0, st, nT, tt_rp, tt_ci, tt_v, zT, zext, uT);
+    hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wf_off, wf_beg, (const int*)nullptr, Wf, uT, zT, 1);
+  }
+  hipLaunchKernelGGL(tops_k_rhs_kernel, dim3((unsigned)((kt + 3) / 4)), dim3(256), 0, st, kt, kt_rp, kt_ci, kt_v, zT, zext + nT, tail.vin);       // z_K -= L_KT z_T
+  CUADMM_HIP_TRY(hipGetLastError());
+  int rc = tail.solve_device(st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tops_u_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, tk_cp, tk_ri, tk_v, tail.vin, zT, DT, uT);             // D_T^-1 z_T - L_KT^T x_K
+  hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wb_off, (const int*)nullptr, wb_len, Wb, uT, xext, 0);  // x_T = W_T^T (...)
+  if (tops_refine) {                                                                                             // x_T += W_T^T (u - L_TT^T x_T); zext's T part is free by now
+    hipLaunchKernelGGL(tops_resid_kernel, dim3((unsigned)(((long long)nT * 32 + 255) / 256)), dim3(256), 0, st, nT, tt_cp, tt_ri, tt_cv, xext, uT, zext);
+    hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wb_off, (const int*)nullptr, wb_len, Wb, zext, xext, 1);
+  }
+  hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((kt + 255) / 256)), dim3(256), 0, st, tail.vin, xext + nT, kt);
+  if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, xext, wvec);                 // w = [L_TB; L_KB]^T [x_T; x_K]
+  launch_sweeps(*this, true, ax, asmc, b, isig, xp, st);                                                        // x_B
+  hipLaunchKernelGGL(tops_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, n1, rid, xp, xext, y);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }

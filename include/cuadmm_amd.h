@@ -176,7 +176,7 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
  *   [0] launches that ran several ADMM iterations (option "batch"), [1] iterations run by them, [2] batches rolled back because
  *   the stopping test fired inside them, [3] threads of the host pool, [4] 1 if the iteration is fused into the projection
  *   kernels, [5] 1 if every block solves for its own multipliers (closed blocks), [6] 1 if the y-solve runs on the device (2: hybrid --
- *   L11 sweeps on the host, L21 products and the tail on the device),
+ *   L11 sweeps on the host, L21 products and the tail on the device; 3: on the device with dense tree tops, option "lead_tops"),
  *   [7] size of the GPU tail of the A A^T factor. */
 int cuadmm_get_counters(const cuadmm_solver* s, double out8[8]);
 /* The in-process group a handle leads after cuadmm_duo_init(device_num_requested = N) from one process (reference
@@ -264,6 +264,11 @@ int cuadmm_aat_tail_plan(const cuadmm_aat* f, int max_k);
 int cuadmm_aat_create_split(int con_num, int vec_len, const int* A_col_ptrs, const int* A_row_ids,
                             const double* A_vals, double eps, int max_k, cuadmm_aat** out);
 int cuadmm_aat_tail_k(const cuadmm_aat* f);
+/* > 0: the cost model chose this tail for the device-side solve with DENSE TREE TOPS -- the leading elimination forest cut at this
+ * height, the nodes above it solved through explicit inverses of their diagonal blocks (engine option "lead_tops") --; 0 otherwise.
+ * cuadmm_aat_plan_allow_tops(0) makes the calling thread's next cuadmm_aat_create_split plan without them (the planner of round 4). */
+int cuadmm_aat_tail_tops(const cuadmm_aat* f);
+void cuadmm_aat_plan_allow_tops(int allow);
 /* Whole (unsplit) factor for a device-side solve: the strict lower triangle of the unit factor L by columns (Lp[m+1], Li, Lx),
  * the pivots D[m], and the elimination forest as lists of columns per tree (tree t: tree_cols[tree_ptr[t] .. tree_ptr[t+1]),
  * ascending).  The sweeps of a solve never leave a tree, so a block-diagonal A A^T (one small tree per group of coupled

@@ -33,6 +33,7 @@ RUNS = {
     "pendulum_N=80/switch=11000": ("pendulum_N=80", 11000, 60, 1000),
     "pendulum_N=80/switch=11000/late=5000": ("pendulum_N=80", 11000, 60, 5000),      # round 4: the long row of the reference's log, backed further out
     "pendulum_N=80/switch=11000/late=20000": ("pendulum_N=80", 11000, 60, 20000),    # round 5: through the sGS -> ADMM switch at 11 000 and 9 000 iterations beyond
+    "pendulum_N=80/switch=11000/late=100000": ("pendulum_N=80", 11000, 60, 100000),  # round 5: the whole run of examples/pendulum/N=80_licols.log (2 h on 8 cores)
     "PushT_N=10_MOMENT/switch=0": ("PushT_N=10_MOMENT", 0, 60, 500),
     "PushT_N=10_MOMENT/switch=11000": ("PushT_N=10_MOMENT", 11000, 60, 500),
     "PushT_N=30_MOMENT/switch=11000": ("PushT_N=30_MOMENT", 11000, 60, 200),

@@ -42,7 +42,13 @@ TOL = {key: (1e-8, 1e-7) for key in TRAJ}
 POBJ_HEAD_TOL = {"PushT_N=30_MOMENT/switch=11000": 1e-6,      # round 4 (dense rows ordered last, device-side sweeps): measured 4.1e-7; was 1e-5
                  # PlanarHand_N=10 (round 4; m = 483 707, the tail at its cap of 32 768 columns): every quantity <= 7.5e-10 except pobj,
                  # 1.3e-8 on the head (5.8e-11 at the late checkpoint) -- the same explicit inverse, measured and stated
-                 "PlanarHand_N=10_MOMENT/switch=11000": 3e-8}
+                 "PlanarHand_N=10_MOMENT/switch=11000": 3e-8,
+                 # PushBox_N=50 (round 5: a tail of 8 448 columns behind dense tree tops; round 4: 30 720 columns, 6.7e-11): pobj 9.2e-8 on the
+                 # head, every other quantity <= 3.5e-10.  Not the tree tops: the same input at the same tail with the WHOLE leading part swept on
+                 # the host (tail_k = 8448, lead_tops = 0: dev_solve 0) deviates by 9.0e-8, at 8 192 columns both by 5e-9, at 8 704 by 4e-8
+                 # (profiles/r05_tops_deviation.txt).  A A^T of this input has 9 301 pivots at the regularisation (1e-15, one of them negative):
+                 # the component of y along such a direction is rounding error / 1e-15, its image under A^T 3e-8 of it -- in the oracle too.
+                 "PushBox_N=50_MOMENT/switch=11000": 2e-7}
 # |got - ref| <= tol * |ref| + ATOL: the absolute part is the roundoff floor of the quantity (1e-11, as in the other trajectory tests;
 # errRp: the y-solve's own rounding error, see above)
 ATOL = {"errRp": 1e-9, "errRd": 1e-11, "pobj": 1e-11, "dobj": 1e-11, "relgap": 1e-11}
@@ -91,14 +97,18 @@ def run_and_compare(key, tmp_path, options, pobj_head_tol):
     dev_head, dev_late, sig_ok = deviations(s, rec)
     c = s.counters()
     print(key, "tail_k", c["tail_k"], "dev_solve", c["dev_solve"], "head", dev_head, "late", dev_late, "sig", sig_ok)
-    if not options and rec["problem"] in ("PlanarHand_N=1_MOMENT", "pendulum_N=80"):
+    if not options and rec["problem"] == "pendulum_N=80":
         assert c["tail_k"] > 0 and c["dev_solve"] == 1          # the paths this test is about are the ones that ran
+    if not options and rec["problem"] == "PlanarHand_N=1_MOMENT":
+        assert c["tail_k"] > 0 and c["dev_solve"] == 3          # round 5: a smaller tail behind dense tree tops (round 4: 17 152 columns, plain sweeps)
     if not options and rec["problem"] == "PushT_N=30_MOMENT":
         assert c["tail_k"] > 0                                  # GPU tail between host-side leading sweeps
     if not options and rec["problem"] in ("PushBox_N=30_MOMENT", "PushBox_N=50_MOMENT"):
-        assert c["dev_solve"] == 1                              # round 4: the planner's larger tail makes the leading forest shallow
+        assert c["dev_solve"] == 3                              # round 5: dense tree tops at the small tail (round 4: a larger tail made the forest shallow)
+    if options and options.get("lead_tops") == 0 and rec["problem"] in ("PushBox_N=30_MOMENT", "PlanarHand_N=1_MOMENT"):
+        assert c["dev_solve"] == 1                              # round 4's plan: the larger tail, plain sweeps
     if not options and rec["problem"] == "PlanarHand_N=10_MOMENT":
-        assert c["dev_solve"] == 2                              # hybrid: L11 sweeps on the host, L21 and the tail on the device
+        assert c["dev_solve"] == 3                              # round 5: the deep forest cut at height 32, dense tree tops (lead_solve.h); round 4: hybrid
     if options and options.get("l21_device") == 2:
         assert c["dev_solve"] == 2
     assert sig_ok
@@ -115,6 +125,12 @@ def run_and_compare(key, tmp_path, options, pobj_head_tol):
 @pytest.mark.parametrize("key", sorted(TRAJ))
 def test_moment_relaxation_trajectory_matches_the_oracle(key, tmp_path):
     run_and_compare(key, tmp_path, None, POBJ_HEAD_TOL.get(key))
+
+
+@pytest.mark.parametrize("key", ["PlanarHand_N=1_MOMENT/switch=0", "PushBox_N=30_MOMENT/switch=11000"])
+def test_round4_plan_without_tree_tops_still_matches_the_oracle(key, tmp_path):
+    """option lead_tops = 0: the planner and the solve of round 4 (a larger tail, plain level-by-level sweeps) -- the same oracle trajectory"""
+    run_and_compare(key, tmp_path, {"lead_tops": 0}, POBJ_HEAD_TOL.get(key))
 
 
 def test_pusht30_with_the_factor_on_the_host_is_exact(tmp_path):
@@ -142,7 +158,7 @@ def test_pushbox30_host_sweeps_and_hybrid_agree(tmp_path):
     the differently associated L21 sums"""
     p = load_problem("PushBox_N=30_MOMENT", tmp_path)
     out = []
-    for opt, mode in (({"tail_k": 10240, "l21_device": 0}, 0), ({"tail_k": 10240, "l21_device": 2}, 2)):
+    for opt, mode in (({"tail_k": 10240, "l21_device": 0, "lead_tops": 0}, 0), ({"tail_k": 10240, "l21_device": 2}, 2)):
         s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
         s.init_problem(problem_to_amd(p))
         s.solve(40, 0.0, 0, 50, 100, 20, 1.05)
@@ -159,7 +175,7 @@ def test_resident_and_streaming_leading_sweeps_agree_bit_for_bit(name, tmp_path)
     sums -- identical iterates, bit for bit."""
     p = load_problem(name, tmp_path)
     out = []
-    for opt in ({}, {"lead_stream": 1}):
+    for opt in ({"lead_tops": 0}, {"lead_tops": 0, "lead_stream": 1}):
         s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
         s.init_problem(problem_to_amd(p))
         s.solve(40, 0.0, 0, 50, 100, 20, 1.05)
@@ -167,3 +183,24 @@ def test_resident_and_streaming_leading_sweeps_agree_bit_for_bit(name, tmp_path)
         out.append((s.info_arr("pobj").copy(), s.info_arr("errRp").copy(), s.y.copy(), s.X.copy()))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,level", [("pendulum_N=80", 6), ("PlanarHand_N=1_MOMENT", 6), ("PlanarHand_N=1_MOMENT", 20)])
+def test_dense_tree_tops_agree_with_the_plain_sweeps(name, level, tmp_path):
+    """lead_solve.h, dense tree tops: the leading forest cut at height `level` (option lead_tops; the automatic choice only cuts forests
+    the sweeps cannot run), the tops solved through explicit inverses of their diagonal blocks -- the same iterates as the plain
+    level-by-level sweeps up to the rounding of the differently associated sums."""
+    p = load_problem(name, tmp_path)
+    out = []
+    k = {"pendulum_N=80": 10496, "PlanarHand_N=1_MOMENT": 17152}[name]        # the same tail on both sides: round 4's plan
+    for opt, mode in (({"tail_k": k, "lead_tops": 0}, 1), ({"tail_k": k, "lead_tops": level}, 3), ({"tail_k": k, "lead_tops": level, "lead_stream": 1}, 3)):
+        s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
+        s.init_problem(problem_to_amd(p))
+        s.solve(60, 0.0, 0, 50, 100, 30, 1.05)
+        assert s.counters()["dev_solve"] == mode and s.counters()["tail_k"] == k
+        out.append(({nm: s.info_arr(nm).copy() for nm in SIX}, s.X.copy(), s.S.copy()))
+    for nm in SIX:
+        assert rel_dev(out[1][0][nm], out[0][0][nm], nm) <= 1e-8, nm
+        assert np.array_equal(out[1][0][nm], out[2][0][nm]), nm        # resident and streaming sweeps of the cut forest: bit for bit
+    for a, b in ((out[0][1], out[1][1]), (out[0][2], out[1][2])):
+        assert np.linalg.norm(a - b) <= 1e-8 * (1 + np.linalg.norm(a))

@@ -398,17 +398,29 @@ def test_aat_tail_plan_takes_a_larger_tail_when_it_makes_a_deep_forest_shallow()
     Li = np.ctypeslib.as_array(C.cast(Lip, C.POINTER(C.c_int)), shape=(int(Lp[-1]),)).copy()
     cp, ri, vx = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
     hs = C.c_void_p()
-    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(hs)))
-    k = lib.cuadmm_aat_tail_k(hs)
-    assert k % 256 == 0 and 18432 <= k <= 20480
-    height, big = _forest_stats(Lp, Li, m, k)
-    assert height <= 256 and big <= 6144
-    assert _forest_stats(Lp, Li, m, 10240)[0] > 1000                 # what the host optimum would have left
-    # a cap below the shallow region keeps the host optimum
-    hc = C.c_void_p()
-    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 16384, C.byref(hc)))
-    assert lib.cuadmm_aat_tail_k(hc) == 10240
-    lib.cuadmm_aat_free(hc); lib.cuadmm_aat_free(hs); lib.cuadmm_aat_free(h)
+    lib.cuadmm_aat_plan_allow_tops(0)                                # the planner of round 4 (engine: option lead_tops = 0)
+    try:
+        check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(hs)))
+        k = lib.cuadmm_aat_tail_k(hs)
+        assert k % 256 == 0 and 18432 <= k <= 20480 and lib.cuadmm_aat_tail_tops(hs) == 0
+        height, big = _forest_stats(Lp, Li, m, k)
+        assert height <= 256 and big <= 6144
+        assert _forest_stats(Lp, Li, m, 10240)[0] > 1000                 # what the host optimum would have left
+        # a cap below the shallow region keeps the host optimum
+        hc = C.c_void_p()
+        check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 16384, C.byref(hc)))
+        assert lib.cuadmm_aat_tail_k(hc) == 10240
+        lib.cuadmm_aat_free(hc); lib.cuadmm_aat_free(hs)
+    finally:
+        lib.cuadmm_aat_plan_allow_tops(1)
+    # Round 5, dense tree tops (csrc/lead_solve.h): with the nodes of height >= 32 solved through explicit inverses the depth of the forest
+    # stops deciding -- a tail BELOW the host optimum, the forest under it as deep as ever (measured 1.81 -> 0.99 ms per sGS iteration)
+    ht = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(m, p.vec_len, P(cp), P(ri), P(vx), 1e-15, 32768, C.byref(ht)))
+    kt = lib.cuadmm_aat_tail_k(ht)
+    assert kt % 256 == 0 and 4096 <= kt <= 10240 and lib.cuadmm_aat_tail_tops(ht) == 32
+    assert _forest_stats(Lp, Li, m, kt)[0] > 1000
+    lib.cuadmm_aat_free(ht); lib.cuadmm_aat_free(h)
 
 
 @pytest.mark.parametrize("name,k", [("PushBox_N=30_MOMENT", 10240), ("pendulum_N=80", 0)])
@@ -531,14 +543,14 @@ def test_host_pool_survives_two_concurrent_solvers():
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name,m,nnzL,tail_k,perm_sha", [
-    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c"),
-    ("pendulum_N=80", 112028, 929430, 10496, "53e3efdb51729949"),
-    ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3"),
-    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a"),
-    ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176"),
+@pytest.mark.parametrize("name,m,nnzL,tail_k,perm_sha,tops_k", [
+    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c", 10752),
+    ("pendulum_N=80", 112028, 929430, 10496, "53e3efdb51729949", 0),
+    ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3", 0),
+    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a", 8448),
+    ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176", 16384),
 ])
-def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha):
+def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha, tops_k):
     """The fill-reducing ordering (own minimum degree with the near-clique exit -- confirmed by an EXACT degree count since round 5 --
     and the dense-row rule) and the tail planner decide nnz(L), the size of the GPU tail and with them every timing and tolerance
     stated for these inputs: a change to either must show up here first (the job of CHOLMOD's analyze in the reference,
@@ -560,13 +572,28 @@ def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k
     rp, ci, v = (np.ascontiguousarray(At.indptr, np.int32), np.ascontiguousarray(At.indices, np.int32), np.ascontiguousarray(At.data))
     h = C.c_void_p()
     lib.cuadmm_aat_factor_nnz.restype = C.c_int64
-    check(lib.cuadmm_aat_create_split(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
-                                      1e-15, 32768, C.byref(h)))
+    # tail_k: the planner of round 4 (option lead_tops = 0); tops_k: the default since round 5 where the solve with dense tree tops
+    # (cut at height 32) wins by the model, 0 where the plan is unchanged
+    lib.cuadmm_aat_plan_allow_tops(0)
+    try:
+        check(lib.cuadmm_aat_create_split(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                          1e-15, 32768, C.byref(h)))
+    finally:
+        lib.cuadmm_aat_plan_allow_tops(1)
     try:
         perm = np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)).copy()
         assert sorted(perm.tolist()) == list(range(m))
         assert int(lib.cuadmm_aat_factor_nnz(h)) == nnzL
-        assert int(lib.cuadmm_aat_tail_k(h)) == tail_k
+        assert int(lib.cuadmm_aat_tail_k(h)) == tail_k and lib.cuadmm_aat_tail_tops(h) == 0
         assert hashlib.sha256(perm.tobytes()).hexdigest()[:16] == perm_sha
+    finally:
+        lib.cuadmm_aat_free(h)
+    h = C.c_void_p()
+    check(lib.cuadmm_aat_create_split(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                      1e-15, 32768, C.byref(h)))
+    try:
+        assert int(lib.cuadmm_aat_tail_k(h)) == (tops_k if tops_k else tail_k)
+        assert lib.cuadmm_aat_tail_tops(h) == (32 if tops_k else 0)
+        assert np.array_equal(np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)), perm)      # the ordering does not depend on the plan
     finally:
         lib.cuadmm_aat_free(h)

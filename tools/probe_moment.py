@@ -8,6 +8,8 @@ from tests.helpers import problem_to_amd
 
 keys = sys.argv[1].split(",") if len(sys.argv) > 1 else sorted(T.TRAJ)
 variants = [{}, {"psd_hint": 0}, {"tail_k": 0}, {"host_solve": 1}, {"tiny_sign": 0}, {"psd_n16": 0, "psd_n32": 0}]
+if len(sys.argv) > 2:          # variants on the command line: "tail_k=8192,lead_tops=32;lead_tops=0"
+    variants = [dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in v.split(",") if kv) for v in sys.argv[2].split(";")]
 for key in keys:
     rec = T.TRAJ[key]
     with tempfile.TemporaryDirectory() as td:

@@ -20,5 +20,5 @@ t = time.time(); s.solve(cap, 1e-3, 0, 50, 100, sw, 1.05); ts = time.time() - t
 st = s.state()
 it = s.info_iter_num
 prof = {k: round(v["ms"] / max(it, 1), 4) for k, v in s.profile().items() if v["launches"]}
-print("RESULT %s switch_admm=%d %s: L %d m %d | init %.2f s | %d iterations in %.2f s (%.3f ms/iter) | errRp %.2e errRd %.2e relgap %.2e pobj %.9e dobj %.9e | tail_k %d | %s"
-      % (name, sw, opts, p.vec_len, p.con_num, ti, it, ts, ts / max(it, 1) * 1e3, st["errRp"], st["errRd"], st["relgap"], st["pobj"], st["dobj"], int(s.counters()["tail_k"]), prof), flush=True)
+print("RESULT %s switch_admm=%d %s: L %d m %d | init %.2f s | %d iterations in %.2f s (%.3f ms/iter) | errRp %.2e errRd %.2e relgap %.2e pobj %.9e dobj %.9e | tail_k %d dev_solve %d | %s"
+      % (name, sw, opts, p.vec_len, p.con_num, ti, it, ts, ts / max(it, 1) * 1e3, st["errRp"], st["errRd"], st["relgap"], st["pobj"], st["dobj"], int(s.counters()["tail_k"]), int(s.counters()["dev_solve"]), prof), flush=True)
