@@ -1157,6 +1157,11 @@ static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
     } else {
       s->lead.release();
     }
+    // the planner sized the tail for the solve with dense tree tops; if that solve could not be built (an inverse failed its check, the
+    // rest of the forest is still too deep) what runs instead is correct but slower than round 4's plan -- option lead_tops = 0 restores it
+    if (cuadmm_aat_tail_tops(s->fac) > 0 && s->sw.lead_tops < 0 && !(s->dev_solve && s->lead.tops) && s->verbose)
+      printf(" y-solve: the tail of %d columns was planned for dense tree tops, which could not be built (%s); option lead_tops = 0 plans without them\n",
+             s->tail.k, cuadmm_last_error());
   }
   if (s->tail.k == 0 && m > 0 && !s->sw.host_solve) {
     int ntrees = 0, maxc = 0;

@@ -23,6 +23,8 @@ struct LeadSolve {
   long long* fptr = nullptr; int* fci = nullptr; double* fv_ = nullptr;     // forward: row of L11 of the node in the slot
   long long* bptr = nullptr; int* bci = nullptr; double* bv_ = nullptr;     // backward: leading rows of its column
   long long* tptr = nullptr; int* tri = nullptr; double* tv_ = nullptr;     // tail rows of every leading column (w = L21^T x2)
+  int* long_cols_d = nullptr;   // leading columns with more than 128 tail rows: a wavefront each in w = L21^T x2 (lead_l21t_long_kernel)
+  int n_long = 0;
   double* D1 = nullptr;
   double* wvec = nullptr;
   // trees: nodes ordered by level inside each tree, per sweep direction
@@ -35,6 +37,11 @@ struct LeadSolve {
   int* trees_stream = nullptr;
   int n_small = 0, n_big = 0, n_stream = 0;
   size_t lds_small = 0, lds_big = 0;
+  // forests of many thousand trees (PlanarHand_N=10 below its tree tops: 19 958 small trees): the trees that need <= 4 KB get a launch of
+  // their own -- at 4 x 16 KB per workgroup two workgroups fit a CU and the small trees took ten rounds of them
+  void *desc_tiny_f = nullptr, *desc_tiny_b = nullptr;
+  int n_tiny = 0;
+  size_t lds_tiny = 0;
   hipStream_t aux = nullptr;    // the big trees' launches run beside the small trees' (fork / join events on the caller's stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool debug = false;           // option lead_debug: forest statistics on stderr at build

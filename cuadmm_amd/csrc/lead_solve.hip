@@ -127,18 +127,34 @@ __global__ __launch_bounds__(256) void lead_tail_rhs_vec_kernel(int k, int n1, c
   if (sub == 0) z2[i] = z[n1 + i] - s;
 }
 
+constexpr int kLongColumn = 128;
 // w[j] = sum over the TAIL rows of column j:  L21[i][j] x2[i]   (8 lanes per leading column; independent of the sweeps)
 __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long* __restrict__ tp, const int* __restrict__ tr, const double* __restrict__ tv,
                                                         const double* __restrict__ x2, double* __restrict__ w) {
   const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int j = gt >> 3, sub = gt & 7;
   if (j >= n1) return;
+  if (tp[j + 1] - tp[j] > kLongColumn) return;               // lead_l21t_long_kernel's
   double s = 0.0;
   for (long long q = tp[j] + sub; q < tp[j + 1]; q += 8) s += tv[q] * x2[tr[q]];
   s += __shfl_xor(s, 4, 64);
   s += __shfl_xor(s, 2, 64);
   s += __shfl_xor(s, 1, 64);
   if (sub == 0) w[j] = s;
+}
+
+// the same for the columns with more than kLongColumn tail rows, one wavefront each: eight lanes walk a column of 1 783 entries
+// (PlanarHand_N=10 below its tree tops) in 223 dependent gathers -- 110 of the kernel's 139 us were that one column's latency
+__global__ __launch_bounds__(256) void lead_l21t_long_kernel(int n_long, const int* __restrict__ cols, const long long* __restrict__ tp, const int* __restrict__ tr,
+                                                             const double* __restrict__ tv, const double* __restrict__ x2, double* __restrict__ w) {
+  const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (i >= n_long) return;
+  const int j = cols[i];
+  double s = 0.0;
+  for (long long q = tp[j] + lane; q < tp[j + 1]; q += 64) s += tv[q] * x2[tr[q]];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) w[j] = s;
 }
 
 // backward, levels root side first:  x[j] = x[j] / D[j] - w[j] - sum_{leading i > j} L11[i][j] x[i]
@@ -414,8 +430,9 @@ __global__ __launch_bounds__(256) void tops_scatter_kernel(int m, int n1, const 
 void LeadSolve::release() {
   for (void* p : {(void*)rp21, (void*)ci21, (void*)v21, (void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)tptr,
                   (void*)tri, (void*)tv_, (void*)D1, (void*)wvec, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f, (void*)lvl_ptr_b, (void*)lvl_off_f,
-                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b, (void*)desc_big_f, (void*)desc_big_b, (void*)trees_stream})
+                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b, (void*)desc_big_f, (void*)desc_big_b, (void*)desc_tiny_f, (void*)desc_tiny_b, (void*)trees_stream})
     if (p) { hipError_t e = hipFree(p); (void)e; }
+  desc_tiny_f = desc_tiny_b = nullptr; n_tiny = 0;
   rp21 = fptr = bptr = tptr = nullptr; ci21 = fci = bci = tri = nullptr; v21 = fv_ = bv_ = tv_ = D1 = wvec = nullptr;
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
   if (aux) { hipError_t e = hipStreamDestroy(aux); (void)e; e = hipEventDestroy(ev_fork); (void)e; e = hipEventDestroy(ev_join); (void)e; aux = nullptr; ev_fork = ev_join = nullptr; }
@@ -427,6 +444,8 @@ void LeadSolve::release() {
   rid = wf_beg = wb_len = kt_ci = tk_ri = nullptr; xp = zext = xext = zT = uT = DT = Wf = Wb = kt_v = tk_v = nullptr;
   wf_off = wb_off = kt_rp = tk_cp = tt_rp = tt_cp = nullptr; tt_ci = tt_ri = nullptr; tt_v = tt_cv = nullptr;
   tops = false; nT = 0; k_tail = 0; tops_bytes = 0; tops_blocks = tops_max = 0;
+  if (long_cols_d) { hipError_t e = hipFree(long_cols_d); (void)e; long_cols_d = nullptr; }
+  n_long = 0;
   if (zfull) { hipError_t e = hipFree(zfull); (void)e; zfull = nullptr; }
   if (h_w) { hipError_t e = hipHostFree(h_w); (void)e; h_w = nullptr; }
   if (h_z) { hipError_t e = hipHostFree(h_z); (void)e; h_z = nullptr; }
@@ -448,8 +467,9 @@ bool LeadSolve::demote_to_hybrid() {
   // keep rp21 / ci21 / v21, tptr / tri / tv_ and wvec; everything of the sweeps goes
   for (void* p : {(void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)D1, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f,
                   (void*)lvl_ptr_b, (void*)lvl_off_f, (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b,
-                  (void*)desc_big_f, (void*)desc_big_b, (void*)trees_stream})
+                  (void*)desc_big_f, (void*)desc_big_b, (void*)desc_tiny_f, (void*)desc_tiny_b, (void*)trees_stream})
     if (p) { hipError_t e = hipFree(p); (void)e; }
+  desc_tiny_f = desc_tiny_b = nullptr; n_tiny = 0;
   fptr = bptr = nullptr; fci = bci = nullptr; fv_ = bv_ = D1 = nullptr;
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
   desc_small_f = desc_small_b = desc_big_f = desc_big_b = nullptr; trees_stream = nullptr; n_small = n_big = n_stream = 0;
@@ -472,6 +492,7 @@ int LeadSolve::apply_l21(double* x, bool x_pinned, TailSolve& tail, hipStream_t 
   int rc = tail.solve_device(st);
   if (rc) return rc;
   hipLaunchKernelGGL(lead_l21t_kernel, dim3((unsigned)(((long long)n1 * 8 + 255) / 256)), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
+  if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, tail.vin, wvec);
   CUADMM_HIP_TRY(hipGetLastError());
   CUADMM_HIP_TRY(hipMemcpyAsync(h_w, wvec, sizeof(double) * (size_t)n1, hipMemcpyDeviceToHost, st));
   double* dst = x_pinned ? x + n1 : h_z + n1;
@@ -636,12 +657,15 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
       if (Li[p] < n1) { bc[(size_t)q] = pos_b[Li[p]]; bv[(size_t)q] = Lx[p]; ++q; }
     bp[(size_t)idx + 1] = q;
   }
+  std::vector<int> long_cols;
   for (int j = 0; j < n1; ++j) {
     long long q = tp[j];
     for (long long p = Lp[j]; p < Lp[j + 1]; ++p)
       if (Li[p] >= n1) { tr[(size_t)q] = Li[p] - n1; tv[(size_t)q] = Lx[p]; ++q; }
     tp[(size_t)j + 1] = q;
+    if (q - tp[j] > kLongColumn) long_cols.push_back(j);
   }
+  n_long = (int)long_cols.size();
   if (debug) {
     long long mx_f = 0, mx_b = 0;
     std::vector<int> cnt((size_t)ntrees, 0);
@@ -659,7 +683,8 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
     if (allow_hybrid && l21_pays()) {
       int rc_;
       if ((rc_ = to_device(rp21, r21)) || (rc_ = to_device(ci21, c21)) || (rc_ = to_device(v21, w21)) ||
-          (rc_ = to_device(tptr, tp)) || (rc_ = to_device(tri, tr)) || (rc_ = to_device(tv_, tv)) || (rc_ = hybrid_buffers(*this))) { release(); return rc_; }
+          (rc_ = to_device(tptr, tp)) || (rc_ = to_device(tri, tr)) || (rc_ = to_device(tv_, tv)) || (rc_ = to_device(long_cols_d, long_cols)) ||
+          (rc_ = hybrid_buffers(*this))) { release(); return rc_; }
       hybrid = true;
     }
     return CUADMM_OK;
@@ -668,8 +693,11 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
   // classes by the LDS a tree needs with its stream resident (the larger of the two sweeps): small trees share a CU in numbers,
   // the few big ones get a launch of their own, anything beyond one workgroup's LDS keeps the streaming kernels
   std::vector<int> t_stream;
-  std::vector<LeadTreeDesc> dsf, dsb, dbf, dbb;        // small / big trees, forward / backward sweep
-  lds_small = lds_big = 0;
+  std::vector<LeadTreeDesc> dsf, dsb, dbf, dbb, dtf, dtb;        // small / big / tiny trees, forward / backward sweep
+  lds_small = lds_big = lds_tiny = 0;
+  // (measured and dropped: a launch of their own for the trees that need <= 4 KB -- eight workgroups per CU instead of two.  The two launches
+  // serialise, and the big trees decide the second one: PlanarHand_N=10 116 -> 2 x 50 us per sweep, PushBox N = 30 / 50 +10 us per sweep.)
+  const bool split_tiny = false;
   {
     int acc = 0;
     std::vector<int> cnt((size_t)ntrees, 0);
@@ -682,18 +710,21 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
       const size_t need = sizeof(double) * (2 * (size_t)cnt[t] + (size_t)nz) + sizeof(int) * (2 * (size_t)cnt[t] + 1 + (size_t)nz + 2 * (size_t)nlev_t + 2) + 16;
       const LeadTreeDesc df{lpf[t], nlf, acc, cnt[t], (int)nzf, 0, fp[acc]}, db{lpb[t], nlb, acc, cnt[t], (int)nzb, 0, bp[acc]};
       if (stream_only || need > kMaxLdsBytes - 1024) t_stream.push_back(t);
+      else if (split_tiny && need <= 4 * 1024) { dtf.push_back(df); dtb.push_back(db); lds_tiny = std::max(lds_tiny, need); }
       else if (need <= 16 * 1024) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
       else { dbf.push_back(df); dbb.push_back(db); lds_big = std::max(lds_big, need); }
       acc += cnt[t];
     }
   }
-  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size();
-  if (debug) fprintf(stderr, "[lead debug] resident trees: %d small (%zu B), %d big (%zu B), %d streaming\n", n_small, lds_small, n_big, lds_big, n_stream);
+  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size(); n_tiny = (int)dtf.size();
+  if (debug) fprintf(stderr, "[lead debug] resident trees: %d tiny (%zu B), %d small (%zu B), %d big (%zu B), %d streaming\n", n_tiny, lds_tiny, n_small, lds_small, n_big,
+                     lds_big, n_stream);
   int rc;
   {
-    LeadTreeDesc *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;
-    if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(trees_stream, t_stream))) return rc;
-    desc_small_f = a0; desc_small_b = a1; desc_big_f = a2; desc_big_b = a3;
+    LeadTreeDesc *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr;
+    if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(a4, dtf)) ||
+        (rc = to_device(a5, dtb)) || (rc = to_device(trees_stream, t_stream))) return rc;
+    desc_small_f = a0; desc_small_b = a1; desc_big_f = a2; desc_big_b = a3; desc_tiny_f = a4; desc_tiny_b = a5;
   }
   // the attribute is per kernel and process-wide: always the hardware maximum, so that a second solver with smaller trees cannot lower it
   if (lds_big > 48 * 1024) {
@@ -709,7 +740,7 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
   if ((rc = to_device(rp21, r21)) || (rc = to_device(ci21, c21)) || (rc = to_device(v21, w21)) ||
       (rc = to_device(fptr, fp)) || (rc = to_device(fci, fc)) || (rc = to_device(fv_, fv)) ||
       (rc = to_device(bptr, bp)) || (rc = to_device(bci, bc)) || (rc = to_device(bv_, bv)) ||
-      (rc = to_device(tptr, tp)) || (rc = to_device(tri, tr)) || (rc = to_device(tv_, tv)) ||
+      (rc = to_device(tptr, tp)) || (rc = to_device(tri, tr)) || (rc = to_device(tv_, tv)) || (rc = to_device(long_cols_d, long_cols)) ||
       (rc = to_device(D1, std::vector<double>(D, D + n1))) || (rc = to_device(nodes_f, nf)) || (rc = to_device(nodes_b, nb)) ||
       (rc = to_device(lvl_ptr_f, lpf)) || (rc = to_device(lvl_ptr_b, lpb)) || (rc = to_device(lvl_off_f, lof)) || (rc = to_device(lvl_off_b, lob)) ||
       (rc = to_device(lvl_g_f, lgf)) || (rc = to_device(lvl_g_b, lgb)))
@@ -933,6 +964,17 @@ static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, c
   const size_t lds_merged = std::max(L.lds_big, 4 * sizeof(double) * (size_t)small_doubles);
   const unsigned grid_merged = (unsigned)(L.n_big + (L.n_small + 3) / 4);
   const double* nul = nullptr;
+  if (L.n_tiny > 0) {                                   // four tiny trees per workgroup at 4 x (<= 4 KB) of LDS: eight workgroups per CU
+    const int td = (int)((L.lds_tiny + 7) / 8);
+    if (!backward)
+      hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3((unsigned)((L.n_tiny + 3) / 4)), dim3(256), 4 * sizeof(double) * (size_t)td, st,
+                         static_cast<const LeadTreeDesc*>(nullptr), 0, static_cast<const LeadTreeDesc*>(L.desc_tiny_f), L.n_tiny, td, L.lvl_off_f, L.lvl_g_f, L.nodes_f,
+                         L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+    else
+      hipLaunchKernelGGL(lead_sweep_merged_kernel<true>, dim3((unsigned)((L.n_tiny + 3) / 4)), dim3(256), 4 * sizeof(double) * (size_t)td, st,
+                         static_cast<const LeadTreeDesc*>(nullptr), 0, static_cast<const LeadTreeDesc*>(L.desc_tiny_b), L.n_tiny, td, L.lvl_off_b, L.lvl_g_b, L.nodes_b,
+                         L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+  }
   if (!backward) {
     if (merged)
       hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.n_big,
@@ -971,6 +1013,7 @@ int LeadSolve::solve(const double* ax, const double* asmc, const double* b, doub
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
   if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
+  if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, tail.vin, wvec);
   launch_sweeps(*this, true, ax, asmc, b, isig, y, st);
   CUADMM_HIP_TRY(hipGetLastError());
   // the solved tail into y: a kernel of its own, not hipMemcpyAsync -- the runtime's device-to-device copy is a blit behind ~15 us of
@@ -1003,6 +1046,7 @@ int LeadSolve::solve_tops(const double* ax, const double* asmc, const double* b,
   }
   hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((kt + 255) / 256)), dim3(256), 0, st, tail.vin, xext + nT, kt);
   if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, xext, wvec);                 // w = [L_TB; L_KB]^T [x_T; x_K]
+  if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, xext, wvec);
   launch_sweeps(*this, true, ax, asmc, b, isig, xp, st);                                                        // x_B
   hipLaunchKernelGGL(tops_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, n1, rid, xp, xext, y);
   CUADMM_HIP_TRY(hipGetLastError());

@@ -52,10 +52,10 @@ def test_two_processes_moment_relaxation_against_the_oracle(name, port, tmp_path
     d = np.load(out)
     assert d["shard"][0] == 0 and 0 < d["shard"][1]                  # rank 0 holds a proper part of the svec
     th = TOL[name.partition(":")[0] + "/switch=11000"][0]
-    # round 4: PushBox_N=30 (m = 154 256) on two ranks -- the planner's larger tail with the whole y-solve on the device (counter 1), and
-    # ":hybrid", L21 on the device with the L11 sweeps on the host pool of every rank (counter 2)
+    # PushBox_N=30 (m = 154 256) on two ranks -- the whole y-solve on the device (round 4: the planner's larger tail, counter 1; round 5: a
+    # small tail behind dense tree tops, counter 3), and ":hybrid", L21 on the device with the L11 sweeps on the host pool of every rank (2)
     if name.startswith("PushBox"):
-        assert d["counters"][6] == (2 if name.endswith(":hybrid") else 1)
+        assert d["counters"][6] == (2 if name.endswith(":hybrid") else 3)
     for nm in SIX:
         ref = np.array([float(x) for x in rec[nm]])
         dev = rel_dev(d[nm][:ref.size], ref, nm)
