@@ -37,11 +37,6 @@ struct LeadSolve {
   int* trees_stream = nullptr;
   int n_small = 0, n_big = 0, n_stream = 0;
   size_t lds_small = 0, lds_big = 0;
-  // forests of many thousand trees (PlanarHand_N=10 below its tree tops: 19 958 small trees): the trees that need <= 4 KB get a launch of
-  // their own -- at 4 x 16 KB per workgroup two workgroups fit a CU and the small trees took ten rounds of them
-  void *desc_tiny_f = nullptr, *desc_tiny_b = nullptr;
-  int n_tiny = 0;
-  size_t lds_tiny = 0;
   hipStream_t aux = nullptr;    // the big trees' launches run beside the small trees' (fork / join events on the caller's stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool debug = false;           // option lead_debug: forest statistics on stderr at build

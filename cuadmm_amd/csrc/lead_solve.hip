@@ -430,9 +430,8 @@ __global__ __launch_bounds__(256) void tops_scatter_kernel(int m, int n1, const 
 void LeadSolve::release() {
   for (void* p : {(void*)rp21, (void*)ci21, (void*)v21, (void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)tptr,
                   (void*)tri, (void*)tv_, (void*)D1, (void*)wvec, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f, (void*)lvl_ptr_b, (void*)lvl_off_f,
-                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b, (void*)desc_big_f, (void*)desc_big_b, (void*)desc_tiny_f, (void*)desc_tiny_b, (void*)trees_stream})
+                  (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b, (void*)desc_big_f, (void*)desc_big_b, (void*)trees_stream})
     if (p) { hipError_t e = hipFree(p); (void)e; }
-  desc_tiny_f = desc_tiny_b = nullptr; n_tiny = 0;
   rp21 = fptr = bptr = tptr = nullptr; ci21 = fci = bci = tri = nullptr; v21 = fv_ = bv_ = tv_ = D1 = wvec = nullptr;
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
   if (aux) { hipError_t e = hipStreamDestroy(aux); (void)e; e = hipEventDestroy(ev_fork); (void)e; e = hipEventDestroy(ev_join); (void)e; aux = nullptr; ev_fork = ev_join = nullptr; }
@@ -467,9 +466,8 @@ bool LeadSolve::demote_to_hybrid() {
   // keep rp21 / ci21 / v21, tptr / tri / tv_ and wvec; everything of the sweeps goes
   for (void* p : {(void*)fptr, (void*)fci, (void*)fv_, (void*)bptr, (void*)bci, (void*)bv_, (void*)D1, (void*)nodes_f, (void*)nodes_b, (void*)lvl_ptr_f,
                   (void*)lvl_ptr_b, (void*)lvl_off_f, (void*)lvl_off_b, (void*)lvl_g_f, (void*)lvl_g_b, (void*)desc_small_f, (void*)desc_small_b,
-                  (void*)desc_big_f, (void*)desc_big_b, (void*)desc_tiny_f, (void*)desc_tiny_b, (void*)trees_stream})
+                  (void*)desc_big_f, (void*)desc_big_b, (void*)trees_stream})
     if (p) { hipError_t e = hipFree(p); (void)e; }
-  desc_tiny_f = desc_tiny_b = nullptr; n_tiny = 0;
   fptr = bptr = nullptr; fci = bci = nullptr; fv_ = bv_ = D1 = nullptr;
   nodes_f = nodes_b = lvl_ptr_f = lvl_ptr_b = lvl_off_f = lvl_off_b = lvl_g_f = lvl_g_b = nullptr;
   desc_small_f = desc_small_b = desc_big_f = desc_big_b = nullptr; trees_stream = nullptr; n_small = n_big = n_stream = 0;
@@ -693,11 +691,10 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
   // classes by the LDS a tree needs with its stream resident (the larger of the two sweeps): small trees share a CU in numbers,
   // the few big ones get a launch of their own, anything beyond one workgroup's LDS keeps the streaming kernels
   std::vector<int> t_stream;
-  std::vector<LeadTreeDesc> dsf, dsb, dbf, dbb, dtf, dtb;        // small / big / tiny trees, forward / backward sweep
-  lds_small = lds_big = lds_tiny = 0;
+  std::vector<LeadTreeDesc> dsf, dsb, dbf, dbb;        // small / big trees, forward / backward sweep
+  lds_small = lds_big = 0;
   // (measured and dropped: a launch of their own for the trees that need <= 4 KB -- eight workgroups per CU instead of two.  The two launches
   // serialise, and the big trees decide the second one: PlanarHand_N=10 116 -> 2 x 50 us per sweep, PushBox N = 30 / 50 +10 us per sweep.)
-  const bool split_tiny = false;
   {
     int acc = 0;
     std::vector<int> cnt((size_t)ntrees, 0);
@@ -710,21 +707,18 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
       const size_t need = sizeof(double) * (2 * (size_t)cnt[t] + (size_t)nz) + sizeof(int) * (2 * (size_t)cnt[t] + 1 + (size_t)nz + 2 * (size_t)nlev_t + 2) + 16;
       const LeadTreeDesc df{lpf[t], nlf, acc, cnt[t], (int)nzf, 0, fp[acc]}, db{lpb[t], nlb, acc, cnt[t], (int)nzb, 0, bp[acc]};
       if (stream_only || need > kMaxLdsBytes - 1024) t_stream.push_back(t);
-      else if (split_tiny && need <= 4 * 1024) { dtf.push_back(df); dtb.push_back(db); lds_tiny = std::max(lds_tiny, need); }
       else if (need <= 16 * 1024) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
       else { dbf.push_back(df); dbb.push_back(db); lds_big = std::max(lds_big, need); }
       acc += cnt[t];
     }
   }
-  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size(); n_tiny = (int)dtf.size();
-  if (debug) fprintf(stderr, "[lead debug] resident trees: %d tiny (%zu B), %d small (%zu B), %d big (%zu B), %d streaming\n", n_tiny, lds_tiny, n_small, lds_small, n_big,
-                     lds_big, n_stream);
+  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size();
+  if (debug) fprintf(stderr, "[lead debug] resident trees: %d small (%zu B), %d big (%zu B), %d streaming\n", n_small, lds_small, n_big, lds_big, n_stream);
   int rc;
   {
-    LeadTreeDesc *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr;
-    if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(a4, dtf)) ||
-        (rc = to_device(a5, dtb)) || (rc = to_device(trees_stream, t_stream))) return rc;
-    desc_small_f = a0; desc_small_b = a1; desc_big_f = a2; desc_big_b = a3; desc_tiny_f = a4; desc_tiny_b = a5;
+    LeadTreeDesc *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;
+    if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(trees_stream, t_stream))) return rc;
+    desc_small_f = a0; desc_small_b = a1; desc_big_f = a2; desc_big_b = a3;
   }
   // the attribute is per kernel and process-wide: always the hardware maximum, so that a second solver with smaller trees cannot lower it
   if (lds_big > 48 * 1024) {
@@ -964,17 +958,6 @@ static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, c
   const size_t lds_merged = std::max(L.lds_big, 4 * sizeof(double) * (size_t)small_doubles);
   const unsigned grid_merged = (unsigned)(L.n_big + (L.n_small + 3) / 4);
   const double* nul = nullptr;
-  if (L.n_tiny > 0) {                                   // four tiny trees per workgroup at 4 x (<= 4 KB) of LDS: eight workgroups per CU
-    const int td = (int)((L.lds_tiny + 7) / 8);
-    if (!backward)
-      hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3((unsigned)((L.n_tiny + 3) / 4)), dim3(256), 4 * sizeof(double) * (size_t)td, st,
-                         static_cast<const LeadTreeDesc*>(nullptr), 0, static_cast<const LeadTreeDesc*>(L.desc_tiny_f), L.n_tiny, td, L.lvl_off_f, L.lvl_g_f, L.nodes_f,
-                         L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
-    else
-      hipLaunchKernelGGL(lead_sweep_merged_kernel<true>, dim3((unsigned)((L.n_tiny + 3) / 4)), dim3(256), 4 * sizeof(double) * (size_t)td, st,
-                         static_cast<const LeadTreeDesc*>(nullptr), 0, static_cast<const LeadTreeDesc*>(L.desc_tiny_b), L.n_tiny, td, L.lvl_off_b, L.lvl_g_b, L.nodes_b,
-                         L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
-  }
   if (!backward) {
     if (merged)
       hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.n_big,
