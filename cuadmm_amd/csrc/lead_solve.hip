@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <atomic>
+#include <new>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -519,7 +520,9 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
       if (largest > 6144 || deepest > 2048) level = 32;
     }
     if (level > 0) {
-      const int rc = build_tops(m_, k_, Lp, Li, Lx, D, level);
+      int rc;
+      try { rc = build_tops(m_, k_, Lp, Li, Lx, D, level); }
+      catch (const std::bad_alloc&) { set_error("lead_solve: the dense tree tops do not fit in host memory"); rc = CUADMM_ERR_FACTOR; }
       if (rc == CUADMM_OK && ready) return CUADMM_OK;
       if (rc != CUADMM_OK && rc != CUADMM_ERR_FACTOR) return rc;
       release();                                       // the cut did not help (or an inverse failed its check): the plain paths decide
@@ -707,7 +710,7 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
       const size_t need = sizeof(double) * (2 * (size_t)cnt[t] + (size_t)nz) + sizeof(int) * (2 * (size_t)cnt[t] + 1 + (size_t)nz + 2 * (size_t)nlev_t + 2) + 16;
       const LeadTreeDesc df{lpf[t], nlf, acc, cnt[t], (int)nzf, 0, fp[acc]}, db{lpb[t], nlb, acc, cnt[t], (int)nzb, 0, bp[acc]};
       if (stream_only || need > kMaxLdsBytes - 1024) t_stream.push_back(t);
-      else if (need <= 16 * 1024) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
+      else if (need <= (size_t)small_kb * 1024) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
       else { dbf.push_back(df); dbb.push_back(db); lds_big = std::max(lds_big, need); }
       acc += cnt[t];
     }
@@ -868,6 +871,7 @@ int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, cons
     for (;;) {
       const int q = next.fetch_add(1);
       if (q >= nblk) return;
+      try {
       const int t0 = blk_ptr[q], n = blk_ptr[q + 1] - t0;
       double* W = wf.data() + base[q];
       for (int r = 0; r < n; ++r) {
@@ -904,6 +908,7 @@ int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, cons
         err = std::max(err, std::fabs(acc - v[r]));
       }
       if (!(err <= 1e-9)) bad.fetch_add(1);
+      } catch (const std::bad_alloc&) { bad.fetch_add(1); }      // (a thread must not let it escape)
     }
   };
   {
