@@ -436,7 +436,9 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
     int kb = 0;
     double cb = 1e300;
     std::vector<std::pair<int, double>> cand;
-    for (int k = std::max(1024, (k_lo / 2 + 255) / 256 * 256); k <= std::min(m - 1, max_k); k += 256) {
+    // (multiples of 1 024: the tail's one-pass kernel holds whole columns per thread of its 1 024-thread workgroups -- 8 448 columns are
+    // padded to 9 216)
+    for (int k = std::max(1024, (k_lo / 2 + 1023) / 1024 * 1024); k <= std::min(m - 1, max_k); k += 1024) {
       if (hmax[(size_t)(m - k)] <= kTopsLevel + 1) break;           // nothing left to cut
       const double c = tops_us(k);
       if (c < 0.0) continue;

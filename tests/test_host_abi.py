@@ -544,10 +544,10 @@ def test_host_pool_survives_two_concurrent_solvers():
 
 
 @pytest.mark.parametrize("name,m,nnzL,tail_k,perm_sha,tops_k", [
-    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c", 10752),
+    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c", 10240),
     ("pendulum_N=80", 112028, 929430, 10496, "53e3efdb51729949", 0),
     ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3", 0),
-    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a", 8448),
+    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a", 8192),
     ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176", 16384),
 ])
 def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha, tops_k):
