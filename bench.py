@@ -341,6 +341,9 @@ def main():
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
+            if local_rank >= torch.cuda.device_count():
+                sys.exit("bench.py: rank %d of %d has no GPU of its own (%d visible) -- one process per GPU; CUADMM_BENCH_BACKEND=gloo lets the "
+                         "ranks share the GPUs that exist (tests)" % (rank, world, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 

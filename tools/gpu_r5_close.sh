@@ -19,6 +19,6 @@ print('$c', round(d['value'],1), 'ms/step', round(d['ms_per_step'],4), 'frac', r
 done
 timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_c2_driver.json 2>gpurun_out/r05_bench_c2_driver.err
 python -c "import json; d=json.load(open('gpurun_out/r05_bench_c2_driver.json')); print('driver', d['value'], d['roofline']['frac'], d['cpu_baseline']['value'])"
-timeout 600 python bench.py --gpus 2 --blocks-per-gpu 5000 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('2 ranks one GPU (gloo):', d['n_gpus'], d['value'], d['allreduce_path']['value'])"
+CUADMM_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --blocks-per-gpu 5000 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('2 ranks one GPU (gloo):', d['n_gpus'], d['value'], d['allreduce_path']['value'])"
 CUADMM_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c1 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c1 on 2 ranks, one GPU (gloo):', d['n_gpus'], round(d['value'],1), d.get('engine_plan'))"
 bash tools/prof_round5.sh c1 2>&1 | tail -2
