@@ -270,7 +270,7 @@ struct cuadmm_solver {
   int opt_tiny_sign = 1;       // option "tiny_sign": 0 never, 1 closed candidates, 2 always
   bool closed_candidate = false;
   int duo_cpu_eig_on_gpu = 0;
-  int opt_hint = 1;            // option "psd_hint": 0 off, 1 one-wavefront kernels, 2 all
+  int opt_hint = 1;            // option "psd_hint": 0 off, 1 one-wavefront kernels + mid-size blocks of the batched-GEMM path, 2 all, 3 one-wavefront kernels only
   LeadSolve lead;               // ... or, with a split factor, the leading sweeps on the device around the GPU tail (lead_solve.hip)
   int forest_trees = 0;
   DevBuf<int> f_tree_ptr, f_tree_cols, f_Li;
@@ -907,13 +907,15 @@ static int init_plan(Solver* s, const InitIn& in, InitCtx& c) {
   s->plan.overlap = true;
   if (!rc && !s->blk_local.empty() && s->opt_hint != 0) {
     // Schedule warm start of the ONE-WAVEFRONT sign kernels (lift steps each block needed in the previous projection): C2 12.0 ->
-    // 11.4 steps (+3 % iterations / s), C4 11.0 -> 10.5.  Not for the batched-GEMM path of the large blocks (C3: 17 -> 18 steps:
-    // the recorded count includes the overshoot of the previous run's bursts, and a failed first probe costs 4 steps there).
+    // 11.4 steps (+3 % iterations / s), C4 11.0 -> 10.5.  On the batched-GEMM path for the mid-size blocks only (groups padded to <= 512,
+    // psd_large.h; psd_hint = 2: every group): one n = 2 000 block loses a step (C3: 17 -> 18 -- the recorded count includes the overshoot
+    // of the previous run's bursts, and a failed first probe costs 4 steps there).
     // The hint ages by one step every 16th projection (PsdPlan::project; inside the task loop of the batched launches).
     if ((rc = s->hint_d.alloc(s->blk_local.size()))) return rc;
     CUADMM_HIP_TRY(hipMemset(s->hint_d.p, 0, sizeof(int) * s->blk_local.size()));
     s->plan.d_hint = s->hint_d.p;
-    if (s->opt_hint == 2) s->plan.sign.d_hint = s->hint_d.p;
+    s->plan.sign.d_hint = s->hint_d.p;
+    s->plan.sign.hint_max_n = s->opt_hint == 2 ? (1 << 30) : (s->opt_hint == 3 ? 0 : 512);      // 3: the one-wavefront kernels only (rounds 2 - 4)
   }
   // step counts per block: for cuadmm_get_psd_steps and for the longest-block-first reordering of the fused launches
   if (!rc && (s->psd_steps || s->plan.fusable()) && !s->blk_local.empty()) {

@@ -21,6 +21,9 @@ struct SignPsd {
   int* d_ids = nullptr;                      // block ids, group after group
   int* d_steps = nullptr;                    // not owned; when set: Newton-Schulz steps taken per block
   int* d_hint = nullptr;                     // not owned; schedule warm start per block (lift steps of the previous projection)
+  int hint_max_n = 512;                      // ... for the groups padded to at most this size: mid-size blocks gain (PlanarHand_N=10's 81 blocks of
+                                             // 66 ... 120: projection 1.03 -> 0.98 ms, taha1a 1.08 -> 1.02), one n = 2 000 block loses a step (C3 17 -> 18).
+                                             // A property of the group, not of the path: launches and one-launch kernel stay bit-identical
   double *X0 = nullptr, *S = nullptr, *Y = nullptr, *T = nullptr, *colsum = nullptr, *scale = nullptr;
   void* d_state = nullptr;                   // 2 x SignDevState per member of the largest group (adaptive schedule, sign_sched.h)
   void* d_done = nullptr;                    // SignDone per member

@@ -892,7 +892,7 @@ void SignPsd::cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max
   sa.p1 = d_part + g.part_off;
   sa.p2 = d_part + part_half + g.part_off;
   sa.group = d_group + 2 * g.slot;
-  sa.hint = d_hint;
+  sa.hint = g.N <= hint_max_n ? d_hint : nullptr;
   sa.ids = d_ids + g.begin;
   sa.count = g.count;
   sa.step = 0;
@@ -948,7 +948,7 @@ int SignPsd::launch_group(Group& g, const double* in, double* out, const long lo
     sa.p1 = d_part + g.part_off;
     sa.p2 = d_part + part_half + g.part_off;
     sa.group = d_group;
-    sa.hint = d_hint;
+    sa.hint = g.N <= hint_max_n ? d_hint : nullptr;
     sa.ids = ids;
     sa.count = cnt;
     sa.step = 0;

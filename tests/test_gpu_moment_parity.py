@@ -207,3 +207,18 @@ def test_dense_tree_tops_agree_with_the_plain_sweeps(name, level, tmp_path):
         assert np.array_equal(out[1][0][nm], out[2][0][nm]), nm        # resident and streaming sweeps of the cut forest: bit for bit
     for a, b in ((out[0][1], out[1][1]), (out[0][2], out[1][2])):
         assert np.linalg.norm(a - b) <= 1e-8 * (1 + np.linalg.norm(a))
+
+
+def test_a_cut_above_every_tree_falls_back_to_the_plain_sweeps(tmp_path):
+    """lead_tops = 500 on pendulum N = 80 (forest 28 levels deep at its tail): no node is that high, there is nothing to cut -- the plain
+    sweeps run (counter 1) and the iterates are those of lead_tops = 0, bit for bit."""
+    p = load_problem("pendulum_N=80", tmp_path)
+    out = []
+    for opt in ({"lead_tops": 0}, {"lead_tops": 500}):
+        s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
+        s.init_problem(problem_to_amd(p))
+        s.solve(30, 0.0, 0, 50, 100, 15, 1.05)
+        assert s.counters()["dev_solve"] == 1
+        out.append((s.info_arr("pobj").copy(), s.y.copy(), s.X.copy()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
