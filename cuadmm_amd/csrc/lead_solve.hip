@@ -406,10 +406,17 @@ __global__ __launch_bounds__(256) void tops_k_rhs_kernel(int kt, const long long
   if (lane == 0) out[i] = zK[i] - s;
 }
 
-// u[c] = z_T[c] / D_T[c] - sum_i L_KT[i][c] x_K[i]   (one wavefront per T column)
+// u[c] = z_T[c] / D_T[c] - sum_i L_KT[i][c] x_K[i]   (one wavefront per T column); the workgroups behind the last column copy the solved
+// tail beside x_T (xK_out: what w = [L_TB; L_KB]^T [x_T; x_K] reads as one vector) -- a launch of its own before
 __global__ __launch_bounds__(256) void tops_u_kernel(int nT, const long long* __restrict__ cp, const int* __restrict__ ri, const double* __restrict__ v,
                                                      const double* __restrict__ xK, const double* __restrict__ zT, const double* __restrict__ DT,
-                                                     double* __restrict__ u) {
+                                                     double* __restrict__ u, double* __restrict__ xK_out, int kt) {
+  const int nb_u = (nT + 3) / 4;
+  if ((int)blockIdx.x >= nb_u) {
+    const int i = ((int)blockIdx.x - nb_u) * 256 + (int)threadIdx.x;
+    if (i < kt) xK_out[i] = xK[i];
+    return;
+  }
   const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
   if (c >= nT) return;
   double s = 0.0;
@@ -1026,13 +1033,13 @@ int LeadSolve::solve_tops(const double* ax, const double* asmc, const double* b,
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = tail.solve_device(st);
   if (rc) return rc;
-  hipLaunchKernelGGL(tops_u_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, tk_cp, tk_ri, tk_v, tail.vin, zT, DT, uT);             // D_T^-1 z_T - L_KT^T x_K
+  hipLaunchKernelGGL(tops_u_kernel, dim3((unsigned)((nT + 3) / 4 + (kt + 255) / 256)), dim3(256), 0, st, nT, tk_cp, tk_ri, tk_v, tail.vin, zT, DT, uT, xext + nT,
+                     kt);                                                                                        // D_T^-1 z_T - L_KT^T x_K;  x_K beside x_T
   hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wb_off, (const int*)nullptr, wb_len, Wb, uT, xext, 0);  // x_T = W_T^T (...)
   if (tops_refine) {                                                                                             // x_T += W_T^T (u - L_TT^T x_T); zext's T part is free by now
     hipLaunchKernelGGL(tops_resid_kernel, dim3((unsigned)(((long long)nT * 32 + 255) / 256)), dim3(256), 0, st, nT, tt_cp, tt_ri, tt_cv, xext, uT, zext);
     hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wb_off, (const int*)nullptr, wb_len, Wb, zext, xext, 1);
   }
-  hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((kt + 255) / 256)), dim3(256), 0, st, tail.vin, xext + nT, kt);
   if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, xext, wvec);                 // w = [L_TB; L_KB]^T [x_T; x_K]
   if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, xext, wvec);
   launch_sweeps(*this, true, ax, asmc, b, isig, xp, st);                                                        // x_B

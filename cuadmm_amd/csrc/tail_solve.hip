@@ -348,23 +348,37 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
   for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)group * K + col] = xa[c]; }
 }
 
-// `part` (with Q slots per row): the exchange slots of ts_onepass_group_kernel, reset to the sentinel for the next solve
-__global__ __launch_bounds__(64) void ts_onepass_reduce_kernel(const double* __restrict__ P, int K, int G, double* __restrict__ x,
-                                                               unsigned long long* __restrict__ part = nullptr, int Q = 0) {
-  const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (col >= K) return;
-  for (int m = 0; m < Q; ++m) part[(size_t)col * Q + m] = TS_SENTINEL;
+// `part` (with Q slots per row): the exchange slots of ts_onepass_group_kernel, reset to the sentinel for the next solve.
+// 32 columns x 8 slices per workgroup: slice q sums the partial vectors g = q G/8 ... (q + 1) G/8 - 1 in order (eight loads in flight), the
+// slices are added in order through LDS -- a fixed association, four dependent round trips instead of the 32 of one thread per column
+// (G = 256 workgroups: 14 us -> 5 us per solve; pendulum / PlanarHand_N=1 / PushBox: 2 - 4 % of an iteration).
+__global__ __launch_bounds__(256) void ts_onepass_reduce_kernel(const double* __restrict__ P, int K, int G, double* __restrict__ x,
+                                                                unsigned long long* __restrict__ part = nullptr, int Q = 0) {
+  __shared__ double red[8][32];
+  const int c = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+  const int col = (int)blockIdx.x * 32 + c;
+  const int per = (G + 7) / 8, g0 = q * per, g1 = g0 + per < G ? g0 + per : G;
   double s = 0.0;
-  int g = 0;
-  for (; g + 8 <= G; g += 8) {                                  // eight loads in flight; workgroup order: fixed
-    double p[8];
+  if (col < K) {
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+      double p[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) p[q] = P[(size_t)(g + q) * K + col];
+      for (int u = 0; u < 8; ++u) p[u] = P[(size_t)(g + u) * K + col];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += p[q];
+      for (int u = 0; u < 8; ++u) s += p[u];
+    }
+    for (; g < g1; ++g) s += P[(size_t)g * K + col];
   }
-  for (; g < G; ++g) s += P[(size_t)g * K + col];
-  x[col] = s;
+  red[q][c] = s;
+  __syncthreads();
+  if (q == 0 && col < K) {
+    double t = red[0][c];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) t += red[u][c];
+    x[col] = t;
+    for (int m = 0; m < Q; ++m) part[(size_t)col * Q + m] = TS_SENTINEL;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -784,7 +798,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
       default: rc = launch(ts_onepass_kernel<20, 1>); break;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);
   } else if (one_pass && xpart && part && K > 32768 && K <= 65536 && !group_retired) {
     // beyond 32 768 columns (round 5, option tail_max_k): EIGHT workgroups share a row, 8 columns per thread, four rows per exchange
     constexpr int Q = 8;
@@ -793,7 +807,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     auto kern = ts_onepass_group_kernel<8, Q, 4, 4>;
     if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, G, vin, part, Q);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q);
   } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
     // measured (tail_solve class per sGS iteration, two solves; two triangular GEMVs for comparison): K = 24 576 (PushBox N = 30, forced)
@@ -810,7 +824,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
     if (rc) return rc;
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, st, xpart, K, G, vin, part, Q);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q);
   } else {
     hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid, r_begin, r_end);
     hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin, 0, 1 << 30);
