@@ -21,4 +21,4 @@ timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_c2_driv
 python -c "import json; d=json.load(open('gpurun_out/r05_bench_c2_driver.json')); print('driver', d['value'], d['roofline']['frac'], d['cpu_baseline']['value'])"
 CUADMM_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --blocks-per-gpu 5000 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('2 ranks one GPU (gloo):', d['n_gpus'], d['value'], d['allreduce_path']['value'])"
 CUADMM_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c1 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c1 on 2 ranks, one GPU (gloo):', d['n_gpus'], round(d['value'],1), d.get('engine_plan'))"
-bash tools/prof_round5.sh c1 2>&1 | tail -2
+bash tools/prof_round5.sh c1 c5 2>&1 | tail -2
