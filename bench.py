@@ -674,6 +674,16 @@ def main():
             out["time_to_tol"] = time_to_tol
         if breakdown is not None:
             out["breakdown_ms_per_iter"] = breakdown      # psd_project / aty_xb / post_proj / spmv_A / copies / comm / host / tail_solve
+        if breakdown is not None and plan.get("tail_k", 0) > 0 and "tail_solve" in breakdown:
+            # supplementary, coupled problems (c1 / c5): the second roofline of their iteration.  The GPU tail of the A A^T solve reads the
+            # packed lower triangle of inv(L22) once per solve (tail_solve.hip: 4 K^2 bytes), HBM-bound; the class time beside it also holds
+            # the leading sweeps, the tree tops and the L21 products
+            k_tail = float(plan["tail_k"])
+            solves = 1 if args.mode == "admm" else 2
+            out["y_solve"] = {"ms_per_iteration": breakdown["tail_solve"], "solves_per_iteration": solves, "tail_k": int(k_tail),
+                              "tail_bytes_per_solve": 4.0 * k_tail * k_tail, "tail_hbm_floor_ms": solves * 4.0 * k_tail * k_tail / 8e12 * 1e3,
+                              "plan": {0: "host", 1: "device sweeps + GPU tail", 2: "hybrid (L11 on the host)", 3: "device sweeps + dense tree tops + GPU tail"}
+                              .get(int(plan.get("dev_solve", 0)), "?")}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cpus()
             out["cpu_baseline"] = cpu_baseline(prob, threads, args.cpu_budget_s)
