@@ -252,7 +252,7 @@ struct cuadmm_solver {
                                   // results are all-reduced (0: every rank applies the whole tail)
     int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
-    int lead_small_kb = 16;       // "lead_small_kb": LDS bound of the trees that share a workgroup in fours (lead_solve.h)
+    int lead_small_kb = 0;        // "lead_small_kb": LDS bound of the trees that share a workgroup in fours (lead_solve.h; 0 = chosen at build from 4 / 8 / 16)
     int lead_tops_refine = 0;     // "lead_tops_refine": one refinement step per direction in the dense tree tops (A/B: measured, no effect -- lead_solve.h)
     int lead_tops = -1;           // "lead_tops": dense tree tops (lead_solve.h): -1 = when the forest is too deep for the sweeps, 0 = never, L = always, cut at height L
     int debug_eig = 0;            // developer aid
@@ -1141,7 +1141,7 @@ static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
     s->lead.debug = s->sw.lead_debug != 0;
     s->lead.force_hybrid = s->sw.l21_device == 2;
     s->lead.tops_refine = s->sw.lead_tops_refine != 0;
-    s->lead.small_kb = std::max(1, std::min(s->sw.lead_small_kb, 36));
+    s->lead.small_kb = std::max(0, std::min(s->sw.lead_small_kb, 36));
     s->lead.tops_level = s->sw.l21_device == 2 ? 0 : (s->sw.lead_tops >= 0 ? s->sw.lead_tops : (cuadmm_aat_tail_tops(s->fac) > 0 ? cuadmm_aat_tail_tops(s->fac) : -1));
     if ((rc = s->lead.build(m, s->tail.k, Lp, Li, Lx, D, s->sw.l21_device != 0))) return rc;
     const double host_us = 1.2e-3 * (double)Lp[m - s->tail.k] + 150.0;

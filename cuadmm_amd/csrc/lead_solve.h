@@ -40,7 +40,7 @@ struct LeadSolve {
   hipStream_t aux = nullptr;    // the big trees' launches run beside the small trees' (fork / join events on the caller's stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool debug = false;           // option lead_debug: forest statistics on stderr at build
-  int small_kb = 16;            // option lead_small_kb: trees that need at most this much LDS share a workgroup in fours (one wavefront each)
+  int small_kb = 0;             // option lead_small_kb: trees that need at most this much LDS share a workgroup in fours (one wavefront each); 0: chosen at build
   bool stream_only = false;     // option lead_stream = 1: every tree on the streaming kernels (A/B, tests)
   bool ready = false;
   double est_us = 0;            // cost model used to decide (per solve)

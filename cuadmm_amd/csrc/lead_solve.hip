@@ -706,18 +706,50 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
   // (measured and dropped: a launch of their own for the trees that need <= 4 KB -- eight workgroups per CU instead of two.  The two launches
   // serialise, and the big trees decide the second one: PlanarHand_N=10 116 -> 2 x 50 us per sweep, PushBox N = 30 / 50 +10 us per sweep.)
   {
-    int acc = 0;
     std::vector<int> cnt((size_t)ntrees, 0);
     for (int j = 0; j < n1; ++j) cnt[tree_of[j]]++;
+    std::vector<size_t> need_of((size_t)ntrees);
+    {
+      int acc = 0;
+      for (int t = 0; t < ntrees; ++t) {
+        const long long nzf = fp[(size_t)acc + cnt[t]] - fp[acc], nzb = bp[(size_t)acc + cnt[t]] - bp[acc];
+        const int nlf = lpf[(size_t)t + 1] - lpf[t] - 1, nlb = lpb[(size_t)t + 1] - lpb[t] - 1;
+        const long long nz = std::max(nzf, nzb);
+        const int nlev_t = std::max(nlf, nlb);
+        need_of[t] = sizeof(double) * (2 * (size_t)cnt[t] + (size_t)nz) + sizeof(int) * (2 * (size_t)cnt[t] + 1 + (size_t)nz + 2 * (size_t)nlev_t + 2) + 16;
+        acc += cnt[t];
+      }
+    }
+    // The bound between the two resident classes.  One launch serves both, so its LDS per workgroup is the larger of the biggest tree and of
+    // four times the largest SMALL one: a low bound lets more workgroups share a CU but turns small trees into workgroups of their own.  Taken
+    // from {4, 8, 16} KB by the rounds of workgroups the launch needs (workgroups / (CUs x workgroups per CU by LDS)) -- the quantity that
+    // ordered every measurement (profiles/r05_lead_small_kb.log: PushBox N = 30 3.1 rounds at 16 KB, 2.6 at 4 KB: 0.93 -> 0.83 ms per
+    // iteration; N = 50 4.8 against 5.8 and PlanarHand_N=10 11.0 against 12.7: 16 KB stays).  The arithmetic of a tree does not depend on
+    // its class: the same bits either way.
+    size_t bound = (size_t)small_kb * 1024;
+    if (small_kb <= 0) {
+      double best = 1e300;
+      for (const size_t cand : {(size_t)16 * 1024, (size_t)8 * 1024, (size_t)4 * 1024}) {          // ties: the larger bound
+        size_t ls = 0, lb = 0;
+        long long ns = 0, nb = 0;
+        for (int t = 0; t < ntrees; ++t) {
+          if (stream_only || need_of[t] > kMaxLdsBytes - 1024) continue;
+          if (need_of[t] <= cand) { ++ns; ls = std::max(ls, need_of[t]); } else { ++nb; lb = std::max(lb, need_of[t]); }
+        }
+        const size_t lds = std::max<size_t>(std::max(lb, 4 * ((ls + 7) / 8 * 8)), 1024);
+        const double per_cu = (double)std::min<size_t>(8, std::max<size_t>(1, kMaxLdsBytes / lds));
+        const double rounds = ((double)nb + (double)((ns + 3) / 4)) / (256.0 * per_cu);
+        if (rounds < 0.98 * best) { best = rounds; bound = cand; }
+      }
+    }
+    int acc = 0;
     for (int t = 0; t < ntrees; ++t) {
       const long long nzf = fp[(size_t)acc + cnt[t]] - fp[acc], nzb = bp[(size_t)acc + cnt[t]] - bp[acc];
       const int nlf = lpf[(size_t)t + 1] - lpf[t] - 1, nlb = lpb[(size_t)t + 1] - lpb[t] - 1;
-      const long long nz = std::max(nzf, nzb);
-      const int nlev_t = std::max(nlf, nlb);
-      const size_t need = sizeof(double) * (2 * (size_t)cnt[t] + (size_t)nz) + sizeof(int) * (2 * (size_t)cnt[t] + 1 + (size_t)nz + 2 * (size_t)nlev_t + 2) + 16;
+      const size_t need = need_of[t];
       const LeadTreeDesc df{lpf[t], nlf, acc, cnt[t], (int)nzf, 0, fp[acc]}, db{lpb[t], nlb, acc, cnt[t], (int)nzb, 0, bp[acc]};
       if (stream_only || need > kMaxLdsBytes - 1024) t_stream.push_back(t);
-      else if (need <= (size_t)small_kb * 1024) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
+      else if (need <= bound) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
       else { dbf.push_back(df); dbb.push_back(db); lds_big = std::max(lds_big, need); }
       acc += cnt[t];
     }
