@@ -428,11 +428,15 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
     if (tri * 16.0 > 2.0e9) return -1.0;                            // both triangles: memory, and the n^3-ish build on the host
     // (the four-rows-per-exchange kernel beyond 24 576 columns: 897 us at k = 32 768 in profiles/r05_tops_PlanarHand_N=10_kernel_stats.csv)
     const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 4.0 / (k <= 24576 ? 3.8e6 : 4.8e6) + 40.0;
+    // (A finer model -- sweeps by the NODES of the rest, 14 + 0.25e-3 n us each, 45 us of short kernels -- is within 10 % of every measured
+    // solve but moves the picks by a notch (PushT_N=30 15 360, PushBox N = 50 9 216 columns) and still leaves pendulum N = 80 where it is,
+    // 176 against 166 us by the models, 148 against 176 measured: not adopted this late.  CUADMM_PLAN_DEBUG=1 prints the figures.)
     return 2.0 * (20.0 + 0.9 * kTopsLevel) + 70.0 + tri * 16.0 / 4.0e6 + 24.0 * (double)Lp[n1] / 3.0e6 + tail;
   };
   // the best tail for that solve: not below half the host optimum (the host factors what the tail does not)
   auto plan_tops = [&](int k_lo, double other_us) {
     if (!g_plan_allow_tops || !tops_out) return 0;
+    const bool plan_debug = getenv("CUADMM_PLAN_DEBUG") != nullptr;      // developer aid: the model's figures on stderr
     int kb = 0;
     double cb = 1e300;
     std::vector<std::pair<int, double>> cand;
@@ -441,6 +445,7 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
     for (int k = std::max(1024, (k_lo / 2 + 1023) / 1024 * 1024); k <= std::min(m - 1, max_k); k += 1024) {
       if (hmax[(size_t)(m - k)] <= kTopsLevel + 1) break;           // nothing left to cut
       const double c = tops_us(k);
+      if (plan_debug) fprintf(stderr, "[plan debug] tops: k %d height %d model %.0f us (other plan %.0f)\n", k, hmax[(size_t)(m - k)], c, other_us);
       if (c < 0.0) continue;
       cand.emplace_back(k, c);
       if (c < cb) { cb = c; kb = k; }
