@@ -252,6 +252,7 @@ struct cuadmm_solver {
                                   // results are all-reduced (0: every rank applies the whole tail)
     int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
+    double tail_pinv_tol = 0.0;   // "tail_pinv_tol": experiment (tail_solve.h)
     int lead_small_kb = 0;        // "lead_small_kb": LDS bound of the trees that share a workgroup in fours (lead_solve.h; 0 = chosen at build from 4 / 8 / 16)
     int lead_tops_refine = 0;     // "lead_tops_refine": one refinement step per direction in the dense tree tops (A/B: measured, no effect -- lead_solve.h)
     int lead_tops = -1;           // "lead_tops": dense tree tops (lead_solve.h): -1 = when the forest is too deep for the sweeps, 0 = never, L = always, cut at height L
@@ -793,6 +794,7 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
       const int64_t* srp; const int* sci; const double* sv;
       rc = cuadmm_aat_tail_schur(s->fac, &srp, &sci, &sv);
       s->tail.one_pass = s->sw.tail_one_pass != 0;
+      s->tail.pinv_tol = s->sw.tail_pinv_tol;
       if (!rc) rc = s->tail.build_from_schur(reinterpret_cast<const long long*>(srp), sci, sv, tk, s->st);
       // The tail is applied as an explicit inverse built without pivoting (tail_solve.hip); with (nearly) dependent
       // constraints the pivots approach the regularisation 1e-15 and inv(L22) could lose accuracy silently.  Probe it with
@@ -1382,6 +1384,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "lead_tops") s->sw.lead_tops = (int)value;
   else if (k == "lead_tops_refine") s->sw.lead_tops_refine = (int)value;
   else if (k == "lead_small_kb") s->sw.lead_small_kb = (int)value;
+  else if (k == "tail_pinv_tol") s->sw.tail_pinv_tol = value;
   else if (k == "l21_device") s->sw.l21_device = (int)value;
   else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
   else if (k == "tail_shard") s->sw.tail_shard = (int)value;

@@ -17,6 +17,8 @@ struct TailSolve {
   unsigned long long* part = nullptr;   // 18 432 < K <= 32 768: per row and member, the exchanged parts of u = W z (ts_onepass_group_kernel)
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
+  double pinv_tol = 0.0;       // option tail_pinv_tol (experiment, DESIGN.md section 4 "Round 5: dense tree tops"): pivots of the tail below it in
+                               // magnitude are treated as zero (1 / d := 0); confirms where the pobj deviations of the moment relaxations come from, fixes nothing
   int apply(hipStream_t st);   // vin <- W^T diag(dinv) W vin
   // Rows of W split over the ranks of a sharded engine (reference's device split: src/duo_solver.cu:269-295): rank p applies the rows
   // of its share of the triangle (equal numbers of entries) and the K partial results are summed by reduce_fn -- the engine's

@@ -515,9 +515,10 @@ __global__ __launch_bounds__(256) void ts_ldlt_update_kernel(double* __restrict_
       }
 }
 
-__global__ void ts_dinv_kernel(const double* __restrict__ d, double* __restrict__ dinv, int K) {
+// pinv_tol > 0 (option tail_pinv_tol, an experiment: see tail_solve.h): a pivot below it in magnitude counts as zero
+__global__ void ts_dinv_kernel(const double* __restrict__ d, double* __restrict__ dinv, int K, double pinv_tol) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < K) dinv[i] = 1.0 / d[i];
+  if (i < K) dinv[i] = fabs(d[i]) < pinv_tol ? 0.0 : 1.0 / d[i];
 }
 
 int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, long long sA, const double* B, long long ldb,
@@ -688,7 +689,7 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return e == hipErrorOutOfMemory ? CUADMM_ERR_INVALID : CUADMM_ERR_NO_DEVICE; }
   hipLaunchKernelGGL(ts_scatter_csr_kernel, dim3(K), dim3(256), 0, st, drp, dci, dval, k, dS, ld);
   if ((rc = ts_ldlt_factor(dS, K, dd, Yp, dflag, st))) { cleanup(); release(); return rc; }
-  hipLaunchKernelGGL(ts_dinv_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dd, dinv, K);
+  hipLaunchKernelGGL(ts_dinv_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dd, dinv, K, pinv_tol);
   int hflag = 0;
   e = hipGetLastError();
   if (e == hipSuccess && staged_d2h(&hflag, dflag, sizeof(int), st)) e = hipErrorUnknown;      // staged: never a runtime copy into pageable memory
