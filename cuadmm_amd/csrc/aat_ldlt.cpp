@@ -395,7 +395,38 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
     const double cost = host_ns * (double)Lp[m - k] + 60e3 + (double)k * k * 8.0 / 4000.0;
     if (cost < best) { best = cost; best_k = k; }
   }
-  if (best_k == 0 || best > 0.7 * total || total < 300e3) return 0;
+  if (best_k == 0 || best > 0.7 * total || total < 300e3) {
+    // WIDE FOREST (round 5): no dense tail pays for itself -- the factor is sparse to the top -- but the host still spends a millisecond per
+    // solve on it (bqp-r1-40-1: m = 269 001, 0.8 M nonzeros, 1.0 of 4.2 ms per iteration with its two PCIe hops).  With a SMALL tail in front of the
+    // device-side sweeps the whole solve stays in HBM: 103 016 trees there, 102 000 of them of one or two nodes (a thread each:
+    // lead_solve.h, micro trees), the rest 105 levels deep.  Taken when every tree fits the sweeps (6 144 nodes, 256 levels), the model says
+    // half the host's time or less, and the forest is not the block-diagonal kind the engine solves with one thread per tree anyway.
+    if (parent && g_plan_allow_tops && m >= 65536 && total >= 500e3) {
+      for (const int k : {1024, 2048, 4096}) {
+        if (k > std::min(m - 1, max_k)) break;
+        const int n1 = m - k;
+        std::vector<int> sz((size_t)n1, 1), ht((size_t)n1, 1);
+        int big = 0, deep = 0, big0 = 0;
+        long long in_trees = 0;
+        for (int j = 0; j < n1; ++j) {
+          const int p = parent[j];
+          if (p >= 0 && p < n1) { sz[p] += sz[j]; ht[p] = std::max(ht[p], ht[j] + 1); }
+          else { big = std::max(big, sz[j]); deep = std::max(deep, ht[j]); if (sz[j] > 2) in_trees += sz[j]; }
+        }
+        {
+          std::vector<int> s0((size_t)m, 1);
+          for (int j = 0; j < m; ++j) { const int p = parent[j]; if (p >= 0) s0[p] += s0[j]; else big0 = std::max(big0, s0[j]); }
+        }
+        if (big0 <= 64 || big > 6144 || deep > 256) continue;
+        const double dev_us = 2.0 * (14.0 + 0.25e-3 * (double)in_trees) + 16.0 + 45.0 + 24.0 * (double)Lp[n1] / 3.0e6 + (double)k * k * 4.0 / 5.1e6 + 28.0;
+        // with the tree tops: the one tree that does not fit a workgroup's LDS with its stream resident (1 681 nodes, 105 levels on the
+        // streaming kernel: 0.8 ms per solve, slower than the host) is cut like every other -- measured 1.33 -> 0.19 ms of y-solve per
+        // iteration, 4.45 -> 3.36 ms per iteration
+        if (dev_us < 0.5 * (total * 1e-3 + 150.0)) { if (tops_out) *tops_out = 32; return k; }
+      }
+    }
+    return 0;
+  }
   if (!parent) return best_k;
   std::vector<int> h((size_t)m, 1), hmax((size_t)m + 1, 0);      // hmax[n1] = height of the forest over columns < n1
   for (int j = 0; j < m; ++j) {

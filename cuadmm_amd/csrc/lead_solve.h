@@ -37,6 +37,12 @@ struct LeadSolve {
   int* trees_stream = nullptr;
   int n_small = 0, n_big = 0, n_stream = 0;
   size_t lds_small = 0, lds_big = 0;
+  // MICRO trees: one or two nodes (bqp-r1-40-1 at a 1 024-column tail: 102 000 of its 103 016 trees).  A wavefront per tree is the wrong shape for
+  // them; when there are thousands, one THREAD takes a tree (lead_micro_kernel) -- a row of such a tree has at most one entry, so the sums are
+  // the wavefront kernels' bit for bit
+  int* micro_first = nullptr;   // first slot of every micro tree (its size: 1 or 2, in micro_cnt)
+  int* micro_cnt = nullptr;
+  int n_micro = 0;
   hipStream_t aux = nullptr;    // the big trees' launches run beside the small trees' (fork / join events on the caller's stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool debug = false;           // option lead_debug: forest statistics on stderr at build

@@ -344,6 +344,28 @@ __global__ __launch_bounds__(256) void lead_sweep_merged_kernel(const LeadTreeDe
   }
 }
 
+// Micro trees (lead_solve.h): one thread per tree of one or two nodes, slots in the sweeps' processing order.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void lead_micro_kernel(int n_micro, const int* __restrict__ first, const int* __restrict__ cnt, const int* __restrict__ nodes,
+                                                         const long long* __restrict__ ptr, const int* __restrict__ ci, const double* __restrict__ v,
+                                                         const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
+                                                         const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
+                                                         const int* __restrict__ rid) {
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= n_micro) return;
+  const int s0 = first[t];
+  const int n0 = nodes[s0];
+  const double x0 = BACKWARD ? x[n0] / D[n0] - w[n0] : lead_rhs_at(ax, asmc, b, isig, rid, n0);
+  x[n0] = x0;
+  if (cnt[t] > 1) {
+    const int n1 = nodes[s0 + 1];
+    double s = 0.0;
+    for (long long q = ptr[s0 + 1]; q < ptr[s0 + 2]; ++q) s += v[q] * (ci[q] == 0 ? x0 : 0.0);      // (one entry: the other node)
+    const double r1 = BACKWARD ? x[n1] / D[n1] - w[n1] : lead_rhs_at(ax, asmc, b, isig, rid, n1);
+    x[n1] = r1 - s;
+  }
+}
+
 // ---- dense tree tops (lead_solve.h) -------------------------------------------------------------------------------------------------
 // rows of the extended tail [T | K] over the B columns: zext[e] = rhs(row e) - sum_j L[e][j] z_B[j]   (LANES lanes per row, fixed order)
 template <int LANES>
@@ -453,6 +475,9 @@ void LeadSolve::release() {
   tops = false; nT = 0; k_tail = 0; tops_bytes = 0; tops_blocks = tops_max = 0;
   if (long_cols_d) { hipError_t e = hipFree(long_cols_d); (void)e; long_cols_d = nullptr; }
   n_long = 0;
+  if (micro_first) { hipError_t e = hipFree(micro_first); (void)e; micro_first = nullptr; }
+  if (micro_cnt) { hipError_t e = hipFree(micro_cnt); (void)e; micro_cnt = nullptr; }
+  n_micro = 0;
   if (zfull) { hipError_t e = hipFree(zfull); (void)e; zfull = nullptr; }
   if (h_w) { hipError_t e = hipHostFree(h_w); (void)e; h_w = nullptr; }
   if (h_z) { hipError_t e = hipHostFree(h_z); (void)e; h_z = nullptr; }
@@ -702,6 +727,8 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
   // the few big ones get a launch of their own, anything beyond one workgroup's LDS keeps the streaming kernels
   std::vector<int> t_stream;
   std::vector<LeadTreeDesc> dsf, dsb, dbf, dbb;        // small / big trees, forward / backward sweep
+  std::vector<int> mfirst, mcnt;                       // micro trees (lead_solve.h)
+  bool split_micro = false;
   lds_small = lds_big = 0;
   // (measured and dropped: a launch of their own for the trees that need <= 4 KB -- eight workgroups per CU instead of two.  The two launches
   // serialise, and the big trees decide the second one: PlanarHand_N=10 116 -> 2 x 50 us per sweep, PushBox N = 30 / 50 +10 us per sweep.)
@@ -742,6 +769,12 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
         if (rounds < 0.98 * best) { best = rounds; bound = cand; }
       }
     }
+    // a launch of their own pays from a few thousand micro trees on (below that they are a fraction of one round of workgroups)
+    {
+      int nm = 0;
+      for (int t = 0; t < ntrees; ++t) nm += cnt[t] <= 2;
+      split_micro = !stream_only && nm >= 8192;
+    }
     int acc = 0;
     for (int t = 0; t < ntrees; ++t) {
       const long long nzf = fp[(size_t)acc + cnt[t]] - fp[acc], nzb = bp[(size_t)acc + cnt[t]] - bp[acc];
@@ -749,14 +782,16 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
       const size_t need = need_of[t];
       const LeadTreeDesc df{lpf[t], nlf, acc, cnt[t], (int)nzf, 0, fp[acc]}, db{lpb[t], nlb, acc, cnt[t], (int)nzb, 0, bp[acc]};
       if (stream_only || need > kMaxLdsBytes - 1024) t_stream.push_back(t);
+      else if (split_micro && cnt[t] <= 2) { mfirst.push_back(acc); mcnt.push_back(cnt[t]); }
       else if (need <= bound) { dsf.push_back(df); dsb.push_back(db); lds_small = std::max(lds_small, need); }
       else { dbf.push_back(df); dbb.push_back(db); lds_big = std::max(lds_big, need); }
       acc += cnt[t];
     }
   }
-  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size();
-  if (debug) fprintf(stderr, "[lead debug] resident trees: %d small (%zu B), %d big (%zu B), %d streaming\n", n_small, lds_small, n_big, lds_big, n_stream);
+  n_small = (int)dsf.size(); n_big = (int)dbf.size(); n_stream = (int)t_stream.size(); n_micro = (int)mfirst.size();
+  if (debug) fprintf(stderr, "[lead debug] resident trees: %d small (%zu B), %d big (%zu B), %d streaming, %d micro\n", n_small, lds_small, n_big, lds_big, n_stream, n_micro);
   int rc;
+  if ((rc = to_device(micro_first, mfirst)) || (rc = to_device(micro_cnt, mcnt))) return rc;
   {
     LeadTreeDesc *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;
     if ((rc = to_device(a0, dsf)) || (rc = to_device(a1, dsb)) || (rc = to_device(a2, dbf)) || (rc = to_device(a3, dbb)) || (rc = to_device(trees_stream, t_stream))) return rc;
@@ -1002,6 +1037,14 @@ static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, c
   const size_t lds_merged = std::max(L.lds_big, 4 * sizeof(double) * (size_t)small_doubles);
   const unsigned grid_merged = (unsigned)(L.n_big + (L.n_small + 3) / 4);
   const double* nul = nullptr;
+  if (L.n_micro > 0) {
+    if (!backward)
+      hipLaunchKernelGGL(lead_micro_kernel<false>, dim3((unsigned)((L.n_micro + 255) / 256)), dim3(256), 0, st, L.n_micro, L.micro_first, L.micro_cnt, L.nodes_f, L.fptr,
+                         L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+    else
+      hipLaunchKernelGGL(lead_micro_kernel<true>, dim3((unsigned)((L.n_micro + 255) / 256)), dim3(256), 0, st, L.n_micro, L.micro_first, L.micro_cnt, L.nodes_b, L.bptr,
+                         L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+  }
   if (!backward) {
     if (merged)
       hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.n_big,

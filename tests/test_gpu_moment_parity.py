@@ -222,3 +222,22 @@ def test_a_cut_above_every_tree_falls_back_to_the_plain_sweeps(tmp_path):
         out.append((s.info_arr("pobj").copy(), s.y.copy(), s.X.copy()))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_wide_forest_plan_agrees_with_the_host_solve(tmp_path):
+    """bqp-r1-40-1 (m = 269 001, a factor of 0.8 M nonzeros: no dense tail pays): round 5's planner puts a 1 024-column tail in front of the
+    device-side sweeps -- 102 000 micro trees on one thread each, the rest cut at height 32 -- instead of the host solve of rounds 1 - 4
+    (option lead_tops = 0).  The same iterates to the rounding of the differently associated sums."""
+    p = load_problem("bqp-r1-40-1", tmp_path)
+    out = []
+    for opt, mode, k in (({"lead_tops": 0}, 0, 0), ({}, 3, 1024)):
+        s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
+        s.init_problem(problem_to_amd(p))
+        s.solve(60, 0.0, 0, 50, 100, 30, 1.05)
+        c = s.counters()
+        assert c["dev_solve"] == mode and c["tail_k"] == k
+        out.append(({nm: s.info_arr(nm).copy() for nm in SIX}, s.X.copy(), s.y.copy()))
+    for nm in SIX:
+        assert rel_dev(out[1][0][nm], out[0][0][nm], nm) <= 1e-8, nm
+    for i in (1, 2):
+        assert np.linalg.norm(out[0][i] - out[1][i]) <= 1e-8 * (1 + np.linalg.norm(out[0][i]))

@@ -549,6 +549,7 @@ def test_host_pool_survives_two_concurrent_solvers():
     ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3", 0),
     ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a", 8192),
     ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176", 16384),
+    ("bqp-r1-40-1", 269001, 816406, 0, "c02eb270d6b7a503", 1024),          # round 5: the wide-forest plan (no dense tail pays; a small one in front of the device-side sweeps)
 ])
 def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha, tops_k):
     """The fill-reducing ordering (own minimum degree with the near-clique exit -- confirmed by an EXACT degree count since round 5 --
