@@ -75,9 +75,6 @@ def cpu_baseline(prob, threads, budget_s=20.0):
                 continue
             raise
         timing[eng] = secs / nslice
-    eng = "lapack" if "lapack" in timing else "ql"
-    threads_eng = tcount[eng]
-
     def timed_projection(e):
         per_block = timing[e]
         n_proj = blk.size if per_block * blk.size <= budget_s / 4 else max(1, int(budget_s / 4 / per_block))
@@ -85,14 +82,26 @@ def cpu_baseline(prob, threads, budget_s=20.0):
         _, secs = cb.psd_project(xb[:Lp], blk[:n_proj], tcount[e], engine=e)
         return n_proj, secs
 
-    n_proj, secs = timed_projection(eng)
-    blocks_per_s = n_proj / secs
+    legs = {}
+    for e in ("lapack", "ql"):
+        if e in timing:
+            n_proj, secs = timed_projection(e)
+            legs[e] = {"projection_blocks_per_s": n_proj / secs, "projection_ms": blk.size / (n_proj / secs) * 1e3, "cores": tcount[e],
+                       "sample_blocks": n_proj, "sample_s": secs}
+    if "lapack" in legs:
+        # ONE thread: what a dsyevd('V','U') + DGEMM of these blocks costs without the bundled OpenBLAS's global buffer lock in the way
+        # (oracle/cpu_eig_baseline.c: T threads serialise on it for small blocks -- the T-thread rate above is the lock's, not the host's)
+        n1 = max(1, min(blk.size, int(1.0 / max(timing["lapack"] * tcount["lapack"], 1e-7))))
+        L1 = int(np.sum(blk[:n1].astype(np.int64) * (blk[:n1] + 1) // 2))
+        _, s1 = cb.psd_project(xb[:L1], blk[:n1], 1, engine="lapack")
+        legs["lapack"]["single_thread_us_per_block"] = s1 / n1 * 1e6
+    # `value` = the FASTER engine's projection-bound rate (the rule of rounds 1 - 4: best-of; round 5 led with LAPACK whenever it
+    # loaded, which on small blocks is the slower one); the reference's own routine is always in `lapack` beside it
+    eng = max(legs, key=lambda e: legs[e]["projection_blocks_per_s"])
+    threads_eng = tcount[eng]
+    blocks_per_s = legs[eng]["projection_blocks_per_s"]
     proj_s_full = blk.size / blocks_per_s
-    port_ql = None
-    if eng == "lapack" and "ql" in timing:
-        nq, sq = timed_projection("ql")
-        port_ql = {"projection_blocks_per_s": nq / sq, "projection_ms": blk.size / (nq / sq) * 1e3, "cores": tcount["ql"],
-                   "engine": "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native)"}
+    n_proj, secs = legs[eng]["sample_blocks"], legs[eng]["sample_s"]
 
     def eig_fn(_bidx, x):
         return cb.psd_project(x, blk, threads_eng, engine=eng)[0]
@@ -110,19 +119,25 @@ def cpu_baseline(prob, threads, budget_s=20.0):
     # run on the host; every vector stage stays on the GPU, so one iteration costs at least one pass of the host projection (plus the
     # D2H / H2D of the matrices, not charged here).  The numpy oracle's whole iteration (its vector stages are single-threaded numpy,
     # not what the reference would run) is reported beside it as `oracle_iters_per_s`.
+    engines = {"lapack": "LAPACK dsyevd('V','U') per block from scipy's bundled OpenBLAS (dlopen, BLAS threads = 1) + DGEMM, static contiguous split "
+                         "over the host threads (duo_solver.cu:344-371)",
+               "ql": "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native), same split"}
     return {"value": 1.0 / proj_s_full, "unit": "iters/s", "cores": threads_eng, "kind": "port",
+            "definition": "1 / (host projection of ALL blocks by the faster of the two host engines): the rate the reference's eig_cpu mode is bounded "
+                          "by (rounds 1 - 4 reported the numpy oracle's whole iterations with the faster engine -- now `oracle_iters_per_s`; round 5 "
+                          "reported this quantity for LAPACK only -- now `lapack`)",
             "eig_engine": "lapack_dsyevd" if eng == "lapack" else "port_ql",
             "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
             "projection_blocks_per_s": blocks_per_s, "projection_ms": proj_s_full * 1e3,
             "oracle_iters_per_s": n_iters / dt,
-            "port_ql": port_ql,
-            "engine": "LAPACK dsyevd('V','U') per block from scipy's bundled OpenBLAS (dlopen, BLAS threads = 1) + DGEMM, static contiguous split over "
-                      "the host threads (duo_solver.cu:344-371)" if eng == "lapack" else
-                      "scalar Householder + implicit-QL port (oracle/eigproj_twin.c, -O3 -march=native); no LAPACK could be loaded: "
-                      + timing.get("lapack_error", ""),
-            "sample": "projection-only: %d of %d blocks in %.2f s on %d host threads -> value = 1 / (host projection of all blocks): the rate "
-                      "the reference's eig_cpu mode is bounded by; oracle_iters_per_s: %d whole ADMM iterations of the numpy oracle with that "
-                      "projection, %.1f s" % (n_proj, blk.size, secs, threads_eng, n_iters, dt)}
+            "lapack": dict(legs["lapack"], value=legs["lapack"]["projection_blocks_per_s"] / blk.size, engine=engines["lapack"]) if "lapack" in legs
+                      else {"error": timing.get("lapack_error", "")},
+            "lapack_single_thread_us_per_block": legs["lapack"]["single_thread_us_per_block"] if "lapack" in legs else None,
+            "port_ql": dict(legs["ql"], value=legs["ql"]["projection_blocks_per_s"] / blk.size, engine=engines["ql"]) if "ql" in legs else None,
+            "engine": engines[eng],
+            "sample": "projection-only: %d of %d blocks in %.2f s on %d host threads -> value = 1 / (host projection of all blocks); "
+                      "oracle_iters_per_s: %d whole ADMM iterations of the numpy oracle with that projection, %.1f s" % (
+                          n_proj, blk.size, secs, threads_eng, n_iters, dt)}
 
 
 def _as_synth(p):
@@ -682,6 +697,9 @@ def main():
             solves = 1 if args.mode == "admm" else 2
             out["y_solve"] = {"ms_per_iteration": breakdown["tail_solve"], "solves_per_iteration": solves, "tail_k": int(k_tail),
                               "tail_bytes_per_solve": 4.0 * k_tail * k_tail, "tail_hbm_floor_ms": solves * 4.0 * k_tail * k_tail / 8e12 * 1e3,
+                              # N > 1: the tail's rows are split over the ranks (1 / N of the triangle's entries each, tail_solve.h)
+                              "tail_bytes_read_per_solve_rank0": solver.tail_info()["bytes_read_per_solve"],
+                              "tail_bytes_resident_rank0": solver.tail_info()["bytes_resident"],
                               "plan": {0: "host", 1: "device sweeps + GPU tail", 2: "hybrid (L11 on the host)", 3: "device sweeps + dense tree tops + GPU tail"}
                               .get(int(plan.get("dev_solve", 0)), "?")}
         if world == 1 and not args.no_cpu_baseline:

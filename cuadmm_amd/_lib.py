@@ -83,6 +83,7 @@ PROTOTYPES = {
     "cuadmm_reset_profile": (C.c_int, [C.c_void_p]),
     "cuadmm_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cuadmm_get_group_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cuadmm_get_tail_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cuadmm_problem_from_txt": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "cuadmm_problem_view_get": (C.c_int, [C.c_void_p, C.POINTER(ProblemView)]),
     "cuadmm_problem_free": (None, [C.c_void_p]),
@@ -118,6 +119,8 @@ PROTOTYPES = {
     "cuadmm_op_gemm_sym": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cuadmm_op_tail_factor_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cuadmm_op_tail_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "cuadmm_op_tail_solve_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cuadmm_tail_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "cuadmm_op_tail_solve_drill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cuadmm_op_batch_eig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cuadmm_op_max_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),

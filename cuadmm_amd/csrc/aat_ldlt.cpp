@@ -456,7 +456,7 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
       if (bcnt[j] > 6144) return -1.0;                              // lead_solve.hip: one tree per workgroup
       tri += 0.5 * (double)tcnt[j] * ((double)tcnt[j] + 1.0);
     }
-    if (tri * 16.0 > 2.0e9) return -1.0;                            // both triangles: memory, and the n^3-ish build on the host
+    if (tri * 16.0 > (double)cuadmm::kLeadTopsMaxBytes) return -1.0;                            // both triangles: memory, and the n^3-ish build on the host
     // (the four-rows-per-exchange kernel beyond 24 576 columns: 897 us at k = 32 768 in profiles/r05_tops_PlanarHand_N=10_kernel_stats.csv)
     const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 4.0 / (k <= 24576 ? 3.8e6 : 4.8e6) + 40.0;
     // (A finer model -- sweeps by the NODES of the rest, 14 + 0.25e-3 n us each, 45 us of short kernels -- is within 10 % of every measured

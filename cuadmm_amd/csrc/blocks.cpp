@@ -193,6 +193,15 @@ int cuadmm_partition_blocks(const int* blk, int mat_num, int world, int* first_b
   return CUADMM_OK;
 }
 
+// row ranges of the dense tail's shards (tail_shard_bound, common.h): out[p] .. out[p + 1] for rank p, world + 1 entries, rows of the
+// PADDED triangle (out[world] = the padded size K of a tail of k columns)
+int cuadmm_tail_shard_bounds(int k, int world, int* out) {
+  if (k < 1 || world < 1 || !out) { set_error("tail_shard_bounds: bad arguments"); return CUADMM_ERR_INVALID; }
+  const int K = tail_padded(k);
+  for (int p = 0; p <= world; ++p) out[p] = tail_shard_bound(K, p, world);
+  return CUADMM_OK;
+}
+
 // host model of the adaptive matrix-sign schedule (sign_sched.h): the kernels run the same state machine per block
 int cuadmm_sign_sched_simulate(double* s, int n, int lagged, double* max_err_out) {
   if (!s || n < 0) { set_error("sign_sched_simulate: bad arguments"); return CUADMM_ERR_INVALID; }

@@ -1,5 +1,6 @@
 // Shared host-side declarations of the engine (error plumbing, small helpers).
 #pragma once
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -51,6 +52,24 @@ struct MatrixSizes {
 };
 void print_blk_census(const std::vector<int>& sizes, const std::vector<int>& nums);
 void partition_blocks(const int* blk, int mat_num, int world, std::vector<int>& first);
+
+// Row boundaries of the tail's shards: rank p of `world` applies rows [tail_shard_bound(K, p, world), tail_shard_bound(K, p + 1, world))
+// of W = inv(L22), in the kernels' row numbering (row 0 is the LONGEST row of the triangle: K entries, row r has K - r): equal shares of
+// the triangle's ENTRIES -- of the bytes a solve reads -- not of its rows; multiples of 8; [0, K) covered, monotone, and a rank whose
+// share rounds away gets an EMPTY range (K = 64, world = 8: ranks 1 and 2 both start at row 8), for which every kernel writes zeros.
+inline int tail_shard_bound(int K, int p, int world) {
+  if (p <= 0) return 0;
+  if (p >= world) return K;
+  const double f = (double)p / (double)world;
+  int r = (int)((double)K * (1.0 - std::sqrt(1.0 - f)));
+  r = (r + 7) / 8 * 8;
+  return r < K ? r : K;
+}
+inline int tail_padded(int k) { return (k + 63) / 64 * 64; }      // TailSolve::K for a tail of k columns
+
+// dense tree tops of the y-solve (lead_solve.h): both packed triangles of the explicit inverses, on the host while they are built
+// and on the device afterwards -- ONE limit for the planner (aat_ldlt.cpp, tops_us) and the build (lead_solve.hip, build_tops)
+constexpr long long kLeadTopsMaxBytes = 2000000000ll;
 
 }  // namespace cuadmm
 

@@ -23,6 +23,7 @@
 // and returns an error (CUADMM_ERR_COMM in the engine), no rank is left waiting, no std::thread is destroyed joinable.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <functional>
 #include <condition_variable>
@@ -43,7 +44,9 @@ struct DuoRank {
   DuoGroup* g = nullptr; int rank = 0; int device = 0;
   double* stage = nullptr; double* sum = nullptr; size_t cap = 0;       // host exchange: page-locked, portable
   double* dstage[2] = {nullptr, nullptr}; size_t dcap = 0;              // device exchange: on this rank's device
-  long long calls = 0;
+  long long calls = 0;         // collectives of the CURRENT duo_group_run call (zeroed for every rank when a call starts: the staging slot
+                               // and the published index derive from it, so the ranks re-agree on it after a call that failed half way)
+  long long inj_calls = 0;     // collectives since the test hook was armed (duo_group_inject)
 };
 
 struct DuoGroup {
@@ -60,6 +63,7 @@ struct DuoGroup {
   // with one barrier per collective a rank may already be publishing for collective k + 1 while a slower one still reads what was
   // published for k (it cannot get further: barrier k + 1 needs everybody), so two sets suffice
   std::vector<size_t> counts;              // [parity * world + rank]
+  std::vector<long long> index;            // [parity * world + rank]: which collective of the call the entry belongs to
   std::vector<const double*> pub;          // [parity * world + rank]
   long long n_allreduce = 0;
   bool device_exchange = false;
@@ -89,14 +93,18 @@ struct DuoGroup {
     ++left;
     if (arrived > 0) { abort.store(true); cv.notify_all(); }
   }
-  void publish(int parity, int r, size_t c, const double* where) {   // read by the others after the barrier
+  void publish(int parity, int r, size_t c, long long idx, const double* where) {   // read by the others after the barrier
     std::lock_guard<std::mutex> lk(mu);
     counts[(size_t)parity * world + r] = c;
+    index[(size_t)parity * world + r] = idx;
     pub[(size_t)parity * world + r] = where;
   }
-  bool counts_agree(int parity, size_t c) {
+  // every rank brought the same length to the same collective of this call: a stale entry of an earlier collective (a rank that
+  // failed and came back with another count of calls) carries another index even when its length matches
+  bool counts_agree(int parity, size_t c, long long idx) {
     std::lock_guard<std::mutex> lk(mu);
-    for (int r = 0; r < world; ++r) if (counts[(size_t)parity * world + r] != c) return false;
+    for (int r = 0; r < world; ++r)
+      if (counts[(size_t)parity * world + r] != c || index[(size_t)parity * world + r] != idx) return false;
     return true;
   }
   const double* published(int parity, int r) { std::lock_guard<std::mutex> lk(mu); return pub[(size_t)parity * world + r]; }
@@ -112,11 +120,18 @@ __global__ void duo_sum_kernel(DuoPeers peers, int world, double* __restrict__ b
   }
 }
 
-static bool duo_injected_failure(DuoRank* me) {
+// test hook: inject = +-(rank * 1e6 + k) fails rank's k-th collective since the hook was armed (negative: throws instead);
+// + 5e8: the rank fails IN FRONT of that collective, without counting it -- a failure between two collectives, which leaves the ranks'
+// counters apart
+constexpr long long kInjectBetween = 500000000;
+static bool duo_injected_failure(DuoRank* me, bool before_counting) {
   const long long inj = me->g->inject;
   if (inj == 0) return false;
-  const long long a = inj < 0 ? -inj : inj;
-  if (a / 1000000 != me->rank || a % 1000000 != me->calls) return false;
+  long long a = inj < 0 ? -inj : inj;
+  const bool between = a >= kInjectBetween;
+  if (between) a -= kInjectBetween;
+  if (between != before_counting) return false;
+  if (a / 1000000 != me->rank || a % 1000000 != me->inj_calls + (before_counting ? 1 : 0)) return false;
   if (inj < 0) throw std::bad_alloc();
   return true;
 }
@@ -141,9 +156,9 @@ static int duo_allreduce_device(DuoRank* me, double* buf, size_t count, hipStrea
     g->raise_abort();
     return 1;
   }
-  g->publish(slot, me->rank, count, me->dstage[slot]);
+  g->publish(slot, me->rank, count, me->calls, me->dstage[slot]);
   if (!g->barrier()) return 1;
-  if (!g->counts_agree(slot, count)) { g->raise_abort(); return 2; }         // ranks issued different collectives
+  if (!g->counts_agree(slot, count, me->calls)) { g->raise_abort(); return 2; }   // ranks issued different collectives
   DuoPeers peers;
   for (int r = 0; r < g->world; ++r) peers.p[r] = g->published(slot, r);     // published before the barrier by their owners
   const unsigned grid = (unsigned)std::min<size_t>((count + 255) / 256, 1024);
@@ -169,9 +184,9 @@ static int duo_allreduce_host(DuoRank* me, double* buf, size_t count, hipStream_
     g->raise_abort();
     return 1;
   }
-  g->publish(0, me->rank, count, nullptr);                                   // (two barriers per collective here: one set is enough)
+  g->publish(0, me->rank, count, me->calls, nullptr);                        // (two barriers per collective here: one set is enough)
   if (!g->barrier()) return 1;
-  if (!g->counts_agree(0, count)) { g->raise_abort(); return 2; }            // ranks issued different collectives
+  if (!g->counts_agree(0, count, me->calls)) { g->raise_abort(); return 2; }   // ranks issued different collectives
   // every rank forms the same sum in the same order
   const double* s0 = g->ranks[0].stage;
   for (size_t i = 0; i < count; ++i) me->sum[i] = s0[i];
@@ -189,8 +204,9 @@ static int duo_allreduce_hook(void* user, double* buf, size_t count, void* hip_s
   DuoRank* me = static_cast<DuoRank*>(user);
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (count == 0) return 0;
-  ++me->calls;
-  if (duo_injected_failure(me)) { me->g->raise_abort(); return 1; }
+  if (duo_injected_failure(me, true)) { me->g->raise_abort(); return 1; }
+  ++me->calls; ++me->inj_calls;
+  if (duo_injected_failure(me, false)) { me->g->raise_abort(); return 1; }
   return me->g->device_exchange ? duo_allreduce_device(me, buf, count, st) : duo_allreduce_host(me, buf, count, st);
 }
 
@@ -217,7 +233,12 @@ cuadmm_solver* duo_group_rank(void* p, int r) { DuoGroup* g = duo_group_of(p); r
 long long duo_group_allreduces(void* p) { return p ? duo_group_of(p)->n_allreduce : 0; }
 int duo_group_exchange(void* p) { return p && duo_group_of(p)->device_exchange ? 1 : 0; }
 int duo_group_distinct_devices(void* p) { return p ? duo_group_of(p)->distinct_devices : 1; }
-void duo_group_inject(void* p, long long v) { if (p) duo_group_of(p)->inject = v; }
+void duo_group_inject(void* p, long long v) {
+  if (!p) return;
+  DuoGroup* g = duo_group_of(p);
+  g->inject = v;
+  for (auto& rk : g->ranks) rk.inj_calls = 0;       // the hook counts from the moment it is armed
+}
 
 // Builds the group around `parent` (rank 0): children with the parent's options, the hook on every rank.  The caller then runs
 // `fn(rank_handle)` on every rank through duo_group_run (init, solve).
@@ -236,6 +257,7 @@ int duo_group_create(cuadmm_solver* parent, int world, int parent_device, bool s
   g->child.assign((size_t)world, nullptr);
   g->ranks.assign((size_t)world, DuoRank{});
   g->counts.assign(2 * (size_t)world, 0);
+  g->index.assign(2 * (size_t)world, -1);
   g->pub.assign(2 * (size_t)world, nullptr);
   g->child[0] = parent;
   for (int r = 0; r < world; ++r) {
@@ -294,7 +316,26 @@ int duo_group_create(cuadmm_solver* parent, int world, int parent_device, bool s
 int duo_group_run(void* p, const std::function<int(cuadmm_solver*, int)>& fn) {
   DuoGroup* g = duo_group_of(p);
   const int N = g->world;
-  { std::lock_guard<std::mutex> lk(g->mu); g->abort.store(false); g->arrived = 0; g->left = 0; }
+  // All threads of the previous call have been joined.  The ranks re-agree on everything the exchange derives from their call
+  // counters: after a call that failed half way the counters differ (a rank that failed between two collectives is one behind the
+  // rank that entered the next one), and with them the staging slot and the publication set each rank would use.
+  // Every call starts with idle devices: the first collective of this call reuses staging slot 1 whatever the previous call's last
+  // one used, and after a FAILED call kernels of its last collective may still be reading their peers' staging buffers.
+  {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (auto& rk : g->ranks) if (hipSetDevice(rk.device) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    if (have_cur) (void)hipSetDevice(cur);
+  }
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->abort.store(false); g->arrived = 0; g->left = 0;
+    for (auto& rk : g->ranks) rk.calls = 0;
+    std::fill(g->counts.begin(), g->counts.end(), (size_t)0);
+    std::fill(g->index.begin(), g->index.end(), -1LL);
+    std::fill(g->pub.begin(), g->pub.end(), nullptr);
+  }
   std::vector<int> rcs((size_t)N, 0);
   std::vector<std::string> msgs((size_t)N);
   // a rank's call, with everything that can go wrong turned into a code + message and the group told about it

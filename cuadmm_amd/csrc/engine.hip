@@ -329,6 +329,7 @@ struct cuadmm_solver {
         if (ev0[k][j]) { hipError_t e = hipEventDestroy(ev0[k][j]); (void)e; }
         if (ev1[k][j]) { hipError_t e = hipEventDestroy(ev1[k][j]); (void)e; }
       }
+    if (ev_early) { hipError_t e = hipEventDestroy(ev_early); (void)e; }
     if (st) { hipError_t e = hipStreamDestroy(st); (void)e; }
     if (rccl_comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(rccl_comm); rccl_comm = nullptr; }
   }
@@ -474,9 +475,10 @@ struct cuadmm_solver {
     // (measured and rejected, round 5: a one-thread kernel storing a sequence number into a mapped pinned word with the host spinning on
     // it instead of this call -- c5 2 494 -> 2 476, c1 1 290 -> 1 274 iters/s: the runtime's wait already spins, the extra launch costs)
     if (solve_next && dev_solve && !out_mapped && st != nullptr) {
-      if (!ev_early) CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
+      // system-scope release: the host reads the pinned h_scal / h_out behind this wait (the stream synchronisation it replaces was one)
+      if (!ev_early) CUADMM_HIP_TRY(hipEventCreateWithFlags(&ev_early, hipEventDisableTiming | hipEventReleaseToSystem));
       CUADMM_HIP_TRY(hipEventRecord(ev_early, st));
-      { int rc = host_solve(); if (rc) return rc; }
+      { int rc = host_solve(); if (rc) { (void)hipStreamSynchronize(st); return rc; } }     // nothing of this iteration stays in flight behind an error
       y_early = true;
       CUADMM_HIP_TRY(hipEventSynchronize(ev_early));
     } else {
@@ -2105,6 +2107,11 @@ int cuadmm_get_counters(const cuadmm_solver* s, double o[8]) {
   o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? (s->lead.tops ? 3 : 1) : (s->lead.hybrid ? 2 : 0); o[7] = (double)s->tail.k;
   return CUADMM_OK;
 }
+int cuadmm_get_tail_info(const cuadmm_solver* s, double o[4]) {
+  if (!s || !o) { set_error("get_tail_info: null"); return CUADMM_ERR_INVALID; }
+  o[0] = (double)s->tail.k; o[1] = s->tail.shard_bytes; o[2] = (double)s->tail.shard_rows; o[3] = s->tail.resident_bytes;
+  return CUADMM_OK;
+}
 int cuadmm_get_group_info(const cuadmm_solver* s, double o[4]) {
   if (!s || !o) { set_error("get_group_info: null"); return CUADMM_ERR_INVALID; }
   o[0] = s->group ? (double)duo_group_world(s->group) : 1.0;
@@ -2147,6 +2154,28 @@ int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, d
   if (!rc) {
     const int lost = t.fail_count(nullptr);
     if (lost != 0) { set_error("tail_solve: %d row exchanges lost (workgroups of a row not co-resident)", lost); return CUADMM_ERR_FACTOR; }
+  }
+  return rc;
+}
+
+int cuadmm_op_tail_solve_sharded(const double* L22_host, const double* D2_host, int k, const double* z_host, int world, int one_pass,
+                                 double* out_host, int* rows_out) {
+  if (!L22_host || !D2_host || !z_host || !out_host || k < 1 || world < 1) { set_error("tail_solve_sharded: bad arguments"); return CUADMM_ERR_INVALID; }
+  TailSolve t;
+  t.one_pass = one_pass != 0;
+  int rc = t.build(L22_host, D2_host, k, nullptr);
+  // the reduction is left out: every rank's partial result comes back as it stands
+  t.reduce_fn = [](void*, double*, size_t, hipStream_t) -> int { return CUADMM_OK; };
+  t.shard_world = world;
+  for (int p = 0; p < world && !rc; ++p) {
+    t.shard_rank = p;
+    std::copy(z_host, z_host + k, out_host + (size_t)p * k);
+    rc = t.solve(out_host + (size_t)p * k, nullptr);
+    if (rows_out) rows_out[p] = t.shard_rows;
+  }
+  if (!rc) {
+    const int lost = t.fail_count(nullptr);
+    if (lost != 0) { set_error("tail_solve_sharded: %d row exchanges lost", lost); return CUADMM_ERR_FACTOR; }
   }
   return rc;
 }

@@ -13,7 +13,6 @@
 #include <atomic>
 #include <new>
 #include <numeric>
-#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -862,7 +861,7 @@ int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, cons
   long long tri_total = 0;
   int bmax = 0;
   for (int q = 0; q < nblk; ++q) { const long long n = blk_ptr[q + 1] - blk_ptr[q]; tri_total += n * (n + 1) / 2; bmax = std::max(bmax, (int)n); }
-  if (tri_total * 16 > (6ll << 30)) return CUADMM_ERR_FACTOR;          // both triangles beyond 6 GB: not this path
+  if (tri_total * 16 > kLeadTopsMaxBytes) return CUADMM_ERR_FACTOR;     // both triangles beyond the planner's own bound (common.h): not this path
   // the B columns in the new order (rows: B ascending, then T, then K -- T rows sorted by their new index)
   std::vector<int64_t> Lp2((size_t)nB + 1, 0);
   std::vector<int> Li2;
@@ -986,11 +985,12 @@ int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, cons
     }
   };
   {
-    const int nth = std::max(1, std::min(std::min(cuadmm_host_pool_threads(), 16), nblk));
-    std::vector<std::thread> th;
-    for (int i = 1; i < nth; ++i) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    // on the SHARED host pool (no threads of its own: the ranks of an in-process group build their tops at the same time, and a
+    // std::thread that cannot start would unwind through joinable ones); blocks are handed out by the counter, so a pool that is busy
+    // -- its caller then runs the chunks inline -- changes nothing but the time
+    const int nth = std::max(1, std::min(cuadmm_host_pool_threads(), nblk));
+    auto* wp = &work;
+    cuadmm_host_parallel_for(nth, [](int, void* p) { (*static_cast<decltype(wp)>(p))(); }, wp);
   }
   if (bad.load() > 0) { set_error("lead_solve: %d of %d dense tree tops fail the check of their inverse", bad.load(), nblk); return CUADMM_ERR_FACTOR; }
   std::vector<double> dt((size_t)nt);

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.h"
+
 namespace cuadmm {
 
 struct TailSolve {
@@ -28,6 +30,7 @@ struct TailSolve {
   void* reduce_user = nullptr;
   int shard_rows = 0;          // rows this rank applied in the last solve
   double shard_bytes = 0;      // bytes of W it read for them
+  double resident_bytes = 0;   // device memory held by this object
   int apply_rows(hipStream_t st, int r_begin, int r_end);
   double build_s = 0, factor_s = 0;
   int build(const double* L22, const double* D2, int k, hipStream_t st);                                        // host factor

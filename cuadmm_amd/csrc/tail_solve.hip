@@ -539,12 +539,14 @@ void TailSolve::release() {
   attr_set = false;
   group_retired = false;
   k = K = 0;
+  resident_bytes = 0;
 }
 
 int TailSolve::alloc(int k_) {
   release();
   k = k_;
-  K = (k + TS_TM - 1) / TS_TM * TS_TM;
+  K = tail_padded(k);
+  static_assert(TS_TM == 64, "tail_padded (tail_solve.h) pads to the tile of the dense kernels");
   const size_t sz = (size_t)K * K;
   CUADMM_HIP_TRY(hipMalloc(&W, sizeof(double) * sz));
   CUADMM_HIP_TRY(hipMalloc(&Wt, sizeof(double) * sz));
@@ -568,6 +570,7 @@ int TailSolve::alloc(int k_) {
     CUADMM_HIP_TRY(hipDeviceSynchronize());
   }
   CUADMM_HIP_TRY(hipHostMalloc(&h_vec, sizeof(double) * (size_t)K, hipHostMallocDefault));
+  resident_bytes = 8.0 * (2.0 * (double)sz + 3.0 * K + (double)K * n_wg) + (part ? 64.0 * K : 0.0);
   return CUADMM_OK;
 }
 
@@ -752,16 +755,8 @@ int TailSolve::apply(hipStream_t st) {
   // this rank's rows r = K - 1 - i (r = 0: the longest row): equal shares of the triangle's entries, boundaries on multiples of 8
   int r_begin = 0, r_end = K;
   if (shard_world > 1) {
-    auto bound = [&](int p) -> int {
-      if (p <= 0) return 0;
-      if (p >= shard_world) return K;
-      const double f = (double)p / (double)shard_world;
-      int r = (int)((double)K * (1.0 - std::sqrt(1.0 - f)));
-      r = (r + 7) / 8 * 8;
-      return r < K ? r : K;
-    };
-    r_begin = bound(shard_rank);
-    r_end = bound(shard_rank + 1);
+    r_begin = tail_shard_bound(K, shard_rank, shard_world);
+    r_end = tail_shard_bound(K, shard_rank + 1, shard_world);
   }
   shard_rows = r_end - r_begin;
   shard_bytes = 8.0 * ((double)(r_end - r_begin) * (double)K - 0.5 * ((double)r_end * r_end - (double)r_begin * r_begin));   // entries of the rows read

@@ -112,6 +112,12 @@ class SDPSolver:
         check(self._lib.cuadmm_get_group_info(self._h, _p(o)))
         return {"engines": int(o[0]), "exchange": "device" if o[1] else "host", "distinct_devices": int(o[2]), "allreduces": int(o[3])}
 
+    def tail_info(self):
+        """The dense GPU tail of the A A^T factor on this rank (cuadmm_get_tail_info)."""
+        o = np.zeros(4)
+        check(self._lib.cuadmm_get_tail_info(self._h, _p(o)))
+        return {"tail_k": int(o[0]), "bytes_read_per_solve": float(o[1]), "rows": int(o[2]), "bytes_resident": float(o[3])}
+
     def set_allreduce(self, fn):
         """fn(dev_ptr:int, count:int, hip_stream:int) -> None : in-place sum over ranks on that stream."""
         def tramp(_user, buf, count, stream):

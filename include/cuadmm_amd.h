@@ -179,6 +179,10 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
  *   L11 sweeps on the host, L21 products and the tail on the device; 3: on the device with dense tree tops, option "lead_tops"),
  *   [7] size of the GPU tail of the A A^T factor. */
 int cuadmm_get_counters(const cuadmm_solver* s, double out8[8]);
+/* The dense GPU tail of the A A^T factor on this rank: [0] its size k (0: none), [1] bytes of inv(L22) this rank read in its last
+ * solve (4 K^2 for the whole triangle; 1 / world of it when the tail is sharded, option "tail_shard"), [2] the rows it applied,
+ * [3] bytes of device memory the tail holds on this rank. */
+int cuadmm_get_tail_info(const cuadmm_solver* s, double out[4]);
 /* The in-process group a handle leads after cuadmm_duo_init(device_num_requested = N) from one process (reference
  * src/duo_solver.cu:487-577): [0] engines in the group (1: no group), [1] exchange of its all-reduce -- 1 = device side (each
  * rank's kernel adds the N staging buffers out of its peers' memory: one shared device, or peer access over xGMI as
@@ -231,6 +235,11 @@ int cuadmm_get_maps_duo(const int* blk, int mat_num, int LARGE, int SMALL, int v
 int cuadmm_inverse_permutation(const int* perm, int n, int* perm_inv);
 /* contiguous block ranges per rank balanced by sum n^3; out has world+1 entries */
 int cuadmm_partition_blocks(const int* blk, int mat_num, int world, int* first_block_out);
+/* Rows of the dense GPU tail of the replicated y-solve (k columns, padded to K = a multiple of 64) that rank p of `world` applies
+ * when the tail is sharded (option "tail_shard"; the reference splits its per-iteration heavy part over the devices,
+ * src/duo_solver.cu:269-295): [out[p], out[p + 1]) in the kernels' numbering (row 0 = the longest row of the triangle), equal shares
+ * of the triangle's ENTRIES, multiples of 8, out[0] = 0, out[world] = K; a range may be empty.  Host arithmetic only. */
+int cuadmm_tail_shard_bounds(int k, int world, int* out);
 
 /* ------------------------------------------------------------------------------------ */
 /* Host (A A^T + eps I) factor + permuted solve: CholeskySolverCPU                        */
@@ -341,6 +350,11 @@ int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, do
 /* The GPU part of the A*A^T solve on its own (tail_solve.hip): z <- L22^-T D2^-1 L22^-1 z for `nrhs` host vectors
  * of length k (contiguous), L22 dense k x k row-major unit lower triangular and D2 the pivots (host pointers). */
 int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs);
+/* The same solve as the ranks of a sharded engine run it (TailSolve::shard_*): out_host receives `world` partial results of k doubles,
+ * partial p = what rank p contributes from its rows [bounds[p], bounds[p + 1]) (cuadmm_tail_shard_bounds) -- their sum in rank order
+ * is the solve; rows_out[p] = the rows rank p applied.  one_pass = 0 runs the two triangular GEMVs instead of the one-pass kernels. */
+int cuadmm_op_tail_solve_sharded(const double* L22_host, const double* D2_host, int k, const double* z_host, int world, int one_pass,
+                                 double* out_host, int* rows_out);
 /* Test hook: failure drill of the row-sharing tail kernel (18 432 < k <= 32 768).  out_host: 4 x k doubles -- the plain solve, the
  * solve of a right-hand side poisoned with a NaN that carries the exchange sentinel's bits, the solve with the lost-exchange
  * counter raised beforehand (NaN), the solve after the object retired to the two-pass kernels; counts[3] = {exchanges lost by the

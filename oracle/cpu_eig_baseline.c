@@ -16,7 +16,9 @@
  * engine = 1 replaces dsyevd + DGEMM by the scalar Householder + implicit-QL twin of oracle/eigproj_twin.c (compiled into
  * the same library with -O3 -march=native): the bundled OpenBLAS takes a global buffer lock in every level-2/3 BLAS call,
  * which serialises T threads on small blocks (measured here: 32 x 32 blocks, 1 -> 8 threads: 0.38 s -> 0.23 s; 100 x 100:
- * 0.35 -> 0.075 s); bench.py times both engines and reports the faster one, saying which.
+ * 0.35 -> 0.075 s).  bench.py times BOTH engines: `cpu_baseline.value` is the faster of the two projection-bound rates (the
+ * `eig_engine` field says which), the LAPACK leg -- the reference's own routine -- is always reported beside it (`lapack`), with its
+ * single-thread time per block (`lapack_single_thread_us_per_block`) so that a reader sees the lock's serialisation for what it is.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>

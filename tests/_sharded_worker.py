@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_sharded_procs.py: one PROCESS per rank (torch.distributed, gloo backend over 127.0.0.1), both
+"""Worker of tests/test_gpu_sharded_procs.py: one PROCESS per rank (torch.distributed, gloo backend over 127.0.0.1), all
 on GPU 0; the all-reduce hook stages the device buffer through the host.  Rank 0 writes the results to argv[1]."""
 import ctypes as C
 import os
@@ -19,7 +19,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 lib = cuadmm_amd.load()
 coupled = sys.argv[2] == "coupled"
-moment = sys.argv[2].partition(":")[0] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a", "PushBox_N=30_MOMENT")
+moment = sys.argv[2].split("+")[0].partition(":")[0] in ("pendulum_N=80", "PlanarHand_N=1_MOMENT", "taha1a", "PushBox_N=30_MOMENT")
 rng = np.random.default_rng(2)
 blk = list(np.array([32] * 20 + [7] * 15 + [15] * 11 + [40, 3, 28])[rng.permutation(49)])
 p = make_synthetic(blk, cons_per_block=3, seed=11)
@@ -48,23 +48,38 @@ def hook(ptr, count, stream):
 
 if moment:
     # BASELINE configs[4] / [0] sharded: coupled constraints, replicated device-side solve (GPU tail + lead solve) on every rank,
-    # 2m+2 all-reduce per half iteration; compared with the committed ORACLE trajectory by the test
+    # 2m+2 all-reduce per half iteration; compared with the committed ORACLE trajectory by the test.  Several cases in one launch
+    # ("a+b+c": the ranks' start-up -- eight torch imports on a 16-CPU box -- is paid once); rank 0 writes <argv[1]>.<i>.npz per case.
     from tests.conftest import load_npz_problem
     from tests.helpers import problem_to_amd
-    name, _, variant = sys.argv[2].partition(":")
-    prob = problem_to_amd(load_npz_problem(name))
-    # ":hybrid": the host-optimal tail with L21 on the device and the L11 sweeps on the host (lead_solve.h), forced -- on every rank
-    opts = {"tail_k": 10240, "l21_device": 2} if variant == "hybrid" else ({"tail_shard": 0} if variant == "noshard" else None)
-    s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world, options=opts, profile=1)
-    s.set_allreduce(hook)
-    s.init_problem(prob)
-    s.solve(60, 0.0, 0, 50, 100, 11000, 1.05)
-    if rank == 0:
-        pr = s.profile()
-        np.savez(sys.argv[1], counters=np.array(list(s.counters().values())), shard=np.array(s.shard()),
-                 tail_bytes=pr["tail_solve"]["bytes_per_launch"], allreduce_launches=pr["allreduce"]["launches"],
-                 **{nm: s.info_arr(nm) for nm in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")})
-    dist.barrier()
+    for idx, case in enumerate(sys.argv[2].split("+")):
+        name, _, variant = case.partition(":")
+        prob = problem_to_amd(load_npz_problem(name))
+        # ":hybrid": the host-optimal tail with L21 on the device and the L11 sweeps on the host (lead_solve.h), forced -- on every rank;
+        # ":noshard": every rank applies the whole dense tail; ":nonext": the y-solve of iteration k + 1 is NOT enqueued ahead of the
+        # host's wait for iteration k (option solve_next = 0: the A/B of that path, same trajectory bit for bit);
+        # ":timers": per-class event timers on (profile = 1; they also switch solve_next off)
+        opts = {"hybrid": {"tail_k": 10240, "l21_device": 2}, "noshard": {"tail_shard": 0}, "nonext": {"solve_next": 0}}.get(variant)
+        calls = [0]
+
+        def counted(ptr, count, stream, calls=calls):
+            calls[0] += 1
+            hook(ptr, count, stream)
+        s = cuadmm_amd.SDPSolver(device=0, verbose=False, rank=rank, world=world, options=opts, profile=1 if variant == "timers" else 0)
+        s.set_allreduce(counted)
+        s.init_problem(prob)
+        s.solve(60, 0.0, 0, 50, 100, 11000, 1.05)
+        ti = s.tail_info()
+        # every rank's share of the dense tail (bytes of inv(L22) read per solve, bytes resident), gathered for the test
+        mine = torch.zeros(world, 3, dtype=torch.float64)
+        mine[rank, 0], mine[rank, 1], mine[rank, 2] = ti["bytes_read_per_solve"], ti["rows"], ti["bytes_resident"]
+        dist.all_reduce(mine)
+        if rank == 0:
+            np.savez("%s.%d.npz" % (sys.argv[1], idx), counters=np.array(list(s.counters().values())), shard=np.array(s.shard()),
+                     tail_bytes=ti["bytes_read_per_solve"], tail_by_rank=mine.numpy(), allreduce_launches=calls[0], world=world,
+                     **{nm: s.info_arr(nm) for nm in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")})
+        del s
+        dist.barrier()
     dist.destroy_process_group()
     sys.exit(0)
 

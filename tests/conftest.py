@@ -13,6 +13,14 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Time budget of `pytest -m gpu` on the GPU box: <= 480 s of the driver's 1 200 s step limit (round 5: 550 s; round 6 starts at 536 s and
+# ends below the budget: profiles/r06_gpu_tests.log carries --durations=25).  What keeps it there: one torchrun launch per WORLD SIZE and
+# group of cases in tests/test_gpu_sharded_procs.py (the ranks' start-up is paid once), 8 soak rounds instead of 23, ONE run of pendulum's
+# 100 000 iterations, and CUADMM_LONG_TESTS=1 for the 125 s host factorisation of PushT_N=30 (profiles/r06_gpu_tests_long.log).
+# A new test that needs more than ~10 s should replace something or join an existing launch.
+GPU_SUITE_BUDGET_S = 480
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: longer CPU test")

@@ -123,11 +123,22 @@ def run_and_compare(key, tmp_path, options, pobj_head_tol):
     for v, nm in ((s.X, "late_X_norm"), (s.S, "late_S_norm")):
         r = float(rec[nm])
         assert abs(np.linalg.norm(v) - r) <= 10 * tl * (1 + r), nm
+    return s
 
 
 @pytest.mark.parametrize("key", sorted(TRAJ))
-def test_moment_relaxation_trajectory_matches_the_oracle(key, tmp_path):
-    run_and_compare(key, tmp_path, None, POBJ_HEAD_TOL.get(key))
+def test_moment_relaxation_trajectory_matches_the_oracle(key, tmp_path, ref_logs):
+    s = run_and_compare(key, tmp_path, None, POBJ_HEAD_TOL.get(key))
+    if key.endswith("/late=100000"):
+        # examples/pendulum/N=80_licols.log runs its full 100 000 iterations (stop_tol 1e-6 is never reached); the same run against the
+        # last row the REFERENCE printed: two fp64 implementations of a 100 000-step nonlinear iteration share the digits its own
+        # contraction preserves -- residuals to ~30 %, objectives to 3 - 4 digits (the oracle itself is 24 % / 11 % / 2 % away from that row
+        # in errRd / relgap / errRp).  (Rounds 2 - 5 ran these 100 000 iterations twice: here and in tests/test_gpu_longrun.py.)
+        row = ref_logs["pendulum_N=80/sGS"]["rows"][-1]
+        assert s.info_iter_num == 100000 == int(row[0])
+        for name, col, rel in (("pobj", 3, 1e-3), ("dobj", 4, 1e-3), ("errRp", 1, 0.3), ("errRd", 2, 0.3), ("relgap", 5, 0.3)):
+            w = float(row[col])
+            assert abs(s.state()[name] - w) <= rel * abs(w), (name, s.state()[name], w)
 
 
 @pytest.mark.parametrize("key", ["PlanarHand_N=1_MOMENT/switch=0", "PushBox_N=30_MOMENT/switch=11000"])
@@ -136,6 +147,8 @@ def test_round4_plan_without_tree_tops_still_matches_the_oracle(key, tmp_path):
     run_and_compare(key, tmp_path, {"lead_tops": 0}, POBJ_HEAD_TOL.get(key))
 
 
+@pytest.mark.skipif(os.environ.get("CUADMM_LONG_TESTS") != "1", reason="125 s of host factorisation (58 M nonzeros on the box's CPUs): run with "
+                    "CUADMM_LONG_TESTS=1 (profiles/r06_gpu_tests_long.log); the default suite stays inside the driver's time limit")
 def test_pusht30_with_the_factor_on_the_host_is_exact(tmp_path):
     """The same input without the GPU tail: 1e-8 on every quantity (what POBJ_HEAD_TOL above is measured against).
     What this does and does not prove: the oracle trajectory of this input took its y-solves from the library's own host LDL^T

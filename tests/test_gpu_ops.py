@@ -223,6 +223,39 @@ def test_tail_solve_op_beyond_one_workgroups_reach(k):
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
 
 
+@pytest.mark.parametrize("k,world,one_pass", [(50, 8, 1), (50, 8, 0), (1000, 3, 1), (1000, 7, 0), (10240, 8, 1), (10240, 5, 0), (18500, 8, 1)])
+def test_tail_solve_sharded_partials_sum_to_the_solve(k, world, one_pass):
+    """The dense tail as the ranks of a sharded engine apply it (TailSolve::shard_*, cuadmm_tail_shard_bounds): rank p takes the rows
+    of its share of the triangle and the partial results are summed by the all-reduce.  All `world` partials from one process: their
+    sum is the solve (1e-13 against scipy), rows_out are the bounds' differences, and a rank with an EMPTY range (k = 50 on eight
+    ranks: rows [8, 8)) contributes exact zeros -- with the one-pass kernels, the row-sharing kernel (k > 18 432) and the two
+    triangular GEMVs alike."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(k + world)
+    L = rng.random((k, k), dtype=np.float32).astype(np.float64)
+    L -= 0.5
+    L *= 1.0 / np.sqrt(k)
+    L = np.tril(L, -1)
+    L[np.diag_indices(k)] = 1.0
+    D = rng.uniform(0.1, 2.0, k) * rng.choice([1.0, 1.0, 1.0, -1.0], k)
+    z = rng.standard_normal(k)
+    ref = sl.solve_triangular(L.T, sl.solve_triangular(L, z, lower=True, unit_diagonal=True) / D, lower=False, unit_diagonal=True)
+    out = np.full((world, k), np.nan)
+    rows = np.zeros(world, np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.cuadmm_op_tail_solve_sharded(P(L), P(D), k, P(z), world, one_pass, P(out), P(rows)))
+    b = np.zeros(world + 1, np.int32)
+    check(lib.cuadmm_tail_shard_bounds(k, world, P(b)))
+    assert np.array_equal(rows, np.diff(b))
+    assert np.all(np.isfinite(out))
+    for p in range(world):
+        if rows[p] == 0:
+            assert not out[p].any(), p                   # nothing to apply: zeros, not garbage
+    if k == 50:
+        assert np.count_nonzero(rows == 0) >= 1
+    assert np.linalg.norm(out.sum(axis=0) - ref) <= 1e-13 * np.linalg.norm(ref)
+
+
 def test_tail_solve_lost_exchange_protocol():
     """What happens when the row-sharing kernel cannot rely on co-residency (HIP does not promise it): a NaN with the sentinel's
     bits in the right-hand side does not stall the exchange (it is canonicalised before it is published); a raised failure

@@ -2,7 +2,7 @@
 
 Its XCD-local barrier was once wrong for a week while every bit-identity test passed -- correct "by eviction": the workgroup-scope
 invalidate did not drop the L1, and a phase streamed enough operands through a CU to push the stale lines out.  What exposed it
-was a CHANGE OF CACHE FOOTPRINT (a two-rank run).  So this test varies the footprint on purpose: >= 200 solves that alternate
+was a CHANGE OF CACHE FOOTPRINT (a two-rank run).  So this test varies the footprint on purpose: 72 solves (207 with CUADMM_SOAK_ROUNDS=23) that alternate
 PlanarHand_N=1 (nine blocks of 66 / 91 / 120), taha1a (ten of 126, one of 252, three of 56) and a 70 / 126 / 252 synthetic
 between the three barrier modes -- members on one XCD through the shared L2 (psd_lg_cluster = 1), agent-scope release / acquire
 (2), one launch per product (0) -- with other kernels' traffic in between (a C2-like bulk projection), all in one process.  Every
@@ -19,7 +19,9 @@ from tests.helpers import problem_to_amd, psd_project_gpu
 
 pytestmark = pytest.mark.gpu
 
-ROUNDS = int(os.environ.get("CUADMM_SOAK_ROUNDS", "23"))          # 23 rounds x 3 problems x 3 modes = 207 solves
+# 23 rounds x 3 problems x 3 modes = 207 solves ran green on every GPU suite of rounds 4 and 5 (CUADMM_SOAK_ROUNDS=23 runs them again:
+# profiles/r06_gpu_tests_long.log); the default suite keeps 8 rounds = 72 solves inside the driver's time limit (tests/conftest.py)
+ROUNDS = int(os.environ.get("CUADMM_SOAK_ROUNDS", "8"))
 
 
 def _taha1a():
@@ -63,4 +65,4 @@ def test_one_launch_barriers_soak_over_changing_cache_footprints():
                     assert np.array_equal(a, b), "%s, psd_lg_cluster = %d, round %d: %s differs from the launch-mode bits" % (name, mode, rnd, what)
                 if (rnd + n_solves) % 4 == 0:            # somebody else's lines through every L1 / L2 now and then
                     psd_project_gpu(bulk[: 528 * (500 + 250 * (n_solves % 9))], bulk_blk[: 500 + 250 * (n_solves % 9)])
-    assert n_solves >= 200 or ROUNDS < 23
+    assert n_solves == 9 * ROUNDS

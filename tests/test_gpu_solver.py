@@ -204,6 +204,15 @@ def test_duo_solver_n_devices_from_one_process(name, sw, problem_dirs):
     assert np.array_equal(two.info_arr("sig"), one.info_arr("sig"))
     for va, vb in ((two.X, one.X), (two.y, one.y), (two.S, one.S)):
         assert va.shape == vb.shape and np.max(np.abs(va - vb)) <= 1e-9 * (1 + np.max(np.abs(vb)))
+    if name.startswith("pendulum") or sw == 0 and name == "ros_2000":
+        # EIGHT engines from one process (the node the reference's device walk is written for, check_gpus.cu:29-43): eight host threads,
+        # eight block ranges, the device-side exchange summing eight staging buffers in rank order, the dense tail split eight ways
+        eight = run(8)
+        assert eight.group_info()["engines"] == 8 and eight.group_info()["exchange"] == "device"
+        for nm in ("errRp", "errRd", "pobj", "dobj", "relgap"):
+            _cmp("duo8:" + nm, eight.info_arr(nm), one.info_arr(nm), rtol=1e-9, atol=1e-12)
+        assert np.array_equal(eight.info_arr("sig"), one.info_arr("sig"))
+        assert np.max(np.abs(eight.X - one.X)) <= 1e-9 * (1 + np.max(np.abs(one.X)))
     # a warm restart through the leader reaches every rank
     two.solve(10, 0.0, 0, 50, 100, sw, 1.05, if_first=False)
     one.solve(10, 0.0, 0, 50, 100, sw, 1.05, if_first=False)
@@ -257,6 +266,40 @@ def test_duo_group_rank_failure_does_not_hang(exchange, inject):
     if inject < 0:
         assert "bad_alloc" in str(ei.value)
     del s
+
+
+@pytest.mark.parametrize("exchange", [0, 1])
+def test_duo_group_is_reusable_after_a_rank_failed_between_collectives(exchange):
+    """A rank fails BETWEEN two collectives (hook + 5e8: in front of its next collective, without counting it) while its peer has
+    already entered that collective: the ranks' call counters are one apart when the call returns.  The group is built to be used
+    again (duo_group_run clears the abort flag), and the device-side exchange derives its staging slot from that counter -- before
+    round 6 the next solve would have summed a STALE staging buffer of the peer (the length check passes: 2m+2 every time).  Now every
+    call re-agrees the counters and publishes the collective's index next to its length.  After the failure the iterate is reset on
+    every rank (set_XyS) and the solve must reproduce a fresh group's trajectory bit for bit."""
+    a = problem_to_amd(load_npz_problem("pendulum_N=80"))
+    rng = np.random.default_rng(5)
+    X0, S0, y0 = rng.standard_normal(a.vec_len) * 1e-2, rng.standard_normal(a.vec_len) * 1e-2, rng.standard_normal(a.con_num) * 1e-2
+
+    def restart(s):
+        s.set_XyS(X0, y0, S0, 1.0)
+        s.solve(12, 0.0, 0, 50, 100, 11000, 1.05, if_first=False)
+        n = s.info_iter_num
+        return [s.info_arr(k)[-n:].copy() for k in ("errRp", "errRd", "pobj", "dobj", "relgap", "sig")] + [s.X, s.y, s.S]
+
+    fresh = _duo_pendulum({"duo_exchange": exchange})
+    fresh.solve(9, 0.0, 0, 50, 100, 11000, 1.05)
+    want = restart(fresh)
+    s = _duo_pendulum({"duo_exchange": exchange})
+    s.solve(9, 0.0, 0, 50, 100, 11000, 1.05)
+    # rank 1 returns an error in front of its next collective (the solve's first one, batch_agree: no iteration has run on either rank,
+    # so the sigma schedule's counters stay equal to the fresh group's) while rank 0 enters and counts it
+    s.set_option("duo_inject_fail", 500000000 + 1 * 1000000 + 1)
+    with pytest.raises(cuadmm_amd.CuadmmError, match="duo group, rank"):
+        s.solve(9, 0.0, 0, 50, 100, 11000, 1.05, if_first=False)
+    s.set_option("duo_inject_fail", 0)
+    got = restart(s)
+    for va, vb in zip(got, want):
+        assert np.array_equal(va, vb)
 
 
 def test_device_side_y_solve_matches_the_host_solve(monkeypatch):

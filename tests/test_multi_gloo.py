@@ -1,4 +1,4 @@
-"""world_size-2 test of the sharded iteration on CPU (gloo): the partition comes from the C ABI
+"""world_size-2 and -4 tests of the sharded iteration on CPU (gloo): the partition comes from the C ABI
 (cuadmm_partition_blocks), each rank iterates only its contiguous block range with the oracle's
 arithmetic, the [A*X | sums | A*(S-C)] packet is all-reduced with torch.distributed, the host solve
 is replicated.  Result must equal the unsharded oracle run (sharding changes only the
@@ -92,22 +92,23 @@ def _worker(rank, world, port, iters, sw, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sw", [0, 10 ** 9])
-def test_sharded_iteration_matches_unsharded_oracle(tmp_path, sw):
+@pytest.mark.parametrize("sw,world", [(0, 2), (10 ** 9, 2), (10 ** 9, 4)])
+def test_sharded_iteration_matches_unsharded_oracle(tmp_path, sw, world):
     import torch.multiprocessing as mp
     from cuadmm_amd.synthetic import make_synthetic
-    iters, world = 8, 2
+    iters = 8
     out = str(tmp_path / "traj_%d.npy")
     mp.spawn(_worker, args=(world, _free_port(), iters, sw, out), nprocs=world, join=True)
     blk = np.array([6] * 10 + [12] * 7 + [3] * 9 + [20] * 2, dtype=np.int32)
     p = make_synthetic(blk, cons_per_block=2, seed=5)
     ref = orc.OracleSolver().init_problem(p)
     info = ref.solve(iters, 0.0, 0, 50, 100, sw, 1.05)
-    t0, t1 = np.load(out % 0), np.load(out % 1)
-    assert np.array_equal(t0, t1)                       # both ranks carry the same replicated scalars
+    t0 = np.load(out % 0)
+    for r in range(1, world):
+        assert np.array_equal(t0, np.load(out % r))     # every rank carries the same replicated scalars
     want = np.array([info.errRp, info.errRd, info.pobj, info.dobj, info.sig]).T
     assert np.max(np.abs(t0 - want) / (1e-9 + np.abs(want))) <= 1e-8
     xs = [np.load((out % r) + ".X.npy") for r in range(world)]
-    assert xs[0][0] == 0 and xs[0][1] == xs[1][0] and xs[1][1] == p.vec_len
+    assert xs[0][0] == 0 and xs[-1][1] == p.vec_len and all(xs[r][1] == xs[r + 1][0] for r in range(world - 1))
     Xs = np.concatenate([x[2:] for x in xs]) * ref.bscale
     assert np.max(np.abs(Xs - ref.X)) <= 1e-9 * (1 + np.max(np.abs(ref.X)))
