@@ -306,6 +306,8 @@ def main():
     ap.add_argument("--c-sparse", action="store_true", help="c2 / c4 with the sparse C of SURVEY 8d (C = A^T y0 + svec(I))")
     ap.add_argument("--projection-only", action="store_true", help="time the PSD projection of Xb ~ N(0,1)^L alone (cuadmm_op_psd_project)")
     ap.add_argument("--time-to-tol", type=float, default=None, help="also run a fresh solve to this tolerance (untimed region) and report it")
+    ap.add_argument("--convergence-cap", type=int, default=None, help="c5: iteration cap of the convergence run with the reference log's parameters "
+                    "(default 100 000, the reference's own; 1 000 000 for profiles/r06_pendulum_convergence.json)")
     ap.add_argument("--blocks-per-gpu", type=int, default=None)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--sharding", choices=["owned", "allreduce"], default="owned")
@@ -566,7 +568,52 @@ def main():
     time_to_tol = None
     if args.time_to_tol is None and args.config in ("c1", "c5"):
         args.time_to_tol = 1e-3
-    if args.time_to_tol:
+    if args.time_to_tol and args.config == "c5":
+        # BASELINE configs[4] AS WRITTEN ("stop_tol=1e-6, end-to-end convergence"), with the parameters of the reference's own run
+        # (examples/pendulum/N=80_licols.log: sGS-ADMM, switch to ADMM at 11 000, sig_update_threshold = 0, stop_tol 1e-6 -- never met in
+        # its 100 000 iterations: final relgap 2.7e-4 after 2 218.7 s).  ONE fresh solve with those parameters up to the cap (default: the
+        # reference's own 100 000; --convergence-cap 1000000 for profiles/r06_pendulum_convergence.json); the first iteration at which
+        # max(errRp, errRd, relgap) falls below 1e-3 / 1e-4 / 1e-5 is read off the per-iteration arrays (the tau rule looks at stop_tol, so
+        # separate solves per tolerance would be other trajectories), its time is that fraction of the solve (the iteration cost is flat).
+        s2 = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, force_comm=force_dist, options=engine_options)
+        if use_comm:
+            s2.set_allreduce(keep[0]) if keep else None
+        s2.init_problem(cuadmm_amd.Problem(prob.vec_len, prob.con_num, prob.blk, prob.At_col_ptrs, prob.At_row_ids,
+                                           prob.At_vals, prob.b_idx, prob.b_vals, prob.C_idx, prob.C_vals))
+        cap = int(args.convergence_cap or 100000)
+        sync()
+        t0 = time.perf_counter()
+        s2.solve(cap, 1e-6, 0, 50, 100, 11000, 1.05)
+        sync()
+        t1 = time.perf_counter() - t0
+        n_it = s2.info_iter_num
+        arrs = {k: s2.info_arr(k) for k in ("errRp", "errRd", "relgap", "pobj", "dobj", "sig")}
+        kkt = np.maximum(np.maximum(arrs["errRp"], arrs["errRd"]), arrs["relgap"])[:n_it]
+        first = {}
+        for tol in (1e-3, 1e-4, 1e-5, 1e-6):
+            hit = np.nonzero(kkt < tol)[0]
+            above = np.nonzero(kkt >= tol)[0]
+            # `iteration`: where the reference's stopping test (pointwise: max(errRp, errRd, relgap) < tol) would have ended the solve;
+            # `stays_below_from`: the iteration after the LAST one above the tolerance within the cap (None: still above at the cap)
+            first["%.0e" % tol] = None if hit.size == 0 else {
+                "iteration": int(hit[0]) + 1, "seconds": t1 * (int(hit[0]) + 1) / n_it,
+                "stays_below_from": None if (above.size and above[-1] == n_it - 1) else (int(above[-1]) + 2 if above.size else 1)}
+        at = {}
+        for it in (11000, 100000, 300000, 1000000):
+            if it <= n_it:
+                at[str(it)] = {k: float(arrs[k][it - 1]) for k in arrs}
+        st2 = s2.state()
+        time_to_tol = {"parameters": "sGS-ADMM, switch_admm = 11000, sig_update_threshold = 0, stages 50 / 100, sigscale 1.05, stop_tol = 1e-6 "
+                                     "(examples/pendulum/N=80_licols.log)",
+                       "iteration_cap": cap, "iterations": n_it, "seconds": t1, "ms_per_iteration": t1 / max(n_it, 1) * 1e3,
+                       "first_below": first, "residuals_at": at,
+                       "final": {k: st2[k] for k in ("errRp", "errRd", "relgap", "pobj", "dobj", "best_KKT")},
+                       "reference": {"iterations": 100000, "seconds": 2218.7, "final": {"errRp": 6.3e-05, "errRd": 2.8e-05, "relgap": 2.7e-04},
+                                     "best_KKT_after_switch": 1.5e-04, "source": "examples/pendulum/N=80_licols.log (hardware unnamed)"},
+                       "note": "stop_tol = 1e-6 is not met by the reference in its 100 000 iterations either; the cap is %s" % (
+                           "the reference's own" if cap == 100000 else "%d iterations (--convergence-cap)" % cap)}
+        del s2
+    elif args.time_to_tol:
         # a fresh solve to the tolerance with the parameters of the reference's logs (untimed region of this benchmark)
         s2 = cuadmm_amd.SDPSolver(device=local_rank, verbose=False, rank=eng_rank, world=eng_world, force_comm=force_dist,
                                   options=engine_options)

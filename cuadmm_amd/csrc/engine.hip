@@ -248,11 +248,15 @@ struct cuadmm_solver {
     int tail_one_pass = 1;        // "tail_one_pass": the GPU tail applied in one pass over inv(L22) (0: two triangular GEMVs)
     int solve_next = 1;           // "solve_next": the y-solve of iteration k + 1 is enqueued before the host waits for iteration k (fetch_out)
     int tail_max_k = 32768;       // "tail_max_k": cap of the planner's GPU tail (<= 65 536: 3 x 8 K^2 bytes while it is built, 2 x 8 K^2 afterwards)
+    int tail_dd = 0;              // "tail_dd": experiment (tail_solve.h)
+    int tail_refine = 0;          // "tail_refine": experiment (tail_solve.h)
+    int tail_prefetch = 1;        // "tail_prefetch": the tail's one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5; A/B)
     int tail_shard = 1;           // "tail_shard": world > 1, replicated solve: every rank applies 1 / world of the tail's rows, the K partial
                                   // results are all-reduced (0: every rank applies the whole tail)
     int l21_device = 1;           // "l21_device": hybrid y-solve allowed (L21 on the device beside the tail when the forest is too deep; 0: host, 2: whenever the sweeps stay on the host)
     int lead_debug = 0;           // "lead_debug": statistics of the leading elimination forest on stderr at init (developer aid)
     double tail_pinv_tol = 0.0;   // "tail_pinv_tol": experiment (tail_solve.h)
+    double pinv_tol = 0.0;        // "pinv_tol": the same for EVERY pivot of the device-side solve (tail, tree tops, leading sweeps): experiment (lead_solve.h)
     int lead_small_kb = 0;        // "lead_small_kb": LDS bound of the trees that share a workgroup in fours (lead_solve.h; 0 = chosen at build from 4 / 8 / 16)
     int lead_tops_refine = 0;     // "lead_tops_refine": one refinement step per direction in the dense tree tops (A/B: measured, no effect -- lead_solve.h)
     int lead_tops = -1;           // "lead_tops": dense tree tops (lead_solve.h): -1 = when the forest is too deep for the sweeps, 0 = never, L = always, cut at height L
@@ -796,7 +800,10 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
       const int64_t* srp; const int* sci; const double* sv;
       rc = cuadmm_aat_tail_schur(s->fac, &srp, &sci, &sv);
       s->tail.one_pass = s->sw.tail_one_pass != 0;
-      s->tail.pinv_tol = s->sw.tail_pinv_tol;
+      s->tail.prefetch = s->sw.tail_prefetch != 0;
+      s->tail.dd_dot = s->sw.tail_dd != 0;
+      s->tail.refine = s->sw.tail_refine != 0;
+      s->tail.pinv_tol = std::max(s->sw.tail_pinv_tol, s->sw.pinv_tol);
       if (!rc) rc = s->tail.build_from_schur(reinterpret_cast<const long long*>(srp), sci, sv, tk, s->st);
       // The tail is applied as an explicit inverse built without pivoting (tail_solve.hip); with (nearly) dependent
       // constraints the pivots approach the regularisation 1e-15 and inv(L22) could lose accuracy silently.  Probe it with
@@ -1142,6 +1149,7 @@ static int init_solve_plan(Solver* s, const InitIn& in, InitCtx& c) {
     const int64_t* Lp; const int* Li; const double* Lx; const double* D;
     if ((rc = cuadmm_aat_factor_arrays(s->fac, &Lp, &Li, &Lx, &D))) return rc;
     s->lead.stream_only = s->sw.lead_stream != 0;
+    s->lead.pinv_tol = s->sw.pinv_tol;
     s->lead.debug = s->sw.lead_debug != 0;
     s->lead.force_hybrid = s->sw.l21_device == 2;
     s->lead.tops_refine = s->sw.lead_tops_refine != 0;
@@ -1387,9 +1395,13 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "lead_tops_refine") s->sw.lead_tops_refine = (int)value;
   else if (k == "lead_small_kb") s->sw.lead_small_kb = (int)value;
   else if (k == "tail_pinv_tol") s->sw.tail_pinv_tol = value;
+  else if (k == "pinv_tol") s->sw.pinv_tol = value;
   else if (k == "l21_device") s->sw.l21_device = (int)value;
   else if (k == "tail_one_pass") s->sw.tail_one_pass = (int)value;
   else if (k == "tail_shard") s->sw.tail_shard = (int)value;
+  else if (k == "tail_prefetch") s->sw.tail_prefetch = (int)value;
+  else if (k == "tail_dd") s->sw.tail_dd = (int)value;
+  else if (k == "tail_refine") s->sw.tail_refine = (int)value;
   else if (k == "tail_max_k") s->sw.tail_max_k = (int)value;
   else if (k == "solve_next") s->sw.solve_next = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;
@@ -2095,6 +2107,8 @@ int cuadmm_get_profile(const cuadmm_solver* s, double out[3 * CUADMM_NUM_KCLASS]
 }
 int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap) {
   if (!s || !out) { set_error("get_psd_steps: null"); return CUADMM_ERR_INVALID; }
+  if (!s->steps_d.p && s->psd_steps && s->initialised && s->blk_local.empty()) return 0;     // a rank without blocks (PlanarHand_N=1 on eight ranks: its
+                                                                                            // n = 120 block alone outweighs a rank's share) has nothing to report
   if (!s->steps_d.p) { set_error("get_psd_steps: set option psd_steps=1 before init"); return CUADMM_ERR_INVALID; }
   const int n = (int)std::min<size_t>(s->steps_d.n, (size_t)std::max(cap, 0));
   CUADMM_HIP_TRY(hipStreamSynchronize(s->st));
@@ -2107,9 +2121,10 @@ int cuadmm_get_counters(const cuadmm_solver* s, double o[8]) {
   o[4] = s->fuse ? 1 : 0; o[5] = s->closed.active ? 1 : 0; o[6] = s->dev_solve ? (s->lead.tops ? 3 : 1) : (s->lead.hybrid ? 2 : 0); o[7] = (double)s->tail.k;
   return CUADMM_OK;
 }
-int cuadmm_get_tail_info(const cuadmm_solver* s, double o[4]) {
+int cuadmm_get_tail_info(const cuadmm_solver* s, double o[6]) {
   if (!s || !o) { set_error("get_tail_info: null"); return CUADMM_ERR_INVALID; }
   o[0] = (double)s->tail.k; o[1] = s->tail.shard_bytes; o[2] = (double)s->tail.shard_rows; o[3] = s->tail.resident_bytes;
+  o[4] = s->tail.inv_resid; o[5] = (s->tail.refine && s->tail.Lm) ? 1.0 : 0.0;
   return CUADMM_OK;
 }
 int cuadmm_get_group_info(const cuadmm_solver* s, double o[4]) {

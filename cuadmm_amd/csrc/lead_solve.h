@@ -47,6 +47,7 @@ struct LeadSolve {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool debug = false;           // option lead_debug: forest statistics on stderr at build
   int small_kb = 0;             // option lead_small_kb: trees that need at most this much LDS share a workgroup in fours (one wavefront each); 0: chosen at build
+  double pinv_tol = 0.0;        // option pinv_tol (experiment): leading pivots below it in magnitude are treated as infinite (1 / d := 0), like the tail's
   bool stream_only = false;     // option lead_stream = 1: every tree on the streaming kernels (A/B, tests)
   bool ready = false;
   double est_us = 0;            // cost model used to decide (per solve)

@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <atomic>
+#include <limits>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -128,13 +130,31 @@ __global__ __launch_bounds__(256) void lead_tail_rhs_vec_kernel(int k, int n1, c
 }
 
 constexpr int kLongColumn = 128;
-// w[j] = sum over the TAIL rows of column j:  L21[i][j] x2[i]   (8 lanes per leading column; independent of the sweeps)
+// w[j] = sum over the TAIL rows of column j:  L21[i][j] x2[i]   (8 lanes per leading column; independent of the sweeps).
+// Columns with more than kLongColumn tail rows take a wavefront each: eight lanes walk a column of 1 783 entries (PlanarHand_N=10 below its
+// tree tops) in 223 dependent gathers -- 110 of the kernel's 139 us were that one column's latency.  ONE launch for both kinds (round 6; two
+// launches until then: 12.5 + 6.7 us on PlanarHand_N=1): workgroups [0, wg_short) walk all columns eight lanes each and skip the long ones,
+// workgroups beyond take four long columns each.  Same sums in the same order as the two kernels.
 __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long* __restrict__ tp, const int* __restrict__ tr, const double* __restrict__ tv,
-                                                        const double* __restrict__ x2, double* __restrict__ w) {
+                                                        const double* __restrict__ x2, double* __restrict__ w, int wg_short, int n_long,
+                                                        const int* __restrict__ cols, double* __restrict__ copy_dst, int copy_n) {
+  // the solved tail into y on the way (it used to be a 5 us launch of its own behind the backward sweeps)
+  for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < copy_n; q += (int)(gridDim.x * blockDim.x)) copy_dst[q] = x2[q];
+  if ((int)blockIdx.x >= wg_short) {
+    const int i = ((int)blockIdx.x - wg_short) * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (i >= n_long) return;
+    const int j = cols[i];
+    double s = 0.0;
+    for (long long q = tp[j] + lane; q < tp[j + 1]; q += 64) s += tv[q] * x2[tr[q]];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) w[j] = s;
+    return;
+  }
   const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int j = gt >> 3, sub = gt & 7;
   if (j >= n1) return;
-  if (tp[j + 1] - tp[j] > kLongColumn) return;               // lead_l21t_long_kernel's
+  if (tp[j + 1] - tp[j] > kLongColumn) return;               // a wavefront's, above
   double s = 0.0;
   for (long long q = tp[j] + sub; q < tp[j + 1]; q += 8) s += tv[q] * x2[tr[q]];
   s += __shfl_xor(s, 4, 64);
@@ -142,19 +162,14 @@ __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long*
   s += __shfl_xor(s, 1, 64);
   if (sub == 0) w[j] = s;
 }
-
-// the same for the columns with more than kLongColumn tail rows, one wavefront each: eight lanes walk a column of 1 783 entries
-// (PlanarHand_N=10 below its tree tops) in 223 dependent gathers -- 110 of the kernel's 139 us were that one column's latency
-__global__ __launch_bounds__(256) void lead_l21t_long_kernel(int n_long, const int* __restrict__ cols, const long long* __restrict__ tp, const int* __restrict__ tr,
-                                                             const double* __restrict__ tv, const double* __restrict__ x2, double* __restrict__ w) {
-  const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-  if (i >= n_long) return;
-  const int j = cols[i];
-  double s = 0.0;
-  for (long long q = tp[j] + lane; q < tp[j + 1]; q += 64) s += tv[q] * x2[tr[q]];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) w[j] = s;
+// returns whether the copy x2[0, copy_n) -> copy_dst rode along (no leading columns: no launch)
+static bool launch_l21t(int n1, const long long* tp, const int* tr, const double* tv, const double* x2, double* w, int n_long, const int* cols, hipStream_t st,
+                        double* copy_dst = nullptr, int copy_n = 0) {
+  if (n1 <= 0) return false;
+  const int wg_short = (int)(((long long)n1 * 8 + 255) / 256);
+  hipLaunchKernelGGL(lead_l21t_kernel, dim3((unsigned)(wg_short + (n_long + 3) / 4)), dim3(256), 0, st, n1, tp, tr, tv, x2, w, wg_short, n_long, cols, copy_dst,
+                     copy_dst ? copy_n : 0);
+  return copy_dst != nullptr;
 }
 
 // backward, levels root side first:  x[j] = x[j] / D[j] - w[j] - sum_{leading i > j} L11[i][j] x[i]
@@ -521,8 +536,7 @@ int LeadSolve::apply_l21(double* x, bool x_pinned, TailSolve& tail, hipStream_t 
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = tail.solve_device(st);
   if (rc) return rc;
-  hipLaunchKernelGGL(lead_l21t_kernel, dim3((unsigned)(((long long)n1 * 8 + 255) / 256)), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
-  if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, tail.vin, wvec);
+  launch_l21t(n1, tptr, tri, tv_, tail.vin, wvec, n_long, long_cols_d, st);
   CUADMM_HIP_TRY(hipGetLastError());
   CUADMM_HIP_TRY(hipMemcpyAsync(h_w, wvec, sizeof(double) * (size_t)n1, hipMemcpyDeviceToHost, st));
   double* dst = x_pinned ? x + n1 : h_z + n1;
@@ -560,6 +574,15 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
     }
   }
   return build_core(m_, k_, Lp, Li, Lx, D, allow_hybrid);
+}
+
+// experiment (option pinv_tol, DESIGN.md section 4 "Round 6: pivots at the regularisation"): pivots below the tolerance in magnitude become
+// +infinity -- the kernels divide by D, so the component along such a direction is dropped (1 / d := 0), here as in the tail's dinv
+static std::vector<double> pinv_pivots(const double* D, int n, double tol) {
+  std::vector<double> out(D, D + n);
+  if (tol > 0.0)
+    for (auto& d : out) if (std::fabs(d) < tol) d = std::numeric_limits<double>::infinity();
+  return out;
 }
 
 int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, const double* Lx, const double* D, bool allow_hybrid) {
@@ -811,7 +834,7 @@ int LeadSolve::build_core(int m_, int k_, const int64_t* Lp, const int* Li, cons
       (rc = to_device(fptr, fp)) || (rc = to_device(fci, fc)) || (rc = to_device(fv_, fv)) ||
       (rc = to_device(bptr, bp)) || (rc = to_device(bci, bc)) || (rc = to_device(bv_, bv)) ||
       (rc = to_device(tptr, tp)) || (rc = to_device(tri, tr)) || (rc = to_device(tv_, tv)) || (rc = to_device(long_cols_d, long_cols)) ||
-      (rc = to_device(D1, std::vector<double>(D, D + n1))) || (rc = to_device(nodes_f, nf)) || (rc = to_device(nodes_b, nb)) ||
+      (rc = to_device(D1, pinv_pivots(D, n1, pinv_tol))) || (rc = to_device(nodes_f, nf)) || (rc = to_device(nodes_b, nb)) ||
       (rc = to_device(lvl_ptr_f, lpf)) || (rc = to_device(lvl_ptr_b, lpb)) || (rc = to_device(lvl_off_f, lof)) || (rc = to_device(lvl_off_b, lob)) ||
       (rc = to_device(lvl_g_f, lgf)) || (rc = to_device(lvl_g_b, lgb)))
     return rc;
@@ -995,6 +1018,7 @@ int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, cons
   if (bad.load() > 0) { set_error("lead_solve: %d of %d dense tree tops fail the check of their inverse", bad.load(), nblk); return CUADMM_ERR_FACTOR; }
   std::vector<double> dt((size_t)nt);
   for (int t = 0; t < nt; ++t) dt[t] = D[tnodes[t]];
+  dt = pinv_pivots(dt.data(), nt, pinv_tol);
   // L_TT by columns for the refinement of the backward solve (the rows of L_TT^T)
   std::vector<long long> cpt((size_t)nt + 1, 0);
   for (long long e = 0; e < rpt[nt]; ++e) cpt[(size_t)cit[(size_t)e] + 1]++;
@@ -1082,13 +1106,12 @@ int LeadSolve::solve(const double* ax, const double* asmc, const double* b, doub
   CUADMM_HIP_TRY(hipGetLastError());
   int rc = tail.solve_device(st);                    // vin <- L22^-T D2^-1 L22^-1 vin (padding beyond k stays zero)
   if (rc) return rc;
-  if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, tail.vin, wvec);
-  if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, tail.vin, wvec);
+  const bool copied = launch_l21t(n1, tptr, tri, tv_, tail.vin, wvec, n_long, long_cols_d, st, y + n1, k);     // ... and the solved tail into y
   launch_sweeps(*this, true, ax, asmc, b, isig, y, st);
   CUADMM_HIP_TRY(hipGetLastError());
-  // the solved tail into y: a kernel of its own, not hipMemcpyAsync -- the runtime's device-to-device copy is a blit behind ~15 us of
-  // command-processor work (kernel trace of pendulum N = 80: 14.7 us idle in front of every one, once per solve)
-  hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, tail.vin, y + n1, k);
+  // (never hipMemcpyAsync: the runtime's device-to-device copy is a blit behind ~15 us of command-processor work -- kernel trace of
+  // pendulum N = 80, round 5)
+  if (!copied) hipLaunchKernelGGL(lead_copy_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, tail.vin, y + n1, k);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
@@ -1115,8 +1138,7 @@ int LeadSolve::solve_tops(const double* ax, const double* asmc, const double* b,
     hipLaunchKernelGGL(tops_resid_kernel, dim3((unsigned)(((long long)nT * 32 + 255) / 256)), dim3(256), 0, st, nT, tt_cp, tt_ri, tt_cv, xext, uT, zext);
     hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wb_off, (const int*)nullptr, wb_len, Wb, zext, xext, 1);
   }
-  if (n1 > 0) hipLaunchKernelGGL(lead_l21t_kernel, dim3((n1 * 8 + 255) / 256), dim3(256), 0, st, n1, tptr, tri, tv_, xext, wvec);                 // w = [L_TB; L_KB]^T [x_T; x_K]
-  if (n_long > 0) hipLaunchKernelGGL(lead_l21t_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, n_long, long_cols_d, tptr, tri, tv_, xext, wvec);
+  launch_l21t(n1, tptr, tri, tv_, xext, wvec, n_long, long_cols_d, st);                                        // w = [L_TB; L_KB]^T [x_T; x_K]
   launch_sweeps(*this, true, ax, asmc, b, isig, xp, st);                                                        // x_B
   hipLaunchKernelGGL(tops_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, n1, rid, xp, xext, y);
   CUADMM_HIP_TRY(hipGetLastError());

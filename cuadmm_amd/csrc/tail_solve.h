@@ -18,6 +18,15 @@ struct TailSolve {
   bool group_retired = false;  // a row exchange was lost once: apply() uses the two triangular GEMVs from then on
   unsigned long long* part = nullptr;   // 18 432 < K <= 32 768: per row and member, the exchanged parts of u = W z (ts_onepass_group_kernel)
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
+  // option tail_refine (experiment, DESIGN.md section 4 "pivots near the regularisation"): one step of iterative refinement of each TRIANGULAR solve against
+  // the factor itself, u <- u + W (z - L u) and x <- x + W^T (v - L^T x) -- W = inv(L) is only as accurate as cond(L) allows, and L carries columns
+  // of size 1 / sqrt(pivot) where the Schur complement is nearly singular; L and L^T are then kept beside W and W^T (two more K x K matrices)
+  bool refine = false;
+  double inv_resid = -1.0;     // || z - L (W z) ||_inf for a probe z at build: the accuracy of the explicit inverse (-1: not measured, e.g. build() from a host factor)
+  double *Lm = nullptr, *Lt = nullptr, *t1 = nullptr, *t2 = nullptr;
+  int apply_refined(hipStream_t st);
+  bool dd_dot = false;         // option tail_dd (experiment): u = W z accumulated in double-double (K <= 10 240 and 14 336 < K <= 16 384 only)
+  bool prefetch = true;        // option tail_prefetch: the one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5)
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   double pinv_tol = 0.0;       // option tail_pinv_tol (experiment, DESIGN.md section 4 "Round 5: dense tree tops"): pivots of the tail below it in
                                // magnitude are treated as zero (1 / d := 0); confirms where the pobj deviations of the moment relaxations come from, fixes nothing

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -155,63 +156,166 @@ __global__ __launch_bounds__(256) void ts_tri_gemv_kernel(const double* __restri
 }
 
 
+// refinement (option tail_refine): out_i = a_i - b_i - sum_{c < i} M[i][c] b_c (LOWER: M = L, unit diagonal implicit) or sum_{c > i} (M = L^T)
+template <bool LOWER>
+__global__ __launch_bounds__(256) void ts_tri_resid_kernel(const double* __restrict__ Mx, long long ld, int K, const double* __restrict__ a,
+                                                           const double* __restrict__ b, double* __restrict__ out) {
+  const int lane = (int)threadIdx.x & 63;
+  const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (i >= K) return;
+  const int lo = LOWER ? 0 : i + 1, hi = LOWER ? i : K;
+  const double* row = Mx + (size_t)i * ld;
+  double s = 0.0;
+  for (int c = lo + lane; c < hi; c += 64) s += row[c] * b[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[i] = (a[i] - b[i]) - s;
+}
+// y += x (SCALE: then y *= d)
+template <bool SCALE>
+__global__ void ts_axpy1_kernel(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ d, int K) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < K) { const double v = y[i] + x[i]; y[i] = SCALE ? v * d[i] : v; }
+}
+
 // x = W^T diag(dinv) W z in ONE pass over W.  The two triangular GEMVs above read W and then W^T: 8 K^2 bytes per solve, and they
 // are what bounds the y-solve of a moment relaxation (PlanarHand_N=1, K = 17 152: 215 + 194 us at 5.5 - 6 TB/s).  Row i of W
 // serves both products -- u_i = W_i z, then x += (dinv_i u_i) W_i^T -- so a workgroup that keeps the row in REGISTERS between
-// the two uses needs it from memory once: 1024 threads, thread t holds columns t, t + 1024, ... (NC of them) of the current
+// the two uses needs it from memory once: 1024 threads, thread t holds NC columns of the current
 // row(s) and of its partial x; z sits in LDS; one block reduction per row group (double-buffered: one barrier).  Workgroup g
 // takes rows K-1-g, K-1-g-G, ... (long rows first, interleaved: equal shares of the triangle); the G partial vectors are summed
 // in workgroup order by ts_onepass_reduce_kernel.  Deterministic; half the HBM traffic.
+// Round 6, 16-BYTE LOADS: thread t holds column PAIRS -- every wavefront owns a contiguous segment of 64 NC columns, pair slot p of it is
+// one coalesced 1 KB access (global_load_dwordx4) -- instead of single columns through 8-byte loads, which this chip serves at 0.54 - 0.70 of
+// the 16-byte rate (MI355X_MICROARCH.md; measured here: 4.4 TB/s at K = 10 240 with dwordx2).  Every load is unconditional and straight-line
+// (a pair above the diagonal reads the row's first pair and is zeroed by a select; a group beyond the range reads row 0 and is multiplied
+// by zero).  PF: the rows of the NEXT group are in flight while the current group is reduced and applied (two register buffers; the
+// compiler's counter for the current group's data, `s_waitcnt vmcnt(N)`, leaves the next group's loads outstanding across the barrier).
+// The association of the sums follows the new column ownership: results differ from rounds 3 - 5 in the last bits, deterministically.
 template <int NC, int RB>
-__global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
-                                                          const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end) {
-  extern __shared__ double ts_zs[];          // z, K doubles (zero beyond K up to 1024 NC)
-  __shared__ double red[2][RB][16];
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[c] : 0.0;
-  double xa[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) xa[c] = 0.0;
-  __syncthreads();
-  // column of (thread, c): every wavefront owns a contiguous segment of 64 NC columns, slot c of it is one coalesced 512-byte access
-  // at a compile-time offset from the segment's base (one address register pair per 8 slots instead of one per slot)
-  const int col0 = wave * (64 * NC) + lane;
-  const double* zs = ts_zs + col0;
-  const int G = (int)gridDim.x, g = (int)blockIdx.x;
-  int it = 0;
-  // rows r = K - 1 - i in [r_begin, r_end): the whole triangle, or this rank's share of it (TailSolve::shard_*)
-  for (int r0 = r_begin + g * RB; r0 < r_end; r0 += G * RB, ++it) {
-    double w[RB][NC], part[RB];
+struct TsRows {
+  static_assert(NC % 2 == 0, "column pairs");
+  double2 w[RB][NC / 2];
+  __device__ __forceinline__ void load(const double* __restrict__ W, long long ld, int K, int col0, int r0, int r_end) {
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
-      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;            // < 0: no such row (all-zero contribution)
-      const double* row = W + (size_t)(i < 0 ? 0 : i) * ld + col0;
-      const int lim = i - col0;                  // slot c is inside the triangle iff 64 c <= lim
+      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : 0;
+      const double* row = W + (size_t)i * ld;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) w[q][c] = 64 * c <= lim ? row[64 * c] : 0.0;     // entries above the diagonal are exact zeros and are not read
+      for (int p = 0; p < NC / 2; ++p) {
+        const int col = col0 + 128 * p;          // the pair (col, col + 1) is inside the triangle iff col <= i (its second half iff col < i)
+        const double2 v = *reinterpret_cast<const double2*>(row + (col <= i ? col : 0));
+        w[q][p].x = col <= i ? v.x : 0.0;        // entries above the diagonal count as exact zeros and are not read
+        w[q][p].y = col < i ? v.y : 0.0;
+      }
     }
+  }
+};
+// error-free transformations for the compensated variant of u_i = W_i z (option tail_dd, an experiment: DESIGN.md section 4, "pivots near the
+// regularisation"): (hi, lo) <- (hi, lo) + a b with the rounding errors of the product and of the sum collected in lo
+__device__ __forceinline__ void dd_fma_acc(double& hi, double& lo, double a, double b) {
+#pragma clang fp contract(off)               // the transformations are exact only with every operation rounded on its own
+  const double pr = a * b, pe = __fma_rn(a, b, -pr);
+  const double s = hi + pr, bb = s - hi;
+  lo += ((hi - (s - bb)) + (pr - bb)) + pe;
+  hi = s;
+}
+__device__ __forceinline__ void dd_add(double& hi, double& lo, double h2, double l2) {
+#pragma clang fp contract(off)
+  const double s = hi + h2, bb = s - hi;
+  lo += ((hi - (s - bb)) + (h2 - bb)) + l2;
+  hi = s;
+}
+template <int NC, int RB, bool DD>
+__device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const double* zs, double (*red)[RB][DD ? 32 : 16], int it, int lane, int wave, int K, int r0,
+                                              int r_end, const double* __restrict__ dinv, double2 (&xa)[NC / 2]) {
+  double part[RB];
 #pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      part[q] = 0.0;
+  for (int q = 0; q < RB; ++q) {
+    part[q] = 0.0;
+    if constexpr (DD) {
+      double lo = 0.0;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) part[q] += w[q][c] * zs[64 * c];
+      for (int p = 0; p < NC / 2; ++p) {
+        const double2 zz = *reinterpret_cast<const double2*>(zs + 128 * p);
+        dd_fma_acc(part[q], lo, R.w[q][p].x, zz.x);
+        dd_fma_acc(part[q], lo, R.w[q][p].y, zz.y);
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) dd_add(part[q], lo, __shfl_xor(part[q], o, 64), __shfl_xor(lo, o, 64));
+      if (lane == 0) { red[it & 1][q][wave] = part[q]; red[it & 1][q][16 + wave] = lo; }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NC / 2; ++p) {
+        const double2 zz = *reinterpret_cast<const double2*>(zs + 128 * p);
+        part[q] += R.w[q][p].x * zz.x;
+        part[q] += R.w[q][p].y * zz.y;
+      }
       part[q] = wave_sum(part[q]);
       if (lane == 0) red[it & 1][q][wave] = part[q];
     }
-    __syncthreads();
+  }
+  __syncthreads();
 #pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;
-      const double* rr = red[it & 1][q];
-      const double u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
-                       (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
-      const double vq = i >= 0 ? u * dinv[i] : 0.0;
+  for (int q = 0; q < RB; ++q) {
+    const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;
+    const double* rr = red[it & 1][q];
+    double u;
+    if constexpr (DD) {
+      double hi = rr[0], lo = rr[16];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) xa[c] += vq * w[q][c];
+      for (int w = 1; w < 16; ++w) dd_add(hi, lo, rr[w], rr[16 + w]);
+      u = hi + lo;
+    } else {
+      u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
+          (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
+    }
+    const double vq = i >= 0 ? u * dinv[i] : 0.0;
+#pragma unroll
+    for (int p = 0; p < NC / 2; ++p) { xa[p].x += vq * R.w[q][p].x; xa[p].y += vq * R.w[q][p].y; }
+  }
+}
+template <int NC, int RB, bool PF, bool DD = false>
+__global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
+                                                          const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end) {
+  extern __shared__ __attribute__((aligned(16))) double ts_zs[];          // z, K doubles (zero beyond K up to 1024 NC)
+  __shared__ double red[2][RB][DD ? 32 : 16];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col0 = wave * (64 * NC) + 2 * lane;
+  const int G = (int)gridDim.x, g = (int)blockIdx.x, step = G * RB;
+  // rows r = K - 1 - i in [r_begin, r_end): the whole triangle, or this rank's share of it (TailSolve::shard_*)
+  int r0 = r_begin + g * RB;
+  TsRows<NC, RB> A;
+  A.load(W, ld, K, col0, r0, r_end);         // the first group travels while z is staged
+  for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[c] : 0.0;
+  double2 xa[NC / 2];
+#pragma unroll
+  for (int p = 0; p < NC / 2; ++p) xa[p] = make_double2(0.0, 0.0);
+  __syncthreads();
+  const double* zs = ts_zs + col0;
+  int it = 0;
+  if constexpr (!PF) {                       // one group in flight (the registers of a second one would spill)
+    for (; r0 < r_end; r0 += step) {
+      if (it) A.load(W, ld, K, col0, r0, r_end);
+      ts_rows_apply<NC, RB, DD>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+    }
+  } else {
+    TsRows<NC, RB> B;
+    while (r0 < r_end) {
+      B.load(W, ld, K, col0, r0 + step, r_end);
+      ts_rows_apply<NC, RB, DD>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+      r0 += step;
+      if (r0 >= r_end) break;
+      A.load(W, ld, K, col0, r0 + step, r_end);
+      ts_rows_apply<NC, RB, DD>(B, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+      r0 += step;
     }
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)g * K + col] = xa[c]; }
+  for (int p = 0; p < NC / 2; ++p) {
+    const int col = col0 + 128 * p;
+    if (col < K) *reinterpret_cast<double2*>(P + (size_t)g * K + col) = xa[p];       // K is a multiple of 64: col + 1 < K too
+  }
 }
 // The one-pass product for tails BEYOND one workgroup's reach (18 432 < K <= 32 768: PushT_N=30 27 136, PushBox N=50 30 720, PlanarHand
 // N=10 32 768).  A row of W no longer fits one CU's registers beside its accumulators (3 x 256 KB at K = 32 768 against 512 KB of
@@ -531,8 +635,8 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 }
 
 void TailSolve::release() {
-  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part}) if (p) { hipError_t e = hipFree(p); (void)e; }
-  part = nullptr;
+  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part, (void*)Lm, (void*)Lt, (void*)t1, (void*)t2}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  part = nullptr; Lm = Lt = t1 = t2 = nullptr;
   if (d_fail) { hipError_t e = hipFree(d_fail); (void)e; d_fail = nullptr; }
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
@@ -540,6 +644,7 @@ void TailSolve::release() {
   group_retired = false;
   k = K = 0;
   resident_bytes = 0;
+  inv_resid = -1.0;
 }
 
 int TailSolve::alloc(int k_) {
@@ -700,6 +805,32 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return CUADMM_ERR_NO_DEVICE; }
   if (hflag) { set_error("Factorization fails! (%d zero or non-finite pivots in the dense tail of A*A^T)", hflag); cleanup(); release(); return CUADMM_ERR_FACTOR; }
   rc = invert(dS, st);
+  if (!rc) {
+    // How good is the explicit inverse?  rho = || z - L (W z) ||_inf / || z ||_inf for a fixed pseudo-random z: ~ u cond(L).  A Schur complement
+    // that is nearly singular gives L columns of size 1 / sqrt(pivot) (PushBox_N=50 at an 8 448-column tail: rho = see profiles/r06_tail_refine.log)
+    std::vector<double> zh((size_t)K, 0.0);
+    unsigned long long seed = 0x243f6a8885a308d3ull;
+    for (int i = 0; i < k; ++i) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; zh[i] = 0.5 + (double)(seed >> 11) * (1.0 / 9007199254740992.0); }
+    double* tmp = nullptr;
+    if (hipMalloc(&tmp, sizeof(double) * (size_t)K) == hipSuccess && staged_h2d(vin, zh.data(), sizeof(double) * (size_t)K, st) == CUADMM_OK) {
+      hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, (const double*)nullptr, vmid, 0, 1 << 30);
+      hipLaunchKernelGGL(ts_tri_resid_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, dS, (long long)K, K, vin, vmid, tmp);
+      std::vector<double> rh((size_t)K);
+      if (hipGetLastError() == hipSuccess && staged_d2h(rh.data(), tmp, sizeof(double) * (size_t)K, st) == CUADMM_OK) {
+        double m = 0.0;
+        for (int i = 0; i < k; ++i) m = std::max(m, std::fabs(rh[i]));
+        inv_resid = m;                       // || z ||_inf ~ 1.5
+      }
+    }
+    if (tmp) { hipError_t e2 = hipFree(tmp); (void)e2; }
+  }
+  if (!rc && refine) {   // the factor itself stays: L (strictly lower part of dS) and its transpose
+    Lm = dS; dS = nullptr;
+    if (hipMalloc(&Lt, sizeof(double) * sz) != hipSuccess || hipMalloc(&t1, sizeof(double) * (size_t)K) != hipSuccess || hipMalloc(&t2, sizeof(double) * (size_t)K) != hipSuccess) rc = CUADMM_ERR_INVALID;
+    if (!rc) rc = ts_transpose(Lm, Lt, K, st);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = CUADMM_ERR_NO_DEVICE;
+    if (!rc) resident_bytes += 16.0 * (double)sz + 16.0 * K;
+  }
   cleanup();
   build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc) release();
@@ -750,8 +881,25 @@ int TailSolve::solve_device(hipStream_t st) {
   return apply(st);
 }
 
+// the two triangular GEMVs with one refinement step each against the factor (experiment, tail_solve.h)
+int TailSolve::apply_refined(hipStream_t st) {
+  const dim3 gr((K + 3) / 4), bl(256), g1((K + 255) / 256);
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, gr, bl, 0, st, W, (long long)K, K, vin, (const double*)nullptr, vmid, 0, 1 << 30);      // u = W z
+  hipLaunchKernelGGL(ts_tri_resid_kernel<true>, gr, bl, 0, st, Lm, (long long)K, K, vin, vmid, t1);                                    // r = z - L u
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, gr, bl, 0, st, W, (long long)K, K, t1, (const double*)nullptr, t2, 0, 1 << 30);         // W r
+  hipLaunchKernelGGL(ts_axpy1_kernel<true>, g1, bl, 0, st, vmid, t2, dinv, K);                                                          // v = D^-1 (u + W r)
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, gr, bl, 0, st, Wt, (long long)K, K, vmid, (const double*)nullptr, vin, 0, 1 << 30);    // x = W^T v
+  hipLaunchKernelGGL(ts_tri_resid_kernel<false>, gr, bl, 0, st, Lt, (long long)K, K, vmid, vin, t1);                                   // s = v - L^T x
+  hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, gr, bl, 0, st, Wt, (long long)K, K, t1, (const double*)nullptr, t2, 0, 1 << 30);       // W^T s
+  hipLaunchKernelGGL(ts_axpy1_kernel<false>, g1, bl, 0, st, vin, t2, (const double*)nullptr, K);
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 // vin <- W^T diag(dinv) W vin
 int TailSolve::apply(hipStream_t st) {
+  // (refined: every rank of a sharded engine applies the WHOLE tail -- the result is replicated, no reduction)
+  if (refine && Lm) { shard_rows = K; shard_bytes = 24.0 * (double)K * K; return apply_refined(st); }
   // this rank's rows r = K - 1 - i (r = 0: the longest row): equal shares of the triangle's entries, boundaries on multiples of 8
   int r_begin = 0, r_end = K;
   if (shard_world > 1) {
@@ -781,17 +929,38 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
       return CUADMM_OK;
     };
     int rc;
-    switch ((nc + 1) / 2) {           // NC = the even number >= nc; two rows in flight while the registers allow it
-      case 1: rc = launch(ts_onepass_kernel<2, 2>); break;
-      case 2: rc = launch(ts_onepass_kernel<4, 2>); break;
-      case 3: rc = launch(ts_onepass_kernel<6, 2>); break;
-      case 4: rc = launch(ts_onepass_kernel<8, 2>); break;
-      case 5: rc = launch(ts_onepass_kernel<10, 2>); break;
-      case 6: rc = launch(ts_onepass_kernel<12, 2>); break;
-      case 7: rc = launch(ts_onepass_kernel<14, 2>); break;
-      case 8: rc = launch(ts_onepass_kernel<16, 1>); break;
-      case 9: rc = launch(ts_onepass_kernel<18, 1>); break;
-      default: rc = launch(ts_onepass_kernel<20, 1>); break;
+    // NC columns per thread (1024 NC >= K), RB rows per group, PF: the next group's rows in flight during the current group's barrier
+    // (two register buffers of RB NC doubles + NC accumulators within 128 VGPRs: two rows per group up to NC = 8, one up to NC = 16, no
+    // second buffer beyond).  Measured per solve inside c1 / c5 (profiles/r06_tail_onepass_ab.txt).  Option tail_prefetch = 0: one group
+    // in flight everywhere (same column ownership; the row grouping -- and with it the last bits -- differs where RB does).
+    if (dd_dot && (nc == 9 || nc == 10)) rc = launch(ts_onepass_kernel<10, 1, true, true>);      // experiment (option tail_dd): compensated u = W z
+    else if (dd_dot && (nc == 15 || nc == 16)) rc = launch(ts_onepass_kernel<16, 1, false, true>);
+    else if (!prefetch) {
+      switch ((nc + 1) / 2) {
+        case 1: rc = launch(ts_onepass_kernel<2, 2, false>); break;
+        case 2: rc = launch(ts_onepass_kernel<4, 2, false>); break;
+        case 3: rc = launch(ts_onepass_kernel<6, 2, false>); break;
+        case 4: rc = launch(ts_onepass_kernel<8, 2, false>); break;
+        case 5: rc = launch(ts_onepass_kernel<10, 2, false>); break;
+        case 6: rc = launch(ts_onepass_kernel<12, 2, false>); break;
+        case 7: rc = launch(ts_onepass_kernel<14, 2, false>); break;
+        case 8: rc = launch(ts_onepass_kernel<16, 1, false>); break;
+        case 9: rc = launch(ts_onepass_kernel<18, 1, false>); break;
+        default: rc = launch(ts_onepass_kernel<20, 1, false>); break;
+      }
+    } else {
+      switch ((nc + 1) / 2) {
+        case 1: rc = launch(ts_onepass_kernel<2, 2, true>); break;
+        case 2: rc = launch(ts_onepass_kernel<4, 2, true>); break;
+        case 3: rc = launch(ts_onepass_kernel<6, 2, true>); break;
+        case 4: rc = launch(ts_onepass_kernel<8, 2, true>); break;
+        case 5: rc = launch(ts_onepass_kernel<10, 1, true>); break;
+        case 6: rc = launch(ts_onepass_kernel<12, 1, true>); break;
+        case 7: rc = launch(ts_onepass_kernel<14, 1, true>); break;
+        case 8: rc = launch(ts_onepass_kernel<16, 1, true>); break;
+        case 9: rc = launch(ts_onepass_kernel<18, 1, false>); break;
+        default: rc = launch(ts_onepass_kernel<20, 1, false>); break;
+      }
     }
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);

@@ -114,9 +114,10 @@ class SDPSolver:
 
     def tail_info(self):
         """The dense GPU tail of the A A^T factor on this rank (cuadmm_get_tail_info)."""
-        o = np.zeros(4)
+        o = np.zeros(6)
         check(self._lib.cuadmm_get_tail_info(self._h, _p(o)))
-        return {"tail_k": int(o[0]), "bytes_read_per_solve": float(o[1]), "rows": int(o[2]), "bytes_resident": float(o[3])}
+        return {"tail_k": int(o[0]), "bytes_read_per_solve": float(o[1]), "rows": int(o[2]), "bytes_resident": float(o[3]),
+                "inverse_residual": float(o[4]), "refined": bool(o[5])}
 
     def set_allreduce(self, fn):
         """fn(dev_ptr:int, count:int, hip_stream:int) -> None : in-place sum over ranks on that stream."""

@@ -63,6 +63,11 @@ void cuadmm_destroy(cuadmm_solver* s);
  *   "graph"         reserved
  *   "tail_shard"    world > 1, coupled constraints: 1 (default) = each rank applies 1 / world of the rows of the dense GPU tail of the
  *                   replicated y-solve and the K partial results are all-reduced; 0 = every rank applies the whole tail
+ *   "tail_refine"   1 = ACCURACY MODE of the dense GPU tail of the y-solve: one refinement step of each triangular solve against the factor itself
+ *                   (u <- u + W (z - L u), x <- x + W^T (v - L^T x)) on top of the explicit inverse W = inv(L22), whose accuracy is u cond(L22) -- a
+ *                   nearly singular Schur complement (large moment relaxations) otherwise leaves 1e-8 ... 1e-7 in the primal objective against an exact
+ *                   LDL^T solve (the reference's contract, include/cuadmm/cholesky_cpu.h:146-155).  Costs 6x the tail's bytes per solve and two more
+ *                   K x K matrices; default 0.  cuadmm_get_tail_info [4] reports the measured accuracy of the explicit inverse.
  *   "duo_share_device", "duo_exchange"   the in-process group of cuadmm_duo_init(device_num_requested = N): all engines on the
  *                   caller's device; all-reduce through device memory (1), host staging (0), chosen by peer accessibility (-1, default)
  *   (every other switch: INTEGRATION.md section 6)
@@ -181,8 +186,10 @@ int cuadmm_get_psd_steps(cuadmm_solver* s, int* out, int cap);
 int cuadmm_get_counters(const cuadmm_solver* s, double out8[8]);
 /* The dense GPU tail of the A A^T factor on this rank: [0] its size k (0: none), [1] bytes of inv(L22) this rank read in its last
  * solve (4 K^2 for the whole triangle; 1 / world of it when the tail is sharded, option "tail_shard"), [2] the rows it applied,
- * [3] bytes of device memory the tail holds on this rank. */
-int cuadmm_get_tail_info(const cuadmm_solver* s, double out[4]);
+ * [3] bytes of device memory the tail holds on this rank, [4] accuracy of its explicit inverse W = inv(L22) measured at init,
+ * || z - L22 (W z) ||_inf for a probe vector z of entries in [0.5, 1.5] (~ unit roundoff x cond(L22); -1: not measured), [5] 1 when option
+ * "tail_refine" is on: every triangular solve of the tail takes one refinement step against the factor itself (6x the bytes per solve). */
+int cuadmm_get_tail_info(const cuadmm_solver* s, double out[6]);
 /* The in-process group a handle leads after cuadmm_duo_init(device_num_requested = N) from one process (reference
  * src/duo_solver.cu:487-577): [0] engines in the group (1: no group), [1] exchange of its all-reduce -- 1 = device side (each
  * rank's kernel adds the N staging buffers out of its peers' memory: one shared device, or peer access over xGMI as

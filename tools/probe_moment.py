@@ -22,7 +22,7 @@ for key in keys:
                 prm["switch_admm"], prm["sigscale"])
         h, l, ok = T.deviations(s, rec)
         c = s.counters()
-        print(key, opt, "tail_k", c["tail_k"], "dev", c["dev_solve"], "head", {k: "%.1e" % v for k, v in h.items()},
+        print(key, opt, "tail_k", c["tail_k"], "dev", c["dev_solve"], "inv_resid %.1e" % s.tail_info()["inverse_residual"], "head", {k: "%.1e" % v for k, v in h.items()},
               "late", {k: "%.1e" % v for k, v in l.items()}, ok, flush=True)
         got = s.info_arr("pobj"); ref = np.array([float(x) for x in rec["pobj"]])
         d = np.abs(got[:len(ref)] - ref)
