@@ -845,6 +845,9 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
       }
     }
     tk = s->tail.k;
+    // a rank of a sharded engine keeps only the rows of inv(L22) it applies (TailSolve::keep_shard; the reference splits its buffers over the
+    // devices too, src/duo_solver.cu:269-295): 1 / world of the triangle per rank instead of W and W^T whole
+    if (tk > 0 && s->world > 1 && !s->local_mode && s->sw.tail_shard != 0 && !s->sw.tail_refine && (rc = s->tail.keep_shard(s->rank, s->world, s->st))) return rc;
     if (s->verbose) {
       const long long lnz = (long long)cuadmm_aat_factor_nnz(s->fac);
       if (tk > 0)
@@ -2176,21 +2179,28 @@ int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, d
 int cuadmm_op_tail_solve_sharded(const double* L22_host, const double* D2_host, int k, const double* z_host, int world, int one_pass,
                                  double* out_host, int* rows_out) {
   if (!L22_host || !D2_host || !z_host || !out_host || k < 1 || world < 1) { set_error("tail_solve_sharded: bad arguments"); return CUADMM_ERR_INVALID; }
-  TailSolve t;
-  t.one_pass = one_pass != 0;
-  int rc = t.build(L22_host, D2_host, k, nullptr);
-  // the reduction is left out: every rank's partial result comes back as it stands
-  t.reduce_fn = [](void*, double*, size_t, hipStream_t) -> int { return CUADMM_OK; };
-  t.shard_world = world;
+  const bool compact = (one_pass & 2) != 0;      // + 2: every rank KEEPS its rows only (TailSolve::keep_shard), one object per rank
+  int rc = CUADMM_OK;
   for (int p = 0; p < world && !rc; ++p) {
-    t.shard_rank = p;
-    std::copy(z_host, z_host + k, out_host + (size_t)p * k);
-    rc = t.solve(out_host + (size_t)p * k, nullptr);
-    if (rows_out) rows_out[p] = t.shard_rows;
-  }
-  if (!rc) {
-    const int lost = t.fail_count(nullptr);
-    if (lost != 0) { set_error("tail_solve_sharded: %d row exchanges lost", lost); return CUADMM_ERR_FACTOR; }
+    TailSolve t;
+    t.one_pass = (one_pass & 1) != 0;
+    if ((rc = t.build(L22_host, D2_host, k, nullptr))) break;
+    // the reduction is left out: every rank's partial result comes back as it stands
+    t.reduce_fn = [](void*, double*, size_t, hipStream_t) -> int { return CUADMM_OK; };
+    t.shard_world = world;
+    const int p_end = compact ? p + 1 : world;   // without compaction ONE object serves every rank in turn
+    for (int q = p; q < p_end && !rc; ++q) {
+      t.shard_rank = q;
+      if (compact && (rc = t.keep_shard(q, world, nullptr))) break;
+      std::copy(z_host, z_host + k, out_host + (size_t)q * k);
+      rc = t.solve(out_host + (size_t)q * k, nullptr);
+      if (rows_out) rows_out[q] = t.shard_rows;
+    }
+    if (!rc) {
+      const int lost = t.fail_count(nullptr);
+      if (lost != 0) { set_error("tail_solve_sharded: %d row exchanges lost", lost); return CUADMM_ERR_FACTOR; }
+    }
+    if (!compact) break;
   }
   return rc;
 }

@@ -41,6 +41,16 @@ struct TailSolve {
   double shard_bytes = 0;      // bytes of W it read for them
   double resident_bytes = 0;   // device memory held by this object
   int apply_rows(hipStream_t st, int r_begin, int r_end);
+  // Round 6: a rank of a sharded engine KEEPS only the rows of W it applies (the reference splits its buffers over the devices too,
+  // src/duo_solver.cu:269-295): after build, keep_shard(rank, world) copies rows [K - r_end, K - r_begin) of W into a compact matrix of their own
+  // width (the triangle's rows end at the diagonal) and frees W and W^T -- 1 / world of the triangle's bytes per rank instead of two K x K squares.
+  // From then on the object applies that range only (shard_rank / shard_world are fixed); the two-GEMV fallback's second pass becomes a
+  // column accumulation over the same rows.  Not with option tail_refine (every rank then applies the whole tail).
+  int keep_shard(int rank, int world, hipStream_t st);
+  bool compact = false;
+  double* Wc = nullptr;        // the kept rows; W then points to Wc - i_lo * ldc (row i of the triangle at W + i * ldc), never dereferenced outside them
+  long long ldc = 0;
+  int i_lo = 0, i_hi = -1;
   double build_s = 0, factor_s = 0;
   int build(const double* L22, const double* D2, int k, hipStream_t st);                                        // host factor
   int build_from_schur(const long long* row_ptr, const int* col, const double* val, int k, hipStream_t st);    // GPU factor

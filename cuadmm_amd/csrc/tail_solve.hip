@@ -199,8 +199,9 @@ struct TsRows {
   __device__ __forceinline__ void load(const double* __restrict__ W, long long ld, int K, int col0, int r0, int r_end) {
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
-      const int i = r0 + q < r_end ? K - 1 - (r0 + q) : 0;
-      const double* row = W + (size_t)i * ld;
+      // (a group beyond the range re-reads the range's LAST row -- always a row this rank holds, keep_shard -- and is multiplied by zero)
+      const int i = K - 1 - (r0 + q < r_end ? r0 + q : r_end - 1);
+      const double* row = W + (long long)i * ld;
 #pragma unroll
       for (int p = 0; p < NC / 2; ++p) {
         const int col = col0 + 128 * p;          // the pair (col, col + 1) is inside the triangle iff col <= i (its second half iff col < i)
@@ -285,6 +286,11 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
   const int G = (int)gridDim.x, g = (int)blockIdx.x, step = G * RB;
   // rows r = K - 1 - i in [r_begin, r_end): the whole triangle, or this rank's share of it (TailSolve::shard_*)
   int r0 = r_begin + g * RB;
+  if (r_begin >= r_end) {                    // an empty share (tail_shard_bound): zeros, and no row is touched
+#pragma unroll
+    for (int p = 0; p < NC / 2; ++p) { const int col = col0 + 128 * p; if (col < K) *reinterpret_cast<double2*>(P + (size_t)g * K + col) = make_double2(0.0, 0.0); }
+    return;
+  }
   TsRows<NC, RB> A;
   A.load(W, ld, K, col0, r0, r_end);         // the first group travels while z is staged
   for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[c] : 0.0;
@@ -353,37 +359,52 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
   const int member = (g >> 3) & (Q - 1), group = (g & 7) + 8 * (g >> (3 + LQ));
   const int G = (int)gridDim.x / Q;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int col0 = (wave * Q + member) * (64 * NC) + lane;
+  // round 6: column PAIRS per thread (global_load_dwordx4; the 8-byte loads of rounds 4 - 5 run at 0.54 - 0.70 of that rate): pair slot p of the
+  // wavefront's segment is columns col0 + 128 p, + 1
+  static_assert(NC % 2 == 0, "column pairs");
+  constexpr int NP = NC / 2;
+  const int col0 = (wave * Q + member) * (64 * NC) + 2 * lane;
   if (fail && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // an earlier exchange was lost: no more waiting
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)group * K + col] = __longlong_as_double((long long)TS_CANON_NAN); }
+    for (int p = 0; p < NP; ++p) {
+      const int col = col0 + 128 * p;
+      const double nan = __longlong_as_double((long long)TS_CANON_NAN);
+      if (col < K) *reinterpret_cast<double2*>(P + (size_t)group * K + col) = make_double2(nan, nan);
+    }
     return;
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) ts_zs[c * 1024 + tid] = col0 + 64 * c < K ? z[col0 + 64 * c] : 0.0;
-  double xa[NC];
+  for (int p = 0; p < NP; ++p) {
+    const int col = col0 + 128 * p;
+    const double2 zz = col < K ? *reinterpret_cast<const double2*>(z + col) : make_double2(0.0, 0.0);      // K is a multiple of 64: col + 1 < K too
+    ts_zs[(2 * p) * 1024 + tid] = zz.x; ts_zs[(2 * p + 1) * 1024 + tid] = zz.y;
+  }
+  double2 xa[NP];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) xa[c] = 0.0;
+  for (int p = 0; p < NP; ++p) xa[p] = make_double2(0.0, 0.0);
   int it = 0;
   for (int r0 = r_begin + group * RB; r0 < r_end; r0 += G * RB, ++it) {
-    double w[RB][NC];
+    double2 w[RB][NP];
     const int seg0 = (wave_u * Q + member) * (64 * NC);   // this wavefront's segment: uniform
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
       const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;            // < 0: no such row (all-zero contribution)
-      const double* row = W + (size_t)(i < 0 ? 0 : i) * ld + col0;
+      const double* row = W + (long long)(i < 0 ? K - 1 - r_begin : i) * ld + col0;      // (never dereferenced for i < 0)
       // a wavefront's segment is inside the triangle (plain loads), outside it (nothing to read) or crosses the diagonal (one segment
       // per row: per-slot predicates): a scalar branch, so the common case carries no exec-mask juggling
       if (seg0 + 64 * NC - 1 <= i) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) w[q][c] = row[64 * c];
+        for (int p = 0; p < NP; ++p) w[q][p] = *reinterpret_cast<const double2*>(row + 128 * p);
       } else if (seg0 > i) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) w[q][c] = 0.0;
+        for (int p = 0; p < NP; ++p) w[q][p] = make_double2(0.0, 0.0);
       } else {
-        const int lim = i - col0;                // slot c is inside the triangle iff 64 c <= lim
 #pragma unroll
-        for (int c = 0; c < NC; ++c) w[q][c] = 64 * c <= lim ? row[64 * c] : 0.0;
+        for (int p = 0; p < NP; ++p) {
+          const int col = col0 + 128 * p;        // the pair is inside the triangle iff col <= i, its second half iff col < i
+          const double2 v = col <= i ? *reinterpret_cast<const double2*>(row + 128 * p) : make_double2(0.0, 0.0);
+          w[q][p] = make_double2(v.x, col < i ? v.y : 0.0);
+        }
       }
     }
     // lane q of the first wavefront exchanges row q: its pivot is in flight across the barrier
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
     for (int q = 0; q < RB; ++q) {
       double s = 0.0;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) s += w[q][c] * ts_zs[c * 1024 + tid];
+      for (int p = 0; p < NP; ++p) { s += w[q][p].x * ts_zs[(2 * p) * 1024 + tid]; s += w[q][p].y * ts_zs[(2 * p + 1) * 1024 + tid]; }
       s = wave_sum(s);
       if (lane == 0) red[it & 1][q][wave] = s;
     }
@@ -445,11 +466,11 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
     for (int q = 0; q < RB; ++q) {
       const double vq = ush[it & 1][q];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) xa[c] += vq * w[q][c];
+      for (int p = 0; p < NP; ++p) { xa[p].x += vq * w[q][p].x; xa[p].y += vq * w[q][p].y; }
     }
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) { const int col = col0 + 64 * c; if (col < K) P[(size_t)group * K + col] = xa[c]; }
+  for (int p = 0; p < NP; ++p) { const int col = col0 + 128 * p; if (col < K) *reinterpret_cast<double2*>(P + (size_t)group * K + col) = xa[p]; }
 }
 
 // `part` (with Q slots per row): the exchange slots of ts_onepass_group_kernel, reset to the sentinel for the next solve.
@@ -635,6 +656,7 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 }
 
 void TailSolve::release() {
+  if (compact) { W = Wc; Wc = nullptr; compact = false; ldc = 0; i_lo = 0; i_hi = -1; }     // (W was an offset view of Wc)
   for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part, (void*)Lm, (void*)Lt, (void*)t1, (void*)t2}) if (p) { hipError_t e = hipFree(p); (void)e; }
   part = nullptr; Lm = Lt = t1 = t2 = nullptr;
   if (d_fail) { hipError_t e = hipFree(d_fail); (void)e; d_fail = nullptr; }
@@ -881,6 +903,39 @@ int TailSolve::solve_device(hipStream_t st) {
   return apply(st);
 }
 
+// second pass of the two-GEMV fallback on a compact shard: P[chunk][j] = sum over this chunk's rows i >= j of W[i][j] v[i] (thread per column,
+// rows in order: deterministic); the chunks are summed by ts_onepass_reduce_kernel
+__global__ __launch_bounds__(256) void ts_colacc_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ v, double* __restrict__ P,
+                                                        int i_lo, int i_hi, int nchunk) {
+  const int j = (int)blockIdx.x * 256 + (int)threadIdx.x, ch = (int)blockIdx.y;
+  if (j >= K) return;
+  const int rows = i_hi - i_lo + 1, per = (rows + nchunk - 1) / nchunk;
+  const int a = i_lo + ch * per, b = a + per - 1 < i_hi ? a + per - 1 : i_hi;
+  double s = 0.0;
+  for (int i = a > j ? a : j; i <= b; ++i) s += W[(long long)i * ld + j] * v[i];
+  P[(size_t)ch * K + j] = s;
+}
+
+int TailSolve::keep_shard(int rank, int world, hipStream_t st) {
+  if (!W || compact || refine || world <= 1) return CUADMM_OK;
+  const int r_b = tail_shard_bound(K, rank, world), r_e = tail_shard_bound(K, rank + 1, world);
+  shard_rank = rank; shard_world = world;
+  i_lo = K - r_e; i_hi = K - 1 - r_b;                      // matrix rows of the kernels' rows [r_b, r_e)
+  const int rows = i_hi - i_lo + 1;
+  ldc = rows > 0 ? ((long long)i_hi + 1 + 63) / 64 * 64 : 64;
+  CUADMM_HIP_TRY(hipMalloc(&Wc, sizeof(double) * (size_t)std::max(rows, 1) * (size_t)ldc));
+  if (rows > 0)
+    CUADMM_HIP_TRY(hipMemcpy2DAsync(Wc, sizeof(double) * (size_t)ldc, W + (size_t)i_lo * K, sizeof(double) * (size_t)K, sizeof(double) * (size_t)ldc, (size_t)rows,
+                                    hipMemcpyDeviceToDevice, st));
+  CUADMM_HIP_TRY(hipStreamSynchronize(st));
+  { hipError_t e = hipFree(W); (void)e; e = hipFree(Wt); (void)e; }
+  Wt = nullptr;
+  W = Wc - (long long)i_lo * ldc;                          // row i of the triangle at W + i * ldc; only rows i_lo .. i_hi exist
+  compact = true;
+  resident_bytes += 8.0 * (double)std::max(rows, 1) * (double)ldc - 16.0 * (double)K * K;
+  return CUADMM_OK;
+}
+
 // the two triangular GEMVs with one refinement step each against the factor (experiment, tail_solve.h)
 int TailSolve::apply_refined(hipStream_t st) {
   const dim3 gr((K + 3) / 4), bl(256), g1((K + 255) / 256);
@@ -906,6 +961,10 @@ int TailSolve::apply(hipStream_t st) {
     r_begin = tail_shard_bound(K, shard_rank, shard_world);
     r_end = tail_shard_bound(K, shard_rank + 1, shard_world);
   }
+  if (compact && (r_begin != K - 1 - i_hi || r_end != K - i_lo)) {
+    set_error("tail_solve: this rank keeps rows %d .. %d of inv(L22) only (keep_shard) but was asked for another share", i_lo, i_hi);
+    return CUADMM_ERR_INVALID;
+  }
   shard_rows = r_end - r_begin;
   shard_bytes = 8.0 * ((double)(r_end - r_begin) * (double)K - 0.5 * ((double)r_end * r_end - (double)r_begin * r_begin));   // entries of the rows read
   { int rc_ = apply_rows(st, r_begin, r_end); if (rc_) return rc_; }
@@ -917,6 +976,7 @@ int TailSolve::apply(hipStream_t st) {
 }
 
 int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
+  const long long ldw = compact ? ldc : (long long)K;      // leading dimension of W (a compact shard keeps its rows at their own width)
   const int nc = (K + 1023) / 1024;
   const size_t lds = sizeof(double) * 1024 * (size_t)(nc + (nc & 1));
   if (one_pass && xpart && lds <= kMaxLdsBytes - 1024 && nc <= 20) {
@@ -925,7 +985,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
         CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));   // process-wide per kernel: the maximum
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, (long long)K, K, vin, dinv, xpart, r_begin, r_end);
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end);
       return CUADMM_OK;
     };
     int rc;
@@ -971,7 +1031,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);
     auto kern = ts_onepass_group_kernel<8, Q, 4, 4>;
     if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
+    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q);
   } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
@@ -984,15 +1044,22 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
     auto launch = [&](auto kern) -> int {
       if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, (long long)K, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
       return CUADMM_OK;
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q);
   } else {
-    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, (long long)K, K, vin, dinv, vmid, r_begin, r_end);
-    hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin, 0, 1 << 30);
+    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, ldw, K, vin, dinv, vmid, r_begin, r_end);
+    if (compact) {     // no W^T on a compact shard: the kept rows are accumulated by columns (chunks of rows, summed in chunk order)
+      const int nchunk = std::max(1, std::min(n_wg, 64));
+      if (i_hi >= i_lo) hipLaunchKernelGGL(ts_colacc_kernel, dim3((K + 255) / 256, nchunk), dim3(256), 0, st, W, ldw, K, vmid, xpart, i_lo, i_hi, nchunk);
+      else CUADMM_HIP_TRY(hipMemsetAsync(xpart, 0, sizeof(double) * (size_t)K * (size_t)nchunk, st));
+      hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, nchunk, vin, (unsigned long long*)nullptr, 0);
+    } else {
+      hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin, 0, 1 << 30);
+    }
   }
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;

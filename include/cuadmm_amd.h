@@ -359,7 +359,8 @@ int cuadmm_op_gemm_sym(int n, const double* A, const double* B, double alpha, do
 int cuadmm_op_tail_solve(const double* L22_host, const double* D2_host, int k, double* z2_host, int nrhs);
 /* The same solve as the ranks of a sharded engine run it (TailSolve::shard_*): out_host receives `world` partial results of k doubles,
  * partial p = what rank p contributes from its rows [bounds[p], bounds[p + 1]) (cuadmm_tail_shard_bounds) -- their sum in rank order
- * is the solve; rows_out[p] = the rows rank p applied.  one_pass = 0 runs the two triangular GEMVs instead of the one-pass kernels. */
+ * is the solve; rows_out[p] = the rows rank p applied.  one_pass: bit 0 = the one-pass kernels (0: the two triangular GEMVs), bit 1 = every rank
+ * keeps only its rows of inv(L22) (one object per rank, as the ranks of an engine do since round 6). */
 int cuadmm_op_tail_solve_sharded(const double* L22_host, const double* D2_host, int k, const double* z_host, int world, int one_pass,
                                  double* out_host, int* rows_out);
 /* Test hook: failure drill of the row-sharing tail kernel (18 432 < k <= 32 768).  out_host: 4 x k doubles -- the plain solve, the

@@ -223,13 +223,15 @@ def test_tail_solve_op_beyond_one_workgroups_reach(k):
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
 
 
-@pytest.mark.parametrize("k,world,one_pass", [(50, 8, 1), (50, 8, 0), (1000, 3, 1), (1000, 7, 0), (10240, 8, 1), (10240, 5, 0), (18500, 8, 1)])
+@pytest.mark.parametrize("k,world,one_pass", [(50, 8, 1), (50, 8, 0), (1000, 3, 1), (1000, 7, 0), (10240, 8, 1), (10240, 5, 0), (18500, 8, 1),
+                                              (50, 8, 3), (50, 8, 2), (1000, 3, 3), (5000, 4, 2), (5000, 8, 3), (18500, 2, 3)])
 def test_tail_solve_sharded_partials_sum_to_the_solve(k, world, one_pass):
     """The dense tail as the ranks of a sharded engine apply it (TailSolve::shard_*, cuadmm_tail_shard_bounds): rank p takes the rows
     of its share of the triangle and the partial results are summed by the all-reduce.  All `world` partials from one process: their
     sum is the solve (1e-13 against scipy), rows_out are the bounds' differences, and a rank with an EMPTY range (k = 50 on eight
     ranks: rows [8, 8)) contributes exact zeros -- with the one-pass kernels, the row-sharing kernel (k > 18 432) and the two
-    triangular GEMVs alike."""
+    triangular GEMVs alike.  one_pass + 2: every rank keeps ONLY its rows of inv(L22) (TailSolve::keep_shard: a compact matrix at the
+    rows' own width, W^T gone -- the fallback's second pass accumulates by columns); same partials."""
     import scipy.linalg as sl
     rng = np.random.default_rng(k + world)
     L = rng.random((k, k), dtype=np.float32).astype(np.float64)

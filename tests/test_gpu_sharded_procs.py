@@ -83,9 +83,14 @@ def test_ranks_of_a_moment_relaxation_against_the_oracle(world, port, cases, tmp
             K = (tk + 63) // 64 * 64
             whole = 4.0 * K * K
             by_rank = d["tail_by_rank"][:, 0]
+            resident = d["tail_by_rank"][:, 2]
             if name.endswith(":noshard"):
                 assert np.all(np.abs(by_rank / whole - 1.0) <= 0.01), (name, by_rank / whole)
+                assert np.all(resident >= 16.0 * K * K)                  # W and W^T whole on every rank
             else:
+                # ... and KEEPS only those rows (round 6, TailSolve::keep_shard): at most twice its share of the triangle (a row is stored up
+                # to the range's widest one) + the partial-result vectors, instead of two K x K squares
+                assert np.all(resident <= 8.0 * K * K / world + 8.0 * K * 400 + 1e6), (name, world, resident / (16.0 * K * K))
                 assert np.all(np.abs(by_rank - whole / world) <= 64.0 * K + 512), (name, world, by_rank / whole)
                 assert abs(by_rank.sum() - whole) <= 8.0 * K + 512
                 assert d["allreduce_launches"] >= 4 * 60, name        # + one per solve for the partial results
