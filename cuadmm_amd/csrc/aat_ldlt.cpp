@@ -434,21 +434,24 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
     const int p = parent[j];
     if (p >= 0 && h[p] < h[j] + 1) h[p] = h[j] + 1;
   }
-  // the device-side solve with dense tree tops at tail size k: model in us per solve, < 0 when it cannot be built
-  constexpr int kTopsLevel = 32;
-  auto tops_us = [&](int k) {
+  // the device-side solve with dense tree tops at tail size k, the forest cut at height lvl: model in us per solve, < 0 when it cannot be built.
+  // Round 6: recalibrated on the kernel times of profiles/r05_c1_kernel_stats.csv and this round's bench lines -- the first model charged the
+  // sweeps 2 (20 + 0.9 lvl) = 98 us at height 32 where PlanarHand_N=1 measures 2 x 25, and 70 us of short kernels where there are 55; it kept
+  // pendulum N = 80 on its plain plan (176 against 166 us by the models; 123 against 171 measured at 6 144 columns and height 16).  The cut is now
+  // chosen from {16, 32} by the same model (round 5 fixed 32: right for the deep forests of PushBox / PlanarHand_N=10, 1 - 4 % behind 16 on the
+  // shallow ones) -- measured picks: profiles/r06_plan_picks.log.
+  auto tops_us = [&](int k, int lvl) {
     const int n1 = m - k;
     if (n1 <= 0) return -1.0;
-    // roots of the leading forest; sizes of the tops (nodes of height >= kTopsLevel: h counts from 1) and of the rest's trees
+    // roots of the leading forest; sizes of the tops (nodes of height > lvl: h counts from 1) and of the rest's trees
     std::vector<int> root((size_t)n1), tcnt((size_t)n1, 0), bcnt((size_t)n1, 0), broot((size_t)n1);
-    long long nnzT = 0;
     int nT = 0;
     for (int j = n1 - 1; j >= 0; --j) {
       const int p = parent[j];
-      const bool top = h[j] > kTopsLevel;
+      const bool top = h[j] > lvl;
       root[j] = (p < 0 || p >= n1) ? j : root[p];
-      if (top) { tcnt[root[j]]++; nnzT += Lp[j + 1] - Lp[j]; ++nT; }
-      else { broot[j] = (p < 0 || p >= n1 || h[p] > kTopsLevel) ? j : broot[p]; bcnt[broot[j]]++; }
+      if (top) { tcnt[root[j]]++; ++nT; }
+      else { broot[j] = (p < 0 || p >= n1 || h[p] > lvl) ? j : broot[p]; bcnt[broot[j]]++; }
     }
     if (nT == 0) return -1.0;
     double tri = 0.0;
@@ -457,40 +460,42 @@ int plan_tail(const int64_t* Lp, int m, int max_k, const int* parent = nullptr, 
       tri += 0.5 * (double)tcnt[j] * ((double)tcnt[j] + 1.0);
     }
     if (tri * 16.0 > (double)cuadmm::kLeadTopsMaxBytes) return -1.0;                            // both triangles: memory, and the n^3-ish build on the host
-    // (the four-rows-per-exchange kernel beyond 24 576 columns: 897 us at k = 32 768 in profiles/r05_tops_PlanarHand_N=10_kernel_stats.csv)
-    const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.1e6 + 28.0 : (double)k * k * 4.0 / (k <= 24576 ? 3.8e6 : 4.8e6) + 40.0;
-    // (A finer model -- sweeps by the NODES of the rest, 14 + 0.25e-3 n us each, 45 us of short kernels -- is within 10 % of every measured
-    // solve but moves the picks by a notch (PushT_N=30 15 360, PushBox N = 50 9 216 columns) and still leaves pendulum N = 80 where it is,
-    // 176 against 166 us by the models, 148 against 176 measured: not adopted this late.  CUADMM_PLAN_DEBUG=1 prints the figures.)
-    return 2.0 * (20.0 + 0.9 * kTopsLevel) + 70.0 + tri * 16.0 / 4.0e6 + 24.0 * (double)Lp[n1] / 3.0e6 + tail;
+    // the tail's one pass with 16-byte loads (round 6): ~5.3 TB/s + its reduction up to 18 432 columns, the row-sharing kernel beyond
+    const double tail = k <= 18432 ? (double)k * k * 4.0 / 5.3e6 + 12.0 : (double)k * k * 4.0 / (k <= 24576 ? 4.2e6 : 5.0e6) + 40.0;
+    // both sweeps over the shallow rest (a wavefront per tree, lvl levels; beyond ~100 000 nodes the launch runs in rounds), the short kernels
+    // of the middle stage, both dense passes over the packed inverses, the two SpMVs over what leaves the rest
+    const double nodes_rest = (double)(n1 - nT);
+    const double sweeps = 2.0 * (12.0 + 0.45 * lvl + 0.2e-3 * std::max(0.0, nodes_rest - 100e3));
+    return sweeps + 55.0 + tri * 16.0 / 4.4e6 + 24.0 * (double)Lp[n1] / 3.0e6 + tail;
   };
   // the best tail for that solve: not below half the host optimum (the host factors what the tail does not)
   auto plan_tops = [&](int k_lo, double other_us) {
     if (!g_plan_allow_tops || !tops_out) return 0;
     const bool plan_debug = getenv("CUADMM_PLAN_DEBUG") != nullptr;      // developer aid: the model's figures on stderr
-    int kb = 0;
+    int kb = 0, lb = 0;
     double cb = 1e300;
-    std::vector<std::pair<int, double>> cand;
+    std::vector<std::pair<std::pair<int, int>, double>> cand;
     // (multiples of 1 024: the tail's one-pass kernel holds whole columns per thread of its 1 024-thread workgroups -- 8 448 columns are
     // padded to 9 216)
-    for (int k = std::max(1024, (k_lo / 2 + 1023) / 1024 * 1024); k <= std::min(m - 1, max_k); k += 1024) {
-      if (hmax[(size_t)(m - k)] <= kTopsLevel + 1) break;           // nothing left to cut
-      const double c = tops_us(k);
-      if (plan_debug) fprintf(stderr, "[plan debug] tops: k %d height %d model %.0f us (other plan %.0f)\n", k, hmax[(size_t)(m - k)], c, other_us);
-      if (c < 0.0) continue;
-      cand.emplace_back(k, c);
-      if (c < cb) { cb = c; kb = k; }
-    }
-    if (kb == 0 || !(cb < 0.8 * other_us)) return 0;
-    // the model is good to ~10 %: of the tails within 8 % of the best the LARGEST (less for the host to factor, smaller tops)
-    for (const auto& kc : cand) if (kc.second <= 1.08 * cb) kb = std::max(kb, kc.first);
-    *tops_out = kTopsLevel;
+    for (const int lvl : {32, 16})
+      for (int k = std::max(1024, k_lo / 2 / 1024 * 1024); k <= std::min(m - 1, max_k); k += 1024) {
+        if (hmax[(size_t)(m - k)] <= lvl + 1) break;                // nothing left to cut
+        const double c = tops_us(k, lvl);
+        if (plan_debug) fprintf(stderr, "[plan debug] tops: k %d cut %d height %d model %.0f us (other plan %.0f)\n", k, lvl, hmax[(size_t)(m - k)], c, other_us);
+        if (c < 0.0) continue;
+        cand.push_back({{k, lvl}, c});
+        if (c < cb) { cb = c; kb = k; lb = lvl; }
+      }
+    if (kb == 0 || !(cb < 0.9 * other_us)) return 0;
+    // the model is good to ~10 %: of the tails within 5 % of the best AT THE SAME CUT the largest (less for the host to factor, smaller tops)
+    for (const auto& kc : cand) if (kc.first.second == lb && kc.second <= 1.05 * cb) kb = std::max(kb, kc.first.first);
+    *tops_out = lb;
     return kb;
   };
   auto dev_us = [&](int k) {
     const double ht = (double)hmax[(size_t)(m - k)];
-    const double tail = k <= 20480 ? (double)k * k * 4.0 / 4.6e6 + 15.0 : (double)k * k * 8.0 / 5.5e6;
-    return 2.0 * (8.0 + 0.65 * ht) + (ht > 40.0 ? 25.0 : 0.0) + tail;
+    const double tail = k <= 20480 ? (double)k * k * 4.0 / 5.3e6 + 12.0 : (double)k * k * 4.0 / 4.2e6 + 40.0;     // (round 6: 16-byte loads; the row-sharing kernel beyond)
+    return 2.0 * (8.0 + 0.65 * ht) + (ht > 40.0 ? 25.0 : 0.0) + 20.0 + tail;                                     // + the right-hand side, L21^T x2: two short kernels
   };
   // Deep forest at the host optimum: the sweeps stay on the host (two PCIe hops per solve) -- UNLESS a larger tail swallows the long
   // chains.  PushBox N = 30 (m = 154 256): height 1 135 up to k = 17 408, 632 at 17 920, 120 at 18 432, 67 at 19 456; with the device-side

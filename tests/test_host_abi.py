@@ -543,15 +543,18 @@ def test_host_pool_survives_two_concurrent_solvers():
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name,m,nnzL,tail_k,perm_sha,tops_k", [
-    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c", 10240),
-    ("pendulum_N=80", 112028, 929430, 10496, "53e3efdb51729949", 0),
-    ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3", 0),
-    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a", 8192),
-    ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176", 16384),
-    ("bqp-r1-40-1", 269001, 816406, 0, "c02eb270d6b7a503", 1024),          # round 5: the wide-forest plan (no dense tail pays; a small one in front of the device-side sweeps)
+PICK_C1 = (9216, 16)
+
+
+@pytest.mark.parametrize("name,m,nnzL,tail_k,perm_sha,tops_k,tops_cut", [
+    ("PlanarHand_N=1_MOMENT", 66008, 13533205, 17152, "52f718bcc8f3773c", PICK_C1[0], PICK_C1[1]),
+    ("pendulum_N=80", 112028, 929430, 10496, "53e3efdb51729949", 7168, 16),      # round 6: tree tops for pendulum too (0.647 -> 0.557 ms per sGS iteration)
+    ("taha1a", 3002, 162451, 3002, "a76f23e6d0979eb3", 0, 0),
+    ("PushBox_N=30_MOMENT", 154256, 2742805, 18688, "54923cf4d0953c4a", 7168, 32),
+    ("PushT_N=30_MOMENT", 53290, 58473104, 27136, "51e27341946f6176", 15360, 16),
+    ("bqp-r1-40-1", 269001, 816406, 0, "c02eb270d6b7a503", 1024, 32),      # round 5: the wide-forest plan (no dense tail pays; a small one in front of the device-side sweeps)
 ])
-def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha, tops_k):
+def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k, perm_sha, tops_k, tops_cut):
     """The fill-reducing ordering (own minimum degree with the near-clique exit -- confirmed by an EXACT degree count since round 5 --
     and the dense-row rule) and the tail planner decide nnz(L), the size of the GPU tail and with them every timing and tolerance
     stated for these inputs: a change to either must show up here first (the job of CHOLMOD's analyze in the reference,
@@ -573,8 +576,9 @@ def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k
     rp, ci, v = (np.ascontiguousarray(At.indptr, np.int32), np.ascontiguousarray(At.indices, np.int32), np.ascontiguousarray(At.data))
     h = C.c_void_p()
     lib.cuadmm_aat_factor_nnz.restype = C.c_int64
-    # tail_k: the planner of round 4 (option lead_tops = 0); tops_k: the default since round 5 where the solve with dense tree tops
-    # (cut at height 32) wins by the model, 0 where the plan is unchanged
+    # tail_k: the planner of round 4 (option lead_tops = 0); tops_k / tops_cut: the default since round 5 where the solve with dense tree tops
+    # wins by the model (round 6: recalibrated on measured kernel times, the cut chosen from {16, 32}: profiles/r06_plan_picks.log), 0 where
+    # the plan is unchanged
     lib.cuadmm_aat_plan_allow_tops(0)
     try:
         check(lib.cuadmm_aat_create_split(int(m), int(L), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
@@ -594,7 +598,7 @@ def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k
                                       1e-15, 32768, C.byref(h)))
     try:
         assert int(lib.cuadmm_aat_tail_k(h)) == (tops_k if tops_k else tail_k)
-        assert lib.cuadmm_aat_tail_tops(h) == (32 if tops_k else 0)
+        assert lib.cuadmm_aat_tail_tops(h) == tops_cut
         assert np.array_equal(np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)), perm)      # the ordering does not depend on the plan
     finally:
         lib.cuadmm_aat_free(h)

@@ -13,7 +13,12 @@ cap = int(sys.argv[3]) if len(sys.argv) > 3 else 30000
 opts = {}
 for kv in sys.argv[4:]:
     k, v = kv.split("="); opts[k] = float(v)
-p = load_npz_problem(name)
+if os.path.isdir(os.path.join(ROOT, "tests", "golden", "problems", name)):      # a TXT fixture (blk.txt.gz ...)
+    import pathlib, tempfile
+    from tests.test_gpu_moment_parity import load_problem
+    p = load_problem(name, pathlib.Path(tempfile.mkdtemp()))
+else:
+    p = load_npz_problem(name)
 s = cuadmm_amd.SDPSolver(verbose=False, profile=1, options=opts)
 t = time.time(); s.init_problem(problem_to_amd(p)); ti = time.time() - t
 t = time.time(); s.solve(cap, 1e-3, 0, 50, 100, sw, 1.05); ts = time.time() - t
