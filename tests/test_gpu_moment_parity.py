@@ -242,11 +242,11 @@ def test_dense_tree_tops_agree_with_the_plain_sweeps(name, level, tmp_path):
 
 
 def test_a_cut_above_every_tree_falls_back_to_the_plain_sweeps(tmp_path):
-    """lead_tops = 500 on pendulum N = 80 (forest 28 levels deep at its tail): no node is that high, there is nothing to cut -- the plain
+    """lead_tops = 500 on pendulum N = 80 (forest 28 levels deep at a 10 496-column tail): no node is that high, there is nothing to cut -- the plain
     sweeps run (counter 1) and the iterates are those of lead_tops = 0, bit for bit."""
     p = load_problem("pendulum_N=80", tmp_path)
     out = []
-    for opt in ({"lead_tops": 0}, {"lead_tops": 500}):
+    for opt in ({"tail_k": 10496, "lead_tops": 0}, {"tail_k": 10496, "lead_tops": 500}):      # (round 4's tail: the planner's own pick has tree tops since round 6)
         s = cuadmm_amd.SDPSolver(verbose=False, options=opt)
         s.init_problem(problem_to_amd(p))
         s.solve(30, 0.0, 0, 50, 100, 15, 1.05)
