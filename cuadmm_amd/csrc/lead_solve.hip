@@ -137,9 +137,11 @@ constexpr int kLongColumn = 128;
 // workgroups beyond take four long columns each.  Same sums in the same order as the two kernels.
 __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long* __restrict__ tp, const int* __restrict__ tr, const double* __restrict__ tv,
                                                         const double* __restrict__ x2, double* __restrict__ w, int wg_short, int n_long,
-                                                        const int* __restrict__ cols, double* __restrict__ copy_dst, int copy_n) {
-  // the solved tail into y on the way (it used to be a 5 us launch of its own behind the backward sweeps)
-  for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < copy_n; q += (int)(gridDim.x * blockDim.x)) copy_dst[q] = x2[q];
+                                                        const int* __restrict__ cols, double* __restrict__ copy_dst, int copy_n,
+                                                        const int* __restrict__ copy_map) {
+  // the solved tail (with tree tops: [x_T | x_K], scattered to the caller's order through copy_map) into y on the way -- it used to be a
+  // 5 us launch of its own behind the backward sweeps
+  for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < copy_n; q += (int)(gridDim.x * blockDim.x)) copy_dst[copy_map ? copy_map[q] : q] = x2[q];
   if ((int)blockIdx.x >= wg_short) {
     const int i = ((int)blockIdx.x - wg_short) * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     if (i >= n_long) return;
@@ -164,11 +166,11 @@ __global__ __launch_bounds__(256) void lead_l21t_kernel(int n1, const long long*
 }
 // returns whether the copy x2[0, copy_n) -> copy_dst rode along (no leading columns: no launch)
 static bool launch_l21t(int n1, const long long* tp, const int* tr, const double* tv, const double* x2, double* w, int n_long, const int* cols, hipStream_t st,
-                        double* copy_dst = nullptr, int copy_n = 0) {
+                        double* copy_dst = nullptr, int copy_n = 0, const int* copy_map = nullptr) {
   if (n1 <= 0) return false;
   const int wg_short = (int)(((long long)n1 * 8 + 255) / 256);
   hipLaunchKernelGGL(lead_l21t_kernel, dim3((unsigned)(wg_short + (n_long + 3) / 4)), dim3(256), 0, st, n1, tp, tr, tv, x2, w, wg_short, n_long, cols, copy_dst,
-                     copy_dst ? copy_n : 0);
+                     copy_dst ? copy_n : 0, copy_map);
   return copy_dst != nullptr;
 }
 
@@ -176,7 +178,8 @@ static bool launch_l21t(int n1, const long long* tp, const int* tr, const double
 __global__ __launch_bounds__(64) void lead_backward_kernel(const int* __restrict__ lvl_ptr, const int* __restrict__ lvl_off, const int* __restrict__ lvl_g,
                                                            const int* __restrict__ nodes, const long long* __restrict__ ptr, const int* __restrict__ ci,
                                                            const double* __restrict__ v, const double* __restrict__ D, const double* __restrict__ w,
-                                                           double* __restrict__ x, int max_nodes, int max_levels, const int* __restrict__ tree_ids) {
+                                                           double* __restrict__ x, int max_nodes, int max_levels, const int* __restrict__ tree_ids,
+                                                           const int* __restrict__ rid, double* __restrict__ yout) {
   extern __shared__ double lead_smem[];
   double* xs = lead_smem;
   int* s_off = reinterpret_cast<int*>(xs + max_nodes);
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(64) void lead_backward_kernel(const int* __restrict
         const double xj = x[j] / D[j] - w[j] - s;
         xs[idx - first] = xj;
         x[j] = xj;
+        if (yout) yout[rid[j]] = xj;
       }
     }
     wave_fence();
@@ -237,7 +241,7 @@ __device__ __forceinline__ void lead_sweep_lds_body(const LeadTreeDesc d, double
                                                     const int* __restrict__ ci, const double* __restrict__ v,
                                                     const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
                                                     const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
-                                                    const int* __restrict__ rid) {
+                                                    const int* __restrict__ rid, double* __restrict__ yout = nullptr) {
   constexpr int NT = 64 * NW;
   const int lane = tid & 63, wave = tid >> 6;
   const int l0 = d.l0, nlev = d.nlev, first = d.first, cnt = d.cnt, nnz = d.nnz;
@@ -319,7 +323,10 @@ __device__ __forceinline__ void lead_sweep_lds_body(const LeadTreeDesc d, double
     if (NW > 1) __syncthreads(); else wave_fence();        // the next level reads xs written by this one
   }
   // the solution leaves in one pass at the end
-  for (int i = tid; i < cnt; i += NT) x[snode[i]] = xs[i];
+  // (yout: the backward sweep of a solve with tree tops writes straight into the caller's y, in the caller's order -- round 6; until then a
+  // scatter kernel of its own behind the sweeps)
+  if (yout) { for (int i = tid; i < cnt; i += NT) yout[rid[snode[i]]] = xs[i]; }
+  else { for (int i = tid; i < cnt; i += NT) x[snode[i]] = xs[i]; }
 }
 
 template <bool BACKWARD, int NW>
@@ -328,9 +335,9 @@ __global__ __launch_bounds__(64 * NW) void lead_sweep_lds_kernel(const LeadTreeD
                                                             const int* __restrict__ ci, const double* __restrict__ v,
                                                             const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
                                                             const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
-                                                            const int* __restrict__ rid) {
+                                                            const int* __restrict__ rid, double* __restrict__ yout) {
   extern __shared__ double lead_smem[];
-  lead_sweep_lds_body<BACKWARD, NW>(desc[blockIdx.x], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x, rid);
+  lead_sweep_lds_body<BACKWARD, NW>(desc[blockIdx.x], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x, rid, yout);
 }
 
 // The few big trees and the many small ones in ONE launch (round 5): workgroups [0, n_big) take a big tree each on four wavefronts,
@@ -344,17 +351,17 @@ __global__ __launch_bounds__(256) void lead_sweep_merged_kernel(const LeadTreeDe
                                                              const int* __restrict__ ci, const double* __restrict__ v,
                                                              const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
                                                              const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
-                                                             const int* __restrict__ rid) {
+                                                             const int* __restrict__ rid, double* __restrict__ yout) {
   extern __shared__ double lead_smem[];
   const int blk = (int)blockIdx.x;
   if (blk < n_big) {
-    lead_sweep_lds_body<BACKWARD, 4>(desc_big[blk], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x, rid);
+    lead_sweep_lds_body<BACKWARD, 4>(desc_big[blk], lead_smem, (int)threadIdx.x, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig, D, w, x, rid, yout);
   } else {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int t = 4 * (blk - n_big) + wave;
     if (t < n_small)
       lead_sweep_lds_body<BACKWARD, 1>(desc_small[t], lead_smem + (size_t)wave * small_doubles, (int)threadIdx.x & 63, lvl_off, lvl_g, nodes, ptr, ci, v, ax, asmc, b, isig,
-                                       D, w, x, rid);
+                                       D, w, x, rid, yout);
   }
 }
 
@@ -364,19 +371,19 @@ __global__ __launch_bounds__(256) void lead_micro_kernel(int n_micro, const int*
                                                          const long long* __restrict__ ptr, const int* __restrict__ ci, const double* __restrict__ v,
                                                          const double* __restrict__ ax, const double* __restrict__ asmc, const double* __restrict__ b, double isig,
                                                          const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ x,
-                                                         const int* __restrict__ rid) {
+                                                         const int* __restrict__ rid, double* __restrict__ yout) {
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= n_micro) return;
   const int s0 = first[t];
   const int n0 = nodes[s0];
   const double x0 = BACKWARD ? x[n0] / D[n0] - w[n0] : lead_rhs_at(ax, asmc, b, isig, rid, n0);
-  x[n0] = x0;
+  if (yout) yout[rid[n0]] = x0; else x[n0] = x0;
   if (cnt[t] > 1) {
     const int n1 = nodes[s0 + 1];
     double s = 0.0;
     for (long long q = ptr[s0 + 1]; q < ptr[s0 + 2]; ++q) s += v[q] * (ci[q] == 0 ? x0 : 0.0);      // (one entry: the other node)
     const double r1 = BACKWARD ? x[n1] / D[n1] - w[n1] : lead_rhs_at(ax, asmc, b, isig, rid, n1);
-    x[n1] = r1 - s;
+    if (yout) yout[rid[n1]] = r1 - s; else x[n1] = r1 - s;
   }
 }
 
@@ -576,7 +583,7 @@ int LeadSolve::build(int m_, int k_, const int64_t* Lp, const int* Li, const dou
   return build_core(m_, k_, Lp, Li, Lx, D, allow_hybrid);
 }
 
-// experiment (option pinv_tol, DESIGN.md section 4 "Round 6: pivots at the regularisation"): pivots below the tolerance in magnitude become
+// experiment (option pinv_tol, NOTEBOOK.md "Round 6"): pivots below the tolerance in magnitude become
 // +infinity -- the kernels divide by D, so the component along such a direction is dropped (1 / d := 0), here as in the tail's dinv
 static std::vector<double> pinv_pivots(const double* D, int n, double tol) {
   std::vector<double> out(D, D + n);
@@ -1055,7 +1062,9 @@ int LeadSolve::build_tops(int m_, int k_, const int64_t* Lp, const int* Li, cons
 
 // the sweeps over the leading forest, one direction: big trees (four wavefronts each) and small ones (one wavefront each, four per
 // workgroup) in ONE launch when both exist, the streaming kernels for trees beyond a workgroup's LDS
-static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st) {
+static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, const double* asmc, const double* b, double isig, double* x, hipStream_t st,
+                          double* yout = nullptr) {
+  double* const ynul = nullptr;
   const bool merged = L.n_big > 0 && L.n_small > 0;
   const int small_doubles = (int)((L.lds_small + 7) / 8);
   const size_t lds_merged = std::max(L.lds_big, 4 * sizeof(double) * (size_t)small_doubles);
@@ -1064,37 +1073,37 @@ static void launch_sweeps(const LeadSolve& L, bool backward, const double* ax, c
   if (L.n_micro > 0) {
     if (!backward)
       hipLaunchKernelGGL(lead_micro_kernel<false>, dim3((unsigned)((L.n_micro + 255) / 256)), dim3(256), 0, st, L.n_micro, L.micro_first, L.micro_cnt, L.nodes_f, L.fptr,
-                         L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+                         L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid, ynul);
     else
       hipLaunchKernelGGL(lead_micro_kernel<true>, dim3((unsigned)((L.n_micro + 255) / 256)), dim3(256), 0, st, L.n_micro, L.micro_first, L.micro_cnt, L.nodes_b, L.bptr,
-                         L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+                         L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid, yout);
   }
   if (!backward) {
     if (merged)
       hipLaunchKernelGGL(lead_sweep_merged_kernel<false>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.n_big,
                          static_cast<const LeadTreeDesc*>(L.desc_small_f), L.n_small, small_doubles, L.lvl_off_f, L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig,
-                         nul, nul, x, L.rid);
+                         nul, nul, x, L.rid, ynul);
     else if (L.n_small > 0)
       hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 1>), dim3(L.n_small), dim3(64), L.lds_small, st, static_cast<const LeadTreeDesc*>(L.desc_small_f), L.lvl_off_f,
-                         L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+                         L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid, ynul);
     else if (L.n_big > 0)
       hipLaunchKernelGGL((lead_sweep_lds_kernel<false, 4>), dim3(L.n_big), dim3(256), L.lds_big, st, static_cast<const LeadTreeDesc*>(L.desc_big_f), L.lvl_off_f, L.lvl_g_f,
-                         L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid);
+                         L.nodes_f, L.fptr, L.fci, L.fv_, ax, asmc, b, isig, nul, nul, x, L.rid, ynul);
     if (L.n_stream > 0) hipLaunchKernelGGL(lead_forward_kernel, dim3(L.n_stream), dim3(64), L.lds_bytes, st, L.lvl_ptr_f, L.lvl_off_f, L.lvl_g_f, L.nodes_f, L.fptr, L.fci, L.fv_,
                                            ax, asmc, b, isig, x, L.max_nodes, L.max_levels, L.trees_stream, L.rid);
   } else {
     if (merged)
       hipLaunchKernelGGL(lead_sweep_merged_kernel<true>, dim3(grid_merged), dim3(256), lds_merged, st, static_cast<const LeadTreeDesc*>(L.desc_big_b), L.n_big,
                          static_cast<const LeadTreeDesc*>(L.desc_small_b), L.n_small, small_doubles, L.lvl_off_b, L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_,
-                         nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+                         nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid, yout);
     else if (L.n_small > 0)
       hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 1>), dim3(L.n_small), dim3(64), L.lds_small, st, static_cast<const LeadTreeDesc*>(L.desc_small_b), L.lvl_off_b,
-                         L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+                         L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid, yout);
     else if (L.n_big > 0)
       hipLaunchKernelGGL((lead_sweep_lds_kernel<true, 4>), dim3(L.n_big), dim3(256), L.lds_big, st, static_cast<const LeadTreeDesc*>(L.desc_big_b), L.lvl_off_b, L.lvl_g_b,
-                         L.nodes_b, L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid);
+                         L.nodes_b, L.bptr, L.bci, L.bv_, nul, nul, nul, 0.0, L.D1, L.wvec, x, L.rid, yout);
     if (L.n_stream > 0) hipLaunchKernelGGL(lead_backward_kernel, dim3(L.n_stream), dim3(64), L.lds_bytes, st, L.lvl_ptr_b, L.lvl_off_b, L.lvl_g_b, L.nodes_b, L.bptr, L.bci, L.bv_,
-                                           L.D1, L.wvec, x, L.max_nodes, L.max_levels, L.trees_stream);
+                                           L.D1, L.wvec, x, L.max_nodes, L.max_levels, L.trees_stream, L.rid, yout);
   }
 }
 
@@ -1138,9 +1147,11 @@ int LeadSolve::solve_tops(const double* ax, const double* asmc, const double* b,
     hipLaunchKernelGGL(tops_resid_kernel, dim3((unsigned)(((long long)nT * 32 + 255) / 256)), dim3(256), 0, st, nT, tt_cp, tt_ri, tt_cv, xext, uT, zext);
     hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wb_off, (const int*)nullptr, wb_len, Wb, zext, xext, 1);
   }
-  launch_l21t(n1, tptr, tri, tv_, xext, wvec, n_long, long_cols_d, st);                                        // w = [L_TB; L_KB]^T [x_T; x_K]
-  launch_sweeps(*this, true, ax, asmc, b, isig, xp, st);                                                        // x_B
-  hipLaunchKernelGGL(tops_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, n1, rid, xp, xext, y);
+  // w = [L_TB; L_KB]^T [x_T; x_K] -- and [x_T | x_K] into y in the caller's order on the way; the backward sweeps then write x_B straight into y
+  // (round 6: the scatter kernel behind them is gone when there are leading columns to sweep)
+  const bool direct = launch_l21t(n1, tptr, tri, tv_, xext, wvec, n_long, long_cols_d, st, y, kext, rid + n1);
+  launch_sweeps(*this, true, ax, asmc, b, isig, xp, st, direct ? y : nullptr);                                  // x_B
+  if (!direct) hipLaunchKernelGGL(tops_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, n1, rid, xp, xext, y);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }

@@ -18,7 +18,7 @@ struct TailSolve {
   bool group_retired = false;  // a row exchange was lost once: apply() uses the two triangular GEMVs from then on
   unsigned long long* part = nullptr;   // 18 432 < K <= 32 768: per row and member, the exchanged parts of u = W z (ts_onepass_group_kernel)
   bool attr_set = false;       // the one-pass kernel's LDS attribute has been raised
-  // option tail_refine (experiment, DESIGN.md section 4 "pivots near the regularisation"): one step of iterative refinement of each TRIANGULAR solve against
+  // option tail_refine (experiment, NOTEBOOK.md "Round 6"): one step of iterative refinement of each TRIANGULAR solve against
   // the factor itself, u <- u + W (z - L u) and x <- x + W^T (v - L^T x) -- W = inv(L) is only as accurate as cond(L) allows, and L carries columns
   // of size 1 / sqrt(pivot) where the Schur complement is nearly singular; L and L^T are then kept beside W and W^T (two more K x K matrices)
   bool refine = false;

@@ -212,7 +212,7 @@ struct TsRows {
     }
   }
 };
-// error-free transformations for the compensated variant of u_i = W_i z (option tail_dd, an experiment: DESIGN.md section 4, "pivots near the
+// error-free transformations for the compensated variant of u_i = W_i z (option tail_dd, an experiment: NOTEBOOK.md "Round 6", "pivots near the
 // regularisation"): (hi, lo) <- (hi, lo) + a b with the rounding errors of the product and of the sum collected in lo
 __device__ __forceinline__ void dd_fma_acc(double& hi, double& lo, double a, double b) {
 #pragma clang fp contract(off)               // the transformations are exact only with every operation rounded on its own

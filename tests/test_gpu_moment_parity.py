@@ -40,7 +40,7 @@ TOL = {key: (1e-8, 1e-7) for key in TRAJ}
 # the objectives (measured, profiles/r05_pendulum_100k.log) -- the oracle itself is 24 % (errRd), 11 % (relgap), 2 % (errRp) away from the row the
 # reference printed there, which is what two fp64 implementations of the reference's arithmetic can be expected to share after 100 000 steps.
 TOL["pendulum_N=80/switch=11000/late=100000"] = (1e-8, 1e-4)
-# pobj on the DEFAULT path of two inputs, stated -- and what it is, since round 6 (profiles/r06_tail_refine.log, DESIGN.md section 4 "What an explicit
+# pobj on the DEFAULT path of two inputs, stated -- and what it is, since round 6 (profiles/r06_tail_refine.log, DESIGN.md section 2, NOTEBOOK.md "Round 6": "What an explicit
 # inverse costs near a singular Schur complement"): the tail is applied as an EXPLICIT inverse W = inv(L22), which is only as accurate as u cond(L22),
 # and L22 carries columns of size 1 / sqrt(pivot) where the Schur complement of a moment relaxation is nearly singular (pivots 1e-14 ... 1e-13 beside the
 # thousands at the regularisation 1e-15).  The error sits in the near-null directions of A A^T and reaches the primal objective at 1e-8 ... 1e-7; every other
