@@ -249,7 +249,8 @@ struct cuadmm_solver {
     int solve_next = 1;           // "solve_next": the y-solve of iteration k + 1 is enqueued before the host waits for iteration k (fetch_out)
     int tail_max_k = 32768;       // "tail_max_k": cap of the planner's GPU tail (<= 65 536: 3 x 8 K^2 bytes while it is built, 2 x 8 K^2 afterwards)
     int tail_dd = 0;              // "tail_dd": experiment (tail_solve.h)
-    int tail_refine = 0;          // "tail_refine": experiment (tail_solve.h)
+    int tail_refine = 0;          // "tail_refine": accuracy mode of the tail (tail_solve.h)
+    int tail_pivot = 1;           // "tail_pivot": the tail's dense LDL^T with diagonal pivoting (0: unpivoted, rounds 2 - 5)
     int tail_prefetch = 1;        // "tail_prefetch": the tail's one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5; A/B)
     int tail_shard = 1;           // "tail_shard": world > 1, replicated solve: every rank applies 1 / world of the tail's rows, the K partial
                                   // results are all-reduced (0: every rank applies the whole tail)
@@ -803,6 +804,7 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
       s->tail.prefetch = s->sw.tail_prefetch != 0;
       s->tail.dd_dot = s->sw.tail_dd != 0;
       s->tail.refine = s->sw.tail_refine != 0;
+      s->tail.pivot = s->sw.tail_pivot != 0;
       s->tail.pinv_tol = std::max(s->sw.tail_pinv_tol, s->sw.pinv_tol);
       if (!rc) rc = s->tail.build_from_schur(reinterpret_cast<const long long*>(srp), sci, sv, tk, s->st);
       // The tail is applied as an explicit inverse built without pivoting (tail_solve.hip); with (nearly) dependent
@@ -1405,6 +1407,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "tail_prefetch") s->sw.tail_prefetch = (int)value;
   else if (k == "tail_dd") s->sw.tail_dd = (int)value;
   else if (k == "tail_refine") s->sw.tail_refine = (int)value;
+  else if (k == "tail_pivot") s->sw.tail_pivot = (int)value;
   else if (k == "tail_max_k") s->sw.tail_max_k = (int)value;
   else if (k == "solve_next") s->sw.solve_next = (int)value;
   else if (k == "debug_eig") s->sw.debug_eig = (int)value;

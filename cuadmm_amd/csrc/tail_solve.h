@@ -24,7 +24,13 @@ struct TailSolve {
   bool refine = false;
   double inv_resid = -1.0;     // || z - L (W z) ||_inf for a probe z at build: the accuracy of the explicit inverse (-1: not measured, e.g. build() from a host factor)
   double *Lm = nullptr, *Lt = nullptr, *t1 = nullptr, *t2 = nullptr;
-  int apply_refined(hipStream_t st);
+  int apply_refined(double* v, hipStream_t st);
+  // option tail_pivot (round 6, default on): the dense LDL^T of the Schur complement with diagonal pivoting (tail_solve.hip, ts_ldlt_factor_pivoted):
+  // P S P^T = L D L^T, perm_d[a] = the tail-local index at position a.  The one-pass kernels gather z through it and scatter x back; the other
+  // paths go through the two scratch vectors pv1 / pv2.  Null after build() from a host factor.
+  bool pivot = true;
+  int* perm_d = nullptr;
+  double *pv1 = nullptr, *pv2 = nullptr;
   bool dd_dot = false;         // option tail_dd (experiment): u = W z accumulated in double-double (K <= 10 240 and 14 336 < K <= 16 384 only)
   bool prefetch = true;        // option tail_prefetch: the one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5)
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)

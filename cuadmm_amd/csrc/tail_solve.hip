@@ -171,6 +171,12 @@ __global__ __launch_bounds__(256) void ts_tri_resid_kernel(const double* __restr
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) out[i] = (a[i] - b[i]) - s;
 }
+// dst[a] = src[perm[a]] (GATHER) or dst[perm[a]] = src[a]: in and out of the factor's pivoting order
+template <bool GATHER>
+__global__ void ts_perm_kernel(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ perm, int K) {
+  const int a = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (a < K) { if (GATHER) dst[a] = src[perm[a]]; else dst[perm[a]] = src[a]; }
+}
 // y += x (SCALE: then y *= d)
 template <bool SCALE>
 __global__ void ts_axpy1_kernel(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ d, int K) {
@@ -278,7 +284,8 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
 }
 template <int NC, int RB, bool PF, bool DD = false>
 __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
-                                                          const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end) {
+                                                          const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end,
+                                                          const int* __restrict__ perm) {
   extern __shared__ __attribute__((aligned(16))) double ts_zs[];          // z, K doubles (zero beyond K up to 1024 NC)
   __shared__ double red[2][RB][DD ? 32 : 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
   }
   TsRows<NC, RB> A;
   A.load(W, ld, K, col0, r0, r_end);         // the first group travels while z is staged
-  for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[c] : 0.0;
+  for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[perm ? perm[c] : c] : 0.0;      // (perm: the factor's pivoting order, TailSolve::perm_d)
   double2 xa[NC / 2];
 #pragma unroll
   for (int p = 0; p < NC / 2; ++p) xa[p] = make_double2(0.0, 0.0);
@@ -348,7 +355,8 @@ __global__ void ts_fill_u64_kernel(unsigned long long* p, size_t n, unsigned lon
 template <int NC, int Q, int RB, int OCC = 8>
 __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                                    const double* __restrict__ dinv, double* __restrict__ P,
-                                                                   unsigned long long* __restrict__ part, int* __restrict__ fail, int r_begin, int r_end) {
+                                                                   unsigned long long* __restrict__ part, int* __restrict__ fail, int r_begin, int r_end,
+                                                                   const int* __restrict__ perm) {
   extern __shared__ double ts_zs[];          // z of this thread's own columns: word (c * 1024 + tid); nobody else reads it
   __shared__ double red[2][RB][16];
   __shared__ double ush[2][RB];
@@ -376,7 +384,8 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int col = col0 + 128 * p;
-    const double2 zz = col < K ? *reinterpret_cast<const double2*>(z + col) : make_double2(0.0, 0.0);      // K is a multiple of 64: col + 1 < K too
+    const double2 zz = col >= K ? make_double2(0.0, 0.0) : perm ? make_double2(z[perm[col]], z[perm[col + 1]])
+                                                                   : *reinterpret_cast<const double2*>(z + col);      // K is a multiple of 64: col + 1 < K too
     ts_zs[(2 * p) * 1024 + tid] = zz.x; ts_zs[(2 * p + 1) * 1024 + tid] = zz.y;
   }
   double2 xa[NP];
@@ -478,7 +487,8 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
 // slices are added in order through LDS -- a fixed association, four dependent round trips instead of the 32 of one thread per column
 // (G = 256 workgroups: 14 us -> 5 us per solve; pendulum / PlanarHand_N=1 / PushBox: 2 - 4 % of an iteration).
 __global__ __launch_bounds__(256) void ts_onepass_reduce_kernel(const double* __restrict__ P, int K, int G, double* __restrict__ x,
-                                                                unsigned long long* __restrict__ part = nullptr, int Q = 0) {
+                                                                unsigned long long* __restrict__ part = nullptr, int Q = 0,
+                                                                const int* __restrict__ perm = nullptr) {
   __shared__ double red[8][32];
   const int c = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
   const int col = (int)blockIdx.x * 32 + c;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) void ts_onepass_reduce_kernel(const double* __
     double t = red[0][c];
 #pragma unroll
     for (int u = 1; u < 8; ++u) t += red[u][c];
-    x[col] = t;
+    x[perm ? perm[col] : col] = t;            // back from the factor's pivoting order
     for (int m = 0; m < Q; ++m) part[(size_t)col * Q + m] = TS_SENTINEL;
   }
 }
@@ -640,6 +650,110 @@ __global__ __launch_bounds__(256) void ts_ldlt_update_kernel(double* __restrict_
       }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same factorisation WITH DIAGONAL PIVOTING (round 6; option tail_pivot, default on): P S P^T = L D L^T with the largest remaining
+// diagonal entry eliminated next (LAPACK dpstrf's rule; for a positive semidefinite S every |L_ij| <= 1).  Why: the tail is applied as
+// an EXPLICIT inverse W = inv(L), accurate to u cond(L); the Schur complement of a large moment relaxation is nearly singular, the
+// unpivoted factor then carries columns of size 1 / sqrt(pivot), and the lost digits surfaced as 1e-8 ... 1e-7 in the primal objective
+// (NOTEBOOK.md "Round 6"; one refinement step per triangular solve -- option tail_refine -- removed them at 6 x the bytes per solve).
+// With pivoting the small pivots come LAST and L stays bounded: the explicit inverse is accurate at no cost per solve.
+// Per column two launches: (A) one workgroup finds the pivot among rows [j, k) of the running diagonal `dg`, swaps it into place --
+// symmetric swap on the lower triangle, permutation and diagonal with it -- and records the pivot; (B) every row below forms its entry
+// of the column from the block's deferred updates (dot over <= 63 earlier columns of the block) and updates its diagonal.  Per block of
+// 64 columns the trailing matrix takes the usual rank-64 update (ts_ldlt_update_kernel) and the diagonal is re-read from it.
+// Padding rows (identity, >= k) never move.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ts_piv_select_kernel(double* __restrict__ S, long long ld, int K, int k, int j, double* __restrict__ dg,
+                                                              int* __restrict__ perm, double* __restrict__ dvec, int* __restrict__ flag) {
+  __shared__ double bv[16];
+  __shared__ int bi[16];
+  __shared__ int s_p;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // argmax of dg over [j, k) (ties: the smallest index, so the choice does not depend on the thread layout)
+  double best = -1.7976931348623157e308;
+  int at = j;
+  for (int i = j + tid; i < k; i += 1024) { const double v = dg[i]; if (v > best) { best = v; at = i; } }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(at, o, 64);
+    if (ov > best || (ov == best && oi < at)) { best = ov; at = oi; }
+  }
+  if (lane == 0) { bv[wave] = best; bi[wave] = at; }
+  __syncthreads();
+  if (tid == 0) {
+    double b = bv[0]; int a = bi[0];
+    for (int w = 1; w < 16; ++w) if (bv[w] > b || (bv[w] == b && bi[w] < a)) { b = bv[w]; a = bi[w]; }
+    s_p = j < k ? a : j;
+  }
+  __syncthreads();
+  const int p = s_p;
+  if (p != j) {
+    // symmetric swap of indices j < p in the lower triangle: row segments left of j, column segments below p, the bent segment between
+    for (int c = tid; c < j; c += 1024) { const double t = S[(size_t)j * ld + c]; S[(size_t)j * ld + c] = S[(size_t)p * ld + c]; S[(size_t)p * ld + c] = t; }
+    for (int i = p + 1 + tid; i < K; i += 1024) { const double t = S[(size_t)i * ld + j]; S[(size_t)i * ld + j] = S[(size_t)i * ld + p]; S[(size_t)i * ld + p] = t; }
+    for (int i = j + 1 + tid; i < p; i += 1024) { const double t = S[(size_t)i * ld + j]; S[(size_t)i * ld + j] = S[(size_t)p * ld + i]; S[(size_t)p * ld + i] = t; }
+    if (tid == 0) {
+      const double t = S[(size_t)j * ld + j]; S[(size_t)j * ld + j] = S[(size_t)p * ld + p]; S[(size_t)p * ld + p] = t;
+      const double g = dg[j]; dg[j] = dg[p]; dg[p] = g;
+      const int q = perm[j]; perm[j] = perm[p]; perm[p] = q;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double d = dg[j];
+    dvec[j] = d;
+    if (d == 0.0 || !(fabs(d) <= 1.7976931348623157e308)) atomicAdd(flag, 1);
+  }
+}
+// column j of L below the diagonal from the block's deferred updates: l_i = (S_ij - sum_{c = b0}^{j-1} L_ic d_c L_jc) / d_j
+__global__ __launch_bounds__(256) void ts_piv_column_kernel(double* __restrict__ S, long long ld, int K, int k, int j, int b0, double* __restrict__ dg,
+                                                            const double* __restrict__ dvec) {
+  __shared__ double yj[64];
+  const int nc = j - b0;
+  if ((int)threadIdx.x < nc) yj[threadIdx.x] = S[(size_t)j * ld + b0 + threadIdx.x] * dvec[b0 + threadIdx.x];
+  __syncthreads();
+  const int i = j + 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= K) return;
+  const double d = dvec[j];
+  const double* row = S + (size_t)i * ld + b0;
+  double s = row[nc];
+  for (int c = 0; c < nc; ++c) s -= row[c] * yj[c];
+  const double l = i < k ? s / d : 0.0;            // (padding rows are decoupled: exact zeros)
+  S[(size_t)i * ld + j] = l;
+  if (i < k) dg[i] -= l * l * d;
+}
+// Y = L_21 D of the finished block for the trailing update (formed at the END of the block: rows still swap while its columns are eliminated)
+__global__ void ts_piv_yp_kernel(const double* __restrict__ S, long long ld, int K, int b0, const double* __restrict__ dvec, double* __restrict__ Yp) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = b0 + 64 + (int)(t >> 6), c = (int)(t & 63);
+  if (i < K) Yp[(size_t)i * 64 + c] = S[(size_t)i * ld + b0 + c] * dvec[b0 + c];
+}
+__global__ void ts_piv_diag_kernel(const double* __restrict__ S, long long ld, int K, int from, double* __restrict__ dg, int* __restrict__ perm, int init) {
+  const int i = from + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < K) { dg[i] = S[(size_t)i * ld + i]; if (init) perm[i] = i; }
+}
+// the unit diagonal of the finished factor's block columns is implicit for ts_unit_lower_inverse; dd: pivots, perm: position -> original index
+int ts_ldlt_factor_pivoted(double* dS, int K, int k, double* dd, double* Yp, double* dg, int* perm, int* dflag, hipStream_t st) {
+  const long long ld = K;
+  const int nbk = K / 64;
+  hipLaunchKernelGGL(ts_piv_diag_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dS, ld, K, 0, dg, perm, 1);
+  for (int b = 0; b < nbk; ++b) {
+    const int b0 = b * 64, T = nbk - b - 1;
+    for (int j = b0; j < b0 + 64; ++j) {
+      hipLaunchKernelGGL(ts_piv_select_kernel, dim3(1), dim3(1024), 0, st, dS, ld, K, k, j, dg, perm, dd, dflag);
+      if (j + 1 < K) hipLaunchKernelGGL(ts_piv_column_kernel, dim3((unsigned)((K - j - 1 + 255) / 256)), dim3(256), 0, st, dS, ld, K, k, j, b0, dg, dd);
+    }
+    if (T > 0) {
+      hipLaunchKernelGGL(ts_piv_yp_kernel, dim3((unsigned)(((long long)(K - b0 - 64) * 64 + 255) / 256)), dim3(256), 0, st, dS, ld, K, b0, dd, Yp);
+      hipLaunchKernelGGL(ts_ldlt_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, st, dS, ld, b0, Yp);
+      hipLaunchKernelGGL(ts_piv_diag_kernel, dim3((K - b0 - 64 + 255) / 256), dim3(256), 0, st, dS, ld, K, b0 + 64, dg, perm, 0);
+    }
+  }
+  CUADMM_HIP_TRY(hipGetLastError());
+  return CUADMM_OK;
+}
+
 // pinv_tol > 0 (option tail_pinv_tol, an experiment: see tail_solve.h): a pivot below it in magnitude counts as zero
 __global__ void ts_dinv_kernel(const double* __restrict__ d, double* __restrict__ dinv, int K, double pinv_tol) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -657,8 +771,8 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 
 void TailSolve::release() {
   if (compact) { W = Wc; Wc = nullptr; compact = false; ldc = 0; i_lo = 0; i_hi = -1; }     // (W was an offset view of Wc)
-  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part, (void*)Lm, (void*)Lt, (void*)t1, (void*)t2}) if (p) { hipError_t e = hipFree(p); (void)e; }
-  part = nullptr; Lm = Lt = t1 = t2 = nullptr;
+  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part, (void*)Lm, (void*)Lt, (void*)t1, (void*)t2, (void*)perm_d, (void*)pv1, (void*)pv2}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  part = nullptr; Lm = Lt = t1 = t2 = nullptr; perm_d = nullptr; pv1 = pv2 = nullptr;
   if (d_fail) { hipError_t e = hipFree(d_fail); (void)e; d_fail = nullptr; }
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
@@ -818,7 +932,18 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
   }
   if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); cleanup(); release(); return e == hipErrorOutOfMemory ? CUADMM_ERR_INVALID : CUADMM_ERR_NO_DEVICE; }
   hipLaunchKernelGGL(ts_scatter_csr_kernel, dim3(K), dim3(256), 0, st, drp, dci, dval, k, dS, ld);
-  if ((rc = ts_ldlt_factor(dS, K, dd, Yp, dflag, st))) { cleanup(); release(); return rc; }
+  if (pivot) {
+    double* dg = nullptr;
+    if (hipMalloc(&perm_d, sizeof(int) * (size_t)K) != hipSuccess || hipMalloc(&pv1, sizeof(double) * (size_t)K) != hipSuccess ||
+        hipMalloc(&pv2, sizeof(double) * (size_t)K) != hipSuccess || hipMalloc(&dg, sizeof(double) * (size_t)K) != hipSuccess) {
+      if (dg) { hipError_t e2 = hipFree(dg); (void)e2; }
+      set_error("tail_solve: out of device memory"); cleanup(); release(); return CUADMM_ERR_INVALID;
+    }
+    rc = ts_ldlt_factor_pivoted(dS, K, k, dd, Yp, dg, perm_d, dflag, st);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = CUADMM_ERR_NO_DEVICE;
+    { hipError_t e2 = hipFree(dg); (void)e2; }
+    if (rc) { cleanup(); release(); return rc; }
+  } else if ((rc = ts_ldlt_factor(dS, K, dd, Yp, dflag, st))) { cleanup(); release(); return rc; }
   hipLaunchKernelGGL(ts_dinv_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dd, dinv, K, pinv_tol);
   int hflag = 0;
   e = hipGetLastError();
@@ -937,7 +1062,7 @@ int TailSolve::keep_shard(int rank, int world, hipStream_t st) {
 }
 
 // the two triangular GEMVs with one refinement step each against the factor (experiment, tail_solve.h)
-int TailSolve::apply_refined(hipStream_t st) {
+int TailSolve::apply_refined(double* vin, hipStream_t st) {      // (vin: the vector in the factor's order, in place)
   const dim3 gr((K + 3) / 4), bl(256), g1((K + 255) / 256);
   hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, gr, bl, 0, st, W, (long long)K, K, vin, (const double*)nullptr, vmid, 0, 1 << 30);      // u = W z
   hipLaunchKernelGGL(ts_tri_resid_kernel<true>, gr, bl, 0, st, Lm, (long long)K, K, vin, vmid, t1);                                    // r = z - L u
@@ -954,7 +1079,15 @@ int TailSolve::apply_refined(hipStream_t st) {
 // vin <- W^T diag(dinv) W vin
 int TailSolve::apply(hipStream_t st) {
   // (refined: every rank of a sharded engine applies the WHOLE tail -- the result is replicated, no reduction)
-  if (refine && Lm) { shard_rows = K; shard_bytes = 24.0 * (double)K * K; return apply_refined(st); }
+  if (refine && Lm) {
+    shard_rows = K; shard_bytes = 24.0 * (double)K * K;
+    if (!perm_d) return apply_refined(vin, st);
+    hipLaunchKernelGGL(ts_perm_kernel<true>, dim3((K + 255) / 256), dim3(256), 0, st, pv1, vin, perm_d, K);
+    { int rc_ = apply_refined(pv1, st); if (rc_) return rc_; }
+    hipLaunchKernelGGL(ts_perm_kernel<false>, dim3((K + 255) / 256), dim3(256), 0, st, vin, pv1, perm_d, K);
+    CUADMM_HIP_TRY(hipGetLastError());
+    return CUADMM_OK;
+  }
   // this rank's rows r = K - 1 - i (r = 0: the longest row): equal shares of the triangle's entries, boundaries on multiples of 8
   int r_begin = 0, r_end = K;
   if (shard_world > 1) {
@@ -985,7 +1118,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
         CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));   // process-wide per kernel: the maximum
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end);
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end, perm_d);
       return CUADMM_OK;
     };
     int rc;
@@ -1023,7 +1156,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
       }
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0, perm_d);
   } else if (one_pass && xpart && part && K > 32768 && K <= 65536 && !group_retired) {
     // beyond 32 768 columns (round 5, option tail_max_k): EIGHT workgroups share a row, 8 columns per thread, four rows per exchange
     constexpr int Q = 8;
@@ -1031,8 +1164,8 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);
     auto kern = ts_onepass_group_kernel<8, Q, 4, 4>;
     if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q);
+    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q, perm_d);
   } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
     // measured (tail_solve class per sGS iteration, two solves; two triangular GEMVs for comparison): K = 24 576 (PushBox N = 30, forced)
@@ -1044,21 +1177,29 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
     auto launch = [&](auto kern) -> int {
       if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end);
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d);
       return CUADMM_OK;
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
     if (rc) return rc;
-    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q);
+    hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q, perm_d);
   } else {
-    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, ldw, K, vin, dinv, vmid, r_begin, r_end);
+    // (with a pivoted factor the vector goes into the factor's order first and back afterwards: two short launches on this fallback only)
+    const double* zin = vin;
+    double* xout = vin;
+    if (perm_d) {
+      hipLaunchKernelGGL(ts_perm_kernel<true>, dim3((K + 255) / 256), dim3(256), 0, st, pv1, vin, perm_d, K);
+      zin = pv1; xout = pv2;
+    }
+    hipLaunchKernelGGL(ts_tri_gemv_kernel<true>, dim3((K + 3) / 4), dim3(256), 0, st, W, ldw, K, zin, dinv, vmid, r_begin, r_end);
     if (compact) {     // no W^T on a compact shard: the kept rows are accumulated by columns (chunks of rows, summed in chunk order)
       const int nchunk = std::max(1, std::min(n_wg, 64));
       if (i_hi >= i_lo) hipLaunchKernelGGL(ts_colacc_kernel, dim3((K + 255) / 256, nchunk), dim3(256), 0, st, W, ldw, K, vmid, xpart, i_lo, i_hi, nchunk);
       else CUADMM_HIP_TRY(hipMemsetAsync(xpart, 0, sizeof(double) * (size_t)K * (size_t)nchunk, st));
-      hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, nchunk, vin, (unsigned long long*)nullptr, 0);
+      hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, nchunk, vin, (unsigned long long*)nullptr, 0, perm_d);
     } else {
-      hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, vin, 0, 1 << 30);
+      hipLaunchKernelGGL(ts_tri_gemv_kernel<false>, dim3((K + 3) / 4), dim3(256), 0, st, Wt, (long long)K, K, vmid, nullptr, xout, 0, 1 << 30);
+      if (perm_d) hipLaunchKernelGGL(ts_perm_kernel<false>, dim3((K + 255) / 256), dim3(256), 0, st, vin, pv2, perm_d, K);
     }
   }
   CUADMM_HIP_TRY(hipGetLastError());

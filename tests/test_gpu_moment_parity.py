@@ -40,21 +40,16 @@ TOL = {key: (1e-8, 1e-7) for key in TRAJ}
 # the objectives (measured, profiles/r05_pendulum_100k.log) -- the oracle itself is 24 % (errRd), 11 % (relgap), 2 % (errRp) away from the row the
 # reference printed there, which is what two fp64 implementations of the reference's arithmetic can be expected to share after 100 000 steps.
 TOL["pendulum_N=80/switch=11000/late=100000"] = (1e-8, 1e-4)
-# pobj on the DEFAULT path of two inputs, stated -- and what it is, since round 6 (profiles/r06_tail_refine.log, DESIGN.md section 2, NOTEBOOK.md "Round 6": "What an explicit
-# inverse costs near a singular Schur complement"): the tail is applied as an EXPLICIT inverse W = inv(L22), which is only as accurate as u cond(L22),
-# and L22 carries columns of size 1 / sqrt(pivot) where the Schur complement of a moment relaxation is nearly singular (pivots 1e-14 ... 1e-13 beside the
-# thousands at the regularisation 1e-15).  The error sits in the near-null directions of A A^T and reaches the primal objective at 1e-8 ... 1e-7; every other
-# quantity stays <= 2.3e-9.  One refinement step of each triangular solve against the factor itself (option tail_refine = 1: 6x the tail's bytes per solve,
-# off by default) removes it -- PushT_N=30 1.1e-7 -> 4.1e-9, PushBox_N=50 at 8 192 / 8 448 / 8 704 columns 3.8e-9 / 8.5e-8 / 4.0e-8 -> 1.4e-10 / 3.6e-11 /
-# 5.2e-11: test_refined_tail_reproduces_the_oracle_whatever_the_cut below holds those at 1e-8 -- where the oracle's own solve is pivoted (SuperLU).
-POBJ_HEAD_TOL = {"PushT_N=30_MOMENT/switch=11000": 3e-7,      # default path: measured 1.1e-7 (16 384-column tail); 4.1e-9 with tail_refine = 1
-                 # PlanarHand_N=10 (m = 483 707, the tail at its cap of 32 768 columns): every quantity <= 7.5e-10 except pobj, 1.3e-8 on the head (5.8e-11 at
-                 # the late checkpoint) -- with and without refinement of the tail and of the tree tops alike (1.3e-8 / 1.4e-8): this is the ORACLE's share.
-                 # Its y-solves came from the library's unpivoted host LDL^T (SuperLU cannot hold the factor), which divides by the same near-zero
-                 # pivots; the same factor code on both sides (tail_k = 0, test_pusht30_with_the_factor_on_the_host_is_exact) agrees to 9.7e-9 only.
-                 "PlanarHand_N=10_MOMENT/switch=11000": 3e-8}
-# (PushBox_N=50 runs at the planner's 8 192 columns: 3.8e-9, inside the common 1e-8.  At 8 448 / 8 704 columns the default path gives 8.5e-8 / 4.0e-8 -- which of the
-# small pivots the explicit inverse holds decides -- so the cut is SWEPT by the refined-tail test below instead of trusted.)
+# pobj of two inputs, stated -- and what it is, since round 6 (profiles/r06_tail_refine.log, r06_tail_pivot.log; DESIGN.md section 2, NOTEBOOK.md "Round 6").
+# Rounds 3 - 5 applied the tail as the explicit inverse of an UNPIVOTED factor: accurate to u cond(L22), and L22 carries columns of size 1 / sqrt(pivot) where
+# the Schur complement of a large moment relaxation is nearly singular -- 1.1e-7 on PushT_N=30, 8.5e-8 on PushBox_N=50 at an 8 448-column tail (3.8e-9 at the
+# planner's 8 192: luck).  Since round 6 the tail's dense LDL^T pivots on the diagonal (option tail_pivot, default): bounded L, accurate inverse at no cost per
+# solve -- PushBox_N=50 <= 1.0e-10 at every cut (its oracle solves with SuperLU's pivoted LU).  What remains on the two inputs below is the ORACLE's share: SuperLU
+# cannot hold their factors, so their golden y-solves came from the library's unpivoted host LDL^T, whose own division by near-zero pivots is in the golden digits
+# (the same factor code on both sides, tail_k = 0, agrees to 9.7e-9 only; the unpivoted tail with one refinement step per triangular solve -- which reproduces that
+# arithmetic's order -- to 4.1e-9).  Every other quantity of every input <= 2.3e-9.
+POBJ_HEAD_TOL = {"PushT_N=30_MOMENT/switch=11000": 5e-8,        # measured 2.7e-8 (rounds 3 - 5, unpivoted tail: 1.1e-7 ... 4.1e-7 at 3e-7 ... 1e-6)
+                 "PlanarHand_N=10_MOMENT/switch=11000": 3e-8}   # measured 1.4e-8 (5.8e-11 at the late checkpoint), with and without pivoting / refinement
 
 # |got - ref| <= tol * |ref| + ATOL: the absolute part is the roundoff floor of the quantity (1e-11, as in the other trajectory tests;
 # errRp: the y-solve's own rounding error, see above)
@@ -145,19 +140,29 @@ def test_moment_relaxation_trajectory_matches_the_oracle(key, tmp_path, ref_logs
             assert abs(s.state()[name] - w) <= rel * abs(w), (name, s.state()[name], w)
 
 
-@pytest.mark.parametrize("key,options", [("PushBox_N=50_MOMENT/switch=11000", {"tail_k": 8192}), ("PushBox_N=50_MOMENT/switch=11000", {"tail_k": 8448}),
-                                         ("PushBox_N=50_MOMENT/switch=11000", {"tail_k": 8704}), ("PushT_N=30_MOMENT/switch=11000", {})])
-def test_refined_tail_reproduces_the_oracle_whatever_the_cut(key, options, tmp_path):
-    """Parity on nearly singular Schur complements as a property of the SOLVE, not of where the planner's cost model cuts: with one
-    refinement step of each triangular solve of the tail against the factor itself (option tail_refine: u <- u + W (z - L u), x <- x + W^T (v - L^T x);
-    the contract being met is the reference's exact LDL^T solve, include/cuadmm/cholesky_cpu.h:89-155 with eps = 1e-15 at src/solver.cu:94) EVERY
-    quantity, the primal objective included, holds the common 1e-8 -- at the planner's tail of PushBox_N=50 and at the two neighbouring cuts where
-    the plain explicit inverse leaves 8.5e-8 / 4.0e-8, and on PushT_N=30 (1.1e-7 plain).  Measured: <= 1.4e-10 (PushBox), 4.1e-9 (PushT)."""
-    s = run_and_compare(key, tmp_path, dict(options, tail_refine=1), None)
+@pytest.mark.parametrize("tail_k", [8192, 8448, 8704])
+def test_parity_does_not_depend_on_where_the_tail_is_cut(tail_k, tmp_path):
+    """Parity on nearly singular Schur complements as a property of the SOLVE, not of where the planner's cost model cuts: PushBox_N=50 at the
+    planner's 8 192 columns and at the two neighbouring cuts where the unpivoted explicit inverse of rounds 3 - 5 left 8.5e-8 / 4.0e-8 in the primal objective
+    (which of the 9 301 pivots at 1e-15 ... 1e-13 the tail held decided).  With the tail's LDL^T pivoted on the diagonal (the default) every quantity holds the
+    common 1e-8 at every cut -- measured <= 1.0e-10 -- and the explicit inverse's own residual || z - L (W z) || is 2e-14 instead of 9e-12.  The contract being
+    met: the reference's exact LDL^T solve, include/cuadmm/cholesky_cpu.h:89-155 with eps = 1e-15 at src/solver.cu:94."""
+    s = run_and_compare("PushBox_N=50_MOMENT/switch=11000", tmp_path, {"tail_k": tail_k}, None)
     ti = s.tail_info()
-    assert ti["refined"] and ti["inverse_residual"] > 0.0
-    if "tail_k" in options:
-        assert ti["tail_k"] == options["tail_k"]
+    assert ti["tail_k"] == tail_k and 0.0 < ti["inverse_residual"] <= 1e-12
+    for nm in SIX:                                            # well inside the tolerance, not at its edge
+        assert rel_dev(s.info_arr(nm)[:60], np.array([float(x) for x in TRAJ["PushBox_N=50_MOMENT/switch=11000"][nm]]), nm) <= 2e-9, nm
+
+
+@pytest.mark.parametrize("key,options,pobj_tol", [("PushBox_N=50_MOMENT/switch=11000", {"tail_k": 8448, "tail_pivot": 0}, None),
+                                                  ("PushT_N=30_MOMENT/switch=11000", {"tail_pivot": 0}, None)])
+def test_refined_unpivoted_tail_reproduces_the_oracle(key, options, pobj_tol, tmp_path):
+    """The accuracy mode that found the cause (option tail_refine: one refinement step of each triangular solve against the factor itself, u <- u + W (z - L u),
+    x <- x + W^T (v - L^T x)) on the UNPIVOTED factor of rounds 3 - 5: every quantity at 1e-8 where the plain explicit inverse leaves 8.5e-8 (PushBox_N=50 at
+    8 448 columns) and 1.1e-7 (PushT_N=30).  Measured 3.6e-11 / 4.1e-9.  Six times the tail's bytes per solve: kept as an option, not the default."""
+    s = run_and_compare(key, tmp_path, dict(options, tail_refine=1), pobj_tol)
+    ti = s.tail_info()
+    assert ti["refined"] and ti["inverse_residual"] > 1e-13      # the unpivoted inverse is the inaccurate one (pivoted: ~2e-14); the refinement repairs the solve
 
 
 @pytest.mark.parametrize("key", ["PlanarHand_N=1_MOMENT/switch=0", "PushBox_N=30_MOMENT/switch=11000"])
