@@ -663,11 +663,9 @@ __global__ __launch_bounds__(256) void ts_ldlt_update_kernel(double* __restrict_
 // 64 columns the trailing matrix takes the usual rank-64 update (ts_ldlt_update_kernel) and the diagonal is re-read from it.
 // Padding rows (identity, >= k) never move.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void ts_piv_select_kernel(double* __restrict__ S, long long ld, int K, int k, int j, double* __restrict__ dg,
-                                                              int* __restrict__ perm, double* __restrict__ dvec, int* __restrict__ flag) {
+__global__ __launch_bounds__(1024) void ts_piv_select_kernel(int k, int j, const double* __restrict__ dg, int* __restrict__ piv) {
   __shared__ double bv[16];
   __shared__ int bi[16];
-  __shared__ int s_p;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // argmax of dg over [j, k) (ties: the smallest index, so the choice does not depend on the thread layout)
   double best = -1.7976931348623157e308;
@@ -684,38 +682,43 @@ __global__ __launch_bounds__(1024) void ts_piv_select_kernel(double* __restrict_
   if (tid == 0) {
     double b = bv[0]; int a = bi[0];
     for (int w = 1; w < 16; ++w) if (bv[w] > b || (bv[w] == b && bi[w] < a)) { b = bv[w]; a = bi[w]; }
-    s_p = j < k ? a : j;
+    piv[0] = j < k ? a : j;
   }
-  __syncthreads();
-  const int p = s_p;
-  if (p != j) {
-    // symmetric swap of indices j < p in the lower triangle: row segments left of j, column segments below p, the bent segment between
-    for (int c = tid; c < j; c += 1024) { const double t = S[(size_t)j * ld + c]; S[(size_t)j * ld + c] = S[(size_t)p * ld + c]; S[(size_t)p * ld + c] = t; }
-    for (int i = p + 1 + tid; i < K; i += 1024) { const double t = S[(size_t)i * ld + j]; S[(size_t)i * ld + j] = S[(size_t)i * ld + p]; S[(size_t)i * ld + p] = t; }
-    for (int i = j + 1 + tid; i < p; i += 1024) { const double t = S[(size_t)i * ld + j]; S[(size_t)i * ld + j] = S[(size_t)p * ld + i]; S[(size_t)p * ld + i] = t; }
-    if (tid == 0) {
-      const double t = S[(size_t)j * ld + j]; S[(size_t)j * ld + j] = S[(size_t)p * ld + p]; S[(size_t)p * ld + p] = t;
-      const double g = dg[j]; dg[j] = dg[p]; dg[p] = g;
-      const int q = perm[j]; perm[j] = perm[p]; perm[p] = q;
-    }
+}
+// symmetric swap of indices j < p = piv[0] in the lower triangle, one thread per index i: row segments left of j, the bent segment between
+// j and p, column segments below p; the diagonal, the running diagonal and the permutation with them
+__global__ __launch_bounds__(256) void ts_piv_swap_kernel(double* __restrict__ S, long long ld, int K, int j, const int* __restrict__ piv,
+                                                          double* __restrict__ dg, int* __restrict__ perm) {
+  const int p = piv[0];
+  if (p == j) return;
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= K) return;
+  double *a, *b;
+  if (i < j) { a = S + (size_t)j * ld + i; b = S + (size_t)p * ld + i; }
+  else if (i == j) {
+    a = S + (size_t)j * ld + j; b = S + (size_t)p * ld + p;
+    const double g = dg[j]; dg[j] = dg[p]; dg[p] = g;
+    const int q = perm[j]; perm[j] = perm[p]; perm[p] = q;
   }
-  __syncthreads();
-  if (tid == 0) {
-    const double d = dg[j];
-    dvec[j] = d;
-    if (d == 0.0 || !(fabs(d) <= 1.7976931348623157e308)) atomicAdd(flag, 1);
-  }
+  else if (i < p) { a = S + (size_t)i * ld + j; b = S + (size_t)p * ld + i; }
+  else if (i == p) return;                                    // S[p][j] keeps its place
+  else { a = S + (size_t)i * ld + j; b = S + (size_t)i * ld + p; }
+  const double t = *a; *a = *b; *b = t;
 }
 // column j of L below the diagonal from the block's deferred updates: l_i = (S_ij - sum_{c = b0}^{j-1} L_ic d_c L_jc) / d_j
 __global__ __launch_bounds__(256) void ts_piv_column_kernel(double* __restrict__ S, long long ld, int K, int k, int j, int b0, double* __restrict__ dg,
-                                                            const double* __restrict__ dvec) {
+                                                            double* __restrict__ dvec, int* __restrict__ flag) {
   __shared__ double yj[64];
   const int nc = j - b0;
   if ((int)threadIdx.x < nc) yj[threadIdx.x] = S[(size_t)j * ld + b0 + threadIdx.x] * dvec[b0 + threadIdx.x];
   __syncthreads();
+  const double d = dg[j];                                     // the pivot: nobody writes dg[j] any more
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dvec[j] = d;
+    if (d == 0.0 || !(fabs(d) <= 1.7976931348623157e308)) atomicAdd(flag, 1);
+  }
   const int i = j + 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i >= K) return;
-  const double d = dvec[j];
   const double* row = S + (size_t)i * ld + b0;
   double s = row[nc];
   for (int c = 0; c < nc; ++c) s -= row[c] * yj[c];
@@ -737,12 +740,19 @@ __global__ void ts_piv_diag_kernel(const double* __restrict__ S, long long ld, i
 int ts_ldlt_factor_pivoted(double* dS, int K, int k, double* dd, double* Yp, double* dg, int* perm, int* dflag, hipStream_t st) {
   const long long ld = K;
   const int nbk = K / 64;
+  int* piv_d = nullptr;                                         // the pivot's index travels from the search to the swap on the device
+  CUADMM_HIP_TRY(hipMalloc(&piv_d, sizeof(int)));
+  int* const piv = piv_d;
   hipLaunchKernelGGL(ts_piv_diag_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dS, ld, K, 0, dg, perm, 1);
   for (int b = 0; b < nbk; ++b) {
     const int b0 = b * 64, T = nbk - b - 1;
     for (int j = b0; j < b0 + 64; ++j) {
-      hipLaunchKernelGGL(ts_piv_select_kernel, dim3(1), dim3(1024), 0, st, dS, ld, K, k, j, dg, perm, dd, dflag);
-      if (j + 1 < K) hipLaunchKernelGGL(ts_piv_column_kernel, dim3((unsigned)((K - j - 1 + 255) / 256)), dim3(256), 0, st, dS, ld, K, k, j, b0, dg, dd);
+      if (j < k) {                                               // (padding columns keep their place)
+        hipLaunchKernelGGL(ts_piv_select_kernel, dim3(1), dim3(1024), 0, st, k, j, dg, piv);
+        hipLaunchKernelGGL(ts_piv_swap_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dS, ld, K, j, piv, dg, perm);
+      }
+      // (the last column has no rows below it: the launch still records its pivot)
+      hipLaunchKernelGGL(ts_piv_column_kernel, dim3((unsigned)std::max(1, (K - j - 1 + 255) / 256)), dim3(256), 0, st, dS, ld, K, k, j, b0, dg, dd, dflag);
     }
     if (T > 0) {
       hipLaunchKernelGGL(ts_piv_yp_kernel, dim3((unsigned)(((long long)(K - b0 - 64) * 64 + 255) / 256)), dim3(256), 0, st, dS, ld, K, b0, dd, Yp);
@@ -750,7 +760,10 @@ int ts_ldlt_factor_pivoted(double* dS, int K, int k, double* dd, double* Yp, dou
       hipLaunchKernelGGL(ts_piv_diag_kernel, dim3((K - b0 - 64 + 255) / 256), dim3(256), 0, st, dS, ld, K, b0 + 64, dg, perm, 0);
     }
   }
-  CUADMM_HIP_TRY(hipGetLastError());
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  { hipError_t e2 = hipFree(piv_d); (void)e2; }
+  if (e != hipSuccess) { set_error("tail_solve: %s", hipGetErrorString(e)); return CUADMM_ERR_NO_DEVICE; }
   return CUADMM_OK;
 }
 
