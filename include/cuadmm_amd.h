@@ -63,7 +63,9 @@ void cuadmm_destroy(cuadmm_solver* s);
  *   "graph"         reserved
  *   "tail_shard"    world > 1, coupled constraints: 1 (default) = each rank applies 1 / world of the rows of the dense GPU tail of the
  *                   replicated y-solve and the K partial results are all-reduced; 0 = every rank applies the whole tail
- *   "tail_refine"   1 = ACCURACY MODE of the dense GPU tail of the y-solve: one refinement step of each triangular solve against the factor itself
+ *   "tail_pivot"    1 (default) = the dense LDL^T of the y-solve's GPU tail pivots on the diagonal (P S P^T = L D L^T, |L_ij| <= 1): its explicit inverse stays
+ *                   accurate where the Schur complement is nearly singular; 0 = the unpivoted elimination order (rounds 2 - 5)
+ *   "tail_refine"   1 = one more accuracy device of the dense GPU tail of the y-solve: one refinement step of each triangular solve against the factor itself
  *                   (u <- u + W (z - L u), x <- x + W^T (v - L^T x)) on top of the explicit inverse W = inv(L22), whose accuracy is u cond(L22) -- a
  *                   nearly singular Schur complement (large moment relaxations) otherwise leaves 1e-8 ... 1e-7 in the primal objective against an exact
  *                   LDL^T solve (the reference's contract, include/cuadmm/cholesky_cpu.h:146-155).  Costs 6x the tail's bytes per solve and two more

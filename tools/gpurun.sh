@@ -93,7 +93,9 @@ P
         c5)    prof c5 python3 "$R/bench.py" --config c5 --steps 100 --warmup 5 --no-cpu-baseline --no-breakdown --time-to-tol 0 ;;
       esac
     done
-    ls "$R/profiles" | grep "r${ROUND}_" ;;
+    # the summaries were written under profiles/ of the box's copy: only gpurun_out/ travels back
+    cp "$R"/profiles/r${ROUND}_*_kernel_stats.csv "$R"/profiles/r${ROUND}_*_pmc_*.json "$G"/ 2>/dev/null
+    ls "$G" | grep "r${ROUND}_.*\(kernel_stats\|pmc_\)" ;;
   trace)
     tag=$1; shift
     ( cd /tmp && export TMPDIR=/tmp
