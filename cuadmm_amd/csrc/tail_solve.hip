@@ -233,9 +233,11 @@ __device__ __forceinline__ void dd_add(double& hi, double& lo, double h2, double
   lo += ((hi - (s - bb)) + (h2 - bb)) + l2;
   hi = s;
 }
-template <int NC, int RB, bool DD>
+template <int NC, int RB, bool DD, int NW = 16>
 __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const double* zs, double (*red)[RB][DD ? 32 : 16], int it, int lane, int wave, int K, int r0,
                                               int r_end, const double* __restrict__ dinv, double2 (&xa)[NC / 2]) {
+  static_assert(NW == 16 || NW == 8, "wavefronts per workgroup");
+  static_assert(!DD || NW == 16, "the compensated variant exists for 1024 threads only");
   double part[RB];
 #pragma unroll
   for (int q = 0; q < RB; ++q) {
@@ -273,6 +275,8 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
 #pragma unroll
       for (int w = 1; w < 16; ++w) dd_add(hi, lo, rr[w], rr[16 + w]);
       u = hi + lo;
+    } else if constexpr (NW == 8) {
+      u = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
     } else {
       u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
           (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
@@ -282,11 +286,16 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
     for (int p = 0; p < NC / 2; ++p) { xa[p].x += vq * R.w[q][p].x; xa[p].y += vq * R.w[q][p].y; }
   }
 }
-template <int NC, int RB, bool PF, bool DD = false>
-__global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
-                                                          const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end,
-                                                          const int* __restrict__ perm) {
-  extern __shared__ __attribute__((aligned(16))) double ts_zs[];          // z, K doubles (zero beyond K up to 1024 NC)
+// NT threads: 1024 (sixteen wavefronts, <= 128 VGPRs each) or 512 -- "fewer, fatter threads", option tail_fat, MEASURED AND OFF: the kernel trace puts the
+// 1024-thread kernel at 4.4 TB/s (77 - 81 us at K = 9 216) with 16-byte loads and prefetch alike, ~2.1 us per row and workgroup -- a round trip per row, whatever
+// its length.  Eight wavefronts of up to 256 VGPRs holding two rows per group and two groups in flight (twice the bytes in flight per CU) ran 92 us at K = 9 216
+// and 48 against 47 at 7 168: bytes in flight are not what bounds it either.  Not understood further this round (NOTEBOOK.md "Round 6").
+template <int NC, int RB, bool PF, bool DD = false, int NT = 1024>
+__global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
+                                                        const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end,
+                                                        const int* __restrict__ perm) {
+  constexpr int NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) double ts_zs[];          // z, K doubles (zero beyond K up to NT NC)
   __shared__ double red[2][RB][DD ? 32 : 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = wave * (64 * NC) + 2 * lane;
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
   }
   TsRows<NC, RB> A;
   A.load(W, ld, K, col0, r0, r_end);         // the first group travels while z is staged
-  for (int c = tid; c < 1024 * NC; c += 1024) ts_zs[c] = c < K ? z[perm ? perm[c] : c] : 0.0;      // (perm: the factor's pivoting order, TailSolve::perm_d)
+  for (int c = tid; c < NT * NC; c += NT) ts_zs[c] = c < K ? z[perm ? perm[c] : c] : 0.0;      // (perm: the factor's pivoting order, TailSolve::perm_d)
   double2 xa[NC / 2];
 #pragma unroll
   for (int p = 0; p < NC / 2; ++p) xa[p] = make_double2(0.0, 0.0);
@@ -310,17 +319,17 @@ __global__ __launch_bounds__(1024) void ts_onepass_kernel(const double* __restri
   if constexpr (!PF) {                       // one group in flight (the registers of a second one would spill)
     for (; r0 < r_end; r0 += step) {
       if (it) A.load(W, ld, K, col0, r0, r_end);
-      ts_rows_apply<NC, RB, DD>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+      ts_rows_apply<NC, RB, DD, NW>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
     }
   } else {
     TsRows<NC, RB> B;
     while (r0 < r_end) {
       B.load(W, ld, K, col0, r0 + step, r_end);
-      ts_rows_apply<NC, RB, DD>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+      ts_rows_apply<NC, RB, DD, NW>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
       r0 += step;
       if (r0 >= r_end) break;
       A.load(W, ld, K, col0, r0 + step, r_end);
-      ts_rows_apply<NC, RB, DD>(B, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+      ts_rows_apply<NC, RB, DD, NW>(B, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
       r0 += step;
     }
   }
@@ -1135,6 +1144,22 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
       return CUADMM_OK;
     };
     int rc;
+    // K <= 10 240: eight fat wavefronts, two rows per group, two groups in flight (above ts_onepass_kernel); NC = columns per thread in steps of 4
+    auto launch512 = [&](auto kern, int ncol) -> int {
+      const size_t lds5 = sizeof(double) * 512 * (size_t)ncol;
+      if (lds5 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), lds5, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end, perm_d);
+      return CUADMM_OK;
+    };
+    if (prefetch && fat && !dd_dot && K <= 10240) {
+      switch ((K + 2047) / 2048) {
+        case 1: rc = launch512(ts_onepass_kernel<4, 2, true, false, 512>, 4); break;
+        case 2: rc = launch512(ts_onepass_kernel<8, 2, true, false, 512>, 8); break;
+        case 3: rc = launch512(ts_onepass_kernel<12, 2, true, false, 512>, 12); break;
+        case 4: rc = launch512(ts_onepass_kernel<16, 2, true, false, 512>, 16); break;
+        default: rc = launch512(ts_onepass_kernel<20, 2, true, false, 512>, 20); break;
+      }
+    } else
     // NC columns per thread (1024 NC >= K), RB rows per group, PF: the next group's rows in flight during the current group's barrier
     // (two register buffers of RB NC doubles + NC accumulators within 128 VGPRs: two rows per group up to NC = 8, one up to NC = 16, no
     // second buffer beyond).  Measured per solve inside c1 / c5 (profiles/r06_tail_onepass_ab.txt).  Option tail_prefetch = 0: one group
