@@ -34,6 +34,8 @@ struct TailSolve {
   bool dd_dot = false;         // option tail_dd (experiment): u = W z accumulated in double-double (K <= 10 240 and 14 336 < K <= 16 384 only)
   bool fat = false;            // option tail_fat (measured, off): K <= 10 240 on 512-thread workgroups of up to 256 VGPRs (two rows per group, two groups in
                                // flight): 92 us against 81 at K = 9 216, 48 against 47 at 7 168 -- NOTEBOOK.md "Round 6"
+  int depth = 1;               // option tail_depth: row groups in flight beyond the current one in the one-pass kernel (tail_solve.hip: ts_onepass_kernel)
+  int order = 0;               // option tail_order: 1 = a workgroup walks its rows alternately from the long and the short end
   bool prefetch = true;        // option tail_prefetch: the one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5)
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   double pinv_tol = 0.0;       // option tail_pinv_tol (experiment, DESIGN.md section 4 "Round 5: dense tree tops"): pivots of the tail below it in

@@ -233,7 +233,7 @@ __device__ __forceinline__ void dd_add(double& hi, double& lo, double h2, double
   lo += ((hi - (s - bb)) + (h2 - bb)) + l2;
   hi = s;
 }
-template <int NC, int RB, bool DD, int NW = 16>
+template <int NC, int RB, bool DD, int NW = 16, bool TIGHT = false>
 __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const double* zs, double (*red)[RB][DD ? 32 : 16], int it, int lane, int wave, int K, int r0,
                                               int r_end, const double* __restrict__ dinv, double2 (&xa)[NC / 2]) {
   static_assert(NW == 16 || NW == 8, "wavefronts per workgroup");
@@ -259,6 +259,8 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
         const double2 zz = *reinterpret_cast<const double2*>(zs + 128 * p);
         part[q] += R.w[q][p].x * zz.x;
         part[q] += R.w[q][p].y * zz.y;
+        // (TIGHT: at the register budget's edge the scheduler otherwise reads every z pair of the row up front -- 2 NC registers -- and spills)
+        if (TIGHT && (p & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
       part[q] = wave_sum(part[q]);
       if (lane == 0) red[it & 1][q][wave] = part[q];
@@ -290,25 +292,40 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
 // 1024-thread kernel at 4.4 TB/s (77 - 81 us at K = 9 216) with 16-byte loads and prefetch alike, ~2.1 us per row and workgroup -- a round trip per row, whatever
 // its length.  Eight wavefronts of up to 256 VGPRs holding two rows per group and two groups in flight (twice the bytes in flight per CU) ran 92 us at K = 9 216
 // and 48 against 47 at 7 168: bytes in flight are not what bounds it either.  Not understood further this round (NOTEBOOK.md "Round 6").
-template <int NC, int RB, bool PF, bool DD = false, int NT = 1024>
+// D: row groups in flight BEYOND the one being applied (a ring of D + 1 register buffers; 0: load, apply, load ...).  With one group ahead
+// the wait at the top of a group still sees a whole memory round trip minus the ~0.3 us a group takes to apply: a row per round trip,
+// whatever its length -- the short rows of the triangle's tip are latency-bound (tools/ubench/tri_stream.hip).
+// ORDER 1: a workgroup walks its rows alternately from the long and from the short end, so the chip streams the same mix of long and short
+// rows from the first microsecond to the last (ORDER 0, rounds 3 - 6: longest first -- every workgroup reaches the tip at the same time and
+// the bytes in flight collapse together).  The partial sums associate in the walk's order: the last bits differ between orders, deterministically.
+template <int NC, int RB, int D, bool DD = false, int NT = 1024, int ORDER = 0>
 __global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                         const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end,
                                                         const int* __restrict__ perm) {
   constexpr int NW = NT / 64;
+  constexpr bool TIGHT = NT == 1024 && NC * RB * (D + 1) + NC >= 40;      // doubles of row data and accumulators per thread: 80 of the 128 registers
   extern __shared__ __attribute__((aligned(16))) double ts_zs[];          // z, K doubles (zero beyond K up to NT NC)
   __shared__ double red[2][RB][DD ? 32 : 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = wave * (64 * NC) + 2 * lane;
   const int G = (int)gridDim.x, g = (int)blockIdx.x, step = G * RB;
   // rows r = K - 1 - i in [r_begin, r_end): the whole triangle, or this rank's share of it (TailSolve::shard_*)
-  int r0 = r_begin + g * RB;
-  if (r_begin >= r_end) {                    // an empty share (tail_shard_bound): zeros, and no row is touched
+  const int first = r_begin + g * RB;
+  const int count = first < r_end ? (r_end - first + step - 1) / step : 0;      // row groups of this workgroup
+  if (count == 0) {                          // an empty share (tail_shard_bound) or more workgroups than row groups: zeros, and no row is touched
 #pragma unroll
     for (int p = 0; p < NC / 2; ++p) { const int col = col0 + 128 * p; if (col < K) *reinterpret_cast<double2*>(P + (size_t)g * K + col) = make_double2(0.0, 0.0); }
     return;
   }
-  TsRows<NC, RB> A;
-  A.load(W, ld, K, col0, r0, r_end);         // the first group travels while z is staged
+  // first row of the j-th group of the walk (beyond the last group: the last group again -- rows this rank holds; ts_rows_apply is not called for it)
+  auto group_row = [&](int j) -> int {
+    j = j < count ? j : count - 1;
+    if (ORDER == 1) { const int h = j >> 1; j = (j & 1) ? count - 1 - h : h; }
+    return first + j * step;
+  };
+  TsRows<NC, RB> buf[D + 1];
+#pragma unroll
+  for (int d = 0; d < (D > 0 ? D : 1); ++d) buf[d].load(W, ld, K, col0, group_row(d), r_end);      // the first groups travel while z is staged
   for (int c = tid; c < NT * NC; c += NT) ts_zs[c] = c < K ? z[perm ? perm[c] : c] : 0.0;      // (perm: the factor's pivoting order, TailSolve::perm_d)
   double2 xa[NC / 2];
 #pragma unroll
@@ -316,21 +333,22 @@ __global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict
   __syncthreads();
   const double* zs = ts_zs + col0;
   int it = 0;
-  if constexpr (!PF) {                       // one group in flight (the registers of a second one would spill)
-    for (; r0 < r_end; r0 += step) {
-      if (it) A.load(W, ld, K, col0, r0, r_end);
-      ts_rows_apply<NC, RB, DD, NW>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
+  if constexpr (D == 0) {                    // one group in flight (the registers of a second one would spill)
+    for (int j = 0; j < count; ++j) {
+      if (j) buf[0].load(W, ld, K, col0, group_row(j), r_end);
+      ts_rows_apply<NC, RB, DD, NW, TIGHT>(buf[0], zs, red, it++, lane, wave, K, group_row(j), r_end, dinv, xa);
     }
   } else {
-    TsRows<NC, RB> B;
-    while (r0 < r_end) {
-      B.load(W, ld, K, col0, r0 + step, r_end);
-      ts_rows_apply<NC, RB, DD, NW>(A, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
-      r0 += step;
-      if (r0 >= r_end) break;
-      A.load(W, ld, K, col0, r0 + step, r_end);
-      ts_rows_apply<NC, RB, DD, NW>(B, zs, red, it++, lane, wave, K, r0, r_end, dinv, xa);
-      r0 += step;
+    int j = 0;
+    while (j < count) {
+#pragma unroll
+      for (int s = 0; s <= D; ++s) {
+        if (j < count) {
+          buf[(s + D) % (D + 1)].load(W, ld, K, col0, group_row(j + D), r_end);
+          ts_rows_apply<NC, RB, DD, NW, TIGHT>(buf[s], zs, red, it++, lane, wave, K, group_row(j), r_end, dinv, xa);
+          ++j;
+        }
+      }
     }
   }
 #pragma unroll
@@ -1153,45 +1171,45 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     };
     if (prefetch && fat && !dd_dot && K <= 10240) {
       switch ((K + 2047) / 2048) {
-        case 1: rc = launch512(ts_onepass_kernel<4, 2, true, false, 512>, 4); break;
-        case 2: rc = launch512(ts_onepass_kernel<8, 2, true, false, 512>, 8); break;
-        case 3: rc = launch512(ts_onepass_kernel<12, 2, true, false, 512>, 12); break;
-        case 4: rc = launch512(ts_onepass_kernel<16, 2, true, false, 512>, 16); break;
-        default: rc = launch512(ts_onepass_kernel<20, 2, true, false, 512>, 20); break;
+        case 1: rc = launch512(ts_onepass_kernel<4, 2, 1, false, 512>, 4); break;
+        case 2: rc = launch512(ts_onepass_kernel<8, 2, 1, false, 512>, 8); break;
+        case 3: rc = launch512(ts_onepass_kernel<12, 2, 1, false, 512>, 12); break;
+        case 4: rc = launch512(ts_onepass_kernel<16, 2, 1, false, 512>, 16); break;
+        default: rc = launch512(ts_onepass_kernel<20, 2, 1, false, 512>, 20); break;
       }
     } else
-    // NC columns per thread (1024 NC >= K), RB rows per group, PF: the next group's rows in flight during the current group's barrier
-    // (two register buffers of RB NC doubles + NC accumulators within 128 VGPRs: two rows per group up to NC = 8, one up to NC = 16, no
-    // second buffer beyond).  Measured per solve inside c1 / c5 (profiles/r06_tail_onepass_ab.txt).  Option tail_prefetch = 0: one group
-    // in flight everywhere (same column ownership; the row grouping -- and with it the last bits -- differs where RB does).
-    if (dd_dot && (nc == 9 || nc == 10)) rc = launch(ts_onepass_kernel<10, 1, true, true>);      // experiment (option tail_dd): compensated u = W z
-    else if (dd_dot && (nc == 15 || nc == 16)) rc = launch(ts_onepass_kernel<16, 1, false, true>);
-    else if (!prefetch) {
-      switch ((nc + 1) / 2) {
-        case 1: rc = launch(ts_onepass_kernel<2, 2, false>); break;
-        case 2: rc = launch(ts_onepass_kernel<4, 2, false>); break;
-        case 3: rc = launch(ts_onepass_kernel<6, 2, false>); break;
-        case 4: rc = launch(ts_onepass_kernel<8, 2, false>); break;
-        case 5: rc = launch(ts_onepass_kernel<10, 2, false>); break;
-        case 6: rc = launch(ts_onepass_kernel<12, 2, false>); break;
-        case 7: rc = launch(ts_onepass_kernel<14, 2, false>); break;
-        case 8: rc = launch(ts_onepass_kernel<16, 1, false>); break;
-        case 9: rc = launch(ts_onepass_kernel<18, 1, false>); break;
-        default: rc = launch(ts_onepass_kernel<20, 1, false>); break;
+    // NC columns per thread (1024 NC >= K), RB rows per group, D groups in flight beyond the current one during its barrier
+    // ((D + 1) register buffers of RB NC doubles + NC accumulators within 128 VGPRs).  Option tail_depth: 0 = one group in flight everywhere
+    // (rounds 3 - 5), 1 = one ahead (two rows per group up to NC = 8, one up to NC = 16, none beyond), 2 / 3 = two / three single rows ahead
+    // where the registers allow (NC <= 12 / NC <= 8).  Option tail_order: the walk of ts_onepass_kernel.  Same column ownership everywhere;
+    // the row grouping and the walk -- and with them the last bits -- differ between the settings.
+    if (dd_dot && (nc == 9 || nc == 10)) rc = launch(ts_onepass_kernel<10, 1, 1, true>);      // experiment (option tail_dd): compensated u = W z
+    else if (dd_dot && (nc == 15 || nc == 16)) rc = launch(ts_onepass_kernel<16, 1, 0, true>);
+    else {
+      const int h = (nc + 1) / 2;            // NC = 2 h
+      int dep = prefetch ? depth : 0;
+      if (h >= 9) dep = 0;
+      else if (h >= 7 && dep > 1) dep = 1;
+      else if (h >= 5 && dep > 2) dep = 2;
+#define CUADMM_TS_ORD(NC_, RB_, D_) (order ? launch(ts_onepass_kernel<NC_, RB_, D_, false, 1024, 1>) : launch(ts_onepass_kernel<NC_, RB_, D_, false, 1024, 0>))
+#define CUADMM_TS_CASE_LOW(NC_)                                   \
+  (dep == 0 ? CUADMM_TS_ORD(NC_, 2, 0) : dep == 1 ? CUADMM_TS_ORD(NC_, 2, 1) : dep == 2 ? CUADMM_TS_ORD(NC_, 1, 2) : CUADMM_TS_ORD(NC_, 1, 3))
+#define CUADMM_TS_CASE_MID(NC_) (dep == 0 ? CUADMM_TS_ORD(NC_, 2, 0) : dep == 1 ? CUADMM_TS_ORD(NC_, 1, 1) : CUADMM_TS_ORD(NC_, 1, 2))
+      switch (h) {
+        case 1: rc = CUADMM_TS_CASE_LOW(2); break;
+        case 2: rc = CUADMM_TS_CASE_LOW(4); break;
+        case 3: rc = CUADMM_TS_CASE_LOW(6); break;
+        case 4: rc = CUADMM_TS_CASE_LOW(8); break;
+        case 5: rc = CUADMM_TS_CASE_MID(10); break;
+        case 6: rc = CUADMM_TS_CASE_MID(12); break;
+        case 7: rc = dep == 0 ? CUADMM_TS_ORD(14, 2, 0) : CUADMM_TS_ORD(14, 1, 1); break;
+        case 8: rc = dep == 0 ? CUADMM_TS_ORD(16, 1, 0) : CUADMM_TS_ORD(16, 1, 1); break;
+        case 9: rc = CUADMM_TS_ORD(18, 1, 0); break;
+        default: rc = CUADMM_TS_ORD(20, 1, 0); break;
       }
-    } else {
-      switch ((nc + 1) / 2) {
-        case 1: rc = launch(ts_onepass_kernel<2, 2, true>); break;
-        case 2: rc = launch(ts_onepass_kernel<4, 2, true>); break;
-        case 3: rc = launch(ts_onepass_kernel<6, 2, true>); break;
-        case 4: rc = launch(ts_onepass_kernel<8, 2, true>); break;
-        case 5: rc = launch(ts_onepass_kernel<10, 1, true>); break;
-        case 6: rc = launch(ts_onepass_kernel<12, 1, true>); break;
-        case 7: rc = launch(ts_onepass_kernel<14, 1, true>); break;
-        case 8: rc = launch(ts_onepass_kernel<16, 1, true>); break;
-        case 9: rc = launch(ts_onepass_kernel<18, 1, false>); break;
-        default: rc = launch(ts_onepass_kernel<20, 1, false>); break;
-      }
+#undef CUADMM_TS_CASE_MID
+#undef CUADMM_TS_CASE_LOW
+#undef CUADMM_TS_ORD
     }
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0, perm_d);

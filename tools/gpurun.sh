@@ -86,6 +86,19 @@ print(sys.argv[2], sys.argv[3], "value %.1f" % d["value"], "steady %.1f" % d["st
       {k: round(v, 4) for k, v in d["breakdown_ms_per_iter"].items()})
 P
     done; done ;;
+  abm)   # abm "k=v k=v;k=v k=v" [cfg ...]: the same lines under SETS of engine options
+    sets=$1; shift
+    IFS=';' read -ra SETS <<< "$sets"
+    for set_ in "${SETS[@]}"; do for c in ${*:-c1 c5}; do
+      tag=$(echo "$set_" | tr ' =' '__'); opts=""
+      for kv in $set_; do opts="$opts --option $kv"; done
+      python bench.py $(bench_args $c) --no-cpu-baseline --time-to-tol 0 $opts > "$G/r${ROUND}_ab_${tag}_$c.json" 2> "$G/r${ROUND}_ab_${tag}_$c.err"
+      python - "$G/r${ROUND}_ab_${tag}_$c.json" "$set_" $c <<'P'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(sys.argv[2], "|", sys.argv[3], "value %.1f" % d["value"], "steady %.1f" % d["steady_state"]["value"], "y_solve", (d.get("y_solve") or {}).get("ms_per_iteration"))
+P
+    done; done ;;
   prof)
     for c in ${*:-c2 c2_20 c4 c1 c5 c3}; do
       case $c in
