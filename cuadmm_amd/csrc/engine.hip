@@ -253,7 +253,9 @@ struct cuadmm_solver {
     int tail_pivot = 1;           // "tail_pivot": the tail's dense LDL^T with diagonal pivoting (0: unpivoted, rounds 2 - 5)
     int tail_fat = 0;             // "tail_fat": the one-pass kernel on 512-thread workgroups with twice the rows in flight for K <= 10 240 (measured: slower; A/B)
     int tail_depth = 1;           // "tail_depth" / "tail_order": ring depth and row walk of the tail's one-pass kernel (tail_solve.hip)
-    int tail_order = 0;
+    int tail_order = 1;
+    int tail_zreg = 1;            // "tail_zreg": z in registers in that kernel where it fits
+    int tail_rb = 0;              // "tail_rb": rows per barrier of that kernel (0: by size)
     int tail_prefetch = 1;        // "tail_prefetch": the tail's one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5; A/B)
     int tail_shard = 1;           // "tail_shard": world > 1, replicated solve: every rank applies 1 / world of the tail's rows, the K partial
                                   // results are all-reduced (0: every rank applies the whole tail)
@@ -807,6 +809,8 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
       s->tail.prefetch = s->sw.tail_prefetch != 0;
       s->tail.depth = s->sw.tail_depth;
       s->tail.order = s->sw.tail_order;
+      s->tail.rows_per_group = s->sw.tail_rb;
+      s->tail.zreg = s->sw.tail_zreg != 0;
       s->tail.fat = s->sw.tail_fat != 0;
       s->tail.dd_dot = s->sw.tail_dd != 0;
       s->tail.refine = s->sw.tail_refine != 0;
@@ -1413,6 +1417,8 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "tail_prefetch") s->sw.tail_prefetch = (int)value;
   else if (k == "tail_depth") { if (value < 0 || value > 3) { set_error("set_option: tail_depth must be 0 .. 3"); return CUADMM_ERR_INVALID; } s->sw.tail_depth = (int)value; }
   else if (k == "tail_order") s->sw.tail_order = value != 0 ? 1 : 0;
+  else if (k == "tail_rb") s->sw.tail_rb = (int)value;
+  else if (k == "tail_zreg") s->sw.tail_zreg = (int)value;
   else if (k == "tail_fat") s->sw.tail_fat = (int)value;
   else if (k == "tail_dd") s->sw.tail_dd = (int)value;
   else if (k == "tail_refine") s->sw.tail_refine = (int)value;

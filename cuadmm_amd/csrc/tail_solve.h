@@ -35,7 +35,9 @@ struct TailSolve {
   bool fat = false;            // option tail_fat (measured, off): K <= 10 240 on 512-thread workgroups of up to 256 VGPRs (two rows per group, two groups in
                                // flight): 92 us against 81 at K = 9 216, 48 against 47 at 7 168 -- NOTEBOOK.md "Round 6"
   int depth = 1;               // option tail_depth: row groups in flight beyond the current one in the one-pass kernel (tail_solve.hip: ts_onepass_kernel)
-  int order = 0;               // option tail_order: 1 = a workgroup walks its rows alternately from the long and the short end
+  bool zreg = true;            // option tail_zreg: the one-pass kernel keeps a thread's entries of z in registers where they fit (0: in LDS, rounds 3 - 6)
+  int rows_per_group = 0;      // option tail_rb: rows that share one barrier in the one-pass kernel (0: two up to 8 192 columns, else one)
+  int order = 1;               // option tail_order: 1 = a workgroup walks its rows alternately from the long and the short end (0: longest first, rounds 3 - 6)
   bool prefetch = true;        // option tail_prefetch: the one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5)
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   double pinv_tol = 0.0;       // option tail_pinv_tol (experiment, DESIGN.md section 4 "Round 5: dense tree tops"): pivots of the tail below it in

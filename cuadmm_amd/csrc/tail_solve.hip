@@ -198,23 +198,36 @@ __global__ void ts_axpy1_kernel(double* __restrict__ y, const double* __restrict
 // by zero).  PF: the rows of the NEXT group are in flight while the current group is reduced and applied (two register buffers; the
 // compiler's counter for the current group's data, `s_waitcnt vmcnt(N)`, leaves the next group's loads outstanding across the barrier).
 // The association of the sums follows the new column ownership: results differ from rounds 3 - 5 in the last bits, deterministically.
+// A wavefront's 64 NC columns relate to row i in one of three ways, and which one is wave-uniform (seg0 = first column of the segment, in scalar
+// registers): INSIDE the triangle (seg0 + 64 NC - 1 <= i: plain loads from one address register and immediates), ABOVE the diagonal (seg0 > i:
+// nothing to read, nothing to multiply -- the wavefront only takes part in the row's barrier), or CROSSING it (one wavefront per row: per-pair
+// predicates; a pair above the diagonal reads the row's first pair and is zeroed by a select).  Half of all (wavefront, row) pairs are ABOVE:
+// before round 6's last version every one of them issued its loads, selects and 4 NC multiply-adds on the port the busy wavefronts share.
+template <int NC>
+__device__ __forceinline__ int ts_seg_class(int seg0, int i) { return seg0 + 64 * NC - 1 <= i ? 0 : (seg0 > i ? 2 : 1); }
 template <int NC, int RB>
 struct TsRows {
   static_assert(NC % 2 == 0, "column pairs");
   double2 w[RB][NC / 2];
-  __device__ __forceinline__ void load(const double* __restrict__ W, long long ld, int K, int col0, int r0, int r_end) {
+  __device__ __forceinline__ void load(const double* __restrict__ W, long long ld, int K, int col0, int seg0, int r0, int r_end) {
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
       // (a group beyond the range re-reads the range's LAST row -- always a row this rank holds, keep_shard -- and is multiplied by zero)
       const int i = K - 1 - (r0 + q < r_end ? r0 + q : r_end - 1);
       const double* row = W + (long long)i * ld;
+      const int cls = ts_seg_class<NC>(seg0, i);
+      if (cls == 0) {
 #pragma unroll
-      for (int p = 0; p < NC / 2; ++p) {
-        const int col = col0 + 128 * p;          // the pair (col, col + 1) is inside the triangle iff col <= i (its second half iff col < i)
-        const double2 v = *reinterpret_cast<const double2*>(row + (col <= i ? col : 0));
-        w[q][p].x = col <= i ? v.x : 0.0;        // entries above the diagonal count as exact zeros and are not read
-        w[q][p].y = col < i ? v.y : 0.0;
-      }
+        for (int p = 0; p < NC / 2; ++p) w[q][p] = *reinterpret_cast<const double2*>(row + col0 + 128 * p);
+      } else if (cls == 1) {
+#pragma unroll
+        for (int p = 0; p < NC / 2; ++p) {
+          const int col = col0 + 128 * p;          // the pair (col, col + 1) is inside the triangle iff col <= i (its second half iff col < i)
+          const double2 v = *reinterpret_cast<const double2*>(row + (col <= i ? col : 0));
+          w[q][p].x = col <= i ? v.x : 0.0;        // entries above the diagonal count as exact zeros and are not read
+          w[q][p].y = col < i ? v.y : 0.0;
+        }
+      }                                            // (ABOVE: the registers keep whatever they held; ts_rows_apply does not touch them)
     }
   }
 };
@@ -233,43 +246,70 @@ __device__ __forceinline__ void dd_add(double& hi, double& lo, double h2, double
   lo += ((hi - (s - bb)) + (h2 - bb)) + l2;
   hi = s;
 }
-template <int NC, int RB, bool DD, int NW = 16, bool TIGHT = false>
-__device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const double* zs, double (*red)[RB][DD ? 32 : 16], int it, int lane, int wave, int K, int r0,
-                                              int r_end, const double* __restrict__ dinv, double2 (&xa)[NC / 2]) {
+// the sum of the sixteen wavefronts' parts, in every lane: lane l takes part l & 15, four butterfly steps on the DPP crossbar inside each row of
+// 16 lanes -- the tree (((0+1)+(2+3))+((4+5)+(6+7))) + (((8+9)+(10+11))+((12+13)+(14+15))) of rounds 3 - 6, bit for bit (every step adds a pair
+// that the old expression added, in one order or the other), for ONE LDS read per wavefront instead of eight 16-byte broadcasts and fifteen adds
+__device__ __forceinline__ double ts_sum16(const double* rr, int lane) {
+  double v = rr[lane & 15];
+  v += sw_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += sw_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += sw_dpp<0x141>(v);   // row_half_mirror
+  v += sw_dpp<0x140>(v);   // row_mirror
+  return v;
+}
+// ZREG: the thread's NC entries of z live in registers (zr) instead of LDS.  They are the same for every row -- the LDS copy only existed for the
+// registers' sake -- and reading them back cost 64 NC bytes of LDS traffic per row and wavefront: with the sixteen wavefronts of a CU behind one
+// LDS port, a third of a row's time (tools/ubench/tri_stream.hip, MODE 3: the tick stamps of wavefront 0).
+template <int NC, int RB, bool DD, int NW = 16, bool TIGHT = false, bool ZREG = false>
+__device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const double* zs, const double2 (&zr)[ZREG ? NC / 2 : 1], double (*red)[RB][DD ? 32 : 16],
+                                              int it, int lane, int wave, int seg0, int K, int r0, int r_end, const double* __restrict__ dinv,
+                                              double2 (&xa)[NC / 2]) {
   static_assert(NW == 16 || NW == 8, "wavefronts per workgroup");
   static_assert(!DD || NW == 16, "the compensated variant exists for 1024 threads only");
-  double part[RB];
+  double part[RB], dv[RB];
+  bool busy[RB];                             // wave-uniform: the wavefront's segment reaches into row q (ts_seg_class: INSIDE or CROSSING)
+#pragma unroll
+  for (int q = 0; q < RB; ++q) {
+    const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;
+    busy[q] = seg0 <= (i >= 0 ? i : K - r_end);     // (a row beyond the range: the class of the row that was loaded in its place)
+    dv[q] = i >= 0 && busy[q] ? dinv[i] : 0.0;      // the pivot travels (a scalar load) while the dot product is formed, not after the barrier
+  }
 #pragma unroll
   for (int q = 0; q < RB; ++q) {
     part[q] = 0.0;
     if constexpr (DD) {
       double lo = 0.0;
+      if (busy[q]) {
 #pragma unroll
-      for (int p = 0; p < NC / 2; ++p) {
-        const double2 zz = *reinterpret_cast<const double2*>(zs + 128 * p);
-        dd_fma_acc(part[q], lo, R.w[q][p].x, zz.x);
-        dd_fma_acc(part[q], lo, R.w[q][p].y, zz.y);
+        for (int p = 0; p < NC / 2; ++p) {
+          const double2 zz = *reinterpret_cast<const double2*>(zs + 128 * p);
+          dd_fma_acc(part[q], lo, R.w[q][p].x, zz.x);
+          dd_fma_acc(part[q], lo, R.w[q][p].y, zz.y);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) dd_add(part[q], lo, __shfl_xor(part[q], o, 64), __shfl_xor(lo, o, 64));
       }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) dd_add(part[q], lo, __shfl_xor(part[q], o, 64), __shfl_xor(lo, o, 64));
       if (lane == 0) { red[it & 1][q][wave] = part[q]; red[it & 1][q][16 + wave] = lo; }
     } else {
+      if (busy[q]) {
 #pragma unroll
-      for (int p = 0; p < NC / 2; ++p) {
-        const double2 zz = *reinterpret_cast<const double2*>(zs + 128 * p);
-        part[q] += R.w[q][p].x * zz.x;
-        part[q] += R.w[q][p].y * zz.y;
-        // (TIGHT: at the register budget's edge the scheduler otherwise reads every z pair of the row up front -- 2 NC registers -- and spills)
-        if (TIGHT && (p & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        for (int p = 0; p < NC / 2; ++p) {
+          double2 zz;
+          if constexpr (ZREG) zz = zr[p]; else zz = *reinterpret_cast<const double2*>(zs + 128 * p);
+          part[q] += R.w[q][p].x * zz.x;
+          part[q] += R.w[q][p].y * zz.y;
+          // (TIGHT: at the register budget's edge the scheduler otherwise reads every z pair of the row up front -- 2 NC registers -- and spills)
+          if (TIGHT && (p & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        part[q] = wave_sum(part[q]);
       }
-      part[q] = wave_sum(part[q]);
       if (lane == 0) red[it & 1][q][wave] = part[q];
     }
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < RB; ++q) {
-    const int i = r0 + q < r_end ? K - 1 - (r0 + q) : -1;
+    if (!busy[q]) continue;                  // every entry of the row in this wavefront's columns is an exact zero
     const double* rr = red[it & 1][q];
     double u;
     if constexpr (DD) {
@@ -280,34 +320,39 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
     } else if constexpr (NW == 8) {
       u = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
     } else {
-      u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
-          (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
+      u = ts_sum16(rr, lane);
     }
-    const double vq = i >= 0 ? u * dinv[i] : 0.0;
+    const double vq = u * dv[q];
 #pragma unroll
     for (int p = 0; p < NC / 2; ++p) { xa[p].x += vq * R.w[q][p].x; xa[p].y += vq * R.w[q][p].y; }
   }
 }
-// NT threads: 1024 (sixteen wavefronts, <= 128 VGPRs each) or 512 -- "fewer, fatter threads", option tail_fat, MEASURED AND OFF: the kernel trace puts the
-// 1024-thread kernel at 4.4 TB/s (77 - 81 us at K = 9 216) with 16-byte loads and prefetch alike, ~2.1 us per row and workgroup -- a round trip per row, whatever
-// its length.  Eight wavefronts of up to 256 VGPRs holding two rows per group and two groups in flight (twice the bytes in flight per CU) ran 92 us at K = 9 216
-// and 48 against 47 at 7 168: bytes in flight are not what bounds it either.  Not understood further this round (NOTEBOOK.md "Round 6").
+// NT threads: 1024 (sixteen wavefronts, <= 128 VGPRs each) or 512 -- "fewer, fatter threads", option tail_fat, measured slower and off.
+// WHAT BOUNDS THIS KERNEL (round 6, tools/ubench/tri_stream.hip + the kernel traces profiles/r06_tail_onepass_study.txt): at K = 9 216 it takes
+// 76.8 us for 340 MB whatever is changed inside it -- rows per barrier (1 / 2), groups in flight (0 ... 3), the walk, z in LDS or in registers,
+// the above-diagonal wavefronts idle or busy, 8- or 16-wavefront workgroups: 76.8 - 78.5 us every time.  A FLAT 16-byte-per-lane read of the same
+// bytes takes 60 - 62 us on the same box (5.5 TB/s at this footprint; 6.3 TB/s at 205 MB, where the Infinity Cache holds the operand), and the
+// kernel adds what a flat read does not have: z and the pivot order gathered at the start (two dependent trips before the first dot product),
+// 256 partial vectors written at the end (19 MB) and the ramp of 256 workgroups that all start on their longest row.  The tick stamps of
+// wavefront 0 (MODE 3 of the micro-benchmark) show it never waits for its own row -- it waits at the barrier for the wavefront whose data is
+// last: the kernel runs at the rate the memory system delivers this access pattern, 79 % of the measured flat-read ceiling, 55 % of 8 TB/s.
 // D: row groups in flight BEYOND the one being applied (a ring of D + 1 register buffers; 0: load, apply, load ...).  With one group ahead
 // the wait at the top of a group still sees a whole memory round trip minus the ~0.3 us a group takes to apply: a row per round trip,
 // whatever its length -- the short rows of the triangle's tip are latency-bound (tools/ubench/tri_stream.hip).
 // ORDER 1: a workgroup walks its rows alternately from the long and from the short end, so the chip streams the same mix of long and short
 // rows from the first microsecond to the last (ORDER 0, rounds 3 - 6: longest first -- every workgroup reaches the tip at the same time and
 // the bytes in flight collapse together).  The partial sums associate in the walk's order: the last bits differ between orders, deterministically.
-template <int NC, int RB, int D, bool DD = false, int NT = 1024, int ORDER = 0>
+template <int NC, int RB, int D, bool DD = false, int NT = 1024, int ORDER = 0, bool ZREG = false>
 __global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                         const double* __restrict__ dinv, double* __restrict__ P, int r_begin, int r_end,
                                                         const int* __restrict__ perm) {
   constexpr int NW = NT / 64;
-  constexpr bool TIGHT = NT == 1024 && NC * RB * (D + 1) + NC >= 40;      // doubles of row data and accumulators per thread: 80 of the 128 registers
+  constexpr bool TIGHT = NT == 1024 && !ZREG && NC * RB * (D + 1) + NC >= 40;      // doubles of row data and accumulators per thread: 80 of the 128 registers
   extern __shared__ __attribute__((aligned(16))) double ts_zs[];          // z, K doubles (zero beyond K up to NT NC)
   __shared__ double red[2][RB][DD ? 32 : 16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = wave * (64 * NC) + 2 * lane;
+  const int seg0 = __builtin_amdgcn_readfirstlane(wave) * (64 * NC);      // first column of the wavefront's segment, wave-uniform (ts_seg_class)
   const int G = (int)gridDim.x, g = (int)blockIdx.x, step = G * RB;
   // rows r = K - 1 - i in [r_begin, r_end): the whole triangle, or this rank's share of it (TailSolve::shard_*)
   const int first = r_begin + g * RB;
@@ -325,18 +370,27 @@ __global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict
   };
   TsRows<NC, RB> buf[D + 1];
 #pragma unroll
-  for (int d = 0; d < (D > 0 ? D : 1); ++d) buf[d].load(W, ld, K, col0, group_row(d), r_end);      // the first groups travel while z is staged
-  for (int c = tid; c < NT * NC; c += NT) ts_zs[c] = c < K ? z[perm ? perm[c] : c] : 0.0;      // (perm: the factor's pivoting order, TailSolve::perm_d)
+  for (int d = 0; d < (D > 0 ? D : 1); ++d) buf[d].load(W, ld, K, col0, seg0, group_row(d), r_end);      // the first groups travel while z is staged
+  double2 zr[ZREG ? NC / 2 : 1];
   double2 xa[NC / 2];
 #pragma unroll
   for (int p = 0; p < NC / 2; ++p) xa[p] = make_double2(0.0, 0.0);
-  __syncthreads();
+  if constexpr (ZREG) {                      // (perm: the factor's pivoting order, TailSolve::perm_d)
+#pragma unroll
+    for (int p = 0; p < NC / 2; ++p) {
+      const int col = col0 + 128 * p;
+      zr[p] = col >= K ? make_double2(0.0, 0.0) : perm ? make_double2(z[perm[col]], z[perm[col + 1]]) : *reinterpret_cast<const double2*>(z + col);
+    }
+  } else {
+    for (int c = tid; c < NT * NC; c += NT) ts_zs[c] = c < K ? z[perm ? perm[c] : c] : 0.0;
+    __syncthreads();
+  }
   const double* zs = ts_zs + col0;
   int it = 0;
   if constexpr (D == 0) {                    // one group in flight (the registers of a second one would spill)
     for (int j = 0; j < count; ++j) {
-      if (j) buf[0].load(W, ld, K, col0, group_row(j), r_end);
-      ts_rows_apply<NC, RB, DD, NW, TIGHT>(buf[0], zs, red, it++, lane, wave, K, group_row(j), r_end, dinv, xa);
+      if (j) buf[0].load(W, ld, K, col0, seg0, group_row(j), r_end);
+      ts_rows_apply<NC, RB, DD, NW, TIGHT, ZREG>(buf[0], zs, zr, red, it++, lane, wave, seg0, K, group_row(j), r_end, dinv, xa);
     }
   } else {
     int j = 0;
@@ -344,8 +398,8 @@ __global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict
 #pragma unroll
       for (int s = 0; s <= D; ++s) {
         if (j < count) {
-          buf[(s + D) % (D + 1)].load(W, ld, K, col0, group_row(j + D), r_end);
-          ts_rows_apply<NC, RB, DD, NW, TIGHT>(buf[s], zs, red, it++, lane, wave, K, group_row(j), r_end, dinv, xa);
+          buf[(s + D) % (D + 1)].load(W, ld, K, col0, seg0, group_row(j + D), r_end);
+          ts_rows_apply<NC, RB, DD, NW, TIGHT, ZREG>(buf[s], zs, zr, red, it++, lane, wave, seg0, K, group_row(j), r_end, dinv, xa);
           ++j;
         }
       }
@@ -383,7 +437,7 @@ template <int NC, int Q, int RB, int OCC = 8>
 __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                                    const double* __restrict__ dinv, double* __restrict__ P,
                                                                    unsigned long long* __restrict__ part, int* __restrict__ fail, int r_begin, int r_end,
-                                                                   const int* __restrict__ perm) {
+                                                                   const int* __restrict__ perm, int order) {
   extern __shared__ double ts_zs[];          // z of this thread's own columns: word (c * 1024 + tid); nobody else reads it
   __shared__ double red[2][RB][16];
   __shared__ double ush[2][RB];
@@ -418,8 +472,13 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
   double2 xa[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) xa[p] = make_double2(0.0, 0.0);
-  int it = 0;
-  for (int r0 = r_begin + group * RB; r0 < r_end; r0 += G * RB, ++it) {
+  // the group's row groups, walked longest first (order 0) or alternately from the long and the short end (order 1, ts_onepass_kernel): the
+  // members of a group share `group` and `count`, so they walk the same sequence and meet in the same exchange slots
+  const int first = r_begin + group * RB, stride = G * RB;
+  const int count = first < r_end ? (r_end - first + stride - 1) / stride : 0;
+  for (int it = 0; it < count; ++it) {
+    const int jw = order ? ((it & 1) ? count - 1 - (it >> 1) : (it >> 1)) : it;
+    const int r0 = first + jw * stride;
     double2 w[RB][NP];
     const int seg0 = (wave_u * Q + member) * (64 * NC);   // this wavefront's segment: uniform
 #pragma unroll
@@ -1116,6 +1175,40 @@ int TailSolve::apply_refined(double* vin, hipStream_t st) {      // (vin: the ve
   return CUADMM_OK;
 }
 
+// Which (NC, RB, D) exist: RB NC (D + 1) doubles of row buffers + NC accumulators per thread within ~104 of the 128 registers a 1024-thread
+// workgroup leaves a wavefront (the rest: z pairs in flight, addresses, the reduction).  Measured by the compiler's own count, not guessed:
+// every instantiation below builds without scratch (tools: -Rpass-analysis=kernel-resource-usage).
+template <int NC, int RB, int D, bool ZREG>
+constexpr bool ts_onepass_fits = (D <= 1 || (RB == 1 && D <= 3 && NC <= 10)) && NC * RB * (D + 1) + NC + (ZREG ? NC : 0) <= 52;
+template <int NC, int RB, int D, class L>
+static int ts_onepass_launch_one(int order, bool zreg, L& launch) {
+  if constexpr (ts_onepass_fits<NC, RB, D, true>) {
+    if (zreg) return order ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 1, true>) : launch(ts_onepass_kernel<NC, RB, D, false, 1024, 0, true>);
+  }
+  if constexpr (ts_onepass_fits<NC, RB, D, false>) {
+    return order ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 1>) : launch(ts_onepass_kernel<NC, RB, D, false, 1024, 0>);
+  } else {
+    (void)order; (void)launch; (void)zreg;
+    return -1;
+  }
+}
+template <int NC, class L>
+static int ts_onepass_launch(int rb, int dep, int order, bool zreg, L& launch) {
+  if (rb == 2) {
+    switch (dep) {
+      case 0: return ts_onepass_launch_one<NC, 2, 0>(order, zreg, launch);
+      case 1: return ts_onepass_launch_one<NC, 2, 1>(order, zreg, launch);
+      default: return ts_onepass_launch_one<NC, 2, 2>(order, zreg, launch);
+    }
+  }
+  switch (dep) {
+    case 0: return ts_onepass_launch_one<NC, 1, 0>(order, zreg, launch);
+    case 1: return ts_onepass_launch_one<NC, 1, 1>(order, zreg, launch);
+    case 2: return ts_onepass_launch_one<NC, 1, 2>(order, zreg, launch);
+    default: return ts_onepass_launch_one<NC, 1, 3>(order, zreg, launch);
+  }
+}
+
 // vin <- W^T diag(dinv) W vin
 int TailSolve::apply(hipStream_t st) {
   // (refined: every rank of a sharded engine applies the WHOLE tail -- the result is replicated, no reduction)
@@ -1186,30 +1279,25 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     if (dd_dot && (nc == 9 || nc == 10)) rc = launch(ts_onepass_kernel<10, 1, 1, true>);      // experiment (option tail_dd): compensated u = W z
     else if (dd_dot && (nc == 15 || nc == 16)) rc = launch(ts_onepass_kernel<16, 1, 0, true>);
     else {
-      const int h = (nc + 1) / 2;            // NC = 2 h
-      int dep = prefetch ? depth : 0;
-      if (h >= 9) dep = 0;
-      else if (h >= 7 && dep > 1) dep = 1;
-      else if (h >= 5 && dep > 2) dep = 2;
-#define CUADMM_TS_ORD(NC_, RB_, D_) (order ? launch(ts_onepass_kernel<NC_, RB_, D_, false, 1024, 1>) : launch(ts_onepass_kernel<NC_, RB_, D_, false, 1024, 0>))
-#define CUADMM_TS_CASE_LOW(NC_)                                   \
-  (dep == 0 ? CUADMM_TS_ORD(NC_, 2, 0) : dep == 1 ? CUADMM_TS_ORD(NC_, 2, 1) : dep == 2 ? CUADMM_TS_ORD(NC_, 1, 2) : CUADMM_TS_ORD(NC_, 1, 3))
-#define CUADMM_TS_CASE_MID(NC_) (dep == 0 ? CUADMM_TS_ORD(NC_, 2, 0) : dep == 1 ? CUADMM_TS_ORD(NC_, 1, 1) : CUADMM_TS_ORD(NC_, 1, 2))
-      switch (h) {
-        case 1: rc = CUADMM_TS_CASE_LOW(2); break;
-        case 2: rc = CUADMM_TS_CASE_LOW(4); break;
-        case 3: rc = CUADMM_TS_CASE_LOW(6); break;
-        case 4: rc = CUADMM_TS_CASE_LOW(8); break;
-        case 5: rc = CUADMM_TS_CASE_MID(10); break;
-        case 6: rc = CUADMM_TS_CASE_MID(12); break;
-        case 7: rc = dep == 0 ? CUADMM_TS_ORD(14, 2, 0) : CUADMM_TS_ORD(14, 1, 1); break;
-        case 8: rc = dep == 0 ? CUADMM_TS_ORD(16, 1, 0) : CUADMM_TS_ORD(16, 1, 1); break;
-        case 9: rc = CUADMM_TS_ORD(18, 1, 0); break;
-        default: rc = CUADMM_TS_ORD(20, 1, 0); break;
+      // the requested grouping, degraded until the instantiation exists (ts_onepass_fits: the row buffers and accumulators within the budget)
+      int rb_ = rows_per_group, dep = prefetch ? depth : 0;
+      if (rb_ != 1 && rb_ != 2) rb_ = nc <= 8 ? 2 : 1;                    // rounds 3 - 6: two rows per group up to NC = 8
+      rc = -1;
+      while (rc == -1) {
+        switch ((nc + 1) / 2) {
+          case 1: rc = ts_onepass_launch<2>(rb_, dep, order, zreg, launch); break;
+          case 2: rc = ts_onepass_launch<4>(rb_, dep, order, zreg, launch); break;
+          case 3: rc = ts_onepass_launch<6>(rb_, dep, order, zreg, launch); break;
+          case 4: rc = ts_onepass_launch<8>(rb_, dep, order, zreg, launch); break;
+          case 5: rc = ts_onepass_launch<10>(rb_, dep, order, zreg, launch); break;
+          case 6: rc = ts_onepass_launch<12>(rb_, dep, order, zreg, launch); break;
+          case 7: rc = ts_onepass_launch<14>(rb_, dep, order, zreg, launch); break;
+          case 8: rc = ts_onepass_launch<16>(rb_, dep, order, zreg, launch); break;
+          case 9: rc = ts_onepass_launch<18>(rb_, dep, order, zreg, launch); break;
+          default: rc = ts_onepass_launch<20>(rb_, dep, order, zreg, launch); break;
+        }
+        if (rc == -1) { if (dep > 0) --dep; else rb_ = 1; }              // (one row, nothing ahead: exists for every NC)
       }
-#undef CUADMM_TS_CASE_MID
-#undef CUADMM_TS_CASE_LOW
-#undef CUADMM_TS_ORD
     }
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, n_wg, vin, (unsigned long long*)nullptr, 0, perm_d);
@@ -1220,7 +1308,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);
     auto kern = ts_onepass_group_kernel<8, Q, 4, 4>;
     if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d);
+    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d, order);
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q, perm_d);
   } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
@@ -1233,7 +1321,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
     auto launch = [&](auto kern) -> int {
       if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d);
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d, order);
       return CUADMM_OK;
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);

@@ -41,9 +41,11 @@ struct Row {
   }
 };
 
+// MODE 3 = MODE 1 with tick stamps (s_memtime, 100 MHz): per workgroup, wavefront 0 accumulates the ticks it spends waiting for a row's data,
+// forming its dot product and wave sum, at the barrier, and in the accumulate -- ticks[g * 8 + 0..3], rows in [4], whole kernel in [5]
 template <int NC, int D, int MODE, int ORDER>
 __global__ __launch_bounds__(1024) void tri_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
-                                                   const double* __restrict__ dinv, double* __restrict__ P) {
+                                                   const double* __restrict__ dinv, double* __restrict__ P, long long* __restrict__ ticks = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double zs_all[];
   __shared__ double red[2][16];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,6 +72,8 @@ __global__ __launch_bounds__(1024) void tri_kernel(const double* __restrict__ W,
   __syncthreads();
   const double* zs = zs_all + col0;
   int j = 0, it = 0;
+  long long tk0 = 0, tw = 0, td = 0, tb = 0, ta = 0;
+  if (MODE == 3) tk0 = (long long)__builtin_amdgcn_s_memtime();
   while (j < count) {
 #pragma unroll
     for (int s = 0; s <= D; ++s) {
@@ -85,6 +89,12 @@ __global__ __launch_bounds__(1024) void tri_kernel(const double* __restrict__ W,
 #pragma unroll
           for (int p = 0; p < NC / 2; ++p) { xa[p].x += R.w[p].x; xa[p].y += R.w[p].y; }
         } else {
+          long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+          if (MODE == 3) {
+            c0 = (long long)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * (NC / 2)) : "memory");      // this row's data (the D newer rows stay in flight)
+            c1 = (long long)__builtin_amdgcn_s_memtime();
+          }
           double part = 0.0;
 #pragma unroll
           for (int p = 0; p < NC / 2; ++p) {
@@ -94,13 +104,20 @@ __global__ __launch_bounds__(1024) void tri_kernel(const double* __restrict__ W,
           }
           part = wave_sum(part);
           if (lane == 0) red[it & 1][wave] = part;
+          if (MODE == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
           __syncthreads();
+          if (MODE == 3) c3 = (long long)__builtin_amdgcn_s_memtime();
           const double* rr = red[it & 1];
           const double u = (((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]))) +
                            (((rr[8] + rr[9]) + (rr[10] + rr[11])) + ((rr[12] + rr[13]) + (rr[14] + rr[15])));
           const double vq = u * dinv[i];
 #pragma unroll
           for (int p = 0; p < NC / 2; ++p) { xa[p].x += vq * R.w[p].x; xa[p].y += vq * R.w[p].y; }
+          if (MODE == 3) {
+            asm volatile("" ::"v"(xa[0].x));
+            const long long c4 = (long long)__builtin_amdgcn_s_memtime();
+            tw += c1 - c0; td += c2 - c1; tb += c3 - c2; ta += c4 - c3;
+          }
           ++it;
         }
         ++j;
@@ -111,6 +128,10 @@ __global__ __launch_bounds__(1024) void tri_kernel(const double* __restrict__ W,
   for (int p = 0; p < NC / 2; ++p) {
     const int col = col0 + 128 * p;
     if (col < K) *reinterpret_cast<double2*>(P + (size_t)g * K + col) = xa[p];
+  }
+  if (MODE == 3 && ticks && tid == 0) {
+    long long* t = ticks + (size_t)g * 8;
+    t[0] = tw; t[1] = td; t[2] = tb; t[3] = ta; t[4] = count; t[5] = (long long)__builtin_amdgcn_s_memtime() - tk0;
   }
 }
 
@@ -145,7 +166,7 @@ __global__ void colsum_kernel(const double* __restrict__ P, int K, int G, double
   x[c] = s;
 }
 
-struct Ctx { double *W, *z, *dinv, *P, *x; int K, G; };
+struct Ctx { double *W, *z, *dinv, *P, *x; long long* ticks; int K, G; };
 
 template <int NC, int D, int MODE, int ORDER>
 static void run(const Ctx& c, const std::vector<double>* ref, std::vector<double>* keep) {
@@ -156,11 +177,11 @@ static void run(const Ctx& c, const std::vector<double>* ref, std::vector<double
   CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(c.G), dim3(1024), lds, 0, c.W, (long long)c.K, c.K, c.z, c.dinv, c.P);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(c.G), dim3(1024), lds, 0, c.W, (long long)c.K, c.K, c.z, c.dinv, c.P, c.ticks);
   CK(hipDeviceSynchronize());
   const int reps = 20;
   CK(hipEventRecord(e0));
-  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(c.G), dim3(1024), lds, 0, c.W, (long long)c.K, c.K, c.z, c.dinv, c.P);
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(c.G), dim3(1024), lds, 0, c.W, (long long)c.K, c.K, c.z, c.dinv, c.P, c.ticks);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -180,6 +201,15 @@ static void run(const Ctx& c, const std::vector<double>* ref, std::vector<double
   }
   printf("K %6d NC %2d MODE %d D %d ORDER %d | %7.1f us  %5.2f TB/s | vgpr %3d spill %d | dev %.1e\n", c.K, NC, MODE, D, ORDER, us, bytes / us * 1e-6,
          fa.numRegs, (int)fa.localSizeBytes, dev);
+  if (MODE == 3) {
+    std::vector<long long> t((size_t)c.G * 8);
+    CK(hipMemcpy(t.data(), c.ticks, sizeof(long long) * t.size(), hipMemcpyDeviceToHost));
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int g = 0; g < c.G; ++g) for (int q = 0; q < 6; ++q) s[q] += (double)t[(size_t)g * 8 + q];
+    // s_memtime ticks at 100 MHz: 10 ns each
+    printf("      wavefront 0, mean over %d workgroups, us per kernel: wait-for-row %.1f  dot+wave-sum %.1f  barrier %.1f  accumulate %.1f  | rows %.1f  kernel %.1f\n", c.G,
+           s[0] / c.G * 1e-2, s[1] / c.G * 1e-2, s[2] / c.G * 1e-2, s[3] / c.G * 1e-2, s[4] / c.G, s[5] / c.G * 1e-2);
+  }
   fflush(stdout);
   CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -188,6 +218,9 @@ template <int NC>
 static void sweep(const Ctx& c) {
   std::vector<double> ref;
   run<NC, 1, 1, 0>(c, nullptr, &ref);      // production shape
+  run<NC, 1, 3, 0>(c, &ref, nullptr);
+  run<NC, 1, 3, 1>(c, &ref, nullptr);
+  if constexpr (NC <= 12) run<NC, 2, 3, 1>(c, &ref, nullptr);
   run<NC, 1, 0, 0>(c, nullptr, nullptr);
   run<NC, 2, 0, 0>(c, nullptr, nullptr);
   run<NC, 1, 0, 1>(c, nullptr, nullptr);
@@ -218,6 +251,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&c.W, sizeof(double) * (size_t)K * K));
     CK(hipMalloc(&c.z, sizeof(double) * K)); CK(hipMalloc(&c.dinv, sizeof(double) * K)); CK(hipMalloc(&c.x, sizeof(double) * K));
     CK(hipMalloc(&c.P, sizeof(double) * (size_t)c.G * K));
+    CK(hipMalloc(&c.ticks, sizeof(long long) * (size_t)c.G * 8));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, c.W, (size_t)K * K, 1u);
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, c.z, (size_t)K, 2u);
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, c.dinv, (size_t)K, 3u);
