@@ -25,6 +25,9 @@ struct SignPsd {
                                              // 66 ... 120: projection 1.03 -> 0.98 ms, taha1a 1.08 -> 1.02), one n = 2 000 block loses a step (C3 17 -> 18).
                                              // A property of the group, not of the path: launches and one-launch kernel stay bit-identical
   double *X0 = nullptr, *S = nullptr, *Y = nullptr, *T = nullptr, *colsum = nullptr, *scale = nullptr;
+  double* Mw = nullptr;                      // fifth matrix per member: M = R - R Y of a clean mega-lift (allocated when a group padded to <= clean_max_n exists)
+  int* d_cont = nullptr;                     // [parity][member]: the next step is a clean mega-lift's second slot
+  int clean_max_n = 480;                     // (below 512: a single block padded to 512 runs the super-block tile order, which has no second slot) like hint_max_n: a property of the group, so launches and one-launch kernel stay bit-identical and C3 pays nothing
   void* d_state = nullptr;                   // 2 x SignDevState per member of the largest group (adaptive schedule, sign_sched.h)
   void* d_done = nullptr;                    // SignDone per member
   double* d_part = nullptr;                  // per-tile partial sums of the schedule statistics (p1 | p2)

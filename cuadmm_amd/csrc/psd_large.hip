@@ -79,7 +79,25 @@ struct SignArgs {
   const int* ids;           // member -> block id
   int count, step;
   unsigned* bar;            // per member: barrier counter of the one-launch variant (lg_sign_cluster_kernel); may be null
+  int* cont;                // [parity][member]: version k says whether step k is the SECOND slot of a clean mega-lift (sign_sched.h); null: never
+  int clean;                // this group's schedule takes clean mega-lifts (padded size <= 512: the fifth matrix per member exists)
+  int cap;                  // the step limit of this projection (a mega-lift's two slots never straddle it)
 };
+// fresh schedule state of a member (version 0)
+__device__ __forceinline__ void lg_fresh_state(const SignArgs& sa, int m, int id, int n) {
+  SignDevState st;
+  st.sched = SignSched();
+  if (sa.hint && sa.hint[id] > 0) st.sched.lift0 = sa.hint[id];
+  st.sched.clean = sa.clean != 0 && sa.cont != nullptr;
+  if (sa.cap > 0 && sa.cap < SignSched::kCap) st.sched.cap = sa.cap;
+  st.mu = 1.0;
+  st.n = n;
+  sa.st[m] = st;
+  sa.done[m].done_at = 0x7fffffff;
+  sa.done[m].steps = 0;
+  if (sa.bar) sa.bar[m] = 0u;
+  if (sa.cont) { sa.cont[m] = 0; sa.cont[sa.count + m] = 0; }
+}
 
 // Sums the statistics' slots in a fixed order (all 256 threads), runs the schedule's decision for step sa.step on thread 0
 // and returns mu to every thread; `writer` stores version step + 1 of the state (exactly one workgroup per member does).
@@ -110,8 +128,11 @@ __device__ __forceinline__ double lg_reduce_decide(const SignArgs& sa, int membe
     v.mu = v.sched.decide<true>(v.n, a, b, 0.0, last);
     red[12] = v.mu;
     red[13] = v.sched.cm;                 // > 0: a mega-lift (sign_sched.h), coefficients -cm, 1 + cm
+    red[14] = (double)v.sched.half;       // clean mega-lift: 1 = this step's output is R = S - S Y, 2 = this step applies S + cmc (M - Y M)
+    red[15] = v.sched.cmc;
     if (writer) {
       sa.st[(size_t)(par ^ 1) * sa.count + member] = v;
+      if (sa.cont) __hip_atomic_store(sa.cont + (size_t)(par ^ 1) * sa.count + member, v.sched.cont ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (last) {
         sa.done[member].steps = v.sched.steps;
         sa.done[member].done_at = sa.step + 1;
@@ -140,13 +161,19 @@ __global__ __launch_bounds__(256) void lg_decide_kernel(SignArgs sa, int ntiles)
 //         slots ||S - S Y||_F^2;   ROLE 4: the same with mu read from the state (lg_decide_kernel ran in between);
 // ROLE 3: the final product: B = the buffer that holds the last iterate (Bb after an even number of steps, B2b after
 //         an odd one).
+// CLEAN MEGA-LIFT (sign_sched.h; B2b = the member's fifth matrix M in roles 1, 2, 4).  Its first slot is an ordinary step whose coefficients
+// (-1, 1) leave R = S - S Y where the next iterate would be; the launches of the SECOND slot find that out from the device state and change
+// operands: ROLE 1 forms M = R - R Y instead of Y = S S -- as a FULL product, the tile and its transpose one after the other, no mirroring
+// (R (I - Y) is symmetric only up to the noise the step removes) -- and ROLE 2 / 4 forms S + cmc (M - Y M), mirrored, in place over the old
+// iterate (which the step before left in the output buffer; an element is read and written by the same thread).
 template <bool MIRROR, int TM, int BK>
 struct LgGemmCfg {
   static constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   static constexpr int SMEM = MIRROR ? (TM * (TM + 1) > 2 * BK * LDS ? TM * (TM + 1) : 2 * BK * LDS) : 2 * BK * LDS;
 };
 // The body of one output tile: workgroup (tile_x of grid_x, member).  smem: LgGemmCfg::SMEM doubles, red: 16 doubles.
-template <bool MIRROR, int TM, int BK, int ROLE>
+// CLEAN: the instantiation knows the second slot of a clean mega-lift (groups that never take one -- C3's single large block -- run the other: not a register more)
+template <bool MIRROR, int TM, int BK, int ROLE, bool CLEAN = false>
 __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
                                                  double alpha, double beta, const double* __restrict__ Eb,
                                                  double* __restrict__ Cb, int sb, const SignArgs& sg, const double* __restrict__ B2b,
@@ -154,8 +181,13 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
+  bool slot2 = false;               // ROLE 1: this step is the second slot of a clean mega-lift
   if (ROLE == 1 || ROLE == 2 || ROLE == 4) {
+    int sl = 0;
+    if (CLEAN && ROLE == 1 && sg.cont)               // (issued with the load of done_at: one trip to the L2, not two)
+      sl = __hip_atomic_load(sg.cont + (size_t)(sg.step & 1) * sg.count + member, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (sg.done[member].done_at <= sg.step) return;   // uniform over the workgroup: before any barrier
+    slot2 = sl != 0;
   }
   if (ROLE == 3) {
     const int steps = sg.done[member].done_at <= sg.step ? sg.done[member].steps : sg.step;   // sg.step = steps enqueued
@@ -192,22 +224,41 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   }
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wy = wave >> 1, wx = wave & 1;
-  const int row0 = by * TM, col0 = bx * TM;
+  int row0 = by * TM, col0 = bx * TM;
   const int r16 = lane & 15, kk = lane >> 4;
   const int nbt = N / TM, ntiles = nbt * (nbt + 1) / 2;
-  if (ROLE == 2) {
-    const double mu = lg_reduce_decide(sg, member, ntiles, bx == 0 && by == 0, red);
-    const double cm = red[13];
+  bool full = false;                // ROLE 1, second slot of a clean mega-lift: the full product M = R - R Y
+  double gamma = 0.0;               // ROLE 2 / 4, second slot: C = E + gamma (M - A B)
+  const double* Madd = nullptr;
+  if (ROLE == 2 || ROLE == 4) {
+    double mu, cm, cmc;
+    int half;
+    if (ROLE == 2) {
+      mu = lg_reduce_decide(sg, member, ntiles, bx == 0 && by == 0, red);
+      cm = red[13]; half = (int)red[14]; cmc = red[15];
+    } else {
+      const SignDevState& v = sg.st[(size_t)((sg.step & 1) ^ 1) * sg.count + member];
+      mu = v.mu; cm = v.sched.cm; half = v.sched.half; cmc = v.sched.cmc;
+    }
     alpha = cm > 0.0 ? -cm : -0.5 * mu * mu * mu;
     beta = cm > 0.0 ? 1.0 + cm : 1.5 * mu;
+    if (CLEAN && half == 1) { alpha = -1.0; beta = 1.0; }
+    if (CLEAN && half == 2) {       // A = Y, B = M, E = C = the old iterate (in the output buffer), + cmc M
+      A = Bb + mat; B = B2b + mat; E = Cb + mat; Madd = B2b + mat;
+      alpha = -cmc; beta = 1.0; gamma = cmc;
+    }
   }
-  if (ROLE == 4) {
-    const SignDevState& v = sg.st[(size_t)((sg.step & 1) ^ 1) * sg.count + member];
-    const double mu = v.mu, cm = v.sched.cm;
-    alpha = cm > 0.0 ? -cm : -0.5 * mu * mu * mu;
-    beta = cm > 0.0 ? 1.0 + cm : 1.5 * mu;
+  if (CLEAN && ROLE == 1 && slot2) {      // A = R (the step before left it where the iterate would be), B = Y, C = M
+    full = true;
+    B = Cb + mat; E = Ab + mat; C = const_cast<double*>(B2b) + mat;
+    alpha = -1.0; beta = 1.0;
   }
 
+  double p0 = 0.0, p1 = 0.0;     // ROLE 1: tr Y, ||Y||_F^2; ROLE 2 / 4: ||S - S Y||_F^2 (this tile's share)
+  // (a full product runs the tile and then its transpose: the same workgroup, operands swapped by symmetry of the ROLES, not of the result)
+  const int npass = (CLEAN && full && by != bx) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  if (pass == 1) { const int t_ = by; by = bx; bx = t_; row0 = by * TM; col0 = bx * TM; }
   lg_v4f64 acc[NTW][NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
@@ -268,7 +319,6 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   // epilogue: D[row = (l>>4) + 4*reg][col = l&15] per 16x16 tile.  The mirrored copy goes through LDS so that it is
   // stored row-wise too (a direct transposed store puts the 16 lanes of a fragment 8N bytes apart: one L2 channel).
   if (MIRROR) __syncthreads();   // everyone is done with As / Bs: Ct overlays them
-  double p0 = 0.0, p1 = 0.0;     // ROLE 1: tr Y, ||Y||_F^2; ROLE 2 / 4: ||S - S Y||_F^2 (this tile's share)
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
@@ -284,22 +334,24 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
           c += beta * ev;
           if (ROLE == 2 || ROLE == 4) { const double d = ev - acc[i][j][r]; p0 += d * d; }
         }
+        if (CLEAN && (ROLE == 2 || ROLE == 4) && Madd) c += gamma * Madd[idx];
         if (ROLE == 1) {
           p1 += acc[i][j][r] * acc[i][j][r];
           if (row == col) p0 += acc[i][j][r];
         }
-        if (!MIRROR || col >= row) C[idx] = c;        // diagonal tiles: the upper triangle decides
-        if (MIRROR) Ct[lcol * (TM + 1) + lrow] = c;
+        if (!MIRROR || full || col >= row) C[idx] = c;        // diagonal tiles: the upper triangle decides (a full product: every entry is its own)
+        if (MIRROR && !full) Ct[lcol * (TM + 1) + lrow] = c;
       }
-  if (MIRROR) {
+  if (MIRROR && !full) {
     __syncthreads();
     const int q = tid % TM;                           // original row   -> column of the mirrored tile
 #pragma unroll 4
     for (int p = tid / TM; p < TM; p += 256 / TM)     // original column -> row of the mirrored tile
       if (by != bx || q < p) C[(size_t)(col0 + p) * N + row0 + q] = Ct[p * (TM + 1) + q];
   }
-  if (ROLE == 1 || ROLE == 2 || ROLE == 4) {
-    // this tile's partial sums -> its fixed slot (read by the next launch)
+  }    // pass
+  if ((ROLE == 1 && !full) || ROLE == 2 || ROLE == 4) {
+    // this tile's partial sums -> its fixed slot (read by the next launch; the full product of a second slot leaves none: nothing reads them)
     const double w = (by == bx) ? 1.0 : 2.0;                 // an off-diagonal tile stands for its mirror image too
     p0 = wave_sum(p0);
     p1 = wave_sum(p1);
@@ -321,13 +373,13 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   }
 }
 
-template <bool MIRROR, int TM, int BK, int ROLE>
+template <bool MIRROR, int TM, int BK, int ROLE, bool CLEAN = false>
 __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
                                                           double alpha, double beta, const double* __restrict__ Eb,
                                                           double* __restrict__ Cb, int sb, SignArgs sg, const double* __restrict__ B2b) {
   __shared__ double smem[LgGemmCfg<MIRROR, TM, BK>::SMEM];
   __shared__ double red[16];
-  lg_gemm_sym_body<MIRROR, TM, BK, ROLE>(N, Ab, Bb, alpha, beta, Eb, Cb, sb, sg, B2b, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, smem, red);
+  lg_gemm_sym_body<MIRROR, TM, BK, ROLE, CLEAN>(N, Ab, Bb, alpha, beta, Eb, Cb, sb, sg, B2b, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, smem, red);
 }
 
 // ---- a handful of mid-size blocks: the WHOLE sign iteration in one launch --------------------------------------------------
@@ -345,7 +397,7 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
 // a workgroup that waits longer than ~2 s gives up and raises the failure counter instead of hanging the device.
 constexpr int kClusterMaxWgs = 224;
 struct ClusterArgs {
-  double *S, *T, *Y, *X0;
+  double *S, *T, *Y, *X0, *M;
   unsigned* bar;            // per member, zeroed by lg_state_init_kernel
   int* xcc;                 // [member][tile]: the XCD every workgroup found itself on
   int* fail;
@@ -396,7 +448,7 @@ __device__ __forceinline__ bool lg_member_barrier(unsigned* bar, unsigned target
 // publishes the XCD it really runs on (HW_REG_XCC_ID), and after a first (agent-scope) barrier each checks that its member's are equal
 // -- only then the light barrier is used.  (Measured and rejected: workgroup-scope read-modify-writes on the counter, hoping they
 // would be served by the shared L2 -- they are not coherent between CUs: the waiters time out.)
-template <int TM, int BK>
+template <int TM, int BK, bool CLEAN>
 __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
   __shared__ double smem[LgGemmCfg<true, TM, BK>::SMEM];
   __shared__ double red[16];
@@ -437,9 +489,9 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
     sg.step = step;
     // done_at is written by this member's writer workgroup during the second product of the step before: ordered by the barrier
     if (__hip_atomic_load(&sg.done[member].done_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) break;
-    lg_gemm_sym_body<true, TM, BK, 1>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
+    lg_gemm_sym_body<true, TM, BK, 1, CLEAN>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, ca.M, member, tile, (int)ntiles, smem, red);
     if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
-    lg_gemm_sym_body<true, TM, BK, 2>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
+    lg_gemm_sym_body<true, TM, BK, 2, CLEAN>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, ca.M, member, tile, (int)ntiles, smem, red);
     if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
     if (local) {
       // the light barrier stands on "same XCD", established once at the start: a workgroup that finds itself elsewhere (a preempted
@@ -604,15 +656,7 @@ __global__ __launch_bounds__(1024) void lg_prep_kernel(const double* __restrict_
   for (int idx = tid; idx < N * N; idx += 1024) S[idx] = X0[idx] * scale;
   if (tid == 0) {
     if (m == 0) { sa.group[0] = sa.count; sa.group[1] = 0; }
-    SignDevState st;
-    st.sched = SignSched();
-    if (sa.hint && sa.hint[id] > 0) st.sched.lift0 = sa.hint[id];
-    st.mu = 1.0;
-    st.n = n;
-    sa.st[m] = st;
-    sa.done[m].done_at = 0x7fffffff;
-    sa.done[m].steps = 0;
-    if (sa.bar) sa.bar[m] = 0u;
+    lg_fresh_state(sa, m, id, n);
   }
 }
 // lg_pack_kernel + lg_steps_out_kernel in one launch (the one-launch variant's epilogue)
@@ -659,10 +703,15 @@ static int lg_gemm_mirror(int N, int count, const double* A, const double* B, do
                           hipStream_t st, const SignArgs& sa, const double* B2, int tile_force = 0) {
   const bool small_tiles = lg_small_tiles(true, N, count, tile_force);
   const int nb = small_tiles ? N / 32 : N / 64;
+  constexpr bool kCanClean = ROLE == 1 || ROLE == 2 || ROLE == 4;
   if (count == 1 && nb >= 16) {
     const int sb = (nb + 7) / 8;                               // 8x8-tile super-blocks per direction
+    if (sa.clean) { set_error("psd sign path: a clean mega-lift group on the super-block order (N = %d)", N); return CUADMM_ERR_INVALID; }
     if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32, ROLE>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb, sa, B2);
     else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16, ROLE>), dim3(sb * (sb + 1) / 2 * 64), dim3(256), 0, st, N, A, B, alpha, beta, E, C, sb, sa, B2);
+  } else if (kCanClean && sa.clean) {
+    if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32, ROLE, kCanClean>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0, sa, B2);
+    else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16, ROLE, kCanClean>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0, sa, B2);
   } else {
     if (small_tiles) hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 32, 32, ROLE>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0, sa, B2);
     else hipLaunchKernelGGL((lg_gemm_sym_kernel<true, 64, 16, ROLE>), dim3(nb * (nb + 1) / 2, count), dim3(256), 0, st, N, A, B, alpha, beta, E, C, 0, sa, B2);
@@ -684,15 +733,7 @@ __global__ void lg_state_init_kernel(SignArgs sa, const int* __restrict__ ids, c
   const int m = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (m == 0) { sa.group[0] = sa.count; sa.group[1] = 0; }
   if (m >= sa.count) return;
-  SignDevState s;
-  s.sched = SignSched();
-  if (sa.hint && sa.hint[ids[m]] > 0) s.sched.lift0 = sa.hint[ids[m]];
-  s.mu = 1.0;
-  s.n = bn[ids[m]];
-  sa.st[m] = s;
-  sa.done[m].done_at = 0x7fffffff;
-  sa.done[m].steps = 0;
-  if (sa.bar) sa.bar[m] = 0u;
+  lg_fresh_state(sa, m, ids[m], bn[ids[m]]);
 }
 __global__ void lg_steps_out_kernel(SignArgs sa, const int* __restrict__ ids, int* __restrict__ steps) {
   const int m = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -796,6 +837,14 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   CUADMM_HIP_TRY(hipMalloc(&S, sizeof(double) * elems));
   CUADMM_HIP_TRY(hipMalloc(&Y, sizeof(double) * elems));
   CUADMM_HIP_TRY(hipMalloc(&T, sizeof(double) * elems));
+  {
+    bool any_clean = false;
+    for (const Group& g : groups) any_clean = any_clean || (opt.lg_clean != 0 && g.N <= clean_max_n);
+    if (any_clean) {
+      CUADMM_HIP_TRY(hipMalloc(&Mw, sizeof(double) * elems));
+      CUADMM_HIP_TRY(hipMalloc(&d_cont, sizeof(int) * 2 * members_cap));
+    }
+  }
   CUADMM_HIP_TRY(hipMalloc(&colsum, sizeof(double) * std::max<size_t>(max_cols, 1)));
   CUADMM_HIP_TRY(hipMalloc(&scale, sizeof(double) * std::max<size_t>(members_cap, 1)));
   CUADMM_HIP_TRY(hipMalloc(&d_state, sizeof(SignDevState) * 2 * members_cap));
@@ -811,12 +860,13 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
 
 void SignPsd::release() {
   if (graph_exec) { hipError_t e = hipGraphExecDestroy(graph_exec); (void)e; graph_exec = nullptr; }
-  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar, (void*)d_xcc})
+  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar, (void*)d_xcc, (void*)Mw, (void*)d_cont})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   if (d_group) { hipError_t e = hipFree(d_group); (void)e; d_group = nullptr; }
   if (h_group) { hipError_t e = hipHostFree(h_group); (void)e; h_group = nullptr; }
   d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr; d_bar = nullptr; d_xcc = nullptr;
   X0 = S = Y = T = colsum = scale = nullptr;
+  Mw = nullptr; d_cont = nullptr;
   groups.clear();
 }
 
@@ -897,8 +947,11 @@ void SignPsd::cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max
   sa.count = g.count;
   sa.step = 0;
   sa.bar = d_bar + g.mem_off;
+  sa.clean = (Mw && opt.lg_clean != 0 && g.N <= clean_max_n) ? 1 : 0;
+  sa.cont = sa.clean ? d_cont + 2 * (size_t)g.mem_off : nullptr;
+  sa.cap = max_steps;
   // psd_lg_cluster = 2: agent-scope barriers always (A/B, tests)
-  cm.ca[i] = ClusterArgs{S + g.ws_off, T + g.ws_off, Y + g.ws_off, X0 + g.ws_off, d_bar + g.mem_off,
+  cm.ca[i] = ClusterArgs{S + g.ws_off, T + g.ws_off, Y + g.ws_off, X0 + g.ws_off, sa.clean ? Mw + g.ws_off : nullptr, d_bar + g.mem_off,
                          d_xcc + (size_t)(kClusterMaxWgs + 64) * (size_t)g.slot, d_fail, g.N, max_steps, g.count, opt.lg_cluster == 2 ? 1 : 0, path.spread};
   cm.wg_begin[i + 1] = cm.wg_begin[i] + (path.cluster_wgs + 7) / 8 * 8;
   cm.mem_begin[i + 1] = cm.mem_begin[i] + g.count;
@@ -914,7 +967,10 @@ int SignPsd::cluster_run(ClusterMulti& cm, bool prologue, const double* in, doub
     if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(lg_prep_kernel)));
     hipLaunchKernelGGL(lg_prep_kernel, dim3(cm.mem_begin[cm.n]), dim3(1024), lds_prep, st, in, boff, bn, cm);
   }
-  hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32>), dim3(cm.wg_begin[cm.n]), dim3(256), 0, st, cm);
+  bool any_clean = false;                      // (the instantiation without the clean mega-lift's second slot when no group takes one: not a register more)
+  for (int i = 0; i < cm.n; ++i) any_clean = any_clean || cm.sg[i].clean != 0;
+  if (any_clean) hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32, true>), dim3(cm.wg_begin[cm.n]), dim3(256), 0, st, cm);
+  else hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32, false>), dim3(cm.wg_begin[cm.n]), dim3(256), 0, st, cm);
   for (int i = 0; i < cm.n; ++i) cm.sg[i].step = cm.ca[i].max_steps;          // the steps enqueued
   const unsigned gx = (unsigned)std::min<size_t>(((size_t)maxN * maxN / 2 + 255) / 256, 1024);
   hipLaunchKernelGGL(lg_pack_steps_kernel, dim3(gx, cm.mem_begin[cm.n]), dim3(256), 0, st, boff, bn, out, d_fail, d_steps, cm);
@@ -953,6 +1009,10 @@ int SignPsd::launch_group(Group& g, const double* in, double* out, const long lo
     sa.count = cnt;
     sa.step = 0;
     sa.bar = d_bar;
+    sa.clean = (Mw && opt.lg_clean != 0 && g.N <= clean_max_n) ? 1 : 0;
+    sa.cont = sa.clean ? d_cont + 2 * (size_t)g.mem_off : nullptr;
+    sa.cap = max_steps;
+    double* const M = sa.clean ? Mw + g.ws_off : nullptr;
     ClusterMulti cm{};
     if (cluster) cluster_add(cm, g, d_fail, max_steps);
     if (!(cluster && N <= 512)) {              // else: the one-launch variant's own prologue (cluster_run)
@@ -982,12 +1042,12 @@ int SignPsd::launch_group(Group& g, const double* in, double* out, const long lo
       for (int it = 0; it < chunk && enq < max_steps; ++it, ++enq) {
         // Y = S*S ; [decision] ; T = 1.5 mu S - 0.5 mu^3 S*Y ; finished members return at once
         sa.step = enq;
-        if ((rc = lg_gemm_mirror<1>(N, cnt, s, s, 1.0, 0.0, nullptr, Y, st, sa, nullptr, opt.lg_tile))) return rc;
+        if ((rc = lg_gemm_mirror<1>(N, cnt, s, s, 1.0, 0.0, nullptr, Y, st, sa, M, opt.lg_tile))) return rc;
         if (decide_kernel) {
           hipLaunchKernelGGL(lg_decide_kernel, dim3(cnt), dim3(256), 0, st, sa, ntiles);
-          if ((rc = lg_gemm_mirror<4>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr, opt.lg_tile))) return rc;
+          if ((rc = lg_gemm_mirror<4>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, M, opt.lg_tile))) return rc;
         } else {
-          if ((rc = lg_gemm_mirror<2>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, nullptr, opt.lg_tile))) return rc;
+          if ((rc = lg_gemm_mirror<2>(N, cnt, s, Y, 0.0, 0.0, s, t, st, sa, M, opt.lg_tile))) return rc;
         }
         std::swap(s, t);
       }

@@ -23,6 +23,7 @@ struct PsdOptions {
   int lg_pad32 = 1;        // psd_lg_pad32: groups on 32 x 32 tiles pad to a multiple of 32
   int lg_decide = 0;       // psd_lg_decide: 0 = by tile count, 1 = decisions inside the product kernels, 2 = a separate kernel
   int lg_merge = 1;        // psd_lg_merge: one-launch groups of different padded sizes share ONE launch (workspaces of their own)
+  int lg_clean = 0;        // psd_lg_clean: 1 = groups padded to at most 512 take the CLEAN mega-lift where it pays (sign_sched.h: two step slots, no cap).  Built, parity-green and OFF: on the shipped inputs it never pays (NOTEBOOK.md "Round 6")
   int lg_cluster = 1;      // psd_lg_cluster: a handful of mid-size blocks run their whole sign iteration in one launch (per-member barriers)
   int graph = 0;           // psd_graph: replay the launch sequence from a hipGraph (measured: no gain)
   int sign_maxsteps = 0;   // psd_sign_maxsteps: cap of the schedule (0: SignSched::kCap)
@@ -38,7 +39,7 @@ struct PsdOptions {
         {"CUADMM_PSD_W32_OCC", &o.w32_occ},       {"CUADMM_PSD_CU_OCC", &o.cu_occ},       {"CUADMM_PSD_OVERLAP", &o.overlap},
         {"CUADMM_PSD_N16", &o.n16_sign},    {"CUADMM_PSD_N32", &o.n32_sign},
         {"CUADMM_PSD_MID", &o.mid},             {"CUADMM_PSD_LG_CLUSTER", &o.lg_cluster}, {"CUADMM_PSD_LDS_TRIPLE", &o.lds_triple},
-        {"CUADMM_PSD_LG_MERGE", &o.lg_merge}};
+        {"CUADMM_PSD_LG_MERGE", &o.lg_merge},   {"CUADMM_PSD_LG_CLEAN", &o.lg_clean}};
     for (auto& t : tab)
       if (const char* e = getenv(t.name)) {
         // historical spellings: N16 / N32 = "eig" (register eigensolver), MID = "eig" | "lds"
@@ -66,6 +67,7 @@ struct PsdOptions {
     else if (k == "psd_lg_decide") lg_decide = v;
     else if (k == "psd_lg_cluster") lg_cluster = v;
     else if (k == "psd_lg_merge") lg_merge = v;
+    else if (k == "psd_lg_clean") lg_clean = v;
     else if (k == "psd_graph") graph = v;
     else if (k == "psd_sign_maxsteps") sign_maxsteps = v;
     else if (k == "psd_sign_sync") sign_sync = v;

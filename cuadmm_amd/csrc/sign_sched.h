@@ -40,6 +40,16 @@
 // variant always used) -- so when the basin is what limits c, one more plain step (needed by the terminal phase anyway) squares it.
 // Everything here is a choice of coefficients for steps the kernels run anyway; the exit tests are untouched.
 //
+// CLEAN MEGA-LIFT (round 6, the batched-GEMM path's groups of padded size <= 512).  The cap above exists because c (S - S Y) amplifies the
+// roundoff of the product S Y, and the part of it that couples the basin to the lifted cluster rotates the resolved eigenvectors.  The cubic
+// in Y that projects that part out,   S <- S + c (I - Y) R (I - Y),   R = S - S Y   (= S (1 + c (1 - S^2)^3) in exact arithmetic: the tiny
+// cluster times 1 + c, a basin eigenvalue 1 - u/2 moved by c u^3 only),   damps the basin's share of R's noise by u on either side and needs no
+// cap: one lift takes the cluster to kMegaTiny whatever the gap.  It costs a second step SLOT: slot 1 is an ordinary step whose output is R
+// (coefficients -1, 1) instead of the next iterate; slot 2 forms M = R - R Y as a FULL product (R (I - Y) is symmetric only up to the very noise
+// it removes: the mirrored upper-triangle product would put it back) and then S + c (M - Y M), mirrored (T R T is symmetric for symmetric R).
+// Matrix-level replica (tools/dbg/clean_mega/msim.py, n = 96 ... 120, gaps 1e-6 ... 1e-13): errors 2e-16 ||X|| like the schedule without any
+// mega-lift (capped: 1e-14), 42 -> 28 steps at a gap of 1e-9 ... 1e-11 (capped: 37 - 39), 44 -> 27 - 29 at 1e-12 (capped: 44).
+//
 // LAGGED variant (batched-GEMM path, psd_large.hip): there g2 of iterate k is only complete after the launch that
 // applies mu_k, so decisions at step k use (a_k, b_k) and g2 of iterate k-1 (plain phase: g_k <= 0.75 g_{k-1}^2).
 //
@@ -95,6 +105,11 @@ struct SignSchedT {
   double csum = 0.0;                           // sum of the mega-lifts' c so far
   bool chain = false;                          // the next step is decided from (tbk, ebk) alone: a further mega-lift or the first probe
   bool mega_on = true;                         // host model only: +8 on the mode switches it off (the schedule of rounds 2-4, for comparison)
+  bool clean = false;                          // the CLEAN mega-lift: S <- S + c (I - Y)(S - S Y)(I - Y), two step slots, no cap on c (see take_mega)
+  bool cont = false;                           // clean: the next step slot is the second half of the mega-lift just decided
+  int half = 0;                                // clean: 1 = the slot just decided forms R = S - S Y, 2 = it applies S + cmc (I - Y) R (I - Y)
+  double cmc = 0.0;
+  int cap = kCap;                              // clean: the caller's step limit when it is below kCap (a mega-lift's two slots never straddle it)
   int k = 0, j = 0, fin = 0, steps = 0;
   // Warm start of the SCHEDULE (not of the iterate): consecutive ADMM iterations project nearly the same spectrum, so the
   // number of lift steps a block needed last time can serve as the length of its first lift phase now.  lift0 = hint from the
@@ -135,8 +150,31 @@ struct SignSchedT {
 
   // takes a mega-lift of (at most) c_want from an iterate whose tiny part is <= tb and whose basin is within eb of 1: sets cm, the
   // propagated bounds and whether the next step continues the chain; false when what the caps leave is not worth a step
-  CUADMM_SCHED_HD bool take_mega(int n, double c_want, double tb, double eb) {
+  // c_want: what the split allows the CAPPED lift (tiny cluster to kMegaTiny, basin kept within kMegaBasin of 1); c_clean: what would take
+  // the cluster to kMegaTiny outright -- the clean lift's (it barely moves the basin), used when `clean` is set and it pays.
+  CUADMM_SCHED_HD bool take_mega(int n, double c_want, double c_clean, double tb, double eb) {
     double c = c_want;
+    if (clean) {
+      // The clean lift costs two step slots, the second one a product and a half: ~2.5 steps for the whole factor 1 + c_clean.  The capped lift
+      // costs one step for what the caps leave (c <= 600, 600 per projection) and 2.295-fold steps for the rest: clean pays when the factor left
+      // over exceeds 2.295^1.5 ~ 3.5.  Its roundoff: x + c x (1 - x^2)^3 moves the basin by <= 9 c eb^3, and what c amplifies is
+      // eps ||S - S Y|| ~ eps tb (the two outer products), i.e. c eps tb <= 0.3 eps: no cap.
+      double cc = c_want;
+      cc = cc < kMegaCMax ? cc : kMegaCMax;
+      cc = cc < kMegaCSum - csum ? cc : kMegaCSum - csum;
+      const double capped = 1.0 + cc >= kMegaMin ? 1.0 + cc : 1.0;
+      if (1.0 + c_clean > 3.5 * capped && 1.0 + c_clean >= kMegaMin * kSlope && steps + 3 <= cap) {
+        cmc = c_clean;
+        half = 1;
+        ++megas;
+        tbk = (1.0 + c_clean) * tb;
+        ebk = eb + 9.0 * c_clean * eb * eb * eb;
+        cont = true;
+        chain = true;
+        k = 0; j = 0; waits = 0;
+        return true;
+      }
+    }
     c = c < kMegaCMax ? c : kMegaCMax;
     c = c < kMegaCSum - csum ? c : kMegaCSum - csum;
     if (!(1.0 + c >= kMegaMin)) return false;
@@ -153,6 +191,7 @@ struct SignSchedT {
   // coefficients of the step decide() returned mu for:  S <- alpha S Y + beta S
   CUADMM_SCHED_HD void coefs(double mu, double& alpha, double& beta) const {
     if (MEGA && cm > 0.0) { alpha = -cm; beta = 1.0 + cm; }
+    else if (MEGA && half == 1) { alpha = -1.0; beta = 1.0; }                  // first slot of a clean mega-lift: the step's output is R = S - S Y
     else { alpha = -0.5 * mu * mu * mu; beta = 1.5 * mu; }
   }
 
@@ -165,6 +204,16 @@ struct SignSchedT {
     double mu = 1.0;
     last = false;
     if (MEGA) cm = 0.0;
+    if (MEGA && cont) {                 // second half of a clean mega-lift: nothing is decided, nothing is read
+      cont = false;
+      half = 2;
+      plain_prev = false;
+      gbl = -1.0;
+      ++steps;
+      if (steps >= kCap) last = true;
+      return 1.0;
+    }
+    if (MEGA) half = 0;
     const bool was_plain = plain;
     double g_now = -1.0;                // !LAG: sqrt(g2) once a branch below needed it (kept in gprev for the host model)
     double gb_now = -1.0;               // the split bound of THIS iterate, where a branch formed it
@@ -182,7 +231,7 @@ struct SignSchedT {
       chain = false;
       const double f1 = kMegaTiny / tbk, f2 = 1.0 + kMegaBasin / (2.14 * ebk + 1e-300);
       const double f = f1 < f2 ? f1 : f2;
-      if (!(G * kTol < 0.5 && tbk > kTol * G && take_mega(n, f - 1.0, tbk, ebk))) { k = 0; mu = kMuP1; j = 1; }
+      if (!(G * kTol < 0.5 && tbk > kTol * G && take_mega(n, f - 1.0, f1 - 1.0, tbk, ebk))) { k = 0; mu = kMuP1; j = 1; }
     } else if (fin > 0) {
       --fin;
       last = fin == 0;
@@ -256,7 +305,7 @@ struct SignSchedT {
           if (MEGA) {
             const double s_hat = sqrt(v + 2.0 * noise);  // what the cluster weighs by the statistics of THIS iterate
             const bool stale = gb > 4.0 * s_hat && waits < 3;   // the bound still carries the basin's error (the lagged g: a step old)
-            if (f_all >= kMegaMin && !stale && take_mega(n, f_all - 1.0, gb, ebm_used)) {
+            if ((f_all >= kMegaMin || (clean && f_tiny >= kMegaMin)) && !stale && take_mega(n, f_all - 1.0, f_tiny - 1.0, gb, ebm_used)) {
               taken = true;                              // (the probes that follow the chain restore [0.5, 1])
             } else if (f_tiny >= kMegaMin || (mega_on && stale && gb >= 0.0 && kMegaTiny / s_hat >= kMegaMin)) {
               ++j; ++waits;                              // a plain step squares the basin's share of the bound (and is not wasted)
@@ -277,7 +326,7 @@ struct SignSchedT {
     plain_prev = was_plain;
     if (!LAG) gprev = g_now;              // only where it was formed; the one-wavefront kernels never read it
     if (MEGA) gbl = (mu == 1.0 && cm == 0.0) ? gb_now : -1.0;
-    G *= (MEGA && cm > 0.0) ? 1.0 + cm : 1.5 * mu;
+    G *= (MEGA && cm > 0.0) ? 1.0 + cm : ((MEGA && half == 1) ? 1.0 + cmc : 1.5 * mu);
     ++steps;
     if (steps >= kCap) last = true;
     return mu;
@@ -294,6 +343,7 @@ using SignSchedPlain = SignSchedT<false>;
 // statistics passed on every step (the reference for the claim that skipping them changes nothing)
 inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int lift0 = 0, int* lifts_out = nullptr) {
   SignSched st;
+  if (lag & 16) { st.clean = true; lag &= 15; }
   if (lag & 8) { st.mega_on = false; lag &= 7; }
   if (lift0 > 0) st.lift0 = lift0;
   double orig_max_err = 0.0;
@@ -321,6 +371,11 @@ inline int sign_sched_simulate(double* s, int n, int lag, double* err_out, int l
     g2_prev = g2; a_prev = a; b_prev = b;
     double al, be;
     st.coefs(mu, al, be);
+    if (st.half == 1) continue;                     // R is formed; the iterate moves in the second slot
+    if (st.half == 2) {
+      for (int i = 0; i < n; ++i) { const double w = 1.0 - s[i] * s[i]; s[i] += st.cmc * s[i] * w * w * w; }
+      continue;
+    }
     for (int i = 0; i < n; ++i) s[i] = be * s[i] + al * s[i] * s[i] * s[i];
   }
   for (int i = 0; i < n; ++i) {

@@ -315,6 +315,43 @@ def test_project_sign_path_one_launch_variant_is_bit_identical(blk, monkeypatch)
     assert np.max(np.abs(one - ref)) <= 2e-12 * max(np.linalg.norm(m, 2) for m in mats) * np.sqrt(2)
 
 
+@pytest.mark.parametrize("blk", [[66, 91, 120, 120, 66, 91], [128, 200, 300], [96, 470, 130]])
+def test_project_sign_path_clean_mega_lift(blk, monkeypatch):
+    """The CLEAN mega-lift (csrc/sign_sched.h; option psd_lg_clean, off by default: it does not pay on the shipped inputs) on spectra with a
+    GAP -- a few eigenvalues of order one, the rest at 1e-9 ... 1e-12 relative, both signs, some exact zeros: two step slots, the second one
+    a full product and a mirrored one.  The one-launch kernel and the per-step launches must agree to the bit, the projection must meet the
+    tolerance of every other test here, and it must be no less accurate than the capped lift it replaces."""
+    blk = np.array(blk, dtype=np.int32)
+    bidx = orc.BlockIndex(blk)
+    rng = np.random.default_rng(int(blk.sum()) + 1)
+    mats, refs = [], []
+    for k, n in enumerate(blk):
+        n = int(n)
+        r = 3 + k
+        lam = np.zeros(n)
+        lam[:r] = rng.uniform(0.2, 1.0, r) * rng.choice([-1.0, 1.0], r)
+        m = n - r - (5 if k % 2 else 0)
+        lam[r:r + m] = 10.0 ** rng.uniform(-12 + k % 3, -9 + k % 3, m) * rng.choice([-1.0, 1.0], m)
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        X = (Q * lam) @ Q.T
+        mats.append(0.5 * (X + X.T))
+        refs.append((Q * np.maximum(lam, 0.0)) @ Q.T)
+    x = np.concatenate([orc.BlockIndex([m.shape[0]]).pack([m[None]]) for m in mats])
+    ref = np.concatenate([orc.BlockIndex([m.shape[0]]).pack([m[None]]) for m in refs])
+    monkeypatch.setenv("CUADMM_PSD_LG_CLEAN", "1")
+    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "1")
+    one = psd_project_gpu(x, blk)
+    monkeypatch.setenv("CUADMM_PSD_LG_CLUSTER", "0")
+    many = psd_project_gpu(x, blk)
+    assert np.array_equal(one, many)
+    monkeypatch.setenv("CUADMM_PSD_LG_CLEAN", "0")
+    capped = psd_project_gpu(x, blk)
+    e_clean, e_capped = np.max(np.abs(one - ref)), np.max(np.abs(capped - ref))
+    assert e_clean <= 2e-12 * np.sqrt(2) and e_capped <= 2e-12 * np.sqrt(2)
+    assert e_clean <= max(e_capped, 4e-15)
+    assert not np.array_equal(one, capped)               # the clean lift did take place (these gaps are 600 times beyond the capped one's reach)
+
+
 @pytest.mark.parametrize("blk", [[252, 56, 56, 56] + [126] * 10, [66, 130, 300, 91, 140], [100, 200, 330, 450]])
 def test_project_sign_path_groups_in_one_launch_are_bit_identical(blk, monkeypatch):
     """One-launch groups of different padded sizes (taha1a: ten blocks of 126 and one of 252) share ONE launch, each with a workspace of

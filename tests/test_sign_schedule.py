@@ -188,3 +188,61 @@ def test_mega_lift_jumps_a_gap_and_leaves_continuous_spectra_alone():
             same += a == b
     assert saved[0] >= 200 * 3 and saved[1] >= 200 * 3                # >= 3 steps per gapped block on average
     assert same >= 0.8 * 400                                          # ... but mostly not: same schedule as rounds 2-4
+
+
+# ---- the CLEAN mega-lift (mode + 16: what the batched-GEMM path's groups padded to <= 512 run; sign_sched.h) -------------------------
+
+def _gap_spectrum(rng, n, r, lo, hi, zeros=0):
+    lam = np.zeros(n)
+    lam[:r] = rng.uniform(0.2, 1.0, r)
+    m = n - r - zeros
+    lam[r:r + m] = 10.0 ** rng.uniform(lo, hi, m)
+    return lam / 1.1
+
+
+def test_clean_mega_lift_meets_the_contract_on_every_spectrum_family():
+    rng = np.random.default_rng(7)
+    for name, spec in _spectra(rng).items():
+        steps, err, s = _run(spec, 1 + 16)
+        assert 1 <= steps <= 64, (name, steps)
+        assert err <= 2.5e-13, (name, steps, err)
+        big = np.abs(spec) >= 1e-11
+        assert np.all(np.abs(1.0 - s[big]) <= 1e-12), (name, steps, s[big])
+
+
+def test_clean_mega_lift_jumps_a_gap_the_capped_one_climbs():
+    """A gap of 1e-9 ... 1e-11 (a relaxation's numerically low-rank iterate): the capped mega-lift takes 600 of the ~1e9 in one step
+    and lifts the rest 2.3-fold per step; the clean one takes it whole for two step slots."""
+    rng = np.random.default_rng(17)
+    tot = {0: 0, 1: 0, 2: 0}
+    for _ in range(40):
+        spec = _gap_spectrum(rng, 120, 8, -11, -9)
+        none, e0, _ = _run(spec, 1 + 8)
+        capped, e1, _ = _run(spec, 1)
+        clean, e2, _ = _run(spec, 1 + 16)
+        assert max(e0, e1, e2) <= 2.5e-13
+        assert clean <= capped and clean <= none - 8, (none, capped, clean)
+        tot[0] += none; tot[1] += capped; tot[2] += clean
+    assert tot[2] <= 0.8 * tot[1], tot
+
+
+def test_clean_mega_lift_leaves_gapless_spectra_alone():
+    rng = np.random.default_rng(19)
+    for _ in range(100):
+        w = rng.standard_normal(96)
+        w /= np.abs(w).sum() * 0.35 + np.abs(w).max()
+        a, _, sa = _run(w, 1)
+        b, _, sb = _run(w, 1 + 16)
+        assert a == b and np.array_equal(sa, sb)      # the same schedule to the bit: C3's single block and the synthetic classes see no change
+
+
+def test_clean_mega_lift_fuzz():
+    rng = np.random.default_rng(23)
+    for t in range(400):
+        n = int(rng.integers(65, 130))
+        r = int(rng.integers(0, 12))
+        lo = float(rng.uniform(-15, -3))
+        spec = _gap_spectrum(rng, n, r, lo, lo + float(rng.uniform(0.0, 3.0)), zeros=int(rng.integers(0, 20)))
+        spec *= rng.choice([-1.0, 1.0], n)
+        steps, err, _ = _run(spec, 1 + 16)
+        assert 1 <= steps <= 64 and err <= 2.5e-13, (t, steps, err)
