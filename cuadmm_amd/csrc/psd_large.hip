@@ -106,6 +106,12 @@ __device__ __forceinline__ double lg_reduce_decide(const SignArgs& sa, int membe
   const int par = sa.step & 1;
   const double* p1 = sa.p1 + (size_t)member * 2 * (size_t)ntiles;
   const double* p2 = sa.p2 + ((size_t)(par ^ 1) * sa.count + member) * (size_t)ntiles;
+  // the state travels first, word by word into LDS (thread t: word t): its trip hides behind the slots' -- it used to follow the two barriers --
+  // and no thread holds the struct in registers across them
+  static_assert(sizeof(SignDevState) % 8 == 0 && sizeof(SignDevState) <= 256, "SignDevState: whole doubles, at most 32");
+  constexpr int kStWords = (int)(sizeof(SignDevState) / 8);
+  __shared__ double st_sh[32];
+  if (tid < kStWords) st_sh[tid] = reinterpret_cast<const double*>(sa.st + ((size_t)par * sa.count + member))[tid];
   double q0 = 0.0, q1 = 0.0, q2 = 0.0;
   for (int t = tid; t < ntiles; t += 256) {
     q0 += p1[2 * t];
@@ -122,7 +128,8 @@ __device__ __forceinline__ double lg_reduce_decide(const SignArgs& sa, int membe
     const double a = (red[0] + red[1]) + (red[2] + red[3]);
     const double b = (red[4] + red[5]) + (red[6] + red[7]);
     const double g2 = (red[8] + red[9]) + (red[10] + red[11]);
-    SignDevState v = sa.st[(size_t)par * sa.count + member];
+    SignDevState v;
+    __builtin_memcpy(&v, st_sh, sizeof(SignDevState));
     v.sched.gprev = sa.step == 0 ? -1.0 : sqrt(g2 > 0.0 ? g2 : 0.0);
     bool last;
     v.mu = v.sched.decide<true>(v.n, a, b, 0.0, last);
@@ -173,11 +180,12 @@ struct LgGemmCfg {
 };
 // The body of one output tile: workgroup (tile_x of grid_x, member).  smem: LgGemmCfg::SMEM doubles, red: 16 doubles.
 // CLEAN: the instantiation knows the second slot of a clean mega-lift (groups that never take one -- C3's single large block -- run the other: not a register more)
-template <bool MIRROR, int TM, int BK, int ROLE, bool CLEAN = false>
+template <bool MIRROR, int TM, int BK, int ROLE, bool CLEAN = false, bool LATE = true>
 __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict__ Ab, const double* __restrict__ Bb,
                                                  double alpha, double beta, const double* __restrict__ Eb,
                                                  double* __restrict__ Cb, int sb, const SignArgs& sg, const double* __restrict__ B2b,
-                                                 const int member, const int tile_x, const int grid_x, double* smem, double* red) {
+                                                 const int member, const int tile_x, const int grid_x, double* smem, double* red,
+                                                 const bool known_live = false) {
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
@@ -186,7 +194,7 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
     int sl = 0;
     if (CLEAN && ROLE == 1 && sg.cont)               // (issued with the load of done_at: one trip to the L2, not two)
       sl = __hip_atomic_load(sg.cont + (size_t)(sg.step & 1) * sg.count + member, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sg.done[member].done_at <= sg.step) return;   // uniform over the workgroup: before any barrier
+    if (!known_live && sg.done[member].done_at <= sg.step) return;   // uniform over the workgroup: before any barrier (the one-launch kernel has just looked)
     slot2 = sl != 0;
   }
   if (ROLE == 3) {
@@ -230,7 +238,7 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   bool full = false;                // ROLE 1, second slot of a clean mega-lift: the full product M = R - R Y
   double gamma = 0.0;               // ROLE 2 / 4, second slot: C = E + gamma (M - A B)
   const double* Madd = nullptr;
-  if (ROLE == 2 || ROLE == 4) {
+  auto decide = [&]() {
     double mu, cm, cmc;
     int half;
     if (ROLE == 2) {
@@ -247,7 +255,12 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
       A = Bb + mat; B = B2b + mat; E = Cb + mat; Madd = B2b + mat;
       alpha = -cmc; beta = 1.0; gamma = cmc;
     }
-  }
+  };
+  // The decision only sets the epilogue's coefficients -- unless a clean mega-lift may change the operands.  Without one (ROLE 2) it runs
+  // BEHIND the first operand loads: the slots' and the state's trips to the L2 overlap the operands' instead of preceding them.
+  // (LATE = false: the one-launch kernel -- the operands live across the state machine cost 46 registers, and three of its workgroups must fit a CU)
+  constexpr bool kLateDecision = ROLE == 2 && !CLEAN && LATE;
+  if ((ROLE == 2 || ROLE == 4) && !kLateDecision) decide();
   if (CLEAN && ROLE == 1 && slot2) {      // A = R (the step before left it where the iterate would be), B = Y, C = M
     full = true;
     B = Cb + mat; E = Ab + mat; C = const_cast<double*>(B2b) + mat;
@@ -287,6 +300,14 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   LG_LOAD(pa0, pa1, pb0, pb1);
   ap += kstep; bp += kstep;
   if (N > BK) LG_LOAD(qa0, qa1, qb0, qb1);               // N is a multiple of BK; an odd number of k-tiles ends after a first half
+  // the epilogue's E values travel with the operands (32 x 32 tiles: four per thread) instead of as a trip of their own behind the k loop
+  constexpr bool kPreE = TM == 32;
+  double epre[kPreE ? 4 : 1];
+  if (kPreE && E) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) epre[r] = E[(size_t)(row0 + wy * WT + kk + 4 * r) * N + col0 + wx * WT + r16];
+  }
+  if (kLateDecision) decide();
   double2* sa = reinterpret_cast<double2*>(As + lk * LDS + lc);
   double2* sb2 = reinterpret_cast<double2*>(Bs + lk * LDS + lc);
 #define LG_COMPUTE()                                                                                              \
@@ -330,7 +351,7 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
         const size_t idx = (size_t)row * N + col;
         double c = alpha * acc[i][j][r];
         if (E) {
-          const double ev = E[idx];
+          const double ev = kPreE ? epre[r] : E[idx];
           c += beta * ev;
           if (ROLE == 2 || ROLE == 4) { const double d = ev - acc[i][j][r]; p0 += d * d; }
         }
@@ -489,9 +510,9 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
     sg.step = step;
     // done_at is written by this member's writer workgroup during the second product of the step before: ordered by the barrier
     if (__hip_atomic_load(&sg.done[member].done_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) break;
-    lg_gemm_sym_body<true, TM, BK, 1, CLEAN>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, ca.M, member, tile, (int)ntiles, smem, red);
+    lg_gemm_sym_body<true, TM, BK, 1, CLEAN, false>(N, s, s, 1.0, 0.0, nullptr, ca.Y, 0, sg, ca.M, member, tile, (int)ntiles, smem, red, true);
     if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
-    lg_gemm_sym_body<true, TM, BK, 2, CLEAN>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, ca.M, member, tile, (int)ntiles, smem, red);
+    lg_gemm_sym_body<true, TM, BK, 2, CLEAN, false>(N, s, ca.Y, 0.0, 0.0, s, t, 0, sg, ca.M, member, tile, (int)ntiles, smem, red, true);
     if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
     if (local) {
       // the light barrier stands on "same XCD", established once at the start: a workgroup that finds itself elsewhere (a preempted
