@@ -653,7 +653,7 @@ def main():
         issued_flops = issued_mfma_flops(blk_local, steps_blk)
         sign_blocks = blk_local > (0 if closed else 8)
         batched = plan["batch_launches"] > 0
-        kernel = {"c1": "psd_project phase: lg_gemm_sym_kernel (n = 66 ... 120, batched upper-triangle fp64-MFMA GEMMs) | psd_sign_lds_kernel (n = 55) | psd_sign_wave_kernel (n <= 28), concurrent streams",
+        kernel = {"c1": "psd_project phase: lg_sign_cluster_kernel (nine blocks of n = 66 ... 120: the whole matrix-sign iteration in one launch of upper-triangle fp64-MFMA tiles) | psd_sign_lds_kernel (n = 33 ... 64) | psd_sign_wave_kernel (n <= 32) | psd_small_reg_kernel (n <= 8), concurrent streams",
                   "c2": ("psd_sign_closed_cu_kernel<2, 16, 4> (several ADMM iterations of every block per launch: y-solve, A^T y, Xb, adaptive matrix-sign projection, S / X updates, "
                          "A X, A (S - C), partial sums; one persistent workgroup per CU)" if batched else
                          "psd_sign_closed_kernel<2, 4> (whole ADMM iteration of a block, one wavefront per block)" if closed else
@@ -662,7 +662,7 @@ def main():
                   "c4": "psd_project phase: psd_sign_closed_kernel<3, 2> (n=45) | <2, 4> (n=28) | <1, 8> (n <= 15), whole iteration per block, concurrent streams" if closed else
                         "psd_project phase: psd_sign_wave_kernel<3, 2> (n=45) | <2, 4> (n=28) | <1, 8> (n=10, 15), fused | psd_small_reg_kernel (n<=6), concurrent streams",
                   "c5": "psd_project phase: psd_sign_lds_kernel<64> (80 blocks of n = 55, one workgroup per block) | psd_sign_wave_kernel<1, 8> (159 blocks of n = 10)"}[args.config]
-        kname = {"c1": "lg_gemm_sym_kernel", "c2": "psd_sign_closed_cu_kernel<2" if batched else ("psd_sign_closed_kernel<2" if closed else "psd_sign_wave_kernel<2"),
+        kname = {"c1": "lg_sign_cluster_kernel", "c2": "psd_sign_closed_cu_kernel<2" if batched else ("psd_sign_closed_kernel<2" if closed else "psd_sign_wave_kernel<2"),
                  "c3": "lg_gemm_sym_kernel", "c4": "psd_sign_closed_kernel<3" if closed else "psd_sign_wave_kernel<3", "c5": "psd_sign_lds_kernel"}[args.config]
         per_s = psd_ms * 1e-3
         traffic = pmc_traffic(kname, args.config)

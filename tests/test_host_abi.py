@@ -602,3 +602,20 @@ def test_ordering_and_tail_plan_of_the_fixtures_are_pinned(name, m, nnzL, tail_k
         assert np.array_equal(np.ctypeslib.as_array(lib.cuadmm_aat_perm(h), shape=(m,)), perm)      # the ordering does not depend on the plan
     finally:
         lib.cuadmm_aat_free(h)
+
+
+def test_engine_options_are_validated_without_a_device():
+    """cuadmm_set_option on a fresh handle touches no device: known keys are accepted, the one-pass kernel's ring depth is range-checked
+    (csrc/engine.hip: tail_depth 0 ... 3), an unknown key is an error with a message."""
+    import ctypes as C
+    lib = cuadmm_amd.load()
+    h = C.c_void_p()
+    assert lib.cuadmm_create(C.byref(h)) == 0
+    try:
+        for key, val in (("tail_order", 0), ("tail_zreg", 0), ("tail_rb", 2), ("tail_depth", 3), ("psd_lg_clean", 1), ("tail_pivot", 1)):
+            assert lib.cuadmm_set_option(h, key.encode(), C.c_double(val)) == 0, key
+        assert lib.cuadmm_set_option(h, b"tail_depth", C.c_double(4)) != 0
+        assert b"tail_depth" in lib.cuadmm_last_error()
+        assert lib.cuadmm_set_option(h, b"no_such_option", C.c_double(1)) != 0
+    finally:
+        lib.cuadmm_destroy(h)
