@@ -41,15 +41,24 @@ __device__ __forceinline__ void sl_upper_tile(int q, int& i, int& j) {
 }
 
 // acc = A * B on the wavefront's upper sub-tile (ti, tj).  A symmetric (read as A[k][row]).  Operands in LDS.
+// kmax: the k-steps beyond the block's true size (a multiple of 8 >= n) multiply rows of zeros -- the padding of the tile -- and are skipped: the
+// kernel is bound by the matrix pipe of the SIMDs that carry three of the ten wavefronts (3 x 16 x 64 cycles per product at NP = 64: the measured
+// 6 k cycles per step), so n = 55 (pendulum's 80 blocks) gets an eighth of its products back (159 -> 149 us).  Same bits: what is skipped adds 0 * 0.
+// Measured and rejected (round 6): twelve wavefronts, the last two sub-tiles split in halves of the k range so that every SIMD carries two and a
+// half (35 instead of 42 MFMAs per product), the second half's accumulators handed over through LDS behind a flag: 149 -> 175 us.
 template <int NP>
-__device__ __forceinline__ sl_v4f64 sl_mma(const double* __restrict__ A, const double* __restrict__ B, int ti, int tj, int lane) {
+__device__ __forceinline__ sl_v4f64 sl_mma(const double* __restrict__ A, const double* __restrict__ B, int ti, int tj, int lane, int kmax = NP) {
   constexpr int LD = SignLdsCfg<NP>::LD;
   const int r16 = lane & 15, kk = lane >> 4;
   const double* arow = A + kk * LD + ti * 16 + r16;
   const double* brow = B + kk * LD + tj * 16 + r16;
   sl_v4f64 acc = sl_v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int k0 = 0; k0 < NP; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k0 * LD], brow[k0 * LD], acc, 0, 0, 0);
+  for (int k0 = 0; k0 < NP; k0 += 8) {
+    if (k0 >= kmax) break;                   // wave-uniform
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k0 * LD], brow[k0 * LD], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[(k0 + 4) * LD], brow[(k0 + 4) * LD], acc, 0, 0, 0);
+  }
   return acc;
 }
 // the sub-tile (ti, tj) of a matrix in LDS, in accumulator layout
@@ -120,6 +129,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   int ti, tj;
   sl_upper_tile<Cfg::NT>(wave, ti, tj);
   const double wgt = ti == tj ? 1.0 : 2.0;
+  const int kmax = __builtin_amdgcn_readfirstlane((n + 7) & ~7);
   sl_unpack<NP>(in, n, S, tid);
   // ||X||_1 = max column sum (symmetric: row sums), S <- X / ||X||_1
   if (tid < 64) {
@@ -140,7 +150,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   bool last = false;
   while (!last) {
     const bool stats = !TRIPLE || sched.needs_stats();
-    const sl_v4f64 y = sl_mma<NP>(S, S, ti, tj, lane);                               // Y = S*S
+    const sl_v4f64 y = sl_mma<NP>(S, S, ti, tj, lane, kmax);                               // Y = S*S
     sl_store<NP>(Y, y, ti, tj, lane);
     double pa = 0.0, pb = 0.0;
     if (stats) {
@@ -153,7 +163,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
       pb = wave_sum(pb) * wgt;
     }
     __syncthreads();
-    const sl_v4f64 z = sl_mma<NP>(S, Y, ti, tj, lane);                               // S*Y
+    const sl_v4f64 z = sl_mma<NP>(S, Y, ti, tj, lane, kmax);                               // S*Y
     const sl_v4f64 e = sl_tile<NP>(S, ti, tj, lane);
     double mu;
     if (stats) {
@@ -185,7 +195,7 @@ __device__ __forceinline__ void psd_sign_lds_body(const double* __restrict__ in,
   sl_unpack<NP>(in, n, Y, tid);
   sl_v4f64 t;
   {
-    const sl_v4f64 z = sl_mma<NP>(Y, S, ti, tj, lane);
+    const sl_v4f64 z = sl_mma<NP>(Y, S, ti, tj, lane, kmax);
     const sl_v4f64 e = sl_tile<NP>(Y, ti, tj, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = 0.5 * z[r] + 0.5 * e[r];
