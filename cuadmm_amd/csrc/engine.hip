@@ -253,7 +253,7 @@ struct cuadmm_solver {
     int tail_pivot = 1;           // "tail_pivot": the tail's dense LDL^T with diagonal pivoting (0: unpivoted, rounds 2 - 5)
     int tail_fat = 0;             // "tail_fat": the one-pass kernel on 512-thread workgroups with twice the rows in flight for K <= 10 240 (measured: slower; A/B)
     int tail_depth = 1;           // "tail_depth" / "tail_order": ring depth and row walk of the tail's one-pass kernel (tail_solve.hip)
-    int tail_order = 1;
+    int tail_order = 2;
     int tail_zreg = 1;            // "tail_zreg": z in registers in that kernel where it fits
     int tail_rb = 0;              // "tail_rb": rows per barrier of that kernel (0: by size)
     int tail_prefetch = 1;        // "tail_prefetch": the tail's one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5; A/B)
@@ -1416,7 +1416,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "tail_shard") s->sw.tail_shard = (int)value;
   else if (k == "tail_prefetch") s->sw.tail_prefetch = (int)value;
   else if (k == "tail_depth") { if (value < 0 || value > 3) { set_error("set_option: tail_depth must be 0 .. 3"); return CUADMM_ERR_INVALID; } s->sw.tail_depth = (int)value; }
-  else if (k == "tail_order") s->sw.tail_order = value != 0 ? 1 : 0;
+  else if (k == "tail_order") s->sw.tail_order = value == 2 ? 2 : (value != 0 ? 1 : 0);
   else if (k == "tail_rb") s->sw.tail_rb = (int)value;
   else if (k == "tail_zreg") s->sw.tail_zreg = (int)value;
   else if (k == "tail_fat") s->sw.tail_fat = (int)value;

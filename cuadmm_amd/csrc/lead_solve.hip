@@ -439,14 +439,15 @@ __global__ __launch_bounds__(256) void tops_resid_kernel(int n, const long long*
 
 // the tail's right-hand side: out[i] = zK[i] - sum_c L_KT[i][c] z_T[c]   (one wavefront per tail row: several hundred entries each)
 __global__ __launch_bounds__(256) void tops_k_rhs_kernel(int kt, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
-                                                         const double* __restrict__ zT, const double* __restrict__ zK, double* __restrict__ out) {
+                                                         const double* __restrict__ zT, const double* __restrict__ zK, double* __restrict__ out,
+                                                         const int* __restrict__ pinv) {
   const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
   if (i >= kt) return;
   double s = 0.0;
   for (long long q = rp[i] + lane; q < rp[i + 1]; q += 64) s += v[q] * zT[ci[q]];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) out[i] = zK[i] - s;
+  if (lane == 0) out[pinv ? pinv[i] : i] = zK[i] - s;      // (pinv: straight into the tail factor's pivoting order, TailSolve::z_scatter)
 }
 
 // u[c] = z_T[c] / D_T[c] - sum_i L_KT[i][c] x_K[i]   (one wavefront per T column); the workgroups behind the last column copy the solved
@@ -1136,8 +1137,10 @@ int LeadSolve::solve_tops(const double* ax, const double* asmc, const double* b,
     hipLaunchKernelGGL(tops_resid_kernel, dim3((unsigned)(((long long)nT * 32 + 255) / 256)), dim3(256), 0, st, nT, tt_rp, tt_ci, tt_v, zT, zext, uT);
     hipLaunchKernelGGL(tops_gemv_kernel, dim3((unsigned)((nT + 3) / 4)), dim3(256), 0, st, nT, wf_off, wf_beg, (const int*)nullptr, Wf, uT, zT, 1);
   }
-  hipLaunchKernelGGL(tops_k_rhs_kernel, dim3((unsigned)((kt + 3) / 4)), dim3(256), 0, st, kt, kt_rp, kt_ci, kt_v, zT, zext + nT, tail.vin);       // z_K -= L_KT z_T
+  const int* pz = tail.z_scatter();                   // the tail reads z in its factor's pivoting order: written there, not gathered
+  hipLaunchKernelGGL(tops_k_rhs_kernel, dim3((unsigned)((kt + 3) / 4)), dim3(256), 0, st, kt, kt_rp, kt_ci, kt_v, zT, zext + nT, tail.vin, pz);   // z_K -= L_KT z_T
   CUADMM_HIP_TRY(hipGetLastError());
+  tail.vin_pivot = pz != nullptr;
   int rc = tail.solve_device(st);
   if (rc) return rc;
   hipLaunchKernelGGL(tops_u_kernel, dim3((unsigned)((nT + 3) / 4 + (kt + 255) / 256)), dim3(256), 0, st, nT, tk_cp, tk_ri, tk_v, tail.vin, zT, DT, uT, xext + nT,

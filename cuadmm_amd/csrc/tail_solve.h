@@ -30,6 +30,11 @@ struct TailSolve {
   // paths go through the two scratch vectors pv1 / pv2.  Null after build() from a host factor.
   bool pivot = true;
   int* perm_d = nullptr;
+  int* pinv_d = nullptr;       // its inverse: a producer that writes z[pinv_d[i]] (z_scatter()) saves the one-pass kernels their gather -- 640 scattered 8-byte
+                               // requests per wavefront before the first dot product -- for the same number of stores
+  bool vin_pivot = false;      // set by such a producer for the NEXT solve_device only
+  bool linear_z_ok() const;
+  const int* z_scatter() const;
   double *pv1 = nullptr, *pv2 = nullptr;
   bool dd_dot = false;         // option tail_dd (experiment): u = W z accumulated in double-double (K <= 10 240 and 14 336 < K <= 16 384 only)
   bool fat = false;            // option tail_fat (measured, off): K <= 10 240 on 512-thread workgroups of up to 256 VGPRs (two rows per group, two groups in
@@ -37,7 +42,7 @@ struct TailSolve {
   int depth = 1;               // option tail_depth: row groups in flight beyond the current one in the one-pass kernel (tail_solve.hip: ts_onepass_kernel)
   bool zreg = true;            // option tail_zreg: the one-pass kernel keeps a thread's entries of z in registers where they fit (0: in LDS, rounds 3 - 6)
   int rows_per_group = 0;      // option tail_rb: rows that share one barrier in the one-pass kernel (0: two up to 8 192 columns, else one)
-  int order = 1;               // option tail_order: 1 = a workgroup walks its rows alternately from the long and the short end (0: longest first, rounds 3 - 6)
+  int order = 2;               // option tail_order: 1 = a workgroup walks its rows alternately from the long and the short end, 2 = and odd workgroups start at the short end (0: longest first, rounds 3 - 6)
   bool prefetch = true;        // option tail_prefetch: the one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5)
   bool one_pass = true;        // option tail_one_pass: x = W^T D^-1 W z in one pass over W (0: two triangular GEMVs)
   double pinv_tol = 0.0;       // option tail_pinv_tol (experiment, DESIGN.md section 4 "Round 5: dense tree tops"): pivots of the tail below it in

@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void ts_tri_resid_kernel(const double* __restr
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) out[i] = (a[i] - b[i]) - s;
 }
+// pinv[perm[a]] = a: where a producer puts entry i of z so that the one-pass kernels read z in the factor's pivoting order WITHOUT a gather
+__global__ void ts_perm_inverse_kernel(const int* __restrict__ perm, int* __restrict__ pinv, int K) {
+  const int a = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (a < K) pinv[perm[a]] = a;
+}
 // dst[a] = src[perm[a]] (GATHER) or dst[perm[a]] = src[a]: in and out of the factor's pivoting order
 template <bool GATHER>
 __global__ void ts_perm_kernel(double* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ perm, int K) {
@@ -339,7 +344,8 @@ __device__ __forceinline__ void ts_rows_apply(const TsRows<NC, RB>& R, const dou
 // D: row groups in flight BEYOND the one being applied (a ring of D + 1 register buffers; 0: load, apply, load ...).  With one group ahead
 // the wait at the top of a group still sees a whole memory round trip minus the ~0.3 us a group takes to apply: a row per round trip,
 // whatever its length -- the short rows of the triangle's tip are latency-bound (tools/ubench/tri_stream.hip).
-// ORDER 1: a workgroup walks its rows alternately from the long and from the short end, so the chip streams the same mix of long and short
+// ORDER 1: a workgroup walks its rows alternately from the long and from the short end (ORDER 2, the default: odd workgroups start at the short
+// end -- 77.7 -> 72.3 / 78.2 -> 75.2 us at K = 9 216, 45.5 -> 44.3 at 7 168 in the kernel trace), so the chip streams the same mix of long and short
 // rows from the first microsecond to the last (ORDER 0, rounds 3 - 6: longest first -- every workgroup reaches the tip at the same time and
 // the bytes in flight collapse together).  The partial sums associate in the walk's order: the last bits differ between orders, deterministically.
 template <int NC, int RB, int D, bool DD = false, int NT = 1024, int ORDER = 0, bool ZREG = false>
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(NT) void ts_onepass_kernel(const double* __restrict
   // first row of the j-th group of the walk (beyond the last group: the last group again -- rows this rank holds; ts_rows_apply is not called for it)
   auto group_row = [&](int j) -> int {
     j = j < count ? j : count - 1;
-    if (ORDER == 1) { const int h = j >> 1; j = (j & 1) ? count - 1 - h : h; }
+    if (ORDER >= 1) { const int h = j >> 1; j = (((j & 1) != 0) != (ORDER == 2 && (g & 1) != 0)) ? count - 1 - h : h; }      // ORDER 2: odd workgroups start at the short end
     return first + j * step;
   };
   TsRows<NC, RB> buf[D + 1];
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
   const int first = r_begin + group * RB, stride = G * RB;
   const int count = first < r_end ? (r_end - first + stride - 1) / stride : 0;
   for (int it = 0; it < count; ++it) {
-    const int jw = order ? ((it & 1) ? count - 1 - (it >> 1) : (it >> 1)) : it;
+    const int jw = order ? ((((it & 1) != 0) != (order == 2 && (group & 1) != 0)) ? count - 1 - (it >> 1) : (it >> 1)) : it;
     const int r0 = first + jw * stride;
     double2 w[RB][NP];
     const int seg0 = (wave_u * Q + member) * (64 * NC);   // this wavefront's segment: uniform
@@ -870,8 +876,8 @@ int ts_gemm(int M, int N, int Kd, double alpha, const double* A, long long lda, 
 
 void TailSolve::release() {
   if (compact) { W = Wc; Wc = nullptr; compact = false; ldc = 0; i_lo = 0; i_hi = -1; }     // (W was an offset view of Wc)
-  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part, (void*)Lm, (void*)Lt, (void*)t1, (void*)t2, (void*)perm_d, (void*)pv1, (void*)pv2}) if (p) { hipError_t e = hipFree(p); (void)e; }
-  part = nullptr; Lm = Lt = t1 = t2 = nullptr; perm_d = nullptr; pv1 = pv2 = nullptr;
+  for (void* p : {(void*)W, (void*)Wt, (void*)dinv, (void*)vin, (void*)vmid, (void*)xpart, (void*)part, (void*)Lm, (void*)Lt, (void*)t1, (void*)t2, (void*)perm_d, (void*)pinv_d, (void*)pv1, (void*)pv2}) if (p) { hipError_t e = hipFree(p); (void)e; }
+  part = nullptr; Lm = Lt = t1 = t2 = nullptr; perm_d = nullptr; pinv_d = nullptr; pv1 = pv2 = nullptr; vin_pivot = false;
   if (d_fail) { hipError_t e = hipFree(d_fail); (void)e; d_fail = nullptr; }
   if (h_vec) { hipError_t e = hipHostFree(h_vec); (void)e; }
   W = Wt = dinv = vin = vmid = h_vec = xpart = nullptr;
@@ -1039,6 +1045,8 @@ int TailSolve::build_from_schur(const long long* row_ptr, const int* col, const 
       set_error("tail_solve: out of device memory"); cleanup(); release(); return CUADMM_ERR_INVALID;
     }
     rc = ts_ldlt_factor_pivoted(dS, K, k, dd, Yp, dg, perm_d, dflag, st);
+    if (!rc && hipMalloc(&pinv_d, sizeof(int) * (size_t)K) == hipSuccess)      // (optional: without it the kernels gather z as before)
+      hipLaunchKernelGGL(ts_perm_inverse_kernel, dim3((K + 255) / 256), dim3(256), 0, st, perm_d, pinv_d, K);
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = CUADMM_ERR_NO_DEVICE;
     { hipError_t e2 = hipFree(dg); (void)e2; }
     if (rc) { cleanup(); release(); return rc; }
@@ -1122,6 +1130,18 @@ int TailSolve::solve(double* z2, hipStream_t st) {
 }
 
 // the same on a right-hand side that is already in `vin` (written by lead_tail_rhs_kernel): nothing crosses PCIe
+// does apply() read z through a kernel that can take it in the factor's order (the one-pass kernels)?  Mirrors the branches of apply_rows.
+bool TailSolve::linear_z_ok() const {
+  if (!perm_d || !pinv_d || !one_pass || !xpart || (refine && Lm)) return false;
+  const int nc = (K + 1023) / 1024;
+  const size_t lds = sizeof(double) * 1024 * (size_t)(nc + (nc & 1));
+  if (lds <= kMaxLdsBytes - 1024 && nc <= 20) return true;
+  return part && K <= 65536 && !group_retired;
+}
+// where entry i of z goes when the producer writes it for the next solve_device (null: in place, the kernels gather).  The producer that
+// uses it sets vin_pivot; one solve later the flag is down again.
+const int* TailSolve::z_scatter() const { return linear_z_ok() ? pinv_d : nullptr; }
+
 int TailSolve::solve_device(hipStream_t st) {
   if (!W) { set_error("tail_solve: not built"); return CUADMM_ERR_INVALID; }
   return apply(st);
@@ -1183,10 +1203,10 @@ constexpr bool ts_onepass_fits = (D <= 1 || (RB == 1 && D <= 3 && NC <= 10)) && 
 template <int NC, int RB, int D, class L>
 static int ts_onepass_launch_one(int order, bool zreg, L& launch) {
   if constexpr (ts_onepass_fits<NC, RB, D, true>) {
-    if (zreg) return order ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 1, true>) : launch(ts_onepass_kernel<NC, RB, D, false, 1024, 0, true>);
+    if (zreg) return order == 2 ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 2, true>) : order ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 1, true>) : launch(ts_onepass_kernel<NC, RB, D, false, 1024, 0, true>);
   }
   if constexpr (ts_onepass_fits<NC, RB, D, false>) {
-    return order ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 1>) : launch(ts_onepass_kernel<NC, RB, D, false, 1024, 0>);
+    return order == 2 ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 2>) : order ? launch(ts_onepass_kernel<NC, RB, D, false, 1024, 1>) : launch(ts_onepass_kernel<NC, RB, D, false, 1024, 0>);
   } else {
     (void)order; (void)launch; (void)zreg;
     return -1;
@@ -1245,13 +1265,18 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
   const long long ldw = compact ? ldc : (long long)K;      // leading dimension of W (a compact shard keeps its rows at their own width)
   const int nc = (K + 1023) / 1024;
   const size_t lds = sizeof(double) * 1024 * (size_t)(nc + (nc & 1));
+  // z as the producer left it: in the caller's order (gathered through perm_d while it is staged) or already in the factor's (z_scatter())
+  const bool z_pivot = vin_pivot;
+  vin_pivot = false;
+  const int* perm_in = z_pivot ? nullptr : perm_d;
+  if (z_pivot && !linear_z_ok()) { set_error("tail_solve: z was written in the factor's order but the pass that reads it that way is gone"); return CUADMM_ERR_INVALID; }
   if (one_pass && xpart && lds <= kMaxLdsBytes - 1024 && nc <= 20) {
     auto launch = [&](auto kern) -> int {
       if (lds > 48 * 1024 && !attr_set) {      // once per object: K, and with it the instantiation, never changes
         CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern)));   // process-wide per kernel: the maximum
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end, perm_d);
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end, perm_in);
       return CUADMM_OK;
     };
     int rc;
@@ -1259,7 +1284,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     auto launch512 = [&](auto kern, int ncol) -> int {
       const size_t lds5 = sizeof(double) * 512 * (size_t)ncol;
       if (lds5 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), lds5, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end, perm_d);
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), lds5, st, W, ldw, K, vin, dinv, xpart, r_begin, r_end, perm_in);
       return CUADMM_OK;
     };
     if (prefetch && fat && !dd_dot && K <= 10240) {
@@ -1308,7 +1333,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);
     auto kern = ts_onepass_group_kernel<8, Q, 4, 4>;
     if (!attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d, order);
+    hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_in, order);
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q, perm_d);
   } else if (one_pass && xpart && part && K <= 32768 && !group_retired) {
     constexpr int Q = 4;
@@ -1321,7 +1346,7 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
     const int G = std::max(8, 2 * n_wg / Q / 8 * 8);            // groups: two workgroups per CU, whole octets (member m of a group: + 8 m)
     auto launch = [&](auto kern) -> int {
       if (lds2 > 48 * 1024 && !attr_set) { CUADMM_HIP_TRY(allow_max_dynamic_lds(reinterpret_cast<const void*>(kern))); attr_set = true; }
-      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_d, order);
+      hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_in, order);
       return CUADMM_OK;
     };
     int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);

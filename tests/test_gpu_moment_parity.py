@@ -165,10 +165,10 @@ def test_refined_unpivoted_tail_reproduces_the_oracle(key, options, pobj_tol, tm
     assert ti["refined"] and ti["inverse_residual"] > 1e-13      # the unpivoted inverse is the inaccurate one (pivoted: ~2e-14); the refinement repairs the solve
 
 
-@pytest.mark.parametrize("options", [{"tail_order": 0, "tail_zreg": 0}, {"tail_depth": 0, "tail_rb": 1}, {"tail_depth": 3, "tail_rb": 1}, {"tail_depth": 2, "tail_rb": 2, "tail_zreg": 0}])
+@pytest.mark.parametrize("options", [{"tail_order": 0, "tail_zreg": 0}, {"tail_order": 1}, {"tail_depth": 0, "tail_rb": 1}, {"tail_depth": 3, "tail_rb": 1}, {"tail_depth": 2, "tail_rb": 2, "tail_zreg": 0}])
 @pytest.mark.parametrize("key", ["pendulum_N=80/switch=11000", "PlanarHand_N=1_MOMENT/switch=0"])
 def test_one_pass_kernel_variants_match_the_oracle(key, options, tmp_path):
-    """The one pass over inv(L22) (csrc/tail_solve.hip: ts_onepass_kernel) under its switches -- longest-first walk with z in LDS (rounds 3 - 6), no
+    """The one pass over inv(L22) (csrc/tail_solve.hip: ts_onepass_kernel) under its switches -- longest-first walk with z in LDS (rounds 3 - 6), the alternating walk without the stagger, no
     row in flight / three rows in flight beyond the current one, two rows per barrier: every instantiation family the dispatcher can reach, at
     7 168 columns (pendulum: NC = 8) and 9 216 (PlanarHand: NC = 10), against the same oracle trajectory at the same tolerance as the default."""
     run_and_compare(key, tmp_path, options, POBJ_HEAD_TOL.get(key))
