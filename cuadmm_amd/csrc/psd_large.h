@@ -15,7 +15,8 @@ struct SignPsd {
   // merged groups (lg_sign_cluster_kernel over several padded sizes), so it has a workspace of its own (ws_off: elements into X0 / S /
   // Y / T; mem_off: members into d_state / d_done / d_bar; part_off: into each half of d_part; slot: which [2] of d_group and which table
   // of d_xcc); the others run on the caller's stream one after the other in the shared region (all offsets 0)
-  struct Group { int N = 0, begin = 0, count = 0, pred = 0, mem_off = 0, slot = 0; bool merged = false; size_t ws_off = 0, part_off = 0; };
+  struct Group { int N = 0, begin = 0, count = 0, pred = 0, mem_off = 0, slot = 0; bool merged = false; size_t ws_off = 0, part_off = 0, cs_off = 0;
+                 mutable int bar_par = 0; };      // cs_off: into colsum_f; bar_par: which of the two barrier-counter sets the next fused projection uses
   PsdOptions opt;                            // the owner's switches (PsdPlan::build copies its own)
   std::vector<Group> groups;                 // same padded size N, bounded workspace
   int* d_ids = nullptr;                      // block ids, group after group
@@ -26,6 +27,7 @@ struct SignPsd {
                                              // A property of the group, not of the path: launches and one-launch kernel stay bit-identical
   double *X0 = nullptr, *S = nullptr, *Y = nullptr, *T = nullptr, *colsum = nullptr, *scale = nullptr;
   double* Mw = nullptr;                      // fifth matrix per member: M = R - R Y of a clean mega-lift (allocated when a group padded to <= clean_max_n exists)
+  double* colsum_f = nullptr;                // fused one-launch prologue: [group][member][LG_CS_ROWS][N] column-sum chunks (every group its own: merged groups run together)
   int* d_cont = nullptr;                     // [parity][member]: the next step is a clean mega-lift's second slot
   int clean_max_n = 480;                     // (below 512: a single block padded to 512 runs the super-block tile order, which has no second slot) like hint_max_n: a property of the group, so launches and one-launch kernel stay bit-identical and C3 pays nothing
   void* d_state = nullptr;                   // 2 x SignDevState per member of the largest group (adaptive schedule, sign_sched.h)
@@ -34,7 +36,9 @@ struct SignPsd {
   size_t part_half = 0;
   int* d_group = nullptr;                    // [members not finished, largest step count] of the group in flight
   int* h_group = nullptr;                    // pinned host copy (polled between chunks of steps)
-  unsigned* d_bar = nullptr;                 // per member: barrier counter of the one-launch variant
+  unsigned* d_bar = nullptr;                 // per member, two sets (members_cap apart): barrier counter of the one-launch variant; a fused projection zeroes the other set
+  mutable int shared_bar_par = 0;            // the counter set the next fused projection of a NON-merged group uses (they share the region at offset 0)
+  size_t bar_stride = 0;                     // members_cap: distance between the two counter sets
   int* d_xcc = nullptr;                      // [member][tile]: XCD of every workgroup of the one-launch variant (run-time check)
   int build(const int* blk, const std::vector<int>& members);
   int launch_group(Group& g, const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st, bool poll);

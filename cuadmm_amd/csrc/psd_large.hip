@@ -84,7 +84,7 @@ struct SignArgs {
   int cap;                  // the step limit of this projection (a mega-lift's two slots never straddle it)
 };
 // fresh schedule state of a member (version 0)
-__device__ __forceinline__ void lg_fresh_state(const SignArgs& sa, int m, int id, int n) {
+__device__ __forceinline__ void lg_fresh_state(const SignArgs& sa, int m, int id, int n, bool reset_bar = true) {
   SignDevState st;
   st.sched = SignSched();
   if (sa.hint && sa.hint[id] > 0) st.sched.lift0 = sa.hint[id];
@@ -95,7 +95,7 @@ __device__ __forceinline__ void lg_fresh_state(const SignArgs& sa, int m, int id
   sa.st[m] = st;
   sa.done[m].done_at = 0x7fffffff;
   sa.done[m].steps = 0;
-  if (sa.bar) sa.bar[m] = 0u;
+  if (sa.bar && reset_bar) sa.bar[m] = 0u;
   if (sa.cont) { sa.cont[m] = 0; sa.cont[sa.count + m] = 0; }
 }
 
@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256) void lg_decide_kernel(SignArgs sa, int ntiles)
 // ROLE 1: C = A*A (Y = S S), leaves the slots tr Y, ||Y||_F^2;
 // ROLE 2: C = 1.5 mu E - 0.5 mu^3 A*B (T from S, Y), mu decided here by every workgroup (lg_reduce_decide), leaves the
 //         slots ||S - S Y||_F^2;   ROLE 4: the same with mu read from the state (lg_decide_kernel ran in between);
+// ROLE 5: the final product of the one-launch kernel with the pack kernel's work in its epilogue: Cb = the block's svec in the output vector
+//         (not offset by the member), entry (row <= col < n_true) goes to col (col + 1) / 2 + row, off-diagonal ones times sqrt 2 -- no dense copy,
+//         no mirror image, no lg_pack_kernel behind it; a non-finite entry raises *fail like that kernel does.
 // ROLE 3: the final product: B = the buffer that holds the last iterate (Bb after an even number of steps, B2b after
 //         an odd one).
 // CLEAN MEGA-LIFT (sign_sched.h; B2b = the member's fifth matrix M in roles 1, 2, 4).  Its first slot is an ordinary step whose coefficients
@@ -185,7 +188,7 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
                                                  double alpha, double beta, const double* __restrict__ Eb,
                                                  double* __restrict__ Cb, int sb, const SignArgs& sg, const double* __restrict__ B2b,
                                                  const int member, const int tile_x, const int grid_x, double* smem, double* red,
-                                                 const bool known_live = false) {
+                                                 const bool known_live = false, const int n_true = 0, int* fail = nullptr) {
   constexpr int LDS = TM + 16;      // row stride (doubles): the 4 k-rows of a fragment read fall on disjoint banks
   constexpr int WT = TM / 2;        // rows / cols per wave
   constexpr int NTW = WT / 16;      // 16x16 MFMA tiles per wave per direction
@@ -208,7 +211,7 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
   const double* A = Ab + mat;
   const double* B = Bb + mat;
   const double* E = Eb ? Eb + mat : nullptr;
-  double* C = Cb + mat;
+  double* C = ROLE == 5 ? Cb : Cb + mat;
   int by, bx;
   if (MIRROR) {
     if (sb > 0) {
@@ -360,10 +363,17 @@ __device__ __forceinline__ void lg_gemm_sym_body(int N, const double* __restrict
           p1 += acc[i][j][r] * acc[i][j][r];
           if (row == col) p0 += acc[i][j][r];
         }
+        if (ROLE == 5) {
+          if (row <= col && col < n_true) {
+            if (!(fabs(c) <= 1.7976931348623157e308) && fail) atomicAdd(fail, 1);
+            C[(size_t)col * (col + 1) / 2 + row] = row == col ? c : c * kSqrt2;
+          }
+        } else {
         if (!MIRROR || full || col >= row) C[idx] = c;        // diagonal tiles: the upper triangle decides (a full product: every entry is its own)
         if (MIRROR && !full) Ct[lcol * (TM + 1) + lrow] = c;
+        }
       }
-  if (MIRROR && !full) {
+  if (MIRROR && !full && ROLE != 5) {
     __syncthreads();
     const int q = tid % TM;                           // original row   -> column of the mirrored tile
 #pragma unroll 4
@@ -416,6 +426,7 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
 // decision overlapped (0.84 ms); relaxed agent-scope atomic loads / stores for everything exchanged instead of the bulk
 // release / acquire, the state carried per workgroup (0.80 ms) -- the trips, not the L2 maintenance, are the cost.  The grid must be co-resident (the host only takes this path for <= kClusterMaxWgs workgroups);
 // a workgroup that waits longer than ~2 s gives up and raises the failure counter instead of hanging the device.
+constexpr int LG_CS_ROWS = 32;       // row chunks of the column sums of |X| (lg_colsum_kernel; the one-launch kernel's prologue keeps the association)
 constexpr int kClusterMaxWgs = 224;
 struct ClusterArgs {
   double *S, *T, *Y, *X0, *M;
@@ -424,6 +435,12 @@ struct ClusterArgs {
   int* fail;
   int N, max_steps, count, force_agent;
   int spread;               // 1: workgroups in plain order (member = w / ntiles) -- a member too large for one XCD's CUs
+  // FUSED (psd_lg_fuse): the one-launch kernel also does lg_prep_kernel's and lg_pack_steps_kernel's work -- its workgroups build X0, the column
+  // sums and S between their first two barriers and the final product stores the svec: one launch per projection instead of three (the
+  // prologue alone was 23 us of a 320 us chain on PlanarHand_N=1)
+  int fused;
+  double* colsum;           // [member][LG_CS_ROWS][N]
+  unsigned* bar_other;      // the counters of the NEXT projection (two sets, alternating): zeroed by this one, since nobody zeroes this one's before it
 };
 // Several groups (different padded sizes N) in one launch: workgroup and member ranges per group.  A relaxation with blocks of 126 and
 // of 252 (taha1a) would otherwise run its two one-launch groups one after the other, each a few workgroups deep and bound by its barriers.
@@ -434,6 +451,7 @@ struct ClusterMulti {
   int mem_begin[kClusterMaxGroups + 1];     // the prologue / epilogue launches run one workgroup (row) per member over all groups
   ClusterArgs ca[kClusterMaxGroups];
   SignArgs sg[kClusterMaxGroups];
+  const double* in; const long long* boff; const int* bn; double* out; int* steps;      // FUSED: the plan's vectors
 };
 // local: every workgroup of the member sits on the SAME XCD (checked at run time, below).  Then their common L2 is the coherence
 // point on the PRODUCER side: a workgroup signals once its own stores have completed (s_waitcnt vmcnt(0): the per-CU L1 writes
@@ -487,6 +505,34 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
   if (member >= ca.count) return;               // the whole workgroup, before any barrier
   unsigned* bar = ca.bar + member;
   unsigned phase = 0;
+  // FUSED prologue, first half (lg_prep_kernel's work spread over the member's workgroups): workgroup `tile` takes the row chunks tile,
+  // tile + ntiles, ... of the LG_CS_ROWS chunks: the block's svec gathered into the dense X0, and per chunk and column the sum of |X0| over the
+  // chunk's rows in row order -- lg_colsum_kernel's association, so the norm, the scale and S carry the bits of the other paths.
+  const int fid = ca.fused ? sg.ids[member] : 0, fn = ca.fused ? cm.bn[fid] : 0;
+  const int crow = (N + LG_CS_ROWS - 1) / LG_CS_ROWS;
+  if (ca.fused) {
+    const double* __restrict__ sv = cm.in + cm.boff[fid];
+    double* __restrict__ X0 = ca.X0 + (size_t)member * N * N;
+    double* __restrict__ cs = ca.colsum + (size_t)member * LG_CS_ROWS * N;
+    for (int z = tile; z < LG_CS_ROWS; z += (int)ntiles) {
+      const int r0 = z * crow, r1 = r0 + crow < N ? r0 + crow : N;
+      for (int c = (int)threadIdx.x; c < N; c += 256) {
+        double sum = 0.0;
+        for (int r = r0; r < r1; ++r) {
+          double v = 0.0;
+          if (r < fn && c < fn) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            v = sv[(long long)hi * (hi + 1) / 2 + lo];
+            if (lo != hi) v *= kSqrt2Inv;
+          }
+          X0[(size_t)r * N + c] = v;
+          sum += fabs(v);
+        }
+        cs[(size_t)z * N + c] = sum;
+      }
+    }
+    if (tile == 0 && threadIdx.x == 0) ca.bar_other[member] = 0u;      // the next projection's counter (this one's was zeroed by the previous projection)
+  }
   int xcc0;                                     // the XCD this workgroup started on
   {
     int x;
@@ -503,6 +549,39 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
     __syncthreads();
   }
   const bool local = s_local != 0;
+  if (ca.fused) {
+    // second half: ||X0||_1 = the largest column sum (chunk sums added in chunk order: lg_scale_kernel), formed by every workgroup for itself;
+    // S = X0 / ||X0||_1 on the workgroup's own rows (the values it stored above); workgroup 0 writes the member's fresh schedule state
+    const double* __restrict__ cs = ca.colsum + (size_t)member * LG_CS_ROWS * N;
+    double* __restrict__ X0 = ca.X0 + (size_t)member * N * N;
+    double* __restrict__ S0 = ca.S + (size_t)member * N * N;
+    double mx = 0.0;
+    for (int c = (int)threadIdx.x; c < N; c += 256) {
+      double v = 0.0;
+      for (int z = 0; z < LG_CS_ROWS; ++z) v += cs[(size_t)z * N + c];
+      mx = (v > mx || !(v == v)) ? v : mx;   // NaN propagates (flagged at the store of the projection)
+    }
+    double* redm = smem;                        // 256 doubles of the tile buffer (free until the first product)
+    redm[threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) { const double v = redm[threadIdx.x + k]; if (v > redm[threadIdx.x] || !(v == v)) redm[threadIdx.x] = v; }
+      __syncthreads();
+    }
+    const double nrm = redm[0];
+    __syncthreads();
+    const double scale = nrm > 0.0 ? 1.0 / nrm : (nrm == 0.0 ? 0.0 : nrm);
+    for (int z = tile; z < LG_CS_ROWS; z += (int)ntiles) {
+      const int r0 = z * crow, r1 = r0 + crow < N ? r0 + crow : N;
+      for (int c = (int)threadIdx.x; c < N; c += 256)
+        for (int r = r0; r < r1; ++r) S0[(size_t)r * N + c] = X0[(size_t)r * N + c] * scale;
+    }
+    if (tile == 0 && threadIdx.x == 0) {
+      if (member == 0) { sg.group[0] = sg.count; sg.group[1] = 0; }
+      lg_fresh_state(sg, member, fid, fn, false);
+    }
+    if (!lg_member_barrier(bar, ntiles * ++phase, local)) { if (threadIdx.x == 0 && ca.fail) atomicAdd(ca.fail, 1); return; }
+  }
   double* s = ca.S;
   double* t = ca.T;
   int step = 0;
@@ -525,7 +604,13 @@ __global__ __launch_bounds__(256) void lg_sign_cluster_kernel(ClusterMulti cm) {
   }
   // P = 0.5 (X0 + X0 S_final); `s` holds the last iterate
   sg.step = step;
-  lg_gemm_sym_body<true, TM, BK, 0>(N, ca.X0, s, 0.5, 0.5, ca.X0, ca.Y, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
+  if (ca.fused) {      // ... stored as the block's svec (ROLE 5), and the step count beside it: lg_pack_steps_kernel's work
+    lg_gemm_sym_body<true, TM, BK, 5>(N, ca.X0, s, 0.5, 0.5, ca.X0, cm.out + cm.boff[fid], 0, sg, nullptr, member, tile, (int)ntiles, smem, red, false, fn, ca.fail);
+    if (cm.steps && tile == 0 && threadIdx.x == 0)
+      cm.steps[fid] = sg.done[member].done_at <= ca.max_steps ? sg.done[member].steps : ca.max_steps;
+  } else {
+    lg_gemm_sym_body<true, TM, BK, 0>(N, ca.X0, s, 0.5, 0.5, ca.X0, ca.Y, 0, sg, nullptr, member, tile, (int)ntiles, smem, red);
+  }
 }
 
 // Group descriptors: member m of the group is block ids[m]; n = bn[id], svec offset boff[id].
@@ -565,7 +650,6 @@ __global__ void lg_pack_kernel(const double* __restrict__ src, const int* __rest
 }
 // column sums of |X| (X symmetric: = row sums) in LG_CS_ROWS row chunks (blockIdx.z), then scale[m] = 1 / max_c colsum
 // (0 for a zero block).  One thread per column over ALL rows takes 0.49 ms at N = 2048 (8 workgroups on 256 CUs).
-constexpr int LG_CS_ROWS = 32;
 __global__ __launch_bounds__(256) void lg_colsum_kernel(const double* __restrict__ Mb, int N, double* __restrict__ colsum) {
   const double* M = Mb + (size_t)blockIdx.y * N * N;
   const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -871,7 +955,14 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   CUADMM_HIP_TRY(hipMalloc(&d_state, sizeof(SignDevState) * 2 * members_cap));
   CUADMM_HIP_TRY(hipMalloc(&d_done, sizeof(SignDone) * members_cap));
   CUADMM_HIP_TRY(hipMalloc(&d_group, sizeof(int) * 2 * (size_t)(1 + n_merged)));
-  CUADMM_HIP_TRY(hipMalloc(&d_bar, sizeof(unsigned) * members_cap));
+  CUADMM_HIP_TRY(hipMalloc(&d_bar, sizeof(unsigned) * 3 * members_cap));      // sets 0 / 1: fused projections, alternating; set 2: the others (zeroed at their start)
+  CUADMM_HIP_TRY(hipMemset(d_bar, 0, sizeof(unsigned) * 3 * members_cap));
+  bar_stride = members_cap;
+  {
+    size_t cs_total = 0;
+    for (Group& g : groups) { g.cs_off = cs_total; cs_total += (size_t)g.count * (size_t)g.N * LG_CS_ROWS; }
+    CUADMM_HIP_TRY(hipMalloc(&colsum_f, sizeof(double) * std::max<size_t>(cs_total, 1)));
+  }
   CUADMM_HIP_TRY(hipMalloc(&d_xcc, sizeof(int) * (size_t)(kClusterMaxWgs + 64) * (size_t)(1 + n_merged)));
   CUADMM_HIP_TRY(hipHostMalloc(&h_group, sizeof(int) * 2, hipHostMallocDefault));
   part_half = max_part + side_part;
@@ -881,13 +972,13 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
 
 void SignPsd::release() {
   if (graph_exec) { hipError_t e = hipGraphExecDestroy(graph_exec); (void)e; graph_exec = nullptr; }
-  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar, (void*)d_xcc, (void*)Mw, (void*)d_cont})
+  for (void* p : {(void*)d_ids, (void*)X0, (void*)S, (void*)Y, (void*)T, (void*)colsum, (void*)scale, (void*)d_state, (void*)d_part, (void*)d_done, (void*)d_bar, (void*)d_xcc, (void*)Mw, (void*)d_cont, (void*)colsum_f})
     if (p) { hipError_t e = hipFree(p); (void)e; }
   if (d_group) { hipError_t e = hipFree(d_group); (void)e; d_group = nullptr; }
   if (h_group) { hipError_t e = hipHostFree(h_group); (void)e; h_group = nullptr; }
   d_ids = nullptr; d_state = nullptr; d_part = nullptr; d_done = nullptr; d_bar = nullptr; d_xcc = nullptr;
   X0 = S = Y = T = colsum = scale = nullptr;
-  Mw = nullptr; d_cont = nullptr;
+  Mw = nullptr; d_cont = nullptr; colsum_f = nullptr;
   groups.clear();
 }
 
@@ -967,13 +1058,21 @@ void SignPsd::cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max
   sa.ids = d_ids + g.begin;
   sa.count = g.count;
   sa.step = 0;
-  sa.bar = d_bar + g.mem_off;
+  // fused prologue / epilogue (psd_lg_fuse; not under a graph capture's replay -- the counter set alternates per projection -- and only where the
+  // one-launch prologue applies at all, N <= 512): this projection counts in set bar_par and zeroes the other one
+  const bool fused = opt.lg_fuse != 0 && opt.graph != 1 && !opt.debug && g.N <= 512;
+  // (the groups that run one after the other share the region at offset 0 and with it the counters: ONE alternation for all of them)
+  int& bar_par = g.merged ? g.bar_par : shared_bar_par;
+  const int par = fused ? bar_par : 2;          // (a projection that is not fused zeroes its counters itself, in a set of its own: it must not dirty the alternating ones)
+  if (fused) bar_par ^= 1;
+  sa.bar = d_bar + (size_t)par * bar_stride + g.mem_off;
   sa.clean = (Mw && opt.lg_clean != 0 && g.N <= clean_max_n) ? 1 : 0;
   sa.cont = sa.clean ? d_cont + 2 * (size_t)g.mem_off : nullptr;
   sa.cap = max_steps;
   // psd_lg_cluster = 2: agent-scope barriers always (A/B, tests)
-  cm.ca[i] = ClusterArgs{S + g.ws_off, T + g.ws_off, Y + g.ws_off, X0 + g.ws_off, sa.clean ? Mw + g.ws_off : nullptr, d_bar + g.mem_off,
-                         d_xcc + (size_t)(kClusterMaxWgs + 64) * (size_t)g.slot, d_fail, g.N, max_steps, g.count, opt.lg_cluster == 2 ? 1 : 0, path.spread};
+  cm.ca[i] = ClusterArgs{S + g.ws_off, T + g.ws_off, Y + g.ws_off, X0 + g.ws_off, sa.clean ? Mw + g.ws_off : nullptr, sa.bar,
+                         d_xcc + (size_t)(kClusterMaxWgs + 64) * (size_t)g.slot, d_fail, g.N, max_steps, g.count, opt.lg_cluster == 2 ? 1 : 0, path.spread,
+                         fused ? 1 : 0, colsum_f + g.cs_off, d_bar + (size_t)(fused ? par ^ 1 : 2) * bar_stride + g.mem_off};
   cm.wg_begin[i + 1] = cm.wg_begin[i] + (path.cluster_wgs + 7) / 8 * 8;
   cm.mem_begin[i + 1] = cm.mem_begin[i] + g.count;
 }
@@ -982,7 +1081,11 @@ void SignPsd::cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max
 int SignPsd::cluster_run(ClusterMulti& cm, bool prologue, const double* in, double* out, const long long* boff, const int* bn, int* d_fail, hipStream_t st) {
   int maxN = 0;
   for (int i = 0; i < cm.n; ++i) maxN = std::max(maxN, cm.ca[i].N);
-  if (prologue) {
+  const bool fused = cm.n > 0 && cm.ca[0].fused != 0;
+  for (int i = 0; i < cm.n; ++i)      // cluster_add chose the counter sets by it: all groups of a launch alike, and never without the prologue being this launch's to do
+    if ((cm.ca[i].fused != 0) != fused || (fused && !prologue)) { set_error("psd sign path: fused and plain one-launch groups in one launch"); return CUADMM_ERR_INVALID; }
+  cm.in = in; cm.boff = boff; cm.bn = bn; cm.out = out; cm.steps = d_steps;
+  if (prologue && !fused) {
     const size_t lds_prep = sizeof(double) * LG_CS_ROWS * (size_t)maxN;
     static LdsCapOnce once;                      // the cap is lifted to the kernel's maximum, once per device
     if (lds_prep > 48 * 1024) CUADMM_HIP_TRY(once(reinterpret_cast<const void*>(lg_prep_kernel)));
@@ -994,7 +1097,7 @@ int SignPsd::cluster_run(ClusterMulti& cm, bool prologue, const double* in, doub
   else hipLaunchKernelGGL((lg_sign_cluster_kernel<32, 32, false>), dim3(cm.wg_begin[cm.n]), dim3(256), 0, st, cm);
   for (int i = 0; i < cm.n; ++i) cm.sg[i].step = cm.ca[i].max_steps;          // the steps enqueued
   const unsigned gx = (unsigned)std::min<size_t>(((size_t)maxN * maxN / 2 + 255) / 256, 1024);
-  hipLaunchKernelGGL(lg_pack_steps_kernel, dim3(gx, cm.mem_begin[cm.n]), dim3(256), 0, st, boff, bn, out, d_fail, d_steps, cm);
+  if (!fused) hipLaunchKernelGGL(lg_pack_steps_kernel, dim3(gx, cm.mem_begin[cm.n]), dim3(256), 0, st, boff, bn, out, d_fail, d_steps, cm);
   CUADMM_HIP_TRY(hipGetLastError());
   return CUADMM_OK;
 }
@@ -1018,7 +1121,7 @@ int SignPsd::launch_group(Group& g, const double* in, double* out, const long lo
     double* const T = this->T + g.ws_off;
     double* const scale = this->scale + g.mem_off;
     int* const d_group = this->d_group + 2 * g.slot;
-    unsigned* const d_bar = this->d_bar + g.mem_off;
+    unsigned* const d_bar = this->d_bar + 2 * bar_stride + g.mem_off;      // (set 2: cluster_add's choice for a projection that is not fused)
     SignArgs sa{};
     sa.st = static_cast<SignDevState*>(d_state) + 2 * (size_t)g.mem_off;
     sa.done = static_cast<SignDone*>(d_done) + g.mem_off;

@@ -322,3 +322,24 @@ def test_device_side_y_solve_matches_the_host_solve(monkeypatch):
         assert np.max(np.abs(a - b)) <= 1e-12 * (1 + np.max(np.abs(b)))      # same operation order; the fp64 division differs in the last bit
     for a, b in zip(runs["device"][3], runs["host"][3]):
         assert np.max(np.abs(a - b) / (1e-300 + np.abs(b))) <= 1e-12      # scalars: device / host summation order of the norms
+
+
+def test_fused_one_launch_sign_kernel_is_bit_identical_across_iterations():
+    """psd_lg_fuse (csrc/psd_large.hip: the one-launch sign kernel does its own prologue -- svec -> X0, column sums, S, state -- and stores the svec
+    itself, and its barrier counters alternate between two sets because nobody zeroes them before it starts) against the three-launch form, over
+    many projections of ONE plan: two mid-size groups that take the fused path (n = 100, 130) beside a 600-block whose one-launch run is NOT fused
+    and zeroes counters of its own (a third set: it must not dirty the alternating ones), and small blocks on other kernels.  Same bits."""
+    from cuadmm_amd.synthetic import make_synthetic
+    q = make_synthetic([100, 600, 130, 100, 20, 7], cons_per_block=6, nnz_per_con=8, seed=77, dense_C=False)
+    p = cuadmm_amd.Problem(q.vec_len, q.con_num, q.blk, q.At_col_ptrs, q.At_row_ids, q.At_vals, q.b_idx, q.b_vals, q.C_idx, q.C_vals)
+    out = []
+    for fuse in (1, 0):
+        s = cuadmm_amd.SDPSolver(verbose=False, options={"psd_lg_fuse": fuse})
+        s.init_problem(p)
+        s.solve(40, 0.0, 0, 50, 100, 0, 1.05)
+        out.append((np.array(s.X), np.array(s.y), np.array(s.S), [np.array(s.info_arr(k)) for k in ("errRp", "errRd", "pobj", "dobj")]))
+    (X1, y1, S1, i1), (X0, y0, S0, i0) = out
+    assert np.array_equal(X1, X0) and np.array_equal(y1, y0) and np.array_equal(S1, S0)
+    for a, b in zip(i1, i0):
+        assert np.array_equal(a, b)
+    assert np.all(np.isfinite(X1)) and i1[0][-1] < i1[0][0]
