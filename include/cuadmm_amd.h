@@ -70,6 +70,13 @@ void cuadmm_destroy(cuadmm_solver* s);
  *                   nearly singular Schur complement (large moment relaxations) otherwise leaves 1e-8 ... 1e-7 in the primal objective against an exact
  *                   LDL^T solve (the reference's contract, include/cuadmm/cholesky_cpu.h:146-155).  Costs 6x the tail's bytes per solve and two more
  *                   K x K matrices; default 0.  cuadmm_get_tail_info [4] reports the measured accuracy of the explicit inverse.
+ *   "tail_order", "tail_zreg", "tail_depth", "tail_rb"   the tail's one pass over inv(L22) (csrc/tail_solve.hip): the workgroups' row walk (2, default:
+ *                   alternately from the long and the short end, odd workgroups starting short; 0 = longest first), z in registers (1) or LDS (0), row groups in
+ *                   flight beyond the current one (0 ... 3, default 1), rows per barrier (0 = by size).  A/B switches: the same solve to the last few bits.
+ *   "psd_lg_fuse"   1 (default) = a handful of blocks of 65 <= n <= 512 run their whole projection -- svec -> dense, norm, every step of the matrix-sign
+ *                   iteration, final product, svec store -- in ONE launch; 0 = prologue and epilogue as launches of their own (bit-identical)
+ *   "psd_lg_clean"  1 = the uncapped ("clean") mega-lift of the sign schedule for groups padded to <= 480 (csrc/sign_sched.h); default 0: measured slower
+ *                   on every shipped input
  *   "duo_share_device", "duo_exchange"   the in-process group of cuadmm_duo_init(device_num_requested = N): all engines on the
  *                   caller's device; all-reduce through device memory (1), host staging (0), chosen by peer accessibility (-1, default)
  *   (every other switch: INTEGRATION.md section 6)
