@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void lg_gemm_sym_kernel(int N, const double* _
 // release / acquire, the state carried per workgroup (0.80 ms) -- the trips, not the L2 maintenance, are the cost.  The grid must be co-resident (the host only takes this path for <= kClusterMaxWgs workgroups);
 // a workgroup that waits longer than ~2 s gives up and raises the failure counter instead of hanging the device.
 constexpr int LG_CS_ROWS = 32;       // row chunks of the column sums of |X| (lg_colsum_kernel; the one-launch kernel's prologue keeps the association)
-constexpr int kClusterMaxWgs = 224;
+constexpr int kClusterMaxWgs = 224;       // default of psd_lg_cluster_wgs
+constexpr int kClusterXccStride = 1024;   // ints per table of d_xcc (the option's upper bound + slack)
 struct ClusterArgs {
   double *S, *T, *Y, *X0, *M;
   unsigned* bar;            // per member, zeroed by lg_state_init_kernel
@@ -902,7 +903,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
   for (Group& g : groups) {
     const LgPath p = lg_path(opt, g.N, g.count);
     if (!(opt.lg_merge != 0 && !opt.debug && p.cluster && g.N <= 512 && n_merged < kClusterMaxGroups &&
-          wgs + g.count * p.ntiles <= kClusterMaxWgs))   // the workgroups that stay (the grid's others leave at once)
+          wgs + g.count * p.ntiles <= std::max(opt.lg_cluster_wgs, 8)))   // the workgroups that stay (the grid's others leave at once)
       continue;
     int add[8];
     bool fits = true;
@@ -963,7 +964,7 @@ int SignPsd::build(const int* blk, const std::vector<int>& members) {
     for (Group& g : groups) { g.cs_off = cs_total; cs_total += (size_t)g.count * (size_t)g.N * LG_CS_ROWS; }
     CUADMM_HIP_TRY(hipMalloc(&colsum_f, sizeof(double) * std::max<size_t>(cs_total, 1)));
   }
-  CUADMM_HIP_TRY(hipMalloc(&d_xcc, sizeof(int) * (size_t)(kClusterMaxWgs + 64) * (size_t)(1 + n_merged)));
+  CUADMM_HIP_TRY(hipMalloc(&d_xcc, sizeof(int) * (size_t)(kClusterXccStride) * (size_t)(1 + n_merged)));
   CUADMM_HIP_TRY(hipHostMalloc(&h_group, sizeof(int) * 2, hipHostMallocDefault));
   part_half = max_part + side_part;
   CUADMM_HIP_TRY(hipMalloc(&d_part, sizeof(double) * 2 * std::max<size_t>(part_half, 1)));   // p1 | p2 (two parities)
@@ -1018,7 +1019,7 @@ static LgPath lg_path(const PsdOptions& opt, int N, int cnt) {
   p.ntiles = nbt * (nbt + 1) / 2;
   p.decide_kernel = opt.lg_decide ? opt.lg_decide == 2 : p.ntiles > 300;
   // a handful of mid-size blocks: every step and the final product in ONE launch (lg_sign_cluster_kernel)
-  p.cluster = opt.lg_cluster != 0 && !p.decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)p.ntiles * cnt <= kClusterMaxWgs;
+  p.cluster = opt.lg_cluster != 0 && !p.decide_kernel && lg_small_tiles(true, N, cnt, opt.lg_tile) && (long long)p.ntiles * cnt <= std::max(opt.lg_cluster_wgs, 8);
   // one XCD has 32 CUs x 4 workgroups of this kernel: a member's workgroups go to ONE XCD only while everything mapped there stays
   // co-resident with room to spare; else plain order over the whole chip (agent-scope barriers)
   p.spread = ((cnt + 7) / 8) * p.ntiles > 96 ? 1 : 0;
@@ -1071,7 +1072,7 @@ void SignPsd::cluster_add(ClusterMulti& cm, const Group& g, int* d_fail, int max
   sa.cap = max_steps;
   // psd_lg_cluster = 2: agent-scope barriers always (A/B, tests)
   cm.ca[i] = ClusterArgs{S + g.ws_off, T + g.ws_off, Y + g.ws_off, X0 + g.ws_off, sa.clean ? Mw + g.ws_off : nullptr, sa.bar,
-                         d_xcc + (size_t)(kClusterMaxWgs + 64) * (size_t)g.slot, d_fail, g.N, max_steps, g.count, opt.lg_cluster == 2 ? 1 : 0, path.spread,
+                         d_xcc + (size_t)kClusterXccStride * (size_t)g.slot, d_fail, g.N, max_steps, g.count, opt.lg_cluster == 2 ? 1 : 0, path.spread,
                          fused ? 1 : 0, colsum_f + g.cs_off, d_bar + (size_t)(fused ? par ^ 1 : 2) * bar_stride + g.mem_off};
   cm.wg_begin[i + 1] = cm.wg_begin[i] + (path.cluster_wgs + 7) / 8 * 8;
   cm.mem_begin[i + 1] = cm.mem_begin[i] + g.count;

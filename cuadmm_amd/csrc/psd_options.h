@@ -25,6 +25,7 @@ struct PsdOptions {
   int lg_merge = 1;        // psd_lg_merge: one-launch groups of different padded sizes share ONE launch (workspaces of their own)
   int lg_clean = 0;        // psd_lg_clean: 1 = groups padded to at most 512 take the CLEAN mega-lift where it pays (sign_sched.h: two step slots, no cap).  Built, parity-green and OFF: on the shipped inputs it never pays (NOTEBOOK.md "Round 6")
   int lg_fuse = 1;         // psd_lg_fuse: the one-launch kernel does its own prologue (svec -> X0, column sums, S, state) and epilogue (svec store): one launch instead of three
+  int lg_cluster_wgs = 224;  // psd_lg_cluster_wgs: the largest grid the one-launch sign kernel takes (its workgroups must be co-resident: four of them fit a CU)
   int lg_cluster = 1;      // psd_lg_cluster: a handful of mid-size blocks run their whole sign iteration in one launch (per-member barriers)
   int graph = 0;           // psd_graph: replay the launch sequence from a hipGraph (measured: no gain)
   int sign_maxsteps = 0;   // psd_sign_maxsteps: cap of the schedule (0: SignSched::kCap)
@@ -41,7 +42,7 @@ struct PsdOptions {
         {"CUADMM_PSD_N16", &o.n16_sign},    {"CUADMM_PSD_N32", &o.n32_sign},
         {"CUADMM_PSD_MID", &o.mid},             {"CUADMM_PSD_LG_CLUSTER", &o.lg_cluster}, {"CUADMM_PSD_LDS_TRIPLE", &o.lds_triple},
         {"CUADMM_PSD_LG_MERGE", &o.lg_merge},   {"CUADMM_PSD_LG_CLEAN", &o.lg_clean},
-        {"CUADMM_PSD_LG_FUSE", &o.lg_fuse}};
+        {"CUADMM_PSD_LG_FUSE", &o.lg_fuse},     {"CUADMM_PSD_LG_CLUSTER_WGS", &o.lg_cluster_wgs}};
     for (auto& t : tab)
       if (const char* e = getenv(t.name)) {
         // historical spellings: N16 / N32 = "eig" (register eigensolver), MID = "eig" | "lds"
@@ -71,6 +72,7 @@ struct PsdOptions {
     else if (k == "psd_lg_merge") lg_merge = v;
     else if (k == "psd_lg_clean") lg_clean = v;
     else if (k == "psd_lg_fuse") lg_fuse = v;
+    else if (k == "psd_lg_cluster_wgs") lg_cluster_wgs = v < 8 ? 8 : (v > 960 ? 960 : v);
     else if (k == "psd_graph") graph = v;
     else if (k == "psd_sign_maxsteps") sign_maxsteps = v;
     else if (k == "psd_sign_sync") sign_sync = v;
