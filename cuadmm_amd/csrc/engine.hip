@@ -254,6 +254,7 @@ struct cuadmm_solver {
     int tail_fat = 0;             // "tail_fat": the one-pass kernel on 512-thread workgroups with twice the rows in flight for K <= 10 240 (measured: slower; A/B)
     int tail_depth = 1;           // "tail_depth" / "tail_order": ring depth and row walk of the tail's one-pass kernel (tail_solve.hip)
     int tail_order = 2;
+    int tail_group_pf = 0;        // "tail_group_pf": see TailSolve::group_pf (measured slower, off)
     int tail_zreg = 1;            // "tail_zreg": z in registers in that kernel where it fits
     int tail_rb = 0;              // "tail_rb": rows per barrier of that kernel (0: by size)
     int tail_prefetch = 1;        // "tail_prefetch": the tail's one-pass kernel keeps the next rows in flight across its barrier (0: rounds 3 - 5; A/B)
@@ -811,6 +812,7 @@ static int init_factor(Solver* s, const InitIn& in, InitCtx& c) {
       s->tail.order = s->sw.tail_order;
       s->tail.rows_per_group = s->sw.tail_rb;
       s->tail.zreg = s->sw.tail_zreg != 0;
+      s->tail.group_pf = s->sw.tail_group_pf != 0;
       s->tail.fat = s->sw.tail_fat != 0;
       s->tail.dd_dot = s->sw.tail_dd != 0;
       s->tail.refine = s->sw.tail_refine != 0;
@@ -1419,6 +1421,7 @@ int cuadmm_set_option(cuadmm_solver* s, const char* key, double value) {
   else if (k == "tail_order") s->sw.tail_order = value == 2 ? 2 : (value != 0 ? 1 : 0);
   else if (k == "tail_rb") s->sw.tail_rb = (int)value;
   else if (k == "tail_zreg") s->sw.tail_zreg = (int)value;
+  else if (k == "tail_group_pf") s->sw.tail_group_pf = (int)value;
   else if (k == "tail_fat") s->sw.tail_fat = (int)value;
   else if (k == "tail_dd") s->sw.tail_dd = (int)value;
   else if (k == "tail_refine") s->sw.tail_refine = (int)value;

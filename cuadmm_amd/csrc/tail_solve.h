@@ -40,6 +40,7 @@ struct TailSolve {
   bool fat = false;            // option tail_fat (measured, off): K <= 10 240 on 512-thread workgroups of up to 256 VGPRs (two rows per group, two groups in
                                // flight): 92 us against 81 at K = 9 216, 48 against 47 at 7 168 -- NOTEBOOK.md "Round 6"
   int depth = 1;               // option tail_depth: row groups in flight beyond the current one in the one-pass kernel (tail_solve.hip: ts_onepass_kernel)
+  bool group_pf = false;       // option tail_group_pf (measured, off): the row-sharing kernel (24 576 < K <= 32 768) with two rows per exchange and the next group in flight across it -- PlanarHand N = 10 4.25 -> 4.47 ms per iteration
   bool zreg = true;            // option tail_zreg: the one-pass kernel keeps a thread's entries of z in registers where they fit (0: in LDS, rounds 3 - 6)
   int rows_per_group = 0;      // option tail_rb: rows that share one barrier in the one-pass kernel (0: two up to 8 192 columns, else one)
   int order = 2;               // option tail_order: 1 = a workgroup walks its rows alternately from the long and the short end, 2 = and odd workgroups start at the short end (0: longest first, rounds 3 - 6)

@@ -439,7 +439,7 @@ __global__ void ts_fill_u64_kernel(unsigned long long* p, size_t n, unsigned lon
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-template <int NC, int Q, int RB, int OCC = 8>
+template <int NC, int Q, int RB, int OCC = 8, bool PF = false>
 __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const double* __restrict__ W, long long ld, int K, const double* __restrict__ z,
                                                                    const double* __restrict__ dinv, double* __restrict__ P,
                                                                    unsigned long long* __restrict__ part, int* __restrict__ fail, int r_begin, int r_end,
@@ -482,10 +482,12 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
   // members of a group share `group` and `count`, so they walk the same sequence and meet in the same exchange slots
   const int first = r_begin + group * RB, stride = G * RB;
   const int count = first < r_end ? (r_end - first + stride - 1) / stride : 0;
-  for (int it = 0; it < count; ++it) {
+  auto row_of = [&](int it) -> int {
     const int jw = order ? ((((it & 1) != 0) != (order == 2 && (group & 1) != 0)) ? count - 1 - (it >> 1) : (it >> 1)) : it;
-    const int r0 = first + jw * stride;
-    double2 w[RB][NP];
+    return first + jw * stride;
+  };
+  // the rows of one group into registers (w), and everything behind the loads (process)
+  auto load_group = [&](double2 (&w)[RB][NP], const int r0) __attribute__((always_inline)) {
     const int seg0 = (wave_u * Q + member) * (64 * NC);   // this wavefront's segment: uniform
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
@@ -508,6 +510,8 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
         }
       }
     }
+  };
+  auto process = [&](double2 (&w)[RB][NP], const int r0, const int it) __attribute__((always_inline)) {
     // lane q of the first wavefront exchanges row q: its pivot is in flight across the barrier
     const int rq = r0 + (tid < RB ? tid : 0);
     const int iq = rq < r_end ? K - 1 - rq : -1;
@@ -568,6 +572,22 @@ __global__ __launch_bounds__(1024, OCC) void ts_onepass_group_kernel(const doubl
       const double vq = ush[it & 1][q];
 #pragma unroll
       for (int p = 0; p < NP; ++p) { xa[p].x += vq * w[q][p].x; xa[p].y += vq * w[q][p].y; }
+    }
+    };
+  if constexpr (!PF) {
+    double2 w[RB][NP];
+    for (int it = 0; it < count; ++it) { load_group(w, row_of(it)); process(w, row_of(it), it); }
+  } else {
+    // PF: the NEXT group's rows travel while this group's parts go round the members -- the ~2 us exchange no longer stands between two loads
+    // (two register buffers: half the rows per exchange of the variant without, the same registers)
+    double2 wA[RB][NP], wB[RB][NP];
+    if (count > 0) load_group(wA, row_of(0));
+    for (int it = 0; it < count; it += 2) {
+      if (it + 1 < count) load_group(wB, row_of(it + 1));
+      process(wA, row_of(it), it);
+      if (it + 1 >= count) break;
+      if (it + 2 < count) load_group(wA, row_of(it + 2));
+      process(wB, row_of(it + 1), it + 1);
     }
   }
 #pragma unroll
@@ -1349,7 +1369,8 @@ int TailSolve::apply_rows(hipStream_t st, int r_begin, int r_end) {
       hipLaunchKernelGGL(kern, dim3(G * Q), dim3(1024), lds2, st, W, ldw, K, vin, dinv, xpart, part, d_fail, r_begin, r_end, perm_in, order);
       return CUADMM_OK;
     };
-    int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
+    // (group_pf: two rows per exchange and the next group's rows in flight across it, instead of four rows and nothing in flight)
+    int rc = small ? launch(ts_onepass_group_kernel<6, Q, 2, 8>) : group_pf ? launch(ts_onepass_group_kernel<8, Q, 2, 4, true>) : launch(ts_onepass_group_kernel<8, Q, 4, 4>);
     if (rc) return rc;
     hipLaunchKernelGGL(ts_onepass_reduce_kernel, dim3((K + 31) / 32), dim3(256), 0, st, xpart, K, G, vin, part, Q, perm_d);
   } else {
